@@ -1,0 +1,70 @@
+"""Shared fixtures: CLEVRTex-7slot config dicts, golden loader, oracle weight dict."""
+import gzip
+import json
+import os
+
+import numpy as np
+import torch
+
+from slotdiffusion_amd import spec
+from tests.detfill import det_value, is_buffer_name, make_inputs  # noqa: F401
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def clevrtex_cfg(num_slots=7):
+    """Restates img_based/configs/sa_ldm/sa_ldm_clevrtex_params-res128.py (values only)."""
+    res = (128, 128)
+    d = 192
+    return dict(
+        resolution=res,
+        slot_dict=dict(num_slots=num_slots, slot_size=d, slot_mlp_size=2 * d, num_iterations=3),
+        enc_dict=dict(resnet='resnet18', use_layer4=False, enc_out_channels=d),
+        dec_dict=dict(
+            resolution=(32, 32),
+            vae_dict=dict(
+                vae_type='VQVAE',
+                enc_dec_dict=dict(resolution=128, in_channels=3, z_channels=3, ch=64,
+                                  ch_mult=[1, 2, 4], num_res_blocks=2, attn_resolutions=[],
+                                  out_ch=3, dropout=0.0),
+                vq_dict=dict(n_embed=4096, embed_dim=3, percept_loss_w=1.0),
+                vqvae_ckp_path='./pretrained/vqvae_clevrtex_params-res128.pth'),
+            unet_dict=dict(in_channels=3, model_channels=128, out_channels=3, num_res_blocks=2,
+                           attention_resolutions=(8, 4, 2), dropout=0.1,
+                           channel_mult=(1, 2, 3, 4), dims=2, use_checkpoint=False,
+                           num_head_channels=32, resblock_updown=False, conv_resample=True,
+                           transformer_depth=1, context_dim=d, n_embed=None),
+            use_ema=False,
+            diffusion_dict=dict(pred_target='eps', z_scale_factor=1., timesteps=1000,
+                                beta_schedule='linear', linear_start=0.0015, linear_end=0.0195,
+                                cosine_s=8e-3, log_every_t=200, logvar_init=0.),
+            conditioning_key='crossattn', cond_stage_key='slots'),
+        loss_dict=dict(use_denoise_loss=True))
+
+
+def load_golden(name='sadiff_b2.npz'):
+    z = np.load(os.path.join(GOLD, name))
+    return {k: (torch.from_numpy(z[k]) if z[k].dtype.kind in 'fiu' else z[k]) for k in z.files}
+
+
+def load_keys():
+    with gzip.open(os.path.join(GOLD, 'state_dict_keys.json.gz'), 'rt') as f:
+        return json.load(f)
+
+
+def oracle_weights(cfg, seed=1234):
+    """{key: fp32 CPU tensor} with tests/detfill.py values (buffers from the schedule)."""
+    from slotdiffusion_amd.module import build_grid, ddpm_schedule
+    sp = spec.sa_diffusion(cfg['resolution'], cfg['slot_dict'], cfg['enc_dict'], cfg['dec_dict'])
+    dd = {k: v for k, v in cfg['dec_dict']['diffusion_dict'].items()
+          if k in ('timesteps', 'beta_schedule', 'linear_start', 'linear_end')}
+    sched = ddpm_schedule(**dd)
+    W = {}
+    for i, p in enumerate(sp):
+        if p.init.startswith('buf:'):
+            key = p.init[4:]
+            W[p.name] = build_grid(p.shape[1:3]) if key == 'grid' else \
+                torch.tensor(sched[key], dtype=torch.float32)
+        else:
+            W[p.name] = det_value(p.name, p.shape, i, seed)
+    return W

@@ -1,0 +1,144 @@
+"""Pins the CPU oracle (oracle/slotdiff_oracle.py) against tensors captured from the real
+reference (tests/golden/sadiff_b2.npz, produced by tools/gen_golden.py in the build container).
+CPU only."""
+import torch
+
+from oracle import slotdiff_oracle as O
+from slotdiffusion_amd import spec
+from tests import common as C
+
+torch.set_num_threads(8)
+_cache = {}
+
+
+def ctx():
+    if not _cache:
+        cfg = C.clevrtex_cfg()
+        _cache.update(cfg=cfg, W=C.oracle_weights(cfg), G=C.load_golden(),
+                      rplan=spec.resnet18_plan(False),
+                      uplan=spec.unet_plan(cfg['dec_dict']['unet_dict']),
+                      ed=cfg['dec_dict']['vae_dict']['enc_dec_dict'])
+        img, t, noise, x_T = C.make_inputs(2)
+        _cache.update(img=img)
+    return _cache
+
+
+def close(a, b, atol, rtol=0.):
+    assert a.shape == b.shape, (a.shape, b.shape)
+    err = (a.double() - b.double()).abs()
+    lim = atol + rtol * b.double().abs()
+    assert bool((err <= lim).all()), f'max err {err.max().item():.3e} (atol {atol})'
+
+
+def test_spec_matches_reference_keys():
+    keys = C.load_keys()
+    cfg = C.clevrtex_cfg()
+    sp = spec.sa_diffusion(cfg['resolution'], cfg['slot_dict'], cfg['enc_dict'], cfg['dec_dict'])
+    ref = keys['img_based/SADiffusion/clevrtex-7slot']
+    assert [(p.name, list(p.shape)) for p in sp] == [(k, s) for k, s, _ in ref['state']]
+    frozen = set(ref['frozen'])
+    mine = [p.name for p in sp if p.trainable and not p.init.startswith('buf')]
+    assert mine == [k for k, _ in ref['params'] if k not in frozen]
+
+
+def test_inputs_regenerate():
+    c = ctx()
+    img = c['img']
+    chk = torch.stack([img.double().sum(), (img.double() ** 2).sum(), img[1, 2, 77, 5].double()])
+    assert torch.equal(chk, c['G']['img_checksum'])
+
+
+def test_encoder_and_slot_attention():
+    c = ctx()
+    W, G = c['W'], c['G']
+    with torch.no_grad():
+        eo = O.encoder_out(W, c['img'], c['rplan'])
+        close(eo[:, 3::8], G['enc_out_sub8'], 2e-5)
+        slots, masks = O.sa_encode(W, c['img'], c['rplan'], 3, training=True)
+        close(slots, G['slots'], 2e-5)
+        close(masks, G['masks_train'], 1e-5)
+        assert torch.equal(masks.argmax(1), G['masks_train_argmax'].long())
+        _, masks_e = O.sa_encode(W, c['img'], c['rplan'], 3, training=False)
+        close(masks_e[:, :, 1::4, 2::4], G['masks_eval_sub4'], 1e-5)
+        assert torch.equal(masks_e.argmax(1), G['masks_eval_argmax'].long())
+
+
+def test_vqvae():
+    c = ctx()
+    W, G, ed = c['W'], c['G'], c['ed']
+    with torch.no_grad():
+        x0 = O.vae_encode(W, c['img'], ed)
+        close(x0, G['x0'], 2e-5)
+        zq, idx = O.vq_quantize(W, G['x0'])
+        assert torch.equal(idx, G['x0_vq_idx'].long())
+        close(zq, G['x0_vq'], 0.)
+        dec = O.vae_decode(W, G['x0'], ed)
+        close(dec[:, :, 1::2, ::2], G['x0_decoded_sub2'], 5e-5)
+
+
+def test_unet_eps_and_loss():
+    c = ctx()
+    W, G = c['W'], c['G']
+    with torch.no_grad():
+        xt = O.q_sample(W, G['x0'], G['t'], G['noise'])
+        close(xt, G['x_t'], 1e-6)
+        eps = O.unet_forward(W, c['uplan'], G['x_t'], G['t'], G['slots'])
+        close(eps, G['eps_pred'], 5e-5)
+        loss = torch.nn.functional.mse_loss(eps, G['noise'])
+        assert abs(float(loss) - float(G['denoise_loss'])) < 1e-5
+        eps_f = O.unet_forward(W, c['uplan'], G['x_t'], G['t_frac'], G['slots'])
+        close(eps_f, G['eps_pred_frac'], 5e-5)
+
+
+def test_noise_schedule_and_orders():
+    c = ctx()
+    W, G = c['W'], c['G']
+    ns = O.NoiseScheduleDiscrete(W['dm_decoder.betas'])
+    close(ns.log_mean_coeff(G['ns_t']), G['ns_log_alpha'], 1e-6, 1e-6)
+    close(ns.lam(G['ns_t']), G['ns_lambda'], 2e-6, 2e-6)
+    close(ns.inverse_lambda(G['ns_lambda']), G['ns_inv_lambda'], 1e-6)
+    outer, orders = O.dpm_orders_and_timesteps(20, 3, 1.0, 1e-3)
+    close(outer, G['dpm_outer'], 0.)
+    assert orders == G['dpm_orders'].tolist() == [3] * 6 + [2]
+
+
+def test_train_step_gradients():
+    c = ctx()
+    G = c['G']
+    W = {k: v.clone() for k, v in c['W'].items()}
+    keys = C.load_keys()['img_based/SADiffusion/clevrtex-7slot']
+    frozen = set(keys['frozen'])
+    train = [k for k, _ in keys['params'] if k not in frozen]
+    for k in train:
+        W[k].requires_grad_(True)
+    slots, _ = O.sa_encode(W, c['img'], c['rplan'], 3, training=True)
+    loss, _, _ = O.ldm_loss(W, c['uplan'], c['ed'], c['img'], slots, G['t'], G['noise'])
+    loss.backward()
+    assert abs(float(loss) - float(G['train_loss'])) < 1e-5
+    gn = sum(float((W[k].grad.double() ** 2).sum()) for k in train) ** 0.5
+    assert abs(gn - float(G['grad_global_norm'])) < 1e-4 * float(G['grad_global_norm'])
+    for k in G:
+        if k.startswith('grad:'):
+            g = W[k[5:]].grad
+            ref = G[k]
+            close(g, ref, 2e-5 * float(ref.abs().max()) + 1e-9)
+    names = list(G['grad_norms_names'])
+    mine = torch.tensor([float(W[n].grad.norm()) for n in names])
+    close(mine, G['grad_norms'], 1e-7, 2e-4)
+
+
+def test_dpm_solver_trajectory():
+    c = ctx()
+    W, G = c['W'], c['G']
+    with torch.no_grad():
+        eps1 = O.unet_forward(W, c['uplan'], G['x_T'], (torch.ones(2) - 1e-3) * 1000., G['slots'])
+        close(eps1, G['nfe0_eps'], 5e-5)
+        trace = []
+        x, samples = O.ldm_sample(W, c['uplan'], c['ed'], G['slots'], G['x_T'], trace=trace)
+        close(torch.stack(trace, 0)[:1], G['dpm_trace'][:1], 1e-4)
+        # the full 20-NFE trajectory passes through 20 VQ quantisations; report agreement
+        diff = (x - G['dpm_final']).abs()
+        frac_bad = float((diff > 1e-3).float().mean())
+        assert frac_bad < 0.01, frac_bad
+        ps = O.psnr(samples, G['samples'])
+        assert float(ps.min()) > 35., ps

@@ -1,0 +1,138 @@
+"""Generate tests/golden/*.npz from the REAL reference (build container only).
+
+    python tools/gen_golden.py            # writes tests/golden/sadiff_b2.npz ...
+
+The reference (img_based SADiffusion, CLEVRTex config, num_slots overridden to 7 as
+BASELINE.json asks) is imported through tools/ref_harness.py, its weights are overwritten by
+tests/detfill.py's deterministic recipe, and inputs/outputs of every hot-path row of
+SURVEY.md section 8(a) are captured in fp32 on CPU.  Only data is stored (no reference code).
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(HERE, '..'))
+import ref_harness as rh                      # noqa: E402
+from tests.detfill import det_fill_, is_buffer_name, make_inputs   # noqa: E402
+
+OUT = os.path.join(HERE, '..', 'tests', 'golden')
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    im = rh.ref_models('img_based')
+    P = rh.ref_params('img_based', 'sa_ldm', 'sa_ldm_clevrtex_params-res128')
+    P.slot_dict['num_slots'] = 7
+    model = im.build_model(P)
+    det_fill_(model.state_dict().items(), skip=is_buffer_name)
+    B = 2
+    img, t, noise, x_T = make_inputs(B)
+    G = dict(t=t, noise=noise, x_T=x_T, img_checksum=torch.stack([img.double().sum(), (img.double() ** 2).sum(), img[1, 2, 77, 5].double()]))
+
+    # ---- a1-a4: encoder + slot attention (train-res masks and eval-res masks)
+    model.train()
+    with torch.no_grad():
+        G['enc_out_sub8'] = model._get_encoder_out(img)[:, 3::8].contiguous()
+        slots, masks = model.encode(img)
+    G['slots'], G['masks_train'] = slots, masks
+    G['masks_train_argmax'] = masks.argmax(1)
+    model.eval()
+    with torch.no_grad():
+        slots_e, masks_e = model.encode(img)
+    assert torch.equal(slots_e, slots)
+    G['masks_eval_sub4'] = masks_e[:, :, 1::4, 2::4].contiguous()
+    G['masks_eval_argmax'] = masks_e.argmax(1)
+
+    dm = model.dm_decoder
+    # ---- a6, a14, a15: VQ-VAE
+    with torch.no_grad():
+        x0 = dm.vae.encode(img)
+        G['x0'] = x0
+        zq, _, (_, _, idx) = dm.vae.vqvae.quantize(x0)
+        G['x0_vq_idx'] = idx
+        G['x0_vq'] = dm.vae.quantize(x0)
+        G['x0_decoded_sub2'] = dm.vae.decode(x0)[:, :, 1::2, ::2].contiguous()
+    # ---- a7-a11: q-sample, UNet eps prediction, loss
+    with torch.no_grad():
+        xt = dm._sample_xt_from_x0(x0=x0, t=t, noise=noise)
+        G['x_t'] = xt
+        G['eps_pred'] = dm.forward(xt, t, context=slots)
+        G['denoise_loss'] = torch.nn.functional.mse_loss(G['eps_pred'], noise)
+        tf = torch.tensor([123.456, 987.125])
+        G['t_frac'] = tf
+        G['eps_pred_frac'] = dm.forward(xt, tf, context=slots)
+    # ---- gradients of the train step (dropout off: eval-mode UNet, train-mode SA has no RNG)
+    model.train()
+    dm.model.eval()   # disables the ResBlock dropout only (no BN anywhere)
+    for p in model.parameters():
+        p.grad = None
+    out = model(dict(img=img))
+    torch.manual_seed(99)
+    # reproduce loss_function with our explicit t / noise
+    x_noisy = dm._sample_xt_from_x0(x0=x0, t=t, noise=noise)
+    pred = dm.forward(x_noisy, t, context=out['slots'])
+    loss = torch.nn.functional.mse_loss(pred, noise)
+    loss.backward()
+    G['train_loss'] = loss.detach()
+    named = dict(model.named_parameters())
+    gn2 = 0.
+    for n, p in named.items():
+        if p.grad is not None:
+            gn2 += float((p.grad.double() ** 2).sum())
+    G['grad_global_norm'] = torch.tensor(gn2 ** 0.5)
+    for n in ['init_latents', 'slot_attention.gru.bias_ih',               'encoder.conv1.weight', 'encoder.layer3.1.bn2.weight', 'dm_decoder.model.diffusion_model.out.2.weight',
+              'dm_decoder.model.diffusion_model.input_blocks.0.0.weight',
+              'dm_decoder.model.diffusion_model.middle_block.1.transformer_blocks.0.attn2.to_out.0.bias',
+              'dm_decoder.model.diffusion_model.output_blocks.5.2.conv.bias',
+              'dm_decoder.model.diffusion_model.input_blocks.4.0.in_layers.0.weight']:
+        G['grad:' + n] = named[n].grad.detach().clone()
+    G['grad_norms_names'] = np.array(sorted(n for n, p in named.items() if p.grad is not None))
+    G['grad_norms'] = torch.tensor([float(named[n].grad.norm()) for n in G['grad_norms_names']])
+
+    # ---- a12/a13: schedule tables + DPM-Solver++ 20-NFE trajectory
+    model.eval()
+    from slotdiffusion.img_based.models.ddpm import dpm_solver as ds
+    ns = ds.NoiseScheduleVP(betas=dm.betas)
+    tt = torch.tensor([1.0, 0.95005, 0.5, 0.123, 0.001])
+    G['ns_t'] = tt
+    G['ns_log_alpha'] = ns.marginal_log_mean_coeff(tt)
+    G['ns_lambda'] = ns.marginal_lambda(tt)
+    G['ns_inv_lambda'] = ns.inverse_lambda(G['ns_lambda'])
+    solver = ds.DPM_Solver(lambda x, t: x, ns, algorithm_type='dpmsolver++')
+    outer, orders = solver.get_orders_and_timesteps_for_singlestep_solver(
+        20, 3, 'time_uniform', 1.0, 1e-3, 'cpu')
+    G['dpm_outer'], G['dpm_orders'] = outer, torch.tensor(orders)
+    with torch.no_grad():
+        dm.model.vae = dm.vae
+        model_fn = ds.model_wrapper(model=dm.model, noise_schedule=ns, model_type='noise',
+                                    guidance_type='classifier-free', condition=slots)
+        sampler = ds.DPM_Solver(model_fn, ns, algorithm_type='dpmsolver++',
+                                correcting_x0_fn=False, vq_denoised=True)
+        x, inter = sampler.sample(x_T.clone(), steps=20, order=3, method='singlestep',
+                                  return_intermediate=True)
+        dm.model.vae = None
+        G['dpm_trace'] = torch.stack(inter, 0)
+        G['dpm_final'] = x
+        G['samples'] = dm.vae.decode(x)
+        # first NFE in isolation (robust parity point): x0-pred at t=T before/after VQ
+        t1 = torch.ones(B)
+        eps1 = dm.forward(x_T, (t1 - 1e-3) * 1000., context=slots)
+        G['nfe0_eps'] = eps1
+
+    os.makedirs(OUT, exist_ok=True)
+    arrs = {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else v) for k, v in G.items()}
+    for k in list(arrs):
+        if arrs[k].dtype == np.int64 and k != 't':
+            arrs[k] = arrs[k].astype(np.int16)
+    np.savez_compressed(os.path.join(OUT, 'sadiff_b2.npz'), **arrs)
+    for k, v in arrs.items():
+        print(k, v.shape, v.dtype)
+
+
+if __name__ == '__main__':
+    main()
