@@ -1,0 +1,282 @@
+/*
+ * sdmi.h -- C ABI of libsdmi.so: the MI355X (gfx950) kernels behind the SlotDiffusion hot path.
+ *
+ * Drop-in boundary.  The reference has no native code: every entry
+ * below replaces the cuDNN/cuBLAS work that a reference Python call site dispatches through
+ * torch.nn.  The host side (slotdiffusion_amd/ python package) binds these with ctypes; INTEGRATION.md
+ * shows the stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - plain C: POD argument structs of raw DEVICE pointers, int dims, dtype enums.  No torch types.
+ *   - caller owns all memory (inputs, outputs, workspaces); the library never allocates.
+ *   - every call is asynchronous on the hipStream_t passed in (passed as void*); no implicit sync.
+ *   - return 0 on success, a negative SDMI_E* code otherwise; sdmi_last_error() gives the text.
+ *   - activations are NHWC ("channels last"): [B][H][W][C], C contiguous.
+ *   - conv / linear weights are [Cout][KH][KW][Cin] (K-contiguous), i.e. the bytes of a
+ *     torch tensor of logical shape [Cout,Cin,KH,KW] held in torch.channels_last.
+ */
+#ifndef SDMI_H_
+#define SDMI_H_
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SDMI_VERSION 100
+
+enum { SDMI_F32 = 0, SDMI_BF16 = 1 };
+enum { SDMI_ACT_NONE = 0, SDMI_ACT_RELU = 1, SDMI_ACT_SILU = 2, SDMI_ACT_GELU = 3 };
+enum { SDMI_OK = 0, SDMI_EINVAL = -1, SDMI_ELAUNCH = -2, SDMI_EUNSUPPORTED = -3 };
+
+int sdmi_version(void);
+const char* sdmi_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Implicit-GEMM convolution / GEMM on the matrix cores.
+ *   out[m][n] = act( alpha * sum_k A[m][k] * W[n][k] + bias[n] + rowvec[b(m)][n] + residual[m][n] )
+ * A is gathered on the fly from an NHWC tensor (im2col never materialised):
+ *   m -> (b, oy, ox);  k -> (kh, kw, ci);  A[m][k] = in[b][oy*stride+kh-pad_t][ox*stride+kw-pad_l][ci]
+ *   (zero outside the image; with ups=1 the input is read through a virtual nearest x2 upsample).
+ * A plain GEMM is the 1x1 case (H=W=1, B=M): rows of A have pitch `lda`.
+ * Replaces: nn.Conv2d / nn.Linear / einsum call sites, e.g.
+ *   video_based/models/unet/unet.py:222,249,255-259,408,542 (ResBlock/in/out convs),
+ *   unet.py:108-121,165-179 (Up/Downsample), attention.py:44-48,175-180 (Linear),
+ *   vqvae/modules.py:23-48,71-91 (VQ-VAE convs, asymmetric pad), resnet.py:12-35.
+ * dtype: SDMI_BF16 -> v_mfma_f32_32x32x16_bf16; SDMI_F32 -> v_mfma_f32_32x32x2_f32 (exact fp32).
+ * Accumulation is always fp32.  Epilogue tensors bias/rowvec are fp32.
+ * split_k > 1: partial sums go to `workspace` (fp32, split_k*M*N) and a second kernel reduces.
+ * batch > 1 (1x1 only): grid.z batches with element strides sa/sw/sc/sr (attention GEMMs).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  const void* a;        /* NHWC activations, `dtype` */
+  const void* w;        /* [N][ldw] weights, `dtype` */
+  void* out;            /* [M][ldc], `out_dtype` */
+  const float* bias;    /* [N] (or [M] when bias_m) or NULL */
+  const float* rowvec;  /* [B][N] per-image vector (time embedding) or NULL */
+  const void* residual; /* [M][ldr] `out_dtype` or NULL */
+  float* workspace;     /* split-K partials or NULL */
+  int dtype, out_dtype;
+  int M, N, K;          /* K = KH*KW*Cin */
+  int lda, ldw, ldc, ldr;
+  int B, H, W, Cin, Ho, Wo, KH, KW, stride, pad_t, pad_l, ups;
+  int act;
+  float alpha;
+  int bias_m;
+  int split_k;
+  int batch;
+  int ldrv;             /* row pitch of rowvec (>= N) */
+  long long sa, sw, sc, sr;
+} SdmiGemmArgs;
+int sdmi_igemm(const SdmiGemmArgs* a, void* stream);
+
+/* wgrad: dW[n][kh][kw][ci] = sum_m dY[m][n] * A[m][(kh,kw,ci)]  (fp32 output, [N][K] like W).
+ * Replaces the weight-gradient half of Conv2d/Linear backward (torch autograd in the reference). */
+typedef struct {
+  const void* a;        /* NHWC activations (forward input), `dtype` */
+  const void* dy;       /* [M][ldy] output gradient, `dtype` */
+  float* dw;            /* [N][K] fp32 (accumulated into when accumulate != 0) */
+  float* dbias;         /* [N] fp32 column sums of dy, or NULL */
+  float* workspace;     /* split partials: splits*N*K floats */
+  int dtype;
+  int M, N, K, lda, ldy;
+  int B, H, W, Cin, Ho, Wo, KH, KW, stride, pad_t, pad_l, ups;
+  int splits;
+  int accumulate;
+} SdmiWgradArgs;
+int sdmi_wgrad(const SdmiWgradArgs* a, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * GroupNorm (+ fused activation) on NHWC, statistics in fp32.
+ * Replaces GroupNorm32/Normalize + SiLU/ReLU/swish: unet/utils.py:120-139, unet.py:219-222,
+ * 243-250, attention.py:77-79, vqvae/modules.py:12-14, resnet.py:8-9.
+ * stats: [B][groups][2] fp32 (mean, rstd) written by sdmi_groupnorm_stats.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  const void* x;       /* [B][HW][C] */
+  void* y;             /* [B][HW][C] (may alias x) */
+  const float* gamma;  /* [C] */
+  const float* beta;   /* [C] */
+  float* stats;        /* [B][groups][2] */
+  float* partial;      /* workspace [B][nsplit][groups][2] */
+  int dtype;
+  int B, HW, C, groups;
+  float eps;
+  int act;
+  int nsplit;
+  const void* residual; /* optional [B][HW][C] added AFTER the affine, before act (ResNet block) */
+} SdmiGroupNormArgs;
+int sdmi_groupnorm_stats(const SdmiGroupNormArgs* a, void* stream);
+int sdmi_groupnorm_apply(const SdmiGroupNormArgs* a, void* stream);
+
+typedef struct {
+  const void* x;       /* forward input */
+  const void* dy;      /* grad of the op output (after act) */
+  void* dx;
+  const float* gamma;
+  const float* beta;
+  const float* stats;  /* from forward */
+  float* dgamma;       /* [C] fp32 (written) */
+  float* dbeta;        /* [C] */
+  float* partial;      /* workspace [B][nsplit][groups][2] + [B][nsplit'][C][2] */
+  int dtype;
+  int B, HW, C, groups;
+  int act;
+  int nsplit;
+  const void* residual; /* forward residual (for act derivative) or NULL */
+  void* dresidual;      /* optional: receives the gradient flowing to the residual branch */
+} SdmiGroupNormBwdArgs;
+int sdmi_groupnorm_bwd(const SdmiGroupNormBwdArgs* a, void* stream);
+
+/* LayerNorm over the last dim (eps 1e-5 default): attention.py:238-240, savi.py:38-54. */
+typedef struct {
+  const void* x; void* y; const float* gamma; const float* beta;
+  float* stats;        /* optional [rows][2] (mean, rstd) saved for backward, or NULL */
+  int dtype; int rows, C, ldx, ldy; float eps;
+} SdmiLayerNormArgs;
+int sdmi_layernorm(const SdmiLayerNormArgs* a, void* stream);
+
+typedef struct {
+  const void* x; const void* dy; void* dx; const float* gamma; const float* stats;
+  float* dgamma; float* dbeta;   /* [C] fp32, accumulated via per-block partials */
+  float* partial;                /* workspace [nblk][C][2] */
+  int dtype; int rows, C; int nblk;
+} SdmiLayerNormBwdArgs;
+int sdmi_layernorm_bwd(const SdmiLayerNormBwdArgs* a, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Multi-head attention, head_dim 32 (UNet self- and slot cross-attention).
+ *   out[b][i][h*32+d] = sum_j softmax_j(scale * q_i . k_j) v_j[d]
+ * Replaces CrossAttention.forward, unet/attention.py:182-206.
+ * q/k/v are [B][S][ld*] with head h at channel offset h*32.  lse (optional): [B][heads][Sq]
+ * log-sum-exp saved for the backward kernel.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  const void* q; const void* k; const void* v; void* out; float* lse;
+  int dtype; int B, heads, Sq, Skv; int ldq, ldk, ldv, ldo; float scale;
+} SdmiAttnArgs;
+int sdmi_attention(const SdmiAttnArgs* a, void* stream);
+
+typedef struct {
+  const void* q; const void* k; const void* v; const void* out; const void* dout; const float* lse;
+  void* dq; void* dk; void* dv;
+  int dtype; int B, heads, Sq, Skv; int ldq, ldk, ldv, ldo; float scale;
+} SdmiAttnBwdArgs;
+int sdmi_attention_bwd(const SdmiAttnBwdArgs* a, void* stream);
+
+/* row softmax in place over [rows][cols] fp32/bf16 with scale (VQ-VAE AttnBlock,
+ * vqvae/modules.py:141-143). */
+typedef struct { void* x; int dtype; int rows, cols, ld; float scale; } SdmiSoftmaxArgs;
+int sdmi_softmax_rows(const SdmiSoftmaxArgs* a, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Fused Slot Attention: ALL iterations in one launch, one workgroup per image.
+ * Replaces SlotAttentionWMask.forward's loop, img_based/models/sa_diffusion.py:40-68
+ * (video twin savi_diffusion.py:40-68): q=Linear(LN(slots)); softmax over slots; +eps, renorm
+ * over tokens; updates=attn^T v; GRUCell; residual MLP.  k,v come from the K/V projection GEMM.
+ * seg [B][M][N] = last-iteration softmax (before +eps); slots_out [B][N][D] fp32.
+ * trace (optional, training): per-iteration saved tensors for the backward kernel.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  const void* k; const void* v;      /* [B][M][ldkv], `dtype` */
+  const float* slots_in;             /* [B][N][D] or [N][D] when slots_bstride == 0 */
+  float* slots_out;                  /* [B][N][D] */
+  float* seg;                        /* [B][M][N] */
+  const float *lnq_g, *lnq_b, *wq;   /* LN(D), [D][D] */
+  const float *w_ih, *w_hh, *b_ih, *b_hh; /* GRUCell [3D][D], [3D] */
+  const float *lnm_g, *lnm_b, *w1, *b1, *w2, *b2; /* MLP LN, [H][D], [H], [D][H], [D] */
+  float* trace;                      /* NULL or [B][iters][SDMI_SA_TRACE_FLOATS(N,D,H)] */
+  int dtype; int B, M, N, D, Hid, iters, ldkv; long long slots_bstride; float eps, scale;
+} SdmiSlotAttnArgs;
+int sdmi_slot_attention(const SdmiSlotAttnArgs* a, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * VQ nearest code (expanded-square distance, first minimum): vqvae/quantize.py:85-94.
+ * z [R][ldz] fp32 (first `dim` channels used) -> idx int64 [R], zq [R][ldz] (straight-through
+ * form z + (e - z), pad channels zeroed).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  const float* z; const float* codebook; long long* idx; float* zq;
+  int R, dim, ldz, n_codes; float scale;
+} SdmiVqArgs;
+int sdmi_vq_nearest(const SdmiVqArgs* a, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Small fused elementwise kernels.
+ * ------------------------------------------------------------------------------------------ */
+/* y = ((c0*x0 + c1*x1) + c2*(x2 - x3)) / div   (fp32; NULL operands skipped, x3 NULL -> c2*x2,
+ * div == 0 -> no division).  Evaluated in exactly this order without FMA contraction so the
+ * DPM-Solver++ updates round like the reference's op-by-op tensor arithmetic
+ * (ddpm/dpm_solver.py:523-534, 665-668, 722-732, 815-831) and q-sample (ddpm/ddpm.py:161-165). */
+typedef struct {
+  float* y; const float* x0; const float* x1; const float* x2; const float* x3;
+  float c0, c1, c2, div; long long n;
+} SdmiLincombArgs;
+int sdmi_lincomb(const SdmiLincombArgs* a, void* stream);
+/* per-row coefficients: y[b][i] = ca[b]*x0[b][i] + cb[b]*x1[b][i] (q-sample with per-image t) */
+typedef struct {
+  float* y; const float* x0; const float* x1; const float* ca; const float* cb; int B; long long per;
+} SdmiRowLincombArgs;
+int sdmi_row_lincomb(const SdmiRowLincombArgs* a, void* stream);
+
+/* layout / dtype conversion: src [B][C][H][W] fp32 (NCHW) <-> dst [B][H][W][Cpad] `dtype` */
+typedef struct { const float* src; void* dst; int dtype; int B, C, H, W, Cpad; } SdmiNchwToNhwcArgs;
+int sdmi_nchw_to_nhwc(const SdmiNchwToNhwcArgs* a, void* stream);
+typedef struct { const void* src; float* dst; int dtype; int B, C, H, W, Cpad; } SdmiNhwcToNchwArgs;
+int sdmi_nhwc_to_nchw(const SdmiNhwcToNchwArgs* a, void* stream);
+/* generic cast/copy of a strided 2-D view: dst[r][c] = (dst_dtype) src[r][c] */
+typedef struct {
+  const void* src; void* dst; int src_dtype, dst_dtype; long long rows; int cols, lds, ldd;
+} SdmiCast2dArgs;
+int sdmi_cast2d(const SdmiCast2dArgs* a, void* stream);
+
+/* sinusoidal timestep embedding [cos | sin], fractional t (unet/utils.py:70-92) -> fp32 [B][dim],
+ * optionally followed by nothing (MLP runs on the GEMM). */
+typedef struct { const float* t; float* out; int B, dim; float max_period; } SdmiTimeEmbArgs;
+int sdmi_timestep_embedding(const SdmiTimeEmbArgs* a, void* stream);
+
+/* y = act(x) elementwise with dtype conversion (SiLU on the time embedding) */
+typedef struct { const void* x; void* y; int src_dtype, dst_dtype, act; long long n; } SdmiActArgs;
+int sdmi_act(const SdmiActArgs* a, void* stream);
+/* GEGLU: y[r][c] = h[r][c] * gelu(h[r][C+c]) (attention.py:46-48); h [rows][2C] */
+typedef struct { const void* h; void* y; int dtype; long long rows; int C; } SdmiGegluArgs;
+int sdmi_geglu(const SdmiGegluArgs* a, void* stream);
+typedef struct { const void* h; const void* dy; void* dh; int dtype; long long rows; int C; } SdmiGegluBwdArgs;
+int sdmi_geglu_bwd(const SdmiGegluBwdArgs* a, void* stream);
+/* y[b][p][c] = x[b][p][c] + pos[p][c] (SoftPositionEmbed, models/utils.py:60-63) */
+typedef struct { const void* x; const float* pos; void* y; int dtype; int B; long long per; } SdmiAddPosArgs;
+int sdmi_add_pos(const SdmiAddPosArgs* a, void* stream);
+/* channel concat of two NHWC tensors (skip connections, unet.py:572) */
+typedef struct { const void* a; const void* b; void* y; int dtype; long long rows; int Ca, Cb; } SdmiConcatArgs;
+int sdmi_concat_channels(const SdmiConcatArgs* a, void* stream);
+/* eval-time mask path: bilinear x(H/h) upsample (align_corners=False) of seg [B][h*w][N] + argmax
+ * over slots -> masks_up [B][N][H][W] fp32 (optional) and idx [B][H][W] int64
+ * (sa_diffusion.py:170-180, test_seg.py argmax). */
+typedef struct {
+  const float* seg; float* up; long long* idx; int B, N, h, w, H, W;
+} SdmiMaskUpArgs;
+int sdmi_mask_upsample_argmax(const SdmiMaskUpArgs* a, void* stream);
+/* mean squared error: out[0] = mean((a-b)^2) (deterministic two-stage), grad optional:
+ * dpred = 2*(a-b)/n * gscale   (ldm.py:82) */
+typedef struct {
+  const void* pred; const float* target; float* out; void* dpred; float* partial;
+  int dtype; long long n; int nblk; float gscale;
+} SdmiMseArgs;
+int sdmi_mse(const SdmiMseArgs* a, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Optimiser: global-norm clip + Adam over a flat fp32 arena (two lr groups), and bf16 shadow
+ * refresh.  Replaces torch.optim.Adam + clip_grad_norm_ (nerv trainer; vb/method.py:291-341).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct { const float* g; float* partial; long long n; int nblk; } SdmiSqSumArgs;
+int sdmi_sqsum_partial(const SdmiSqSumArgs* a, void* stream);
+typedef struct {
+  float* p; const float* g; float* m; float* v; void* shadow_bf16; /* optional */
+  const float* sq_partial; int nblk;     /* global norm^2 = sum(sq_partial[0..nblk)) */
+  long long n; float lr, beta1, beta2, eps, clip; int step;
+} SdmiAdamArgs;
+int sdmi_adam_clip(const SdmiAdamArgs* a, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SDMI_H_ */

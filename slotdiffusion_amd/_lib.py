@@ -1,0 +1,114 @@
+"""ctypes binding of libsdmi.so, generated from include/sdmi.h at import time.
+
+The argument structs and the exported function list are parsed from the C header, so the Python
+side can never drift from the ABI.  There is NO fallback: if the shared library is missing or a
+declared symbol cannot be resolved, importing the compute path raises.
+"""
+import ctypes
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+HEADER = os.path.join(_HERE, '..', 'include', 'sdmi.h')
+LIBPATH = os.path.join(_HERE, 'libsdmi.so')
+
+_CT = {
+    'int': ctypes.c_int, 'float': ctypes.c_float, 'long long': ctypes.c_longlong,
+}
+
+
+def _strip_comments(src):
+    return re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+
+
+def parse_header(path=HEADER):
+    """-> (structs {name: [(field, ctype)]}, functions {name: arg struct name or None}, enums)."""
+    src = _strip_comments(open(path).read())
+    structs = {}
+    for body, name in re.findall(r'typedef\s+struct\s*\{(.*?)\}\s*(\w+)\s*;', src, flags=re.S):
+        fields = []
+        for decl in body.split(';'):
+            decl = ' '.join(decl.split())
+            if not decl:
+                continue
+            m = re.match(r'^(const\s+)?(void|float|int|long long)\s*(.*)$', decl)
+            assert m, f'cannot parse field declaration {decl!r} in {name}'
+            base, rest = m.group(2), m.group(3)
+            for item in rest.split(','):
+                item = item.strip()
+                is_ptr = item.startswith('*')
+                fname = item.lstrip('* ').strip()
+                if is_ptr or base == 'void':
+                    fields.append((fname, ctypes.c_void_p))
+                else:
+                    fields.append((fname, _CT[base]))
+        structs[name] = fields
+    funcs = {}
+    for ret, fname, args in re.findall(r'\b(int|const char\*)\s+(sdmi_\w+)\s*\(([^)]*)\)\s*;', src):
+        m = re.match(r'\s*const\s+(\w+)\s*\*', args)
+        funcs[fname] = m.group(1) if m else None
+    enums = {}
+    for body in re.findall(r'enum\s*\{(.*?)\}\s*;', src, flags=re.S):
+        for item in body.split(','):
+            if '=' in item:
+                k, v = item.split('=')
+                enums[k.strip()] = int(v.strip())
+    return structs, funcs, enums
+
+
+STRUCTS, FUNCS, ENUMS = parse_header()
+F32, BF16 = ENUMS['SDMI_F32'], ENUMS['SDMI_BF16']
+ACT = {None: 0, 'none': 0, 'relu': ENUMS['SDMI_ACT_RELU'], 'silu': ENUMS['SDMI_ACT_SILU'],
+       'gelu': ENUMS['SDMI_ACT_GELU']}
+
+
+def _make_struct(name, fields):
+    return type(name, (ctypes.Structure,), {'_fields_': fields})
+
+
+CSTRUCT = {n: _make_struct(n, f) for n, f in STRUCTS.items()}
+
+_lib = None
+
+
+class SdmiError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libsdmi.so (built by slotdiffusion_amd.csrc.build); fail loudly if absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIBPATH):
+            raise SdmiError(
+                f'{LIBPATH} not found: the HIP extension is required (no fallback path). '
+                'Build it with `python -m slotdiffusion_amd.csrc.build`.')
+        L = ctypes.CDLL(LIBPATH)
+        for fname, sname in FUNCS.items():
+            fn = getattr(L, fname)          # AttributeError if a declared symbol is missing
+            if fname == 'sdmi_last_error':
+                fn.restype = ctypes.c_char_p
+                fn.argtypes = []
+            elif sname is None:
+                fn.restype = ctypes.c_int
+                fn.argtypes = []
+            else:
+                fn.restype = ctypes.c_int
+                fn.argtypes = [ctypes.POINTER(CSTRUCT[sname]), ctypes.c_void_p]
+        _lib = L
+    return _lib
+
+
+def call(fname, stream, **kw):
+    """Invoke `fname` with its argument struct filled from keyword args (missing fields = 0)."""
+    L = lib()
+    sname = FUNCS[fname]
+    args = CSTRUCT[sname]()
+    names = {f for f, _ in STRUCTS[sname]}
+    for k, v in kw.items():
+        if k not in names:
+            raise KeyError(f'{sname} has no field {k}')
+        setattr(args, k, v)
+    rc = getattr(L, fname)(ctypes.byref(args), stream)
+    if rc != 0:
+        raise SdmiError(f'{fname} failed ({rc}): {L.sdmi_last_error().decode()}')

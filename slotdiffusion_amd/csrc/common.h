@@ -1,0 +1,112 @@
+// Shared device helpers for libsdmi (gfx950 only: wave64, MFMA, 160 KiB LDS).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/sdmi.h"
+
+typedef unsigned short bf16_t;  // raw bf16 bits
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+void sdmi_set_error(const char* fmt, ...);
+int sdmi_check_launch(const char* what);
+
+#define SDMI_REQUIRE(cond, msg)                       \
+  do {                                                \
+    if (!(cond)) {                                    \
+      sdmi_set_error("%s: %s", __func__, msg);        \
+      return SDMI_EINVAL;                             \
+    }                                                 \
+  } while (0)
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t h) {
+  return __uint_as_float(((uint32_t)h) << 16);
+}
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {  // round-to-nearest-even
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+  static constexpr int VEC = 4;  // elements per 16-byte vector
+  __device__ static __forceinline__ float ld(const float* p) { return *p; }
+  __device__ static __forceinline__ void st(float* p, float v) { *p = v; }
+};
+template <> struct Elem<bf16_t> {
+  static constexpr int VEC = 8;
+  __device__ static __forceinline__ float ld(const bf16_t* p) { return bf16_to_f32(*p); }
+  __device__ static __forceinline__ void st(bf16_t* p, float v) { *p = f32_to_bf16(v); }
+};
+
+// 16-byte vector <-> VEC floats
+template <typename T> __device__ __forceinline__ void unpack16(const uint4& v, float* f);
+template <> __device__ __forceinline__ void unpack16<float>(const uint4& v, float* f) {
+  f[0] = __uint_as_float(v.x); f[1] = __uint_as_float(v.y);
+  f[2] = __uint_as_float(v.z); f[3] = __uint_as_float(v.w);
+}
+template <> __device__ __forceinline__ void unpack16<bf16_t>(const uint4& v, float* f) {
+  f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+  f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+  f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
+  f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
+}
+template <typename T> __device__ __forceinline__ uint4 pack16(const float* f);
+template <> __device__ __forceinline__ uint4 pack16<float>(const float* f) {
+  return make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]),
+                    __float_as_uint(f[3]));
+}
+template <> __device__ __forceinline__ uint4 pack16<bf16_t>(const float* f) {
+  uint4 v;
+  v.x = (uint32_t)f32_to_bf16(f[0]) | ((uint32_t)f32_to_bf16(f[1]) << 16);
+  v.y = (uint32_t)f32_to_bf16(f[2]) | ((uint32_t)f32_to_bf16(f[3]) << 16);
+  v.z = (uint32_t)f32_to_bf16(f[4]) | ((uint32_t)f32_to_bf16(f[5]) << 16);
+  v.w = (uint32_t)f32_to_bf16(f[6]) | ((uint32_t)f32_to_bf16(f[7]) << 16);
+  return v;
+}
+
+__device__ __forceinline__ float act_apply(float x, int act) {
+  switch (act) {
+    case SDMI_ACT_RELU: return x > 0.f ? x : 0.f;
+    case SDMI_ACT_SILU: return x / (1.f + __expf(-x));
+    case SDMI_ACT_GELU: return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f));
+    default: return x;
+  }
+}
+// derivative of act wrt its pre-activation input x
+__device__ __forceinline__ float act_grad(float x, int act) {
+  switch (act) {
+    case SDMI_ACT_RELU: return x > 0.f ? 1.f : 0.f;
+    case SDMI_ACT_SILU: {
+      float s = 1.f / (1.f + __expf(-x));
+      return s * (1.f + x * (1.f - s));
+    }
+    case SDMI_ACT_GELU: {
+      float c = 0.5f * (1.f + erff(x * 0.70710678118654752440f));
+      return c + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
+    }
+    default: return 1.f;
+  }
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+static inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }

@@ -1,0 +1,333 @@
+// Small HBM-bound fused elementwise kernels (include/sdmi.h, "Small fused elementwise kernels").
+#include "common.h"
+
+namespace {
+
+constexpr int EW_THREADS = 256;
+static inline int ew_blocks(long long n, int per_thread = 1) {
+  long long b = (n + (long long)EW_THREADS * per_thread - 1) / ((long long)EW_THREADS * per_thread);
+  if (b > 4096) b = 4096;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+#define GRID_STRIDE(i, n)                                                         \
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < (n); \
+       i += (long long)gridDim.x * blockDim.x)
+
+__global__ void lincomb_kernel(SdmiLincombArgs p) {
+  GRID_STRIDE(i, p.n) {
+    float v = 0.f;
+    if (p.x0) v = p.c0 * p.x0[i];
+    if (p.x1) {
+      const float t = p.c1 * p.x1[i];
+      v = p.x0 ? v + t : t;
+    }
+    if (p.x2) {
+      const float d = p.x3 ? p.x2[i] - p.x3[i] : p.x2[i];
+      v = v + p.c2 * d;
+    }
+    if (p.div != 0.f) v = v / p.div;
+    p.y[i] = v;
+  }
+}
+
+__global__ void row_lincomb_kernel(SdmiRowLincombArgs p) {
+  const long long n = (long long)p.B * p.per;
+  GRID_STRIDE(i, n) {
+    const int b = (int)(i / p.per);
+    p.y[i] = p.ca[b] * p.x0[i] + p.cb[b] * p.x1[i];
+  }
+}
+
+template <typename T>
+__global__ void nchw_to_nhwc_kernel(SdmiNchwToNhwcArgs p) {
+  const long long n = (long long)p.B * p.H * p.W * p.Cpad;
+  GRID_STRIDE(i, n) {
+    const int c = (int)(i % p.Cpad);
+    const long long pix = i / p.Cpad;
+    const int hw = p.H * p.W;
+    const int b = (int)(pix / hw);
+    const int r = (int)(pix - (long long)b * hw);
+    const float v = c < p.C ? p.src[((long long)b * p.C + c) * hw + r] : 0.f;
+    Elem<T>::st((T*)p.dst + i, v);
+  }
+}
+
+template <typename T>
+__global__ void nhwc_to_nchw_kernel(SdmiNhwcToNchwArgs p) {
+  const long long n = (long long)p.B * p.C * p.H * p.W;
+  GRID_STRIDE(i, n) {
+    const int hw = p.H * p.W;
+    const int r = (int)(i % hw);
+    const long long bc = i / hw;
+    const int c = (int)(bc % p.C);
+    const int b = (int)(bc / p.C);
+    p.dst[i] = Elem<T>::ld((const T*)p.src + ((long long)b * hw + r) * p.Cpad + c);
+  }
+}
+
+template <typename S, typename D>
+__global__ void cast2d_kernel(SdmiCast2dArgs p) {
+  const long long n = p.rows * p.cols;
+  GRID_STRIDE(i, n) {
+    const long long r = i / p.cols;
+    const int c = (int)(i - r * p.cols);
+    Elem<D>::st((D*)p.dst + r * p.ldd + c, Elem<S>::ld((const S*)p.src + r * p.lds + c));
+  }
+}
+
+__global__ void time_emb_kernel(SdmiTimeEmbArgs p) {
+  const int half = p.dim / 2;
+  const long long n = (long long)p.B * p.dim;
+  GRID_STRIDE(i, n) {
+    const int b = (int)(i / p.dim), j = (int)(i % p.dim);
+    const int f = j < half ? j : j - half;
+    const float freq = expf(-logf(p.max_period) * (float)f / (float)half);
+    const float arg = p.t[b] * freq;
+    p.out[i] = j < half ? cosf(arg) : sinf(arg);
+  }
+}
+
+template <typename S, typename D>
+__global__ void act_kernel(SdmiActArgs p) {
+  GRID_STRIDE(i, p.n) {
+    Elem<D>::st((D*)p.y + i, act_apply(Elem<S>::ld((const S*)p.x + i), p.act));
+  }
+}
+
+template <typename T>
+__global__ void geglu_kernel(SdmiGegluArgs p) {
+  constexpr int VEC = Elem<T>::VEC;
+  const int cv = p.C / VEC;
+  const long long n = p.rows * cv;
+  GRID_STRIDE(i, n) {
+    const long long r = i / cv;
+    const int c = (int)(i - r * cv) * VEC;
+    const T* h = (const T*)p.h + r * 2 * p.C;
+    float x[VEC], g[VEC];
+    unpack16<T>(*reinterpret_cast<const uint4*>(h + c), x);
+    unpack16<T>(*reinterpret_cast<const uint4*>(h + p.C + c), g);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) x[j] *= act_apply(g[j], SDMI_ACT_GELU);
+    *reinterpret_cast<uint4*>((T*)p.y + r * p.C + c) = pack16<T>(x);
+  }
+}
+
+template <typename T>
+__global__ void geglu_bwd_kernel(SdmiGegluBwdArgs p) {
+  constexpr int VEC = Elem<T>::VEC;
+  const int cv = p.C / VEC;
+  const long long n = p.rows * cv;
+  GRID_STRIDE(i, n) {
+    const long long r = i / cv;
+    const int c = (int)(i - r * cv) * VEC;
+    const T* h = (const T*)p.h + r * 2 * p.C;
+    T* dh = (T*)p.dh + r * 2 * p.C;
+    float x[VEC], g[VEC], dy[VEC], dx[VEC], dg[VEC];
+    unpack16<T>(*reinterpret_cast<const uint4*>(h + c), x);
+    unpack16<T>(*reinterpret_cast<const uint4*>(h + p.C + c), g);
+    unpack16<T>(*reinterpret_cast<const uint4*>((const T*)p.dy + r * p.C + c), dy);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      dx[j] = dy[j] * act_apply(g[j], SDMI_ACT_GELU);
+      dg[j] = dy[j] * x[j] * act_grad(g[j], SDMI_ACT_GELU);
+    }
+    *reinterpret_cast<uint4*>(dh + c) = pack16<T>(dx);
+    *reinterpret_cast<uint4*>(dh + p.C + c) = pack16<T>(dg);
+  }
+}
+
+template <typename T>
+__global__ void add_pos_kernel(SdmiAddPosArgs p) {
+  constexpr int VEC = Elem<T>::VEC;
+  const long long per_v = p.per / VEC;
+  const long long n = (long long)p.B * per_v;
+  GRID_STRIDE(i, n) {
+    const long long o = (i % per_v) * VEC;
+    float x[VEC];
+    unpack16<T>(*reinterpret_cast<const uint4*>((const T*)p.x + i * VEC), x);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) x[j] += p.pos[o + j];
+    *reinterpret_cast<uint4*>((T*)p.y + i * VEC) = pack16<T>(x);
+  }
+}
+
+template <typename T>
+__global__ void concat_kernel(SdmiConcatArgs p) {
+  constexpr int VEC = Elem<T>::VEC;
+  const int cva = p.Ca / VEC, cvb = p.Cb / VEC, cv = cva + cvb;
+  const long long n = p.rows * cv;
+  GRID_STRIDE(i, n) {
+    const long long r = i / cv;
+    const int c = (int)(i - r * cv);
+    const uint4 v = c < cva
+                        ? *reinterpret_cast<const uint4*>((const T*)p.a + r * p.Ca + c * VEC)
+                        : *reinterpret_cast<const uint4*>((const T*)p.b + r * p.Cb + (c - cva) * VEC);
+    *reinterpret_cast<uint4*>((T*)p.y + r * (p.Ca + p.Cb) + c * VEC) = v;
+  }
+}
+
+// bilinear upsample (align_corners=False, torch's area_pixel source index) + argmax over slots
+__global__ void mask_up_kernel(SdmiMaskUpArgs p) {
+  const long long n = (long long)p.B * p.H * p.W;
+  const float sy = (float)p.h / (float)p.H, sx = (float)p.w / (float)p.W;
+  GRID_STRIDE(i, n) {
+    const int x = (int)(i % p.W);
+    const int y = (int)((i / p.W) % p.H);
+    const int b = (int)(i / ((long long)p.W * p.H));
+    float fy = sy * ((float)y + 0.5f) - 0.5f;
+    float fx = sx * ((float)x + 0.5f) - 0.5f;
+    if (fy < 0.f) fy = 0.f;
+    if (fx < 0.f) fx = 0.f;
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = y0 + (y0 < p.h - 1 ? 1 : 0), x1 = x0 + (x0 < p.w - 1 ? 1 : 0);
+    const float ly1 = fy - (float)y0, ly0 = 1.f - ly1;
+    const float lx1 = fx - (float)x0, lx0 = 1.f - lx1;
+    const float* s = p.seg + (long long)b * p.h * p.w * p.N;
+    float best = -INFINITY;
+    int bi = 0;
+    for (int k = 0; k < p.N; ++k) {
+      const float v00 = s[((long long)y0 * p.w + x0) * p.N + k];
+      const float v01 = s[((long long)y0 * p.w + x1) * p.N + k];
+      const float v10 = s[((long long)y1 * p.w + x0) * p.N + k];
+      const float v11 = s[((long long)y1 * p.w + x1) * p.N + k];
+      const float v = ly0 * (lx0 * v00 + lx1 * v01) + ly1 * (lx0 * v10 + lx1 * v11);
+      if (p.up) p.up[(((long long)b * p.N + k) * p.H + y) * p.W + x] = v;
+      if (v > best) { best = v; bi = k; }
+    }
+    if (p.idx) p.idx[i] = bi;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void mse_kernel(SdmiMseArgs p) {
+  __shared__ double red[4];
+  double acc = 0.0;
+  const float gs = 2.f * p.gscale / (float)p.n;
+  GRID_STRIDE(i, p.n) {
+    const float d = Elem<T>::ld((const T*)p.pred + i) - p.target[i];
+    acc += (double)d * (double)d;
+    if (p.dpred) Elem<T>::st((T*)p.dpred + i, d * gs);
+  }
+  acc = wave_sum_d(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) p.partial[blockIdx.x] = (float)(red[0] + red[1] + red[2] + red[3]);
+}
+__global__ void mse_final_kernel(SdmiMseArgs p) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    double s = 0.0;
+    for (int i = 0; i < p.nblk; ++i) s += (double)p.partial[i];
+    p.out[0] = (float)(s / (double)p.n);
+  }
+}
+
+}  // namespace
+
+#define ST ((hipStream_t)stream)
+
+extern "C" int sdmi_lincomb(const SdmiLincombArgs* a, void* stream) {
+  SDMI_REQUIRE(a && a->y && a->n >= 0, "bad args");
+  if (a->n == 0) return SDMI_OK;
+  hipLaunchKernelGGL(lincomb_kernel, dim3(ew_blocks(a->n)), dim3(EW_THREADS), 0, ST, *a);
+  return sdmi_check_launch("lincomb");
+}
+extern "C" int sdmi_row_lincomb(const SdmiRowLincombArgs* a, void* stream) {
+  SDMI_REQUIRE(a && a->y && a->x0 && a->x1 && a->ca && a->cb, "null pointer");
+  hipLaunchKernelGGL(row_lincomb_kernel, dim3(ew_blocks((long long)a->B * a->per)),
+                     dim3(EW_THREADS), 0, ST, *a);
+  return sdmi_check_launch("row_lincomb");
+}
+extern "C" int sdmi_nchw_to_nhwc(const SdmiNchwToNhwcArgs* a, void* stream) {
+  SDMI_REQUIRE(a && a->src && a->dst && a->Cpad >= a->C, "bad args");
+  const long long n = (long long)a->B * a->H * a->W * a->Cpad;
+  if (a->dtype == SDMI_BF16)
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16_t>, dim3(ew_blocks(n)), dim3(EW_THREADS), 0, ST, *a);
+  else
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3(ew_blocks(n)), dim3(EW_THREADS), 0, ST, *a);
+  return sdmi_check_launch("nchw_to_nhwc");
+}
+extern "C" int sdmi_nhwc_to_nchw(const SdmiNhwcToNchwArgs* a, void* stream) {
+  SDMI_REQUIRE(a && a->src && a->dst && a->Cpad >= a->C, "bad args");
+  const long long n = (long long)a->B * a->H * a->W * a->C;
+  if (a->dtype == SDMI_BF16)
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16_t>, dim3(ew_blocks(n)), dim3(EW_THREADS), 0, ST, *a);
+  else
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, dim3(ew_blocks(n)), dim3(EW_THREADS), 0, ST, *a);
+  return sdmi_check_launch("nhwc_to_nchw");
+}
+extern "C" int sdmi_cast2d(const SdmiCast2dArgs* a, void* stream) {
+  SDMI_REQUIRE(a && a->src && a->dst, "null pointer");
+  const int g = ew_blocks(a->rows * a->cols);
+  const bool sb = a->src_dtype == SDMI_BF16, db = a->dst_dtype == SDMI_BF16;
+  if (sb && db) hipLaunchKernelGGL((cast2d_kernel<bf16_t, bf16_t>), dim3(g), dim3(EW_THREADS), 0, ST, *a);
+  else if (sb) hipLaunchKernelGGL((cast2d_kernel<bf16_t, float>), dim3(g), dim3(EW_THREADS), 0, ST, *a);
+  else if (db) hipLaunchKernelGGL((cast2d_kernel<float, bf16_t>), dim3(g), dim3(EW_THREADS), 0, ST, *a);
+  else hipLaunchKernelGGL((cast2d_kernel<float, float>), dim3(g), dim3(EW_THREADS), 0, ST, *a);
+  return sdmi_check_launch("cast2d");
+}
+extern "C" int sdmi_timestep_embedding(const SdmiTimeEmbArgs* a, void* stream) {
+  SDMI_REQUIRE(a && a->t && a->out && a->dim % 2 == 0, "bad args");
+  hipLaunchKernelGGL(time_emb_kernel, dim3(ew_blocks((long long)a->B * a->dim)), dim3(EW_THREADS),
+                     0, ST, *a);
+  return sdmi_check_launch("timestep_embedding");
+}
+extern "C" int sdmi_act(const SdmiActArgs* a, void* stream) {
+  SDMI_REQUIRE(a && a->x && a->y, "null pointer");
+  const int g = ew_blocks(a->n);
+  const bool sb = a->src_dtype == SDMI_BF16, db = a->dst_dtype == SDMI_BF16;
+  if (sb && db) hipLaunchKernelGGL((act_kernel<bf16_t, bf16_t>), dim3(g), dim3(EW_THREADS), 0, ST, *a);
+  else if (sb) hipLaunchKernelGGL((act_kernel<bf16_t, float>), dim3(g), dim3(EW_THREADS), 0, ST, *a);
+  else if (db) hipLaunchKernelGGL((act_kernel<float, bf16_t>), dim3(g), dim3(EW_THREADS), 0, ST, *a);
+  else hipLaunchKernelGGL((act_kernel<float, float>), dim3(g), dim3(EW_THREADS), 0, ST, *a);
+  return sdmi_check_launch("act");
+}
+extern "C" int sdmi_geglu(const SdmiGegluArgs* a, void* stream) {
+  SDMI_REQUIRE(a && a->h && a->y, "null pointer");
+  const int vec = a->dtype == SDMI_BF16 ? 8 : 4;
+  SDMI_REQUIRE(a->C % vec == 0, "C must be a multiple of the vector width");
+  const int g = ew_blocks(a->rows * (a->C / vec));
+  if (a->dtype == SDMI_BF16) hipLaunchKernelGGL(geglu_kernel<bf16_t>, dim3(g), dim3(EW_THREADS), 0, ST, *a);
+  else hipLaunchKernelGGL(geglu_kernel<float>, dim3(g), dim3(EW_THREADS), 0, ST, *a);
+  return sdmi_check_launch("geglu");
+}
+extern "C" int sdmi_geglu_bwd(const SdmiGegluBwdArgs* a, void* stream) {
+  SDMI_REQUIRE(a && a->h && a->dy && a->dh, "null pointer");
+  const int vec = a->dtype == SDMI_BF16 ? 8 : 4;
+  SDMI_REQUIRE(a->C % vec == 0, "C must be a multiple of the vector width");
+  const int g = ew_blocks(a->rows * (a->C / vec));
+  if (a->dtype == SDMI_BF16) hipLaunchKernelGGL(geglu_bwd_kernel<bf16_t>, dim3(g), dim3(EW_THREADS), 0, ST, *a);
+  else hipLaunchKernelGGL(geglu_bwd_kernel<float>, dim3(g), dim3(EW_THREADS), 0, ST, *a);
+  return sdmi_check_launch("geglu_bwd");
+}
+extern "C" int sdmi_add_pos(const SdmiAddPosArgs* a, void* stream) {
+  SDMI_REQUIRE(a && a->x && a->pos && a->y, "null pointer");
+  const int vec = a->dtype == SDMI_BF16 ? 8 : 4;
+  SDMI_REQUIRE(a->per % vec == 0, "per-image size must be a multiple of the vector width");
+  const int g = ew_blocks((long long)a->B * (a->per / vec));
+  if (a->dtype == SDMI_BF16) hipLaunchKernelGGL(add_pos_kernel<bf16_t>, dim3(g), dim3(EW_THREADS), 0, ST, *a);
+  else hipLaunchKernelGGL(add_pos_kernel<float>, dim3(g), dim3(EW_THREADS), 0, ST, *a);
+  return sdmi_check_launch("add_pos");
+}
+extern "C" int sdmi_concat_channels(const SdmiConcatArgs* a, void* stream) {
+  SDMI_REQUIRE(a && a->a && a->b && a->y, "null pointer");
+  const int vec = a->dtype == SDMI_BF16 ? 8 : 4;
+  SDMI_REQUIRE(a->Ca % vec == 0 && a->Cb % vec == 0, "channel counts must be vector multiples");
+  const int g = ew_blocks(a->rows * ((a->Ca + a->Cb) / vec));
+  if (a->dtype == SDMI_BF16) hipLaunchKernelGGL(concat_kernel<bf16_t>, dim3(g), dim3(EW_THREADS), 0, ST, *a);
+  else hipLaunchKernelGGL(concat_kernel<float>, dim3(g), dim3(EW_THREADS), 0, ST, *a);
+  return sdmi_check_launch("concat_channels");
+}
+extern "C" int sdmi_mask_upsample_argmax(const SdmiMaskUpArgs* a, void* stream) {
+  SDMI_REQUIRE(a && a->seg && (a->up || a->idx), "null pointer");
+  hipLaunchKernelGGL(mask_up_kernel, dim3(ew_blocks((long long)a->B * a->H * a->W)),
+                     dim3(EW_THREADS), 0, ST, *a);
+  return sdmi_check_launch("mask_upsample_argmax");
+}
+extern "C" int sdmi_mse(const SdmiMseArgs* a, void* stream) {
+  SDMI_REQUIRE(a && a->pred && a->target && a->out && a->partial && a->nblk >= 1, "bad args");
+  if (a->dtype == SDMI_BF16) hipLaunchKernelGGL(mse_kernel<bf16_t>, dim3(a->nblk), dim3(256), 0, ST, *a);
+  else hipLaunchKernelGGL(mse_kernel<float>, dim3(a->nblk), dim3(256), 0, ST, *a);
+  hipLaunchKernelGGL(mse_final_kernel, dim3(1), dim3(64), 0, ST, *a);
+  return sdmi_check_launch("mse");
+}

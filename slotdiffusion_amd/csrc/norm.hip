@@ -1,0 +1,235 @@
+// GroupNorm(+activation) on NHWC, LayerNorm, row softmax -- HBM-bound wavefront-reduction kernels.
+//
+// GroupNorm thread organisation: a workgroup of 256 threads views image b as [HW][C/VEC] 16-byte
+// vectors.  Thread t owns vector column cv = t % CVp (CVp = next power of two >= C/VEC) and walks
+// rows r = t / CVp, + 256/CVp, ... so its channels -- hence gamma/beta/group -- never change and
+// every wave reads whole 128-byte lines.  Statistics are accumulated per thread in fp32 over short
+// strided runs, combined across threads and splits in fp64, deterministically (no atomics).
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ int next_pow2(int v) {
+  int p = 1;
+  while (p < v) p <<= 1;
+  return p;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gn_stats_kernel(SdmiGroupNormArgs p) {
+  constexpr int VEC = Elem<T>::VEC;
+  __shared__ float part[256][VEC][2];
+  const int b = blockIdx.y, split = blockIdx.x;
+  const int CV = p.C / VEC, CVp = next_pow2(CV);
+  const int R = 256 / CVp;
+  const int cv = threadIdx.x % CVp, r0 = threadIdx.x / CVp;
+  const int rows_per = (p.HW + p.nsplit - 1) / p.nsplit;
+  const int row_begin = split * rows_per;
+  int row_end = row_begin + rows_per;
+  if (row_end > p.HW) row_end = p.HW;
+  float s[VEC], ss[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) s[j] = ss[j] = 0.f;
+  if (cv < CV) {
+    const T* xb = (const T*)p.x + (long long)b * p.HW * p.C + cv * VEC;
+    for (int row = row_begin + r0; row < row_end; row += R) {
+      const uint4 v = *reinterpret_cast<const uint4*>(xb + (long long)row * p.C);
+      float f[VEC];
+      unpack16<T>(v, f);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) { s[j] += f[j]; ss[j] += f[j] * f[j]; }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) { part[threadIdx.x][j][0] = s[j]; part[threadIdx.x][j][1] = ss[j]; }
+  __syncthreads();
+  // 2 threads per group: (sum | sumsq)
+  if (threadIdx.x < 2 * p.groups) {
+    const int g = threadIdx.x >> 1, which = threadIdx.x & 1;
+    const int cpg = p.C / p.groups;
+    double acc = 0.0;
+    for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+      const int ccv = c / VEC, j = c % VEC;
+      for (int r = 0; r < R; ++r) acc += (double)part[r * CVp + ccv][j][which];
+    }
+    p.partial[(((long long)b * p.nsplit + split) * p.groups + g) * 2 + which] = (float)acc;
+  }
+}
+
+// finalize: mean / rstd per (b, group) from the split partials. one thread per (b, g).
+__global__ void gn_finalize_kernel(SdmiGroupNormArgs p) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= p.B * p.groups) return;
+  const int b = idx / p.groups, g = idx % p.groups;
+  double s = 0.0, ss = 0.0;
+  for (int k = 0; k < p.nsplit; ++k) {
+    const float* q = p.partial + (((long long)b * p.nsplit + k) * p.groups + g) * 2;
+    s += (double)q[0];
+    ss += (double)q[1];
+  }
+  const double n = (double)p.HW * (p.C / p.groups);
+  const double mean = s / n;
+  double var = ss / n - mean * mean;
+  if (var < 0.0) var = 0.0;
+  p.stats[idx * 2 + 0] = (float)mean;
+  p.stats[idx * 2 + 1] = (float)(1.0 / sqrt(var + (double)p.eps));
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gn_apply_kernel(SdmiGroupNormArgs p, int rows_per) {
+  constexpr int VEC = Elem<T>::VEC;
+  const int b = blockIdx.y;
+  const int CV = p.C / VEC, CVp = next_pow2(CV);
+  const int R = 256 / CVp;
+  const int cv = threadIdx.x % CVp, r0 = threadIdx.x / CVp;
+  if (cv >= CV) return;
+  const int row_begin = blockIdx.x * rows_per;
+  int row_end = row_begin + rows_per;
+  if (row_end > p.HW) row_end = p.HW;
+  const int cpg = p.C / p.groups;
+  float sc[VEC], sh[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    const int c = cv * VEC + j;
+    const int g = c / cpg;
+    const float mean = p.stats[(b * p.groups + g) * 2 + 0];
+    const float rstd = p.stats[(b * p.groups + g) * 2 + 1];
+    sc[j] = rstd * p.gamma[c];
+    sh[j] = p.beta[c] - mean * sc[j];
+  }
+  const long long base = (long long)b * p.HW * p.C + cv * VEC;
+  const T* xb = (const T*)p.x + base;
+  T* yb = (T*)p.y + base;
+  const T* rb = p.residual ? (const T*)p.residual + base : nullptr;
+  for (int row = row_begin + r0; row < row_end; row += R) {
+    const long long o = (long long)row * p.C;
+    const uint4 v = *reinterpret_cast<const uint4*>(xb + o);
+    float f[VEC];
+    unpack16<T>(v, f);
+    if (rb) {
+      float rr[VEC];
+      unpack16<T>(*reinterpret_cast<const uint4*>(rb + o), rr);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) f[j] = act_apply(f[j] * sc[j] + sh[j] + rr[j], p.act);
+    } else {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) f[j] = act_apply(f[j] * sc[j] + sh[j], p.act);
+    }
+    *reinterpret_cast<uint4*>(yb + o) = pack16<T>(f);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// LayerNorm: one wave per row, two-pass in registers (C <= 1024).
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_kernel(SdmiLayerNormArgs p) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= p.rows) return;
+  const T* x = (const T*)p.x + (long long)row * p.ldx;
+  T* y = (T*)p.y + (long long)row * p.ldy;
+  float v[16];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int c = i * 64 + lane;
+    v[i] = c < p.C ? Elem<T>::ld(x + c) : 0.f;
+    s += v[i];
+  }
+  const float mean = wave_sum(s) / (float)p.C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int c = i * 64 + lane;
+    const float d = c < p.C ? v[i] - mean : 0.f;
+    q += d * d;
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)p.C + p.eps);
+  if (p.stats && lane == 0) { p.stats[row * 2] = mean; p.stats[row * 2 + 1] = rstd; }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int c = i * 64 + lane;
+    if (c < p.C) Elem<T>::st(y + c, (v[i] - mean) * rstd * p.gamma[c] + p.beta[c]);
+  }
+}
+
+// row softmax in place with scale: one wave per row, three L2-resident sweeps.
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_rows_kernel(SdmiSoftmaxArgs p) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= p.rows) return;
+  T* x = (T*)p.x + row * p.ld;
+  float m = -INFINITY;
+  for (int c = lane; c < p.cols; c += 64) m = fmaxf(m, Elem<T>::ld(x + c) * p.scale);
+  m = wave_max(m);
+  float s = 0.f;
+  for (int c = lane; c < p.cols; c += 64) s += __expf(Elem<T>::ld(x + c) * p.scale - m);
+  s = wave_sum(s);
+  const float inv = 1.f / s;
+  for (int c = lane; c < p.cols; c += 64)
+    Elem<T>::st(x + c, __expf(Elem<T>::ld(x + c) * p.scale - m) * inv);
+}
+
+}  // namespace
+
+static int gn_validate(const SdmiGroupNormArgs* a) {
+  SDMI_REQUIRE(a && a->x && a->gamma && a->beta && a->stats, "null pointer");
+  const int vec = a->dtype == SDMI_BF16 ? 8 : 4;
+  SDMI_REQUIRE(a->C % vec == 0 && a->C / vec <= 256, "C must be a multiple of the vector width");
+  SDMI_REQUIRE(a->groups > 0 && a->groups <= 128 && a->C % a->groups == 0, "bad groups");
+  SDMI_REQUIRE(a->nsplit >= 1, "nsplit");
+  return SDMI_OK;
+}
+
+extern "C" int sdmi_groupnorm_stats(const SdmiGroupNormArgs* a, void* stream) {
+  int rc = gn_validate(a);
+  if (rc) return rc;
+  SDMI_REQUIRE(a->partial, "partial workspace required");
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(a->nsplit, a->B);
+  if (a->dtype == SDMI_BF16) hipLaunchKernelGGL(gn_stats_kernel<bf16_t>, grid, dim3(256), 0, st, *a);
+  else hipLaunchKernelGGL(gn_stats_kernel<float>, grid, dim3(256), 0, st, *a);
+  const int n = a->B * a->groups;
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3((n + 255) / 256), dim3(256), 0, st, *a);
+  return sdmi_check_launch("groupnorm_stats");
+}
+
+extern "C" int sdmi_groupnorm_apply(const SdmiGroupNormArgs* a, void* stream) {
+  int rc = gn_validate(a);
+  if (rc) return rc;
+  SDMI_REQUIRE(a->y, "null output");
+  hipStream_t st = (hipStream_t)stream;
+  // ~32 KiB of activations per workgroup, at least one row-sweep each
+  const long long row_bytes = (long long)a->C * (a->dtype == SDMI_BF16 ? 2 : 4);
+  int rows_per = (int)((32768 + row_bytes - 1) / row_bytes);
+  if (rows_per < 4) rows_per = 4;
+  if (rows_per > a->HW) rows_per = a->HW;
+  dim3 grid((a->HW + rows_per - 1) / rows_per, a->B);
+  if (a->dtype == SDMI_BF16)
+    hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, grid, dim3(256), 0, st, *a, rows_per);
+  else
+    hipLaunchKernelGGL(gn_apply_kernel<float>, grid, dim3(256), 0, st, *a, rows_per);
+  return sdmi_check_launch("groupnorm_apply");
+}
+
+extern "C" int sdmi_layernorm(const SdmiLayerNormArgs* a, void* stream) {
+  SDMI_REQUIRE(a && a->x && a->y && a->gamma && a->beta, "null pointer");
+  SDMI_REQUIRE(a->C > 0 && a->C <= 1024, "C must be <= 1024");
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid((a->rows + 3) / 4);
+  if (a->dtype == SDMI_BF16) hipLaunchKernelGGL(layernorm_kernel<bf16_t>, grid, dim3(256), 0, st, *a);
+  else hipLaunchKernelGGL(layernorm_kernel<float>, grid, dim3(256), 0, st, *a);
+  return sdmi_check_launch("layernorm");
+}
+
+extern "C" int sdmi_softmax_rows(const SdmiSoftmaxArgs* a, void* stream) {
+  SDMI_REQUIRE(a && a->x && a->rows > 0 && a->cols > 0, "bad args");
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid((a->rows + 3) / 4);
+  if (a->dtype == SDMI_BF16)
+    hipLaunchKernelGGL(softmax_rows_kernel<bf16_t>, grid, dim3(256), 0, st, *a);
+  else
+    hipLaunchKernelGGL(softmax_rows_kernel<float>, grid, dim3(256), 0, st, *a);
+  return sdmi_check_launch("softmax_rows");
+}

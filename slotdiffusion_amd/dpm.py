@@ -1,0 +1,137 @@
+"""DPM-Solver++ (singlestep, order 3, uniform time grid) for the discrete LDM schedule.
+
+Reference: video_based/models/ddpm/dpm_solver.py -- NoiseScheduleVP('discrete') 160-235,
+model_wrapper 238-416, DPM_Solver.sample singlestep branch 1310-1328 with the dpmsolver++
+second/third updates 716-732 / 804-831, as driven by CondDDPM.generate_imgs
+(cond_ddpm.py:155-193: steps=20, order=3, method='singlestep', vq_denoised=True).
+
+MI355X-side design: every scalar the solver needs (alpha, sigma, lambda, expm1 coefficients,
+intermediate times) depends only on the beta table, so the whole 20-NFE plan is computed ONCE on
+the host -- with fp32 torch CPU tensor ops, i.e. the same arithmetic the reference performs on its
+schedule tensors -- and the device loop is a fixed sequence of kernels with no host<->device
+synchronisation (the reference calls `.item()` per outer step, dpm_solver.py:1319).  The device
+updates are single fused `sdmi_lincomb` launches that round like the reference's op-by-op tensor
+expressions.
+"""
+import torch
+
+
+class DiscreteSchedule:
+    """log(alpha_t) table on t_i = (i+1)/N with piecewise-linear interpolation (fp32)."""
+
+    def __init__(self, betas):
+        betas = torch.as_tensor(betas, dtype=torch.float32).cpu()
+        self.log_alpha = (0.5 * torch.log(1 - betas).cumsum(dim=0)).float()
+        self.N = int(self.log_alpha.numel())
+        self.t_array = torch.linspace(0., 1., self.N + 1)[1:].float()
+        self.T = 1.0
+
+    @staticmethod
+    def _interp(x, xp, yp):
+        # keypoint segment containing x (outermost segments extrapolate), then the two-point form
+        K = xp.numel()
+        idx = torch.searchsorted(xp, x.contiguous(), right=False)
+        lo = torch.where(idx == 0, torch.zeros_like(idx),
+                         torch.where(idx == K, torch.full_like(idx, K - 2), idx - 1))
+        xa, xb, ya, yb = xp[lo], xp[lo + 1], yp[lo], yp[lo + 1]
+        return ya + (x - xa) * (yb - ya) / (xb - xa)
+
+    def log_mean_coeff(self, t):
+        return self._interp(t.reshape(-1), self.t_array, self.log_alpha)
+
+    def alpha(self, t):
+        return torch.exp(self.log_mean_coeff(t))
+
+    def std(self, t):
+        return torch.sqrt(1. - torch.exp(2. * self.log_mean_coeff(t)))
+
+    def lam(self, t):
+        lm = self.log_mean_coeff(t)
+        return lm - 0.5 * torch.log(1. - torch.exp(2. * lm))
+
+    def inverse_lambda(self, lamb):
+        la = -0.5 * torch.logaddexp(torch.zeros((1,)), -2. * lamb)
+        return self._interp(la.reshape(-1), torch.flip(self.log_alpha, [0]),
+                            torch.flip(self.t_array, [0]))
+
+
+def singlestep_orders(steps, order):
+    """How `steps` function evaluations are split over solver orders (dpm_solver.py:597-616)."""
+    if order == 3:
+        K = steps // 3 + 1
+        if steps % 3 == 0:
+            return [3] * (K - 2) + [2, 1]
+        if steps % 3 == 1:
+            return [3] * (K - 1) + [1]
+        return [3] * (K - 1) + [2]
+    if order == 2:
+        return [2] * (steps // 2) + ([1] if steps % 2 else [])
+    return [1] * steps
+
+
+def build_plan(betas, steps=20, order=3):
+    """-> dict(steps=[...], outer, orders): host-side plan driving the device loop.
+
+    Each outer step has `order` evaluations; every evaluation record carries
+      t_input : model time (t - 1/N) * 1000                (model_wrapper, 345-346)
+      sigma, alpha : x0 = (x - sigma*eps) / alpha            (data_prediction_fn, 523-534)
+    plus the lincomb coefficients (to_s1, to_s2, final) of the exponential-integrator updates.
+    """
+    ns = DiscreteSchedule(betas)
+    t_0, t_T = 1.0 / ns.N, ns.T
+    orders = singlestep_orders(steps, order)
+    grid = torch.linspace(t_T, t_0, steps + 1)
+    outer = grid[torch.cumsum(torch.tensor([0] + orders), 0)]
+    f = lambda v: float(v.reshape(-1)[0])
+    plan = []
+    for i, od in enumerate(orders):
+        s, t = outer[i], outer[i + 1]
+        inner = torch.linspace(s.item(), t.item(), od + 1)
+        lam_in = ns.lam(inner)
+        h_in = lam_in[-1] - lam_in[0]
+        r1 = None if od <= 1 else (lam_in[1] - lam_in[0]) / h_in
+        r2 = None if od <= 2 else (lam_in[2] - lam_in[0]) / h_in
+        s1d, t1d = s.reshape(1), t.reshape(1)
+        lam_s, lam_t = ns.lam(s1d), ns.lam(t1d)
+        h = lam_t - lam_s
+        sig_s, sig_t = ns.std(s1d), ns.std(t1d)
+        alpha_t = torch.exp(ns.log_mean_coeff(t1d))
+        phi_1 = torch.expm1(-h)
+
+        def rec(tc):
+            return dict(t=f(tc), t_input=f((tc - 1. / ns.N) * 1000.), sigma=f(ns.std(tc)),
+                        alpha=f(ns.alpha(tc)))
+
+        step = dict(order=od, evals=[rec(s1d)])
+        if od == 1:
+            step['final'] = dict(c0=f(sig_t / sig_s), c1=f(-(alpha_t * phi_1)))
+        else:
+            if r1 is None:
+                r1 = torch.tensor(0.5)
+            s1 = ns.inverse_lambda(lam_s + r1 * h)
+            sig_s1 = ns.std(s1)
+            alpha_s1 = torch.exp(ns.log_mean_coeff(s1))
+            phi_11 = torch.expm1(-r1 * h)
+            step['evals'].append(rec(s1))
+            step['to_s1'] = dict(c0=f(sig_s1 / sig_s), c1=f(-(alpha_s1 * phi_11)))
+            if od == 2:
+                step['final'] = dict(c0=f(sig_t / sig_s), c1=f(-(alpha_t * phi_1)),
+                                     c2=f(-((0.5 / r1) * (alpha_t * phi_1))), which=1)
+            else:
+                s2 = ns.inverse_lambda(lam_s + r2 * h)
+                sig_s2 = ns.std(s2)
+                alpha_s2 = torch.exp(ns.log_mean_coeff(s2))
+                phi_12 = torch.expm1(-r2 * h)
+                phi_22 = torch.expm1(-r2 * h) / (r2 * h) + 1.
+                phi_2 = phi_1 / h + 1.
+                step['evals'].append(rec(s2))
+                step['to_s2'] = dict(c0=f(sig_s2 / sig_s), c1=f(-(alpha_s2 * phi_12)),
+                                     c2=f(r2 / r1 * (alpha_s2 * phi_22)))
+                step['final'] = dict(c0=f(sig_t / sig_s), c1=f(-(alpha_t * phi_1)),
+                                     c2=f((1. / r2) * (alpha_t * phi_2)), which=2)
+        plan.append(step)
+    return dict(steps=plan, outer=outer, orders=orders)
+
+
+def plan_t_inputs(plan):
+    return [e['t_input'] for st in plan['steps'] for e in st['evals']]

@@ -1,0 +1,345 @@
+"""Model classes with the reference's registry surface, executed by the HIP engine.
+
+Class / method / key names follow the reference so a `scripts/train.py`-style driver and the
+evaluation scripts can switch packages:
+  SADiffusion ............ slotdiffusion/img_based/models/sa_diffusion.py:73-246
+  LDM (model.dm_decoder) . slotdiffusion/img_based/models/ddpm/ldm.py:18-129, cond_ddpm.py:134-212
+  VQVAEWrapper (.vae) .... slotdiffusion/video_based/models/vqvae/VQVAE.py:152-194
+Tensors cross this boundary in the reference's layout (NCHW fp32 images / latents, [B,N,D] slots);
+inside, everything is NHWC in the compute dtype (fp32 for parity runs, bf16 for throughput).
+"""
+import copy
+import os
+
+import torch
+
+from . import dpm, engine, ops, spec
+from .module import FlatModule, _Node
+
+_DTYPES = {'fp32': torch.float32, 'float32': torch.float32, 'bf16': torch.bfloat16,
+           'bfloat16': torch.bfloat16}
+
+
+def default_compute_dtype():
+    return _DTYPES[os.environ.get('SDMI_DTYPE', 'fp32').lower()]
+
+
+class _Owned(_Node):
+    """Container node that can reach the root model (kept out of the module tree)."""
+
+    def _bind(self, root):
+        object.__setattr__(self, '_root_ref', root)
+
+    @property
+    def root(self):
+        return self._root_ref
+
+
+class VQVAEWrapper(_Owned):
+    """`model.dm_decoder.vae`: encode / decode / quantize on NCHW fp32 tensors."""
+
+    @torch.no_grad()
+    def encode(self, x):
+        r = self.root
+        z = engine.vae_encode(r.bank(), r._to_nhwc(x), r.ed, scale_factor=r.z_scale)
+        return ops.nhwc_to_nchw(z, 3)
+
+    @torch.no_grad()
+    def decode(self, h, quantize=True):
+        r = self.root
+        img = engine.vae_decode(r.bank(), r._latent_nhwc(h), r.ed, scale_factor=r.z_scale,
+                                quantize=quantize)
+        return ops.nhwc_to_nchw(img, 3)
+
+    @torch.no_grad()
+    def quantize(self, h):
+        r = self.root
+        _, zq = ops.vq_nearest(r._latent_nhwc(h), r.bank().f(r.vq_key), scale=r.z_scale,
+                               want_idx=False)
+        return ops.nhwc_to_nchw(zq, 3)
+
+    @torch.no_grad()
+    def quantize_indices(self, h):
+        r = self.root
+        idx, _ = ops.vq_nearest(r._latent_nhwc(h), r.bank().f(r.vq_key), scale=r.z_scale,
+                                want_zq=False)
+        return idx
+
+
+class LDM(_Owned):
+    """`model.dm_decoder`: denoising loss + DPM-Solver++ sampling of the slot-conditioned LDM."""
+    use_ema = False
+    cond_stage_key = 'slots'
+    clip_denoised = False
+    vq_denoised = True
+    pred_target = 'eps'
+
+    @property
+    def num_timesteps(self):
+        return self.betas.shape[0]
+
+    def ema_scope(self, context=None):
+        import contextlib
+        return contextlib.nullcontext()        # use_ema=False in every shipped LDM config
+
+    def _training_step_end(self, *a, **k):
+        pass
+
+    # -- a7/a8 ---------------------------------------------------------------------------
+    def loss_function(self, data_dict, t=None, noise=None):
+        """ldm.py:59-83; t / noise may be supplied (fixtures) or are drawn like the reference."""
+        r = self.root
+        img, slots = data_dict['img'], data_dict[self.cond_stage_key]
+        B = img.shape[0]
+        bank = r.bank()
+        with torch.no_grad():
+            x0 = engine.vae_encode(bank, r._to_nhwc(img), r.ed, scale_factor=r.z_scale)
+        if t is None:
+            t = torch.randint(0, self.num_timesteps, (B,), device=img.device).long()
+        if noise is None:
+            noise = torch.randn(B, 3, x0.shape[1], x0.shape[2], device=img.device)
+        nz = ops.nchw_to_nhwc(noise, torch.float32, 4)
+        ca = self.sqrt_alphas_bar[t].contiguous()
+        cb = self.sqrt_one_minus_alphas_bar[t].contiguous()
+        xt = ops.row_lincomb(x0, nz, ca, cb)
+        pred = r._unet_eps(xt, t.float(), slots)
+        loss = ops.mse(pred, nz)
+        # the 4th (zero pad) channel adds no error but is counted in n: rescale 4/3
+        return {'denoise_loss': (loss * (4.0 / 3.0)).reshape(())}
+
+    # -- a12/a13 -------------------------------------------------------------------------
+    @torch.no_grad()
+    def generate_imgs(self, cond, batch_size=16, ret_intermed=False, verbose=False,
+                      use_ddim=False, use_dpm=True, x_T=None, same_noise=False, **kwargs):
+        """cond_ddpm.py:134-212 (DPM-Solver branch). Returns latents [B,3,h,w] (NCHW fp32)."""
+        if not use_dpm or use_ddim:
+            raise NotImplementedError('hot path covers the DPM-Solver++ sampler (use_dpm=True)')
+        r = self.root
+        if cond.dim() == 2:
+            cond = cond.unsqueeze(0).expand(batch_size, -1, -1)
+        cond = cond.contiguous()
+        h, w = r.latent_res
+        if x_T is None:
+            if same_noise:
+                x_T = torch.randn(1, 3, h, w, device=cond.device).repeat(batch_size, 1, 1, 1)
+            else:
+                x_T = torch.randn(batch_size, 3, h, w, device=cond.device)
+        x = ops.nchw_to_nhwc(x_T, torch.float32, 4)
+        x, inter = r._dpm_sample(x, cond, ret_intermed)
+        out = ops.nhwc_to_nchw(x, 3)
+        if ret_intermed:
+            return out, torch.stack([ops.nhwc_to_nchw(i, 3) for i in inter], 0)
+        return out
+
+    @torch.no_grad()
+    def log_images(self, batch, ret_intermed=False, **kwargs):
+        """ldm.py:86-131 with ret_intermed=False (grids need torchvision, out of scope)."""
+        cond = batch[self.cond_stage_key]
+        B = cond.shape[0]
+        ret = self.generate_imgs(cond=cond, batch_size=B, ret_intermed=False, **kwargs)
+        return {'samples': self.vae.decode(ret)}
+
+
+class SADiffusion(FlatModule):
+    """SlotDiffusion on images (registry name 'SADiffusion')."""
+
+    def __init__(self, resolution, slot_dict, enc_dict, dec_dict, loss_dict=None, eps=1e-6,
+                 compute_dtype=None, seed=0):
+        dec_dict = copy.deepcopy(dec_dict)
+        dd = dec_dict['diffusion_dict']
+        sp = spec.sa_diffusion(resolution, slot_dict, enc_dict, dec_dict)
+        sched = {k: dd[k] for k in ('timesteps', 'beta_schedule', 'linear_start', 'linear_end')
+                 if k in dd}
+        super().__init__(sp, schedule_kwargs=sched, seed=seed,
+                         node_classes={'dm_decoder': LDM, 'dm_decoder.vae': VQVAEWrapper})
+        assert dd.get('pred_target', 'eps') == 'eps', 'hot path covers eps-prediction'
+        self.resolution = tuple(resolution)
+        self.eps = eps
+        self.slot_dict, self.enc_dict, self.dec_dict = dict(slot_dict), dict(enc_dict), dec_dict
+        self.loss_dict = dict(loss_dict or {'use_denoise_loss': True})
+        self.num_slots = slot_dict['num_slots']
+        self.slot_size = slot_dict['slot_size']
+        self.num_iterations = slot_dict['num_iterations']
+        div = 8 if enc_dict['use_layer4'] else 4
+        self.visual_resolution = tuple(r // div for r in self.resolution)
+        self.latent_res = tuple(dec_dict['resolution'])
+        self.ed = dec_dict['vae_dict']['enc_dec_dict']
+        self.z_scale = float(dd.get('z_scale_factor', 1.))
+        self.vq_key = 'dm_decoder.vae.vqvae.quantize.embedding.weight'
+        self.rplan = spec.resnet18_plan(enc_dict['use_layer4'])
+        self.unet_cfg = dec_dict['unet_dict']
+        self.testing = False
+        self.compute_dtype = compute_dtype or default_compute_dtype()
+        self.dm_decoder._bind(self)
+        self.dm_decoder.vae._bind(self)
+        self._bank = None
+        self._unet = None
+        self._plan = None
+        self.use_graph = os.environ.get('SDMI_GRAPH', '1') != '0'
+        self._graph_cache = {}
+
+    # -- plumbing ------------------------------------------------------------------------
+    @property
+    def device(self):
+        return self.init_latents.device
+
+    @property
+    def dtype(self):
+        return self.init_latents.dtype
+
+    def set_compute_dtype(self, dt):
+        self.compute_dtype = _DTYPES[dt] if isinstance(dt, str) else dt
+        self.invalidate_weights()
+        return self
+
+    def invalidate_weights(self):
+        self._bank = None
+        self._unet = None
+        self._graph_cache = {}
+
+    def load_state_dict(self, *a, **k):
+        r = super().load_state_dict(*a, **k)
+        self.invalidate_weights()
+        return r
+
+    def load_weight(self, path, strict=True):
+        ckp = torch.load(path, map_location='cpu')
+        self.load_state_dict(ckp.get('state_dict', ckp), strict=strict)
+
+    def _apply(self, fn, recurse=True):
+        r = super()._apply(fn, recurse)
+        self.invalidate_weights()
+        return r
+
+    def bank(self):
+        if self._bank is None:
+            self._bank = engine.WeightBank(self.tensors(), self.compute_dtype)
+        return self._bank
+
+    def unet(self):
+        if self._unet is None:
+            self._unet = engine.UNetRunner(self.bank(), self.unet_cfg)
+        return self._unet
+
+    def _to_nhwc(self, img):
+        return ops.nchw_to_nhwc(img.float(), self.compute_dtype, ops.vec_of(self.compute_dtype))
+
+    def _latent_nhwc(self, z):
+        return ops.nchw_to_nhwc(z.float(), torch.float32, 4)
+
+    def _ctx(self, slots):
+        s = slots.contiguous().float()
+        return s if self.compute_dtype == torch.float32 else ops.act(s, None, self.compute_dtype)
+
+    def _unet_in(self, x):
+        """fp32 latent state [B,h,w,4] -> UNet input in compute dtype with vector-padded channels."""
+        if self.compute_dtype == torch.float32:
+            return x
+        return ops.cast2d(x, self.compute_dtype, cols=3, ldd=ops.vec_of(self.compute_dtype))
+
+    def _unet_eps(self, xt, t, slots):
+        u = self.unet()
+        return u.forward(self._unet_in(xt), u.time_rowvecs(t), u.context_kv(self._ctx(slots)))
+
+    # -- sampler -------------------------------------------------------------------------
+    def _dpm_sample(self, x, cond, ret_intermed=False, steps=None):
+        """x [B,h,w,4] fp32 noise -> x_0; zero host syncs inside the loop."""
+        steps = steps or max(20, self.dm_decoder.num_timesteps // 50)
+        if self._plan is None or self._plan[0] != steps:
+            betas = self.dm_decoder.betas.detach().float().cpu().numpy()
+            self._plan = (steps, dpm.build_plan(betas, steps=steps, order=3))
+        plan = self._plan[1]
+        u = self.unet()
+        bank = self.bank()
+        ctx_kv = u.context_kv(self._ctx(cond))
+        tin = torch.tensor(dpm.plan_t_inputs(plan), dtype=torch.float32, device=x.device)
+        rv_all = u.time_rowvecs(tin)                         # [NFE, sum Cout] fp32
+        B = x.shape[0]
+        code = bank.f(self.vq_key)
+        nfe = [0]
+
+        def data_pred(xc, e):
+            rv = rv_all[nfe[0]:nfe[0] + 1].expand(B, -1)      # pitch-0 view: same row for all b
+            nfe[0] += 1
+            eps = u.forward(self._unet_in(xc), rv, ctx_kv)
+            x0 = ops.lincomb(1.0, xc, -e['sigma'], eps, div=e['alpha'])
+            return ops.vq_nearest(x0, code, scale=self.z_scale, want_idx=False)[1]
+
+        inter = []
+        for st in plan['steps']:
+            ev = st['evals']
+            m_s = data_pred(x, ev[0])
+            if st['order'] >= 2:
+                c = st['to_s1']
+                x_s1 = ops.lincomb(c['c0'], x, c['c1'], m_s)
+                m_s1 = data_pred(x_s1, ev[1])
+            if st['order'] == 3:
+                c = st['to_s2']
+                x_s2 = ops.lincomb(c['c0'], x, c['c1'], m_s, c['c2'], m_s1, m_s)
+                m_s2 = data_pred(x_s2, ev[2])
+            f = st['final']
+            if st['order'] == 1:
+                x = ops.lincomb(f['c0'], x, f['c1'], m_s)
+            else:
+                m_last = m_s1 if f['which'] == 1 else m_s2
+                x = ops.lincomb(f['c0'], x, f['c1'], m_s, f['c2'], m_last, m_s)
+            if ret_intermed:
+                inter.append(x)
+        return x, inter
+
+    # -- a1-a4 ---------------------------------------------------------------------------
+    @torch.no_grad()
+    def encode(self, img, init_slots=None):
+        """sa_diffusion.py:155-183 -> slots [B,N,D] fp32, masks [B,N,h,w] (train) / [B,N,H,W]."""
+        B, _, H, W = img.shape
+        bank = self.bank()
+        tok = engine.encoder_out(bank, self._to_nhwc(img), self.rplan)
+        init = self.init_latents[0] if init_slots is None else init_slots.contiguous().float()
+        slots, seg = engine.slot_attention(bank, tok, init, self.num_iterations, self.eps)
+        h, w = self.visual_resolution
+        if not self.training and (h, w) != (H, W):
+            masks, _ = ops.mask_upsample_argmax(seg, h, w, H, W)
+        else:
+            masks = seg.permute(0, 2, 1).reshape(B, self.num_slots, h, w)
+        return slots, masks
+
+    def forward(self, data_dict, **kwargs):
+        if kwargs.pop('log_images', False):
+            return self.log_images(data_dict, **kwargs)
+        assert kwargs == {}
+        slots, masks = self.encode(data_dict['img'])
+        return {'masks': masks, 'slots': slots}
+
+    def calc_train_loss(self, data_dict, out_dict):
+        """sa_diffusion.py:206-213."""
+        ddpm_dict = {'img': data_dict['img'], 'slots': out_dict['slots']}
+        for k in ('t', 'noise'):
+            if k in data_dict:
+                ddpm_dict[k] = data_dict[k]
+        return self.dm_decoder.loss_function(ddpm_dict, t=ddpm_dict.get('t'),
+                                             noise=ddpm_dict.get('noise'))
+
+    @torch.no_grad()
+    def calc_eval_loss(self, data_dict, out_dict):
+        return self.calc_train_loss(data_dict, out_dict)
+
+    @torch.no_grad()
+    def log_images(self, data_dict, **kwargs):
+        """sa_diffusion.py:228-241: slots -> DPM-Solver++ -> VQ-VAE decode."""
+        out_dict = self.forward(data_dict)
+        log = self.dm_decoder.log_images({'img': data_dict['img'], 'slots': out_dict['slots']},
+                                         **kwargs)
+        log['masks'] = out_dict['masks']
+        return log
+
+    def _training_step_end(self, method=None):
+        self.dm_decoder._training_step_end()
+
+
+def build_model(params):
+    """img_based registry (img_based/models/__init__.py:12-39) for the hot-path models."""
+    if params.model == 'SADiffusion':
+        return SADiffusion(resolution=params.resolution, slot_dict=params.slot_dict,
+                           enc_dict=params.enc_dict, dec_dict=params.dec_dict,
+                           loss_dict=params.loss_dict)
+    raise NotImplementedError(f'{params.model} is not on the MI355X hot path yet')

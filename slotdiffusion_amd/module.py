@@ -100,8 +100,9 @@ def _init_tensor(p, gen, sched):
 class FlatModule(nn.Module):
     """nn.Module whose parameters/buffers are created from a list of spec.P."""
 
-    def __init__(self, spec_list, schedule_kwargs=None, seed=0):
+    def __init__(self, spec_list, schedule_kwargs=None, seed=0, node_classes=None):
         super().__init__()
+        node_classes = node_classes or {}
         self._spec = list(spec_list)
         gen = torch.Generator().manual_seed(seed)
         sched = ddpm_schedule(**schedule_kwargs) if schedule_kwargs is not None else None
@@ -111,9 +112,10 @@ class FlatModule(nn.Module):
                 t = t.contiguous(memory_format=torch.channels_last)
             parts = p.name.split('.')
             node = self
-            for part in parts[:-1]:
+            for depth, part in enumerate(parts[:-1]):
                 if not hasattr(node, part):
-                    node.add_module(part, _Node())
+                    cls = node_classes.get('.'.join(parts[:depth + 1]), _Node)
+                    node.add_module(part, cls())
                 node = getattr(node, part)
             if p.init.startswith('buf:'):
                 node.register_buffer(parts[-1], t)

@@ -1,0 +1,318 @@
+"""Tensor-level wrappers over the libsdmi C ABI (forward kernels).
+
+PyTorch is plumbing here: tensors provide device memory (`data_ptr()`) and the current HIP
+stream; every FLOP happens in the hand-written kernels of ``csrc/``.  All activations are NHWC.
+"""
+import torch
+
+from . import _lib
+from ._lib import ACT, BF16, F32, call
+
+_DT = {torch.float32: F32, torch.bfloat16: BF16}
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dt(t):
+    return _DT[t.dtype]
+
+
+def _p(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def vec_of(dtype):
+    return 8 if dtype == torch.bfloat16 else 4
+
+
+def _need_gpu(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _lib.SdmiError('libsdmi kernels need device tensors (no CPU fallback)')
+
+
+# ------------------------------------------------------------------------------------------
+# implicit GEMM
+# ------------------------------------------------------------------------------------------
+def conv2d(x, w, bias=None, *, kh=3, kw=3, stride=1, pad=(1, 1, 1, 1), ups=False, cout=None,
+           rowvec=None, residual=None, act=None, out=None, out_dtype=None, ldc=None,
+           split_k=0):
+    """x [B,H,W,Cin] NHWC; w [Cout][kh][kw][Cin] (flat or 4-D channels_last view).
+    pad = (top, bottom, left, right).  Returns [B,Ho,Wo,ldc or Cout]."""
+    _need_gpu(x, w)
+    B, H, W, Cin = x.shape
+    assert x.is_contiguous()
+    Hs, Ws = (2 * H, 2 * W) if ups else (H, W)
+    Ho = (Hs + pad[0] + pad[1] - kh) // stride + 1
+    Wo = (Ws + pad[2] + pad[3] - kw) // stride + 1
+    K = kh * kw * Cin
+    N = cout if cout is not None else w.numel() // K
+    assert w.numel() == N * K, (w.shape, N, K)
+    odt = out_dtype or x.dtype
+    ldc = ldc or N
+    if out is None:
+        out = (torch.zeros if ldc != N else torch.empty)((B, Ho, Wo, ldc), dtype=odt, device=x.device)
+    M = B * Ho * Wo
+    ws = None
+    # split-K workspace for skinny problems (few tiles, deep K)
+    if split_k != 1:
+        t64 = ((M + 63) // 64) * ((N + 63) // 64)
+        t128 = ((M + 127) // 128) * ((N + 127) // 128)
+        if not (N > 64 and t128 >= 96) and t64 < 192 and K * x.element_size() >= 2048:
+            ws = torch.empty((16 * M * N,), dtype=torch.float32, device=x.device)
+    call('sdmi_igemm', _stream(), a=_p(x), w=_p(w), out=_p(out), bias=_p(bias), rowvec=_p(rowvec),
+         residual=_p(residual), workspace=_p(ws), dtype=_dt(x), out_dtype=_DT[odt], M=M, N=N, K=K,
+         lda=Cin, ldw=K, ldc=ldc, ldr=(residual.shape[-1] if residual is not None else 0),
+         B=B, H=H, W=W, Cin=Cin, Ho=Ho, Wo=Wo, KH=kh, KW=kw, stride=stride, pad_t=pad[0],
+         pad_l=pad[2], ups=int(ups), act=ACT[act], alpha=1.0, bias_m=0,
+         ldrv=(rowvec.stride(0) if rowvec is not None else 0),
+         split_k=(split_k if ws is not None or split_k == 1 else 1), batch=1)
+    return out
+
+
+def linear(x, w, bias=None, *, act=None, residual=None, out=None, out_dtype=None, n=None,
+           alpha=1.0, lda=None, k=None):
+    """x [..., K] (last dim contiguous; row pitch lda) ; w [N, K] -> [..., N]."""
+    _need_gpu(x, w)
+    K = k or x.shape[-1]
+    lda = lda or x.stride(-2) if x.dim() > 1 else K
+    M = x.numel() // x.shape[-1]
+    N = n if n is not None else w.numel() // K
+    odt = out_dtype or x.dtype
+    if out is None:
+        out = torch.empty(x.shape[:-1] + (N,), dtype=odt, device=x.device)
+    ws = None
+    t64 = ((M + 63) // 64) * ((N + 63) // 64)
+    t128 = ((M + 127) // 128) * ((N + 127) // 128)
+    if not (N > 64 and t128 >= 96) and t64 < 192 and K * x.element_size() >= 2048:
+        ws = torch.empty((16 * M * N,), dtype=torch.float32, device=x.device)
+    call('sdmi_igemm', _stream(), a=_p(x), w=_p(w), out=_p(out), bias=_p(bias),
+         residual=_p(residual), workspace=_p(ws), dtype=_dt(x), out_dtype=_DT[odt], M=M, N=N, K=K,
+         lda=lda, ldw=K, ldc=out.stride(-2) if out.dim() > 1 else N,
+         ldr=(residual.stride(-2) if residual is not None else 0), B=M, H=1, W=1, Cin=K, Ho=1,
+         Wo=1, KH=1, KW=1, stride=1, pad_t=0, pad_l=0, ups=0, act=ACT[act], alpha=alpha,
+         bias_m=0, split_k=(0 if ws is not None else 1), batch=1)
+    return out
+
+
+def bmm_nt(a, b, out, *, alpha=1.0, bias_m=None):
+    """Batched out[z] = alpha * a[z] @ b[z]^T (+ bias_m[:, None]); a [Z,M,K], b [Z,N,K]."""
+    _need_gpu(a, b, out)
+    Z, M, K = a.shape
+    N = b.shape[1]
+    call('sdmi_igemm', _stream(), a=_p(a), w=_p(b), out=_p(out), bias=_p(bias_m), dtype=_dt(a),
+         out_dtype=_dt(out), M=M, N=N, K=K, lda=a.stride(1), ldw=b.stride(1), ldc=out.stride(1),
+         B=M, H=1, W=1, Cin=K, Ho=1, Wo=1, KH=1, KW=1, stride=1, act=0, alpha=alpha,
+         bias_m=int(bias_m is not None), split_k=1, batch=Z, sa=a.stride(0),
+         sw=(b.stride(0) if b.shape[0] == Z and Z > 1 else 0), sc=out.stride(0))
+    return out
+
+
+# ------------------------------------------------------------------------------------------
+# normalisation
+# ------------------------------------------------------------------------------------------
+def group_norm(x, gamma, beta, *, eps, act=None, groups=32, residual=None, out=None,
+               return_stats=False):
+    """x [B,H,W,C] (or [B,HW,C]) NHWC -> same shape; fp32 statistics."""
+    _need_gpu(x)
+    B, C = x.shape[0], x.shape[-1]
+    HW = x.numel() // (B * C)
+    nsplit = max(1, min(16, HW // 64))
+    partial = torch.empty((B * nsplit * groups * 2,), dtype=torch.float32, device=x.device)
+    stats = torch.empty((B, groups, 2), dtype=torch.float32, device=x.device)
+    if out is None:
+        out = torch.empty_like(x)
+    kw = dict(x=_p(x), y=_p(out), gamma=_p(gamma), beta=_p(beta), stats=_p(stats),
+              partial=_p(partial), dtype=_dt(x), B=B, HW=HW, C=C, groups=groups, eps=eps,
+              act=ACT[act], nsplit=nsplit, residual=_p(residual))
+    call('sdmi_groupnorm_stats', _stream(), **kw)
+    call('sdmi_groupnorm_apply', _stream(), **kw)
+    return (out, stats) if return_stats else out
+
+
+def layer_norm(x, gamma, beta, *, eps=1e-5, out=None, stats=None):
+    _need_gpu(x)
+    C = x.shape[-1]
+    rows = x.numel() // C
+    if out is None:
+        out = torch.empty_like(x)
+    call('sdmi_layernorm', _stream(), x=_p(x), y=_p(out), gamma=_p(gamma), beta=_p(beta),
+         stats=_p(stats), dtype=_dt(x), rows=rows, C=C, ldx=C, ldy=C, eps=eps)
+    return out
+
+
+def softmax_rows_(x, scale=1.0):
+    cols = x.shape[-1]
+    call('sdmi_softmax_rows', _stream(), x=_p(x), dtype=_dt(x), rows=x.numel() // cols, cols=cols,
+         ld=cols, scale=scale)
+    return x
+
+
+# ------------------------------------------------------------------------------------------
+# attention
+# ------------------------------------------------------------------------------------------
+def attention(q, k, v, heads, *, out=None, lse=None):
+    """q [B,Sq,*] k,v [B,Skv,*] (views with last-dim stride 1; head h at channel h*32)."""
+    _need_gpu(q, k, v)
+    B, Sq = q.shape[0], q.shape[1]
+    Skv = k.shape[1]
+    C = heads * 32
+    if out is None:
+        out = torch.empty((B, Sq, C), dtype=q.dtype, device=q.device)
+    call('sdmi_attention', _stream(), q=_p(q), k=_p(k), v=_p(v), out=_p(out), lse=_p(lse),
+         dtype=_dt(q), B=B, heads=heads, Sq=Sq, Skv=Skv, ldq=q.stride(1), ldk=k.stride(1),
+         ldv=v.stride(1), ldo=out.stride(1), scale=32 ** -0.5)
+    return out
+
+
+def slot_attention(k, v, slots_in, P, *, iters, eps, trace=None):
+    """k, v [B,M,D] views (row pitch = stride(1)); slots_in [N,D] or [B,N,D] fp32.
+    P: dict of fp32 weights (lnq_g, lnq_b, wq, w_ih, w_hh, b_ih, b_hh, lnm_g, lnm_b, w1, b1, w2, b2).
+    Returns slots [B,N,D] fp32, seg [B,M,N] fp32."""
+    _need_gpu(k, v, slots_in)
+    B, M, D = k.shape
+    N = slots_in.shape[-2]
+    Hid = P['w1'].shape[0]
+    slots = torch.empty((B, N, D), dtype=torch.float32, device=k.device)
+    seg = torch.empty((B, M, N), dtype=torch.float32, device=k.device)
+    call('sdmi_slot_attention', _stream(), k=_p(k), v=_p(v), slots_in=_p(slots_in),
+         slots_out=_p(slots), seg=_p(seg), trace=_p(trace), dtype=_dt(k), B=B, M=M, N=N, D=D,
+         Hid=Hid, iters=iters, ldkv=k.stride(1),
+         slots_bstride=(N * D if slots_in.dim() == 3 else 0), eps=eps, scale=D ** -0.5,
+         **{n: _p(P[n]) for n in ('lnq_g', 'lnq_b', 'wq', 'w_ih', 'w_hh', 'b_ih', 'b_hh',
+                                  'lnm_g', 'lnm_b', 'w1', 'b1', 'w2', 'b2')})
+    return slots, seg
+
+
+# ------------------------------------------------------------------------------------------
+# VQ + elementwise
+# ------------------------------------------------------------------------------------------
+def vq_nearest(z, codebook, *, scale=1.0, want_idx=True, want_zq=True):
+    """z [..., ldz] fp32 NHWC latent (first 3 channels used). -> (idx int64 [...], zq like z)."""
+    _need_gpu(z, codebook)
+    ldz = z.shape[-1]
+    R = z.numel() // ldz
+    idx = torch.empty(z.shape[:-1], dtype=torch.int64, device=z.device) if want_idx else None
+    zq = torch.empty_like(z) if want_zq else None
+    call('sdmi_vq_nearest', _stream(), z=_p(z), codebook=_p(codebook), idx=_p(idx), zq=_p(zq), R=R,
+         dim=codebook.shape[1], ldz=ldz, n_codes=codebook.shape[0], scale=scale)
+    return idx, zq
+
+
+def lincomb(c0=0., x0=None, c1=0., x1=None, c2=0., x2=None, x3=None, div=0., out=None):
+    """out = ((c0*x0 + c1*x1) + c2*(x2 - x3)) / div  (fp32 tensors; see sdmi.h)."""
+    ref = x0 if x0 is not None else (x1 if x1 is not None else x2)
+    _need_gpu(ref)
+    if out is None:
+        out = torch.empty_like(ref)
+    call('sdmi_lincomb', _stream(), y=_p(out), x0=_p(x0), x1=_p(x1), x2=_p(x2), x3=_p(x3),
+         c0=float(c0), c1=float(c1), c2=float(c2), div=float(div), n=out.numel())
+    return out
+
+
+def row_lincomb(x0, x1, ca, cb, out=None):
+    B = x0.shape[0]
+    if out is None:
+        out = torch.empty_like(x0)
+    call('sdmi_row_lincomb', _stream(), y=_p(out), x0=_p(x0), x1=_p(x1), ca=_p(ca), cb=_p(cb), B=B,
+         per=x0.numel() // B)
+    return out
+
+
+def nchw_to_nhwc(src, dtype, cpad=None):
+    _need_gpu(src)
+    B, C, H, W = src.shape
+    cpad = cpad or C
+    dst = torch.empty((B, H, W, cpad), dtype=dtype, device=src.device)
+    call('sdmi_nchw_to_nhwc', _stream(), src=_p(src.contiguous()), dst=_p(dst), dtype=_DT[dtype],
+         B=B, C=C, H=H, W=W, Cpad=cpad)
+    return dst
+
+
+def nhwc_to_nchw(src, C=None):
+    _need_gpu(src)
+    B, H, W, cpad = src.shape
+    C = C or cpad
+    dst = torch.empty((B, C, H, W), dtype=torch.float32, device=src.device)
+    call('sdmi_nhwc_to_nchw', _stream(), src=_p(src), dst=_p(dst), dtype=_dt(src), B=B, C=C, H=H,
+         W=W, Cpad=cpad)
+    return dst
+
+
+def cast2d(src, dst_dtype, cols=None, out=None, ldd=None):
+    """Cast a [rows, lds] matrix (first `cols` columns) into [rows, ldd] of dst_dtype."""
+    _need_gpu(src)
+    lds = src.shape[-1]
+    cols = cols or lds
+    rows = src.numel() // lds
+    ldd = ldd or cols
+    if out is None:
+        out = (torch.zeros if ldd != cols else torch.empty)(src.shape[:-1] + (ldd,),
+                                                            dtype=dst_dtype, device=src.device)
+    call('sdmi_cast2d', _stream(), src=_p(src), dst=_p(out), src_dtype=_dt(src),
+         dst_dtype=_DT[dst_dtype], rows=rows, cols=cols, lds=lds, ldd=ldd)
+    return out
+
+
+def timestep_embedding(t, dim, max_period=10000.):
+    _need_gpu(t)
+    out = torch.empty((t.shape[0], dim), dtype=torch.float32, device=t.device)
+    call('sdmi_timestep_embedding', _stream(), t=_p(t), out=_p(out), B=t.shape[0], dim=dim,
+         max_period=max_period)
+    return out
+
+
+def act(x, kind, dst_dtype=None):
+    _need_gpu(x)
+    dst_dtype = dst_dtype or x.dtype
+    y = torch.empty(x.shape, dtype=dst_dtype, device=x.device)
+    call('sdmi_act', _stream(), x=_p(x), y=_p(y), src_dtype=_dt(x), dst_dtype=_DT[dst_dtype],
+         act=ACT[kind], n=x.numel())
+    return y
+
+
+def geglu(h):
+    C = h.shape[-1] // 2
+    y = torch.empty(h.shape[:-1] + (C,), dtype=h.dtype, device=h.device)
+    call('sdmi_geglu', _stream(), h=_p(h), y=_p(y), dtype=_dt(h), rows=h.numel() // (2 * C), C=C)
+    return y
+
+
+def add_pos(x, pos):
+    """x [B, P, C] + pos [P, C] (fp32)."""
+    y = torch.empty_like(x)
+    B = x.shape[0]
+    call('sdmi_add_pos', _stream(), x=_p(x), pos=_p(pos), y=_p(y), dtype=_dt(x), B=B,
+         per=x.numel() // B)
+    return y
+
+
+def concat_channels(a, b):
+    Ca, Cb = a.shape[-1], b.shape[-1]
+    y = torch.empty(a.shape[:-1] + (Ca + Cb,), dtype=a.dtype, device=a.device)
+    call('sdmi_concat_channels', _stream(), a=_p(a), b=_p(b), y=_p(y), dtype=_dt(a),
+         rows=a.numel() // Ca, Ca=Ca, Cb=Cb)
+    return y
+
+
+def mask_upsample_argmax(seg, h, w, H, W, want_up=True):
+    """seg [B, h*w, N] fp32 -> (up [B,N,H,W] fp32 or None, idx [B,H,W] int64)."""
+    B, _, N = seg.shape
+    up = torch.empty((B, N, H, W), dtype=torch.float32, device=seg.device) if want_up else None
+    idx = torch.empty((B, H, W), dtype=torch.int64, device=seg.device)
+    call('sdmi_mask_upsample_argmax', _stream(), seg=_p(seg), up=_p(up), idx=_p(idx), B=B, N=N,
+         h=h, w=w, H=H, W=W)
+    return up, idx
+
+
+def mse(pred, target, want_grad=False, gscale=1.0):
+    n = pred.numel()
+    nblk = max(1, min(1024, (n + 2047) // 2048))
+    partial = torch.empty((nblk,), dtype=torch.float32, device=pred.device)
+    out = torch.empty((1,), dtype=torch.float32, device=pred.device)
+    dpred = torch.empty_like(pred) if want_grad else None
+    call('sdmi_mse', _stream(), pred=_p(pred), target=_p(target), out=_p(out), dpred=_p(dpred),
+         partial=_p(partial), dtype=_dt(pred), n=n, nblk=nblk, gscale=gscale)
+    return (out, dpred) if want_grad else out

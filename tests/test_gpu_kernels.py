@@ -1,0 +1,331 @@
+"""Per-kernel parity on a real MI355X: every libsdmi kernel (called through the C ABI via
+slotdiffusion_amd.ops) against the fp32 torch-CPU restatement of the same op.
+
+Tolerances: fp32 path  -> |err| <= 2e-5 * scale (+ index outputs bit-exact);
+            bf16 path  -> relative L2 error <= 1.5e-2 (bf16 has 8 mantissa bits)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = 'cuda'
+
+
+def _ops():
+    from slotdiffusion_amd import ops
+    return ops
+
+
+def rel_l2(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def check(out, ref, dtype, what=''):
+    out = out.float().cpu()
+    if dtype == torch.float32:
+        scale = float(ref.abs().max()) + 1e-6
+        err = float((out - ref).abs().max())
+        assert err <= 2e-5 * scale + 1e-6, f'{what}: fp32 max err {err:.3e} (scale {scale:.3e})'
+    else:
+        e = rel_l2(out, ref)
+        assert e <= 1.5e-2, f'{what}: bf16 rel-L2 {e:.3e}'
+
+
+def q(t, dtype):
+    """Quantise a CPU fp32 tensor to the compute dtype's grid (so both sides see equal inputs)."""
+    return t.to(dtype).float()
+
+
+def nhwc(t, dtype, cpad=None):
+    t = t.permute(0, 2, 3, 1).contiguous()
+    if cpad and cpad != t.shape[-1]:
+        t = F.pad(t, (0, cpad - t.shape[-1]))
+    return t.to(dtype).to(DEV)
+
+
+def pack_w(w, dtype, cpad=None):
+    """[Cout,Cin,kh,kw] -> [Cout, kh*kw*Cpad] K-contiguous."""
+    w = w.permute(0, 2, 3, 1).contiguous()
+    if cpad and cpad != w.shape[-1]:
+        w = F.pad(w, (0, cpad - w.shape[-1]))
+    return w.reshape(w.shape[0], -1).to(dtype).to(DEV)
+
+
+CONV_CASES = [
+    # B, Cin, Cout, H, k, stride, pad(t,b,l,r), ups, extras
+    (2, 16, 32, 12, 3, 1, (1, 1, 1, 1), False, ''),
+    (3, 64, 128, 16, 3, 1, (1, 1, 1, 1), False, 'bias,rowvec,res,silu'),
+    (2, 128, 128, 32, 3, 1, (1, 1, 1, 1), False, 'bias'),            # 128x128 tiles
+    (2, 32, 48, 16, 3, 2, (1, 1, 1, 1), False, 'bias'),              # UNet Downsample
+    (2, 32, 40, 16, 3, 2, (0, 1, 0, 1), False, 'bias'),              # VQ-VAE asymmetric pad
+    (2, 32, 64, 8, 3, 1, (1, 1, 1, 1), True, 'bias'),                # nearest x2 folded in
+    (2, 3, 64, 16, 3, 1, (1, 1, 1, 1), False, 'bias'),               # Cin=3 (channel padded)
+    (2, 128, 3, 16, 3, 1, (1, 1, 1, 1), False, 'bias'),              # Cout=3
+    (2, 64, 96, 8, 1, 1, (0, 0, 0, 0), False, 'bias,res'),           # 1x1
+    (2, 64, 128, 16, 1, 2, (0, 0, 0, 0), False, ''),                 # ResNet downsample 1x1 s2
+    (4, 512, 512, 4, 3, 1, (1, 1, 1, 1), False, 'bias,rowvec'),      # skinny: split-K path
+    (1, 896, 384, 8, 3, 1, (1, 1, 1, 1), False, 'bias'),             # non power-of-two Cin
+]
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('case', CONV_CASES)
+def test_igemm_conv(case, dtype):
+    ops = _ops()
+    B, Cin, Cout, H, k, stride, pad, ups, extras = case
+    g = torch.Generator().manual_seed(hash(case) % 10000)
+    x = q(torch.randn(B, Cin, H, H, generator=g), dtype)
+    w = q(torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k), dtype)
+    bias = torch.randn(Cout, generator=g) if 'bias' in extras else None
+    xin = F.interpolate(x, scale_factor=2, mode='nearest') if ups else x
+    ref = F.conv2d(F.pad(xin, (pad[2], pad[3], pad[0], pad[1])), w, bias, stride=stride)
+    Ho = ref.shape[2]
+    rowvec = torch.randn(B, Cout, generator=g) if 'rowvec' in extras else None
+    res = q(torch.randn(B, Cout, Ho, Ho, generator=g), dtype) if 'res' in extras else None
+    if rowvec is not None:
+        ref = ref + rowvec[:, :, None, None]
+    if res is not None:
+        ref = ref + res
+    if 'silu' in extras:
+        ref = F.silu(ref)
+    vec = ops.vec_of(dtype)
+    cpad = (Cin + vec - 1) // vec * vec
+    out = ops.conv2d(nhwc(x, dtype, cpad), pack_w(w, dtype, cpad),
+                     bias.to(DEV) if bias is not None else None, kh=k, kw=k, stride=stride,
+                     pad=pad, ups=ups, rowvec=rowvec.to(DEV) if rowvec is not None else None,
+                     residual=nhwc(res, dtype) if res is not None else None,
+                     act='silu' if 'silu' in extras else None)
+    assert out.shape == (B, Ho, Ho, Cout)
+    check(out.permute(0, 3, 1, 2), ref, dtype, f'conv {case}')
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('mnk', [(70, 50, 24), (448, 512, 192), (1024, 4096, 512), (64, 1536, 512),
+                                 (4, 2944, 512), (8192, 192, 256)])
+def test_igemm_linear(mnk, dtype):
+    ops = _ops()
+    M, N, K = mnk
+    g = torch.Generator().manual_seed(M + N + K)
+    x = q(torch.randn(M, K, generator=g), dtype)
+    w = q(torch.randn(N, K, generator=g) / math.sqrt(K), dtype)
+    b = torch.randn(N, generator=g)
+    r = q(torch.randn(M, N, generator=g), dtype)
+    ref = F.gelu(F.linear(x, w, b) + r)
+    out = ops.linear(x.to(dtype).to(DEV), w.to(dtype).to(DEV), b.to(DEV),
+                     residual=r.to(dtype).to(DEV), act='gelu')
+    check(out, ref, dtype, f'linear {mnk}')
+    # fp32 output from a low-precision GEMM + strided A view
+    xx = torch.cat([x, x], 1).to(dtype).to(DEV)
+    out2 = ops.linear(xx[:, K:], w.to(dtype).to(DEV), b.to(DEV), out_dtype=torch.float32)
+    check(out2, F.linear(x, w, b), dtype, 'linear strided/f32 out')
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_bmm_nt_and_softmax(dtype):
+    ops = _ops()
+    g = torch.Generator().manual_seed(5)
+    Z, S, C = 2, 160, 64
+    qk = q(torch.randn(Z, S, 2 * C, generator=g), dtype)
+    sc = torch.empty(Z, S, S, dtype=dtype, device=DEV)
+    qkd = qk.to(dtype).to(DEV)
+    ops.bmm_nt(qkd[..., :C], qkd[..., C:], sc)
+    ref = torch.bmm(qk[..., :C], qk[..., C:].transpose(1, 2))
+    check(sc, ref, dtype, 'bmm_nt')
+    ops.softmax_rows_(sc, scale=C ** -0.5)
+    refs = F.softmax(q(ref, dtype) * C ** -0.5, dim=-1)
+    if dtype == torch.float32:
+        check(sc, refs, dtype, 'softmax rows')
+    else:
+        assert rel_l2(sc, refs) < 3e-2
+    # weight-as-row-operand form with per-row bias (V^T in the VQ-VAE attention)
+    wv = q(torch.randn(C, C, generator=g) / 8, dtype)
+    h = q(torch.randn(Z, S, C, generator=g), dtype)
+    bv = torch.randn(C, generator=g)
+    vt = torch.empty(Z, C, S, dtype=dtype, device=DEV)
+    ops.bmm_nt(wv.to(dtype).to(DEV).unsqueeze(0).expand(Z, C, C), h.to(dtype).to(DEV), vt,
+               bias_m=bv.to(DEV))
+    check(vt, (F.linear(h, wv, bv)).transpose(1, 2), dtype, 'bmm_nt weight-row')
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('shape', [(2, 64, 16, 'silu', 1e-5), (3, 128, 32, 'silu', 1e-5),
+                                   (2, 896, 8, 'silu', 1e-5), (2, 384, 8, None, 1e-6),
+                                   (2, 64, 64, 'relu', 1e-5), (1, 1024, 4, 'silu', 1e-5)])
+def test_groupnorm(shape, dtype):
+    ops = _ops()
+    B, C, H, act, eps = shape
+    g = torch.Generator().manual_seed(C + H)
+    x = q(torch.randn(B, C, H, H, generator=g) * 2 + 0.7, dtype)
+    gam, bet = 1 + 0.1 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
+    ref = F.group_norm(x, 32, gam, bet, eps)
+    ref = {'silu': F.silu, 'relu': F.relu, None: lambda v: v}[act](ref)
+    out = ops.group_norm(nhwc(x, dtype), gam.to(DEV), bet.to(DEV), eps=eps, act=act)
+    check(out.permute(0, 3, 1, 2), ref, dtype, f'groupnorm {shape}')
+    # fused residual + relu (ResNet BasicBlock tail)
+    r = q(torch.randn(B, C, H, H, generator=g), dtype)
+    out = ops.group_norm(nhwc(x, dtype), gam.to(DEV), bet.to(DEV), eps=eps, act='relu',
+                         residual=nhwc(r, dtype))
+    check(out.permute(0, 3, 1, 2), F.relu(F.group_norm(x, 32, gam, bet, eps) + r), dtype,
+          'groupnorm+res')
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('C', [192, 256, 384, 512])
+def test_layernorm(C, dtype):
+    ops = _ops()
+    g = torch.Generator().manual_seed(C)
+    x = q(torch.randn(37, C, generator=g) * 1.5 - 0.3, dtype)
+    gam, bet = 1 + 0.1 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
+    out = ops.layer_norm(x.to(dtype).to(DEV), gam.to(DEV), bet.to(DEV))
+    check(out, F.layer_norm(x, (C,), gam, bet, 1e-5), dtype, f'layernorm {C}')
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('cfg', [(2, 8, 256, 256), (2, 12, 64, 64), (3, 16, 16, 16), (2, 8, 256, 7),
+                                 (2, 16, 16, 15)])
+def test_attention(cfg, dtype):
+    ops = _ops()
+    B, heads, Sq, Skv = cfg
+    C = heads * 32
+    g = torch.Generator().manual_seed(Sq * 7 + Skv)
+    qq = q(torch.randn(B, Sq, C, generator=g), dtype)
+    kv = q(torch.randn(B, Skv, 2 * C, generator=g), dtype)
+
+    def split(t, S):
+        return t.view(B, S, heads, 32).permute(0, 2, 1, 3)
+    sim = torch.einsum('bhid,bhjd->bhij', split(qq, Sq), split(kv[..., :C].contiguous(), Skv)) * 32 ** -0.5
+    ref = torch.einsum('bhij,bhjd->bhid', sim.softmax(-1), split(kv[..., C:].contiguous(), Skv))
+    ref = ref.permute(0, 2, 1, 3).reshape(B, Sq, C)
+    kvd = kv.to(dtype).to(DEV)
+    out = ops.attention(qq.to(dtype).to(DEV), kvd[..., :C], kvd[..., C:], heads)
+    check(out, ref, dtype, f'attention {cfg}')
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('cfg', [(2, 7, 192, 384, 3, 1024), (2, 15, 192, 384, 2, 256),
+                                 (1, 11, 128, 256, 3, 100)])
+def test_slot_attention_fused(cfg, dtype):
+    from oracle import slotdiff_oracle as O
+    ops = _ops()
+    B, N, D, Hd, iters, M = cfg
+    g = torch.Generator().manual_seed(N * D)
+    r = lambda *s: torch.randn(*s, generator=g)
+    name = 'sa'
+    W = {f'{name}.project_q.0.weight': 1 + 0.1 * r(D), f'{name}.project_q.0.bias': 0.1 * r(D),
+         f'{name}.project_q.1.weight': r(D, D) / math.sqrt(D),
+         f'{name}.gru.weight_ih': r(3 * D, D) / math.sqrt(D), f'{name}.gru.weight_hh': r(3 * D, D) / math.sqrt(D),
+         f'{name}.gru.bias_ih': 0.1 * r(3 * D), f'{name}.gru.bias_hh': 0.1 * r(3 * D),
+         f'{name}.mlp.0.weight': 1 + 0.1 * r(D), f'{name}.mlp.0.bias': 0.1 * r(D),
+         f'{name}.mlp.1.weight': r(Hd, D) / math.sqrt(D), f'{name}.mlp.1.bias': 0.1 * r(Hd),
+         f'{name}.mlp.3.weight': r(D, Hd) / math.sqrt(Hd), f'{name}.mlp.3.bias': 0.1 * r(D)}
+    kv = q(r(B, M, 2 * D), dtype)
+    k, v = kv[..., :D], kv[..., D:]
+    init = r(N, D)
+    # oracle with identity input-LN / projections: feed k, v directly
+    slots = init.repeat(B, 1, 1)
+    seg = None
+    for it in range(iters):
+        prev = slots
+        qv = F.linear(F.layer_norm(slots, (D,), W[f'{name}.project_q.0.weight'],
+                                   W[f'{name}.project_q.0.bias']), W[f'{name}.project_q.1.weight'])
+        att = F.softmax(D ** -0.5 * torch.einsum('bmc,bnc->bmn', k, qv), dim=-1)
+        if it == iters - 1:
+            seg = att.clone()
+        att = att + 1e-6
+        att = att / att.sum(1, keepdim=True)
+        upd = torch.einsum('bmn,bmc->bnc', att, v)
+        slots = O.gru_cell(W, f'{name}.gru', upd.reshape(B * N, D), prev.reshape(B * N, D)).view(B, N, D)
+        hid = F.relu(F.linear(F.layer_norm(slots, (D,), W[f'{name}.mlp.0.weight'], W[f'{name}.mlp.0.bias']),
+                              W[f'{name}.mlp.1.weight'], W[f'{name}.mlp.1.bias']))
+        slots = slots + F.linear(hid, W[f'{name}.mlp.3.weight'], W[f'{name}.mlp.3.bias'])
+    P = dict(lnq_g=W[f'{name}.project_q.0.weight'], lnq_b=W[f'{name}.project_q.0.bias'],
+             wq=W[f'{name}.project_q.1.weight'], w_ih=W[f'{name}.gru.weight_ih'],
+             w_hh=W[f'{name}.gru.weight_hh'], b_ih=W[f'{name}.gru.bias_ih'], b_hh=W[f'{name}.gru.bias_hh'],
+             lnm_g=W[f'{name}.mlp.0.weight'], lnm_b=W[f'{name}.mlp.0.bias'], w1=W[f'{name}.mlp.1.weight'],
+             b1=W[f'{name}.mlp.1.bias'], w2=W[f'{name}.mlp.3.weight'], b2=W[f'{name}.mlp.3.bias'])
+    P = {a: b.contiguous().to(DEV) for a, b in P.items()}
+    kvd = kv.to(dtype).to(DEV)
+    s_out, seg_out = ops.slot_attention(kvd[..., :D], kvd[..., D:], init.to(DEV), P, iters=iters,
+                                        eps=1e-6)
+    # math is fp32 in both dtypes (inputs identical after quantisation) -> fp32-level tolerance
+    check(s_out, slots, torch.float32, f'slots {cfg}')
+    check(seg_out, seg, torch.float32, f'seg {cfg}')
+    agree = (seg_out.cpu().argmax(-1) == seg.argmax(-1)).float().mean()
+    assert agree == 1.0, f'mask argmax agreement {agree}'
+
+
+def test_vq_nearest_bit_exact():
+    from oracle import slotdiff_oracle as O
+    ops = _ops()
+    g = torch.Generator().manual_seed(11)
+    cb = torch.randn(4096, 3, generator=g) / math.sqrt(3)
+    z = torch.randn(4, 3, 32, 32, generator=g) * 1.3
+    W = {'p.quantize.embedding.weight': cb}
+    zq_ref, idx_ref = O.vq_quantize(W, z, 'p')
+    zp = F.pad(z.permute(0, 2, 3, 1), (0, 1)).contiguous().to(DEV)
+    idx, zq = ops.vq_nearest(zp, cb.to(DEV))
+    assert torch.equal(idx.cpu(), idx_ref), float((idx.cpu() != idx_ref).float().mean())
+    assert torch.equal(zq.cpu()[..., :3], zq_ref.permute(0, 2, 3, 1))
+    assert float(zq[..., 3].abs().max()) == 0.
+    # adversarial near-ties: latents on code midpoints
+    zt = ((cb[:2048] + cb[2048:]) * 0.5).view(2, 1024, 3).permute(0, 2, 1).reshape(2, 3, 32, 32)
+    _, idx_ref = O.vq_quantize(W, zt, 'p')
+    idx, _ = ops.vq_nearest(F.pad(zt.permute(0, 2, 3, 1), (0, 1)).contiguous().to(DEV), cb.to(DEV))
+    assert torch.equal(idx.cpu(), idx_ref)
+
+
+def test_elementwise_family():
+    ops = _ops()
+    g = torch.Generator().manual_seed(3)
+    a, b, c = (torch.randn(2, 32, 32, 4, generator=g) for _ in range(3))
+    out = ops.lincomb(0.7, a.to(DEV), -1.3, b.to(DEV), 0.25, c.to(DEV), b.to(DEV), div=0.9)
+    ref = ((0.7 * a + (-1.3) * b) + 0.25 * (c - b)) / 0.9
+    assert float((out.cpu() - ref).abs().max()) <= 2e-6
+    out = ops.lincomb(1.0, a.to(DEV), -0.5, b.to(DEV), div=0.3)
+    assert torch.equal(out.cpu(), (a - 0.5 * b) / torch.tensor(0.3))
+    ca, cb = torch.rand(2, generator=g), torch.rand(2, generator=g)
+    out = ops.row_lincomb(a.to(DEV), b.to(DEV), ca.to(DEV), cb.to(DEV))
+    assert float((out.cpu() - (ca.view(2, 1, 1, 1) * a + cb.view(2, 1, 1, 1) * b)).abs().max()) <= 1e-6
+    # layouts
+    x = torch.randn(2, 3, 8, 8, generator=g)
+    for dt in (torch.float32, torch.bfloat16):
+        n = ops.nchw_to_nhwc(x.to(DEV), dt, 8)
+        assert n.shape == (2, 8, 8, 8) and float(n[..., 3:].float().abs().max()) == 0
+        back = ops.nhwc_to_nchw(n, 3)
+        assert torch.equal(back.cpu(), x.to(dt).float())
+    # timestep embedding, fractional t
+    from oracle import slotdiff_oracle as O
+    t = torch.tensor([0., 37., 123.456, 998.999])
+    emb = ops.timestep_embedding(t.to(DEV), 128)
+    assert float((emb.cpu() - O.timestep_embedding(t, 128)).abs().max()) <= 3e-4  # args up to 1e3 rad
+    small = torch.tensor([0.5, 3.25])
+    assert float((ops.timestep_embedding(small.to(DEV), 128).cpu() - O.timestep_embedding(small, 128)).abs().max()) <= 2e-6
+    # geglu, concat, add_pos, act
+    h = torch.randn(5, 7, 2 * 64, generator=g)
+    xg, gate = h.chunk(2, -1)
+    assert float((ops.geglu(h.to(DEV)).cpu() - xg * F.gelu(gate)).abs().max()) <= 2e-6
+    p, r = torch.randn(3, 10, 16, generator=g), torch.randn(3, 10, 24, generator=g)
+    assert torch.equal(ops.concat_channels(p.to(DEV), r.to(DEV)).cpu(), torch.cat([p, r], -1))
+    pos = torch.randn(10, 16, generator=g)
+    assert torch.equal(ops.add_pos(p.to(DEV), pos.to(DEV)).cpu(), p + pos)
+    assert float((ops.act(p.to(DEV), 'silu').cpu() - F.silu(p)).abs().max()) <= 2e-6
+    # mse
+    pr, tg = torch.randn(2, 32, 32, 4, generator=g), torch.randn(2, 32, 32, 4, generator=g)
+    val, grad = ops.mse(pr.to(DEV), tg.to(DEV), want_grad=True)
+    assert abs(float(val) - float(F.mse_loss(pr, tg))) <= 1e-6
+    assert float((grad.cpu() - 2 * (pr - tg) / pr.numel()).abs().max()) <= 1e-9
+
+
+def test_mask_upsample_argmax_matches_torch():
+    ops = _ops()
+    g = torch.Generator().manual_seed(2)
+    seg = torch.softmax(torch.randn(2, 32 * 32, 7, generator=g) * 2, -1)
+    m = seg.permute(0, 2, 1).reshape(2 * 7, 1, 32, 32)
+    ref = F.interpolate(m, (128, 128), mode='bilinear', align_corners=False).view(2, 7, 128, 128)
+    up, idx = ops.mask_upsample_argmax(seg.to(DEV), 32, 32, 128, 128)
+    assert float((up.cpu() - ref).abs().max()) <= 2e-7
+    assert torch.equal(idx.cpu(), ref.argmax(1))

@@ -1,0 +1,92 @@
+"""CPU-side checks: C-ABI exports, host logic (DPM plan, model registry/keys), loud failure
+without a GPU.  No kernel is launched here."""
+import pytest
+import torch
+
+from slotdiffusion_amd import _lib, dpm, module
+from tests import common as C
+
+
+def test_library_exports_every_declared_symbol():
+    structs, funcs, enums = _lib.parse_header()
+    assert len(funcs) >= 25 and 'sdmi_igemm' in funcs and 'sdmi_slot_attention' in funcs
+    L = _lib.lib()                       # raises if the .so or any declared symbol is missing
+    assert L.sdmi_version() == 100
+    for name in funcs:
+        assert hasattr(L, name), name
+
+
+def test_ops_refuse_cpu_tensors():
+    from slotdiffusion_amd import ops
+    x = torch.zeros(1, 4, 4, 8)
+    with pytest.raises(_lib.SdmiError):
+        ops.group_norm(x, torch.ones(8), torch.zeros(8), eps=1e-5, groups=2)
+
+
+def test_invalid_arguments_are_rejected_without_launch():
+    # validation happens before any HIP call, so this is safe on a GPU-less host
+    with pytest.raises(_lib.SdmiError):
+        _lib.call('sdmi_igemm', None, a=16, w=16, out=16, dtype=7, M=1, N=1, K=1)
+    assert b'dtype' in _lib.lib().sdmi_last_error()
+
+
+def test_dpm_plan_matches_oracle_exactly():
+    from oracle import slotdiff_oracle as O
+    betas = torch.tensor(module.ddpm_schedule(1000, 'linear', 0.0015, 0.0195)['betas'],
+                         dtype=torch.float32)
+    plan = dpm.build_plan(betas, 20, 3)
+    G = C.load_golden()
+    assert torch.equal(plan['outer'], G['dpm_outer'])
+    assert plan['orders'] == G['dpm_orders'].tolist()
+    ns = O.NoiseScheduleDiscrete(betas)
+    outer, orders = O.dpm_orders_and_timesteps(20, 3, 1.0, 1e-3)
+    f = lambda v: float(v.reshape(-1)[0])
+    nfe = 0
+    for i, od in enumerate(orders):
+        c = O.dpm_step_coeffs(ns, outer[i], outer[i + 1], od)
+        st = plan['steps'][i]
+        assert st['order'] == od and len(st['evals']) == od
+        nfe += od
+        assert st['evals'][0]['sigma'] == f(ns.std(c['s'])) and st['evals'][0]['alpha'] == f(ns.alpha(c['s']))
+        assert st['evals'][0]['t_input'] == f((c['s'] - 1e-3) * 1000.)
+        assert st['final']['c0'] == f(c['sigma_t'] / c['sigma_s'])
+        assert st['final']['c1'] == f(-(c['alpha_t'] * c['phi_1']))
+        if od >= 2:
+            assert st['evals'][1]['t'] == f(c['s1'])
+            assert st['to_s1']['c0'] == f(c['sigma_s1'] / c['sigma_s'])
+            assert st['to_s1']['c1'] == f(-(c['alpha_s1'] * c['phi_11']))
+        if od == 2:
+            assert st['final']['c2'] == f(-(0.5 / c['r1']) * (c['alpha_t'] * c['phi_1']))
+        if od == 3:
+            assert st['evals'][2]['t'] == f(c['s2'])
+            assert st['to_s2']['c2'] == f(c['r2'] / c['r1'] * (c['alpha_s2'] * c['phi_22']))
+            assert st['final']['c2'] == f((1. / c['r2']) * (c['alpha_t'] * c['phi_2']))
+    assert nfe == 20 and len(dpm.plan_t_inputs(plan)) == 20
+
+
+def test_model_registry_and_checkpoint_keys():
+    from slotdiffusion_amd.models import SADiffusion, build_model
+    cfg = C.clevrtex_cfg()
+
+    class P:
+        model = 'SADiffusion'
+    for k, v in cfg.items():
+        setattr(P, k, v)
+    m = build_model(P)
+    assert isinstance(m, SADiffusion)
+    ref = C.load_keys()['img_based/SADiffusion/clevrtex-7slot']
+    sd = m.state_dict()
+    assert [(k, list(v.shape)) for k, v in sd.items()] == [(k, s) for k, s, _ in ref['state']]
+    frozen = {n for n, p in m.named_parameters() if not p.requires_grad}
+    assert frozen == set(ref['frozen'])
+    # optimizer grouping contract: 'dm_decoder' in the parameter name (method.py:307-313)
+    assert any('dm_decoder' in n for n, _ in m.named_parameters())
+    w = dict(m.named_parameters())['dm_decoder.model.diffusion_model.input_blocks.1.0.in_layers.2.weight']
+    assert w.is_contiguous(memory_format=torch.channels_last)
+    # round trip through a reference-layout (NCHW-contiguous) state dict
+    sd2 = {k: v.clone().contiguous() for k, v in sd.items()}
+    m.load_state_dict(sd2)
+    assert dict(m.named_parameters())[
+        'encoder.conv1.weight'].is_contiguous(memory_format=torch.channels_last)
+    # schedule buffers equal the oracle's recipe
+    assert torch.equal(m.dm_decoder.betas, C.oracle_weights(cfg)['dm_decoder.betas'])
