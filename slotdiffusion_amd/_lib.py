@@ -99,8 +99,57 @@ def lib():
     return _lib
 
 
+class KernelTimer:
+    """Optional per-call HIP-event timing (bench.py's roofline leg).  Events are recorded on the
+    stream the kernels are launched on (torch's current stream), so the durations are those of
+    the launches themselves.  Enable with `with KernelTimer() as kt: ...; kt.summary()`."""
+    active = None
+
+    def __init__(self):
+        self.records = []
+
+    def __enter__(self):
+        KernelTimer.active = self
+        return self
+
+    def __exit__(self, *a):
+        KernelTimer.active = None
+
+    def summary(self):
+        import torch
+        torch.cuda.synchronize()
+        out = {}
+        for name, e0, e1, meta in self.records:
+            d = out.setdefault(name, dict(calls=0, ms=0.0, flops=0.0, bytes=0.0))
+            d['calls'] += 1
+            d['ms'] += e0.elapsed_time(e1)
+            d['flops'] += meta.get('flops', 0.0)
+            d['bytes'] += meta.get('bytes', 0.0)
+        return out
+
+
+def _meta(fname, kw):
+    if fname == 'sdmi_igemm':
+        b = max(1, kw.get('batch', 1))
+        return dict(flops=2.0 * kw['M'] * kw['N'] * kw['K'] * b)
+    return {}
+
+
 def call(fname, stream, **kw):
     """Invoke `fname` with its argument struct filled from keyword args (missing fields = 0)."""
+    kt = KernelTimer.active
+    if kt is not None:
+        import torch
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _call(fname, stream, **kw)
+        e1.record()
+        kt.records.append((fname, e0, e1, _meta(fname, kw)))
+        return
+    _call(fname, stream, **kw)
+
+
+def _call(fname, stream, **kw):
     L = lib()
     sname = FUNCS[fname]
     args = CSTRUCT[sname]()

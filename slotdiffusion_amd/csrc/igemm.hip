@@ -115,8 +115,13 @@ __global__ __launch_bounds__(256) void igemm_kernel(SdmiGemmArgs p, int tiles_m,
   u32x4 ra[A_VECS], rb[B_VECS];
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
 
+  // Loads are issued unconditionally from a clamped (always valid) address so the compiler can
+  // keep all of a tile's global loads in flight together; out-of-image / K-tail vectors are
+  // zeroed when the registers are written to LDS (mask bits travel with the tile).
+  unsigned okmask = 0;
   auto load_tile = [&]() __attribute__((always_inline)) {
     const bool k_ok = kk < p.K;
+    okmask = 0;
 #pragma unroll
     for (int i = 0; i < A_VECS; ++i) {
       bool ok = a_ok[i] && k_ok;
@@ -134,11 +139,15 @@ __global__ __launch_bounds__(256) void igemm_kernel(SdmiGemmArgs p, int tiles_m,
         }
         off = (a_pix[i] + (long long)iy * p.W + ix) * p.lda + ci;
       }
-      ra[i] = ok ? *reinterpret_cast<const u32x4*>(Ag + off) : zero4;
+      off = ok ? off : 0;
+      okmask |= (ok ? 1u : 0u) << i;
+      ra[i] = *reinterpret_cast<const u32x4*>(Ag + off);
     }
 #pragma unroll
     for (int i = 0; i < B_VECS; ++i) {
-      rb[i] = (b_ok[i] && k_ok) ? *reinterpret_cast<const u32x4*>(Wg + b_off[i] + kk) : zero4;
+      const bool ok = b_ok[i] && k_ok;
+      okmask |= (ok ? 1u : 0u) << (A_VECS + i);
+      rb[i] = *reinterpret_cast<const u32x4*>(Wg + (ok ? b_off[i] + kk : 0));
     }
     // advance k state to the next tile
     kk += BK;
@@ -155,12 +164,14 @@ __global__ __launch_bounds__(256) void igemm_kernel(SdmiGemmArgs p, int tiles_m,
 #pragma unroll
     for (int i = 0; i < A_VECS; ++i) {
       const int row = (tid + i * 256) / VPR;
-      *reinterpret_cast<u32x4*>(base + row * ROWB + kc * 16) = ra[i];
+      *reinterpret_cast<u32x4*>(base + row * ROWB + kc * 16) =
+          ((okmask >> i) & 1u) ? ra[i] : zero4;
     }
 #pragma unroll
     for (int i = 0; i < B_VECS; ++i) {
       const int row = (tid + i * 256) / VPR;
-      *reinterpret_cast<u32x4*>(base + BM * ROWB + row * ROWB + kc * 16) = rb[i];
+      *reinterpret_cast<u32x4*>(base + BM * ROWB + row * ROWB + kc * 16) =
+          ((okmask >> (A_VECS + i)) & 1u) ? rb[i] : zero4;
     }
   };
 
@@ -242,32 +253,80 @@ __global__ __launch_bounds__(256) void igemm_kernel(SdmiGemmArgs p, int tiles_m,
   const char* resp = (const char*)p.residual;
   const long long zc = (long long)zb * p.sc, zr = (long long)zb * p.sr;
   const int HoWo = p.Ho * p.Wo;
+  const bool out_bf16 = p.out_dtype == SDMI_BF16;
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int n = n0 + wn * WTN + j * 32 + col_l;
-      if (n >= p.N) continue;
-      const float bn = (p.bias && !p.bias_m) ? p.bias[n] : 0.f;
+      const bool n_ok = n < p.N;
+      const float bn = (p.bias && !p.bias_m && n_ok) ? p.bias[n] : 0.f;
+      const int mbase = m0 + wm * WTM + i * 32 + row_l;
+      // phase 1: gather every epilogue operand of this 32x32 tile.  Indices are clamped into
+      // range so all loads are unconditional and in flight together (`out` may alias
+      // `residual`, so no load may be interleaved with the stores of phase 2).
+      const int nc = n_ok ? n : p.N - 1;
+      float add[16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + row_l;
-        if (m >= p.M) continue;
-        float v = acc[i][j][r] * p.alpha + bn;
-        if (p.bias && p.bias_m) v += p.bias[m];
-        if (p.rowvec) {
+      for (int r = 0; r < 16; ++r) add[r] = bn;
+      if (p.bias && p.bias_m) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = min(mbase + (r & 3) + 8 * (r >> 2), p.M - 1);
+          add[r] += p.bias[m];
+        }
+      }
+      if (p.rowvec) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = min(mbase + (r & 3) + 8 * (r >> 2), p.M - 1);
           const int b = hw_shift >= 0 ? (m >> hw_shift) : (m / HoWo);
-          v += p.rowvec[(long long)b * p.ldrv + n];
+          add[r] += p.rowvec[(long long)b * p.ldrv + nc];
         }
-        if (resp) {
-          const long long ro = zr + (long long)m * p.ldr + n;
-          v += p.out_dtype == SDMI_BF16 ? bf16_to_f32(((const bf16_t*)resp)[ro])
-                                        : ((const float*)resp)[ro];
+      }
+      if (resp) {
+        if (out_bf16) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int m = min(mbase + (r & 3) + 8 * (r >> 2), p.M - 1);
+            add[r] += bf16_to_f32(((const bf16_t*)resp)[zr + (long long)m * p.ldr + nc]);
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int m = min(mbase + (r & 3) + 8 * (r >> 2), p.M - 1);
+            add[r] += ((const float*)resp)[zr + (long long)m * p.ldr + nc];
+          }
         }
-        v = act_apply(v, p.act);
-        const long long oo = zc + (long long)m * p.ldc + n;
-        if (p.out_dtype == SDMI_BF16) ((bf16_t*)outp)[oo] = f32_to_bf16(v);
-        else ((float*)outp)[oo] = v;
+      }
+      // phase 2: finish and store (uniform switches hoisted out of the element loops)
+      float v[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] = acc[i][j][r] * p.alpha + add[r];
+      if (p.act == SDMI_ACT_SILU) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = act_apply(v[r], SDMI_ACT_SILU);
+      } else if (p.act == SDMI_ACT_RELU) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.f);
+      } else if (p.act == SDMI_ACT_GELU) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = act_apply(v[r], SDMI_ACT_GELU);
+      }
+      if (out_bf16) {
+        bf16_t* o = (bf16_t*)outp + zc + n;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = mbase + (r & 3) + 8 * (r >> 2);
+          if (n_ok && m < p.M) o[(long long)m * p.ldc] = f32_to_bf16(v[r]);
+        }
+      } else {
+        float* o = (float*)outp + zc + n;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = mbase + (r & 3) + 8 * (r >> 2);
+          if (n_ok && m < p.M) o[(long long)m * p.ldc] = v[r];
+        }
       }
     }
 }
@@ -348,7 +407,7 @@ int dispatch(const SdmiGemmArgs& p, hipStream_t st) {
   }
   const int batch = p.batch > 0 ? p.batch : 1;
   const long long t128 = (long long)((p.M + 127) / 128) * ((p.N + 127) / 128) * batch;
-  const bool big = p.N > 64 && t128 >= 96;
+  const bool big = p.N > 64 && t128 >= 192;
   // K tile: 128 bytes of K per row when K is deep enough, else 64
   const int kbytes = p.K * (int)sizeof(T);
   const bool wide = kbytes >= 512;
@@ -357,7 +416,7 @@ int dispatch(const SdmiGemmArgs& p, hipStream_t st) {
   else if (!big && batch == 1 && p.workspace) {
     const long long t64 = (long long)((p.M + 63) / 64) * ((p.N + 63) / 64);
     const int nk = (kbytes + (wide ? 127 : 63)) / (wide ? 128 : 64);
-    while (t64 * split_k < 192 && split_k * 2 <= nk / 4 && split_k < 16) split_k *= 2;
+    while (t64 * split_k < 384 && split_k * 2 <= nk / 4 && split_k < 16) split_k *= 2;
   }
   if (split_k > 1 && !p.workspace) split_k = 1;
   (void)VEC;

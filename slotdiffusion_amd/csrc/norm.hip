@@ -56,29 +56,33 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(SdmiGroupNormArgs p) {
   }
 }
 
-// finalize: mean / rstd per (b, group) from the split partials. one thread per (b, g).
-__global__ void gn_finalize_kernel(SdmiGroupNormArgs p) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= p.B * p.groups) return;
-  const int b = idx / p.groups, g = idx % p.groups;
-  double s = 0.0, ss = 0.0;
-  for (int k = 0; k < p.nsplit; ++k) {
-    const float* q = p.partial + (((long long)b * p.nsplit + k) * p.groups + g) * 2;
-    s += (double)q[0];
-    ss += (double)q[1];
-  }
-  const double n = (double)p.HW * (p.C / p.groups);
-  const double mean = s / n;
-  double var = ss / n - mean * mean;
-  if (var < 0.0) var = 0.0;
-  p.stats[idx * 2 + 0] = (float)mean;
-  p.stats[idx * 2 + 1] = (float)(1.0 / sqrt(var + (double)p.eps));
-}
-
 template <typename T>
 __global__ __launch_bounds__(256) void gn_apply_kernel(SdmiGroupNormArgs p, int rows_per) {
   constexpr int VEC = Elem<T>::VEC;
+  __shared__ float s_stats[128][2];
   const int b = blockIdx.y;
+  // mean / rstd of this image's groups from the split partials (fp64 combine, fixed order)
+  if ((int)threadIdx.x < p.groups) {
+    const int g = threadIdx.x;
+    double s = 0.0, ss = 0.0;
+    for (int k = 0; k < p.nsplit; ++k) {
+      const float* q = p.partial + (((long long)b * p.nsplit + k) * p.groups + g) * 2;
+      s += (double)q[0];
+      ss += (double)q[1];
+    }
+    const double n = (double)p.HW * (p.C / p.groups);
+    const double mean = s / n;
+    double var = ss / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float mf = (float)mean, rf = (float)(1.0 / sqrt(var + (double)p.eps));
+    s_stats[g][0] = mf;
+    s_stats[g][1] = rf;
+    if (blockIdx.x == 0) {
+      p.stats[(b * p.groups + g) * 2 + 0] = mf;
+      p.stats[(b * p.groups + g) * 2 + 1] = rf;
+    }
+  }
+  __syncthreads();
   const int CV = p.C / VEC, CVp = next_pow2(CV);
   const int R = 256 / CVp;
   const int cv = threadIdx.x % CVp, r0 = threadIdx.x / CVp;
@@ -92,8 +96,8 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(SdmiGroupNormArgs p, int 
   for (int j = 0; j < VEC; ++j) {
     const int c = cv * VEC + j;
     const int g = c / cpg;
-    const float mean = p.stats[(b * p.groups + g) * 2 + 0];
-    const float rstd = p.stats[(b * p.groups + g) * 2 + 1];
+    const float mean = s_stats[g][0];
+    const float rstd = s_stats[g][1];
     sc[j] = rstd * p.gamma[c];
     sh[j] = p.beta[c] - mean * sc[j];
   }
@@ -190,15 +194,13 @@ extern "C" int sdmi_groupnorm_stats(const SdmiGroupNormArgs* a, void* stream) {
   dim3 grid(a->nsplit, a->B);
   if (a->dtype == SDMI_BF16) hipLaunchKernelGGL(gn_stats_kernel<bf16_t>, grid, dim3(256), 0, st, *a);
   else hipLaunchKernelGGL(gn_stats_kernel<float>, grid, dim3(256), 0, st, *a);
-  const int n = a->B * a->groups;
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3((n + 255) / 256), dim3(256), 0, st, *a);
   return sdmi_check_launch("groupnorm_stats");
 }
 
 extern "C" int sdmi_groupnorm_apply(const SdmiGroupNormArgs* a, void* stream) {
   int rc = gn_validate(a);
   if (rc) return rc;
-  SDMI_REQUIRE(a->y, "null output");
+  SDMI_REQUIRE(a->y && a->partial, "null output / partial");
   hipStream_t st = (hipStream_t)stream;
   // ~32 KiB of activations per workgroup, at least one row-sweep each
   const long long row_bytes = (long long)a->C * (a->dtype == SDMI_BF16 ? 2 : 4);

@@ -60,7 +60,7 @@ def conv2d(x, w, bias=None, *, kh=3, kw=3, stride=1, pad=(1, 1, 1, 1), ups=False
     if split_k != 1:
         t64 = ((M + 63) // 64) * ((N + 63) // 64)
         t128 = ((M + 127) // 128) * ((N + 127) // 128)
-        if not (N > 64 and t128 >= 96) and t64 < 192 and K * x.element_size() >= 2048:
+        if not (N > 64 and t128 >= 192) and t64 < 384 and K * x.element_size() >= 2048:
             ws = torch.empty((16 * M * N,), dtype=torch.float32, device=x.device)
     call('sdmi_igemm', _stream(), a=_p(x), w=_p(w), out=_p(out), bias=_p(bias), rowvec=_p(rowvec),
          residual=_p(residual), workspace=_p(ws), dtype=_dt(x), out_dtype=_DT[odt], M=M, N=N, K=K,
@@ -86,7 +86,7 @@ def linear(x, w, bias=None, *, act=None, residual=None, out=None, out_dtype=None
     ws = None
     t64 = ((M + 63) // 64) * ((N + 63) // 64)
     t128 = ((M + 127) // 128) * ((N + 127) // 128)
-    if not (N > 64 and t128 >= 96) and t64 < 192 and K * x.element_size() >= 2048:
+    if not (N > 64 and t128 >= 192) and t64 < 384 and K * x.element_size() >= 2048:
         ws = torch.empty((16 * M * N,), dtype=torch.float32, device=x.device)
     call('sdmi_igemm', _stream(), a=_p(x), w=_p(w), out=_p(out), bias=_p(bias),
          residual=_p(residual), workspace=_p(ws), dtype=_dt(x), out_dtype=_DT[odt], M=M, N=N, K=K,
