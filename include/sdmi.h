@@ -65,6 +65,8 @@ typedef struct {
   int split_k;
   int batch;
   int ldrv;             /* row pitch of rowvec (>= N) */
+  int zins;             /* >1: input is read through virtual zero-insertion upsampling by zins
+                           (data-gradient of a stride-`zins` conv: flipped weights, stride=1) */
   long long sa, sw, sc, sr;
 } SdmiGemmArgs;
 int sdmi_igemm(const SdmiGemmArgs* a, void* stream);
@@ -262,6 +264,54 @@ typedef struct {
   int dtype; long long n; int nblk; float gscale;
 } SdmiMseArgs;
 int sdmi_mse(const SdmiMseArgs* a, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Backward helpers.
+ * ------------------------------------------------------------------------------------------ */
+/* dgrad operand: dst[ci][kh'][kw'][co] = src[co][KH-1-kh'][KW-1-kw'][ci]  (flip + transpose), so the
+ * data gradient of a conv is sdmi_igemm on dY with this operand (pad' = K-1-pad, zins = stride). */
+typedef struct { const void* src; void* dst; int dtype; int Cout, KH, KW, Cin, CoutPad; } SdmiPackDgradArgs;
+/* dst row pitch CoutPad >= Cout (pad columns must be pre-zeroed by the caller) */
+int sdmi_pack_dgrad(const SdmiPackDgradArgs* a, void* stream);
+/* out[g][n] = sum over the `rows_per` consecutive rows of group g of x[m][n] (fp32 out):
+ * gradient of the per-image time-embedding row vector, bias gradients (rows_per = M). */
+typedef struct { const void* x; float* out; int dtype; int groups, rows_per, N, ldx; } SdmiRowGroupSumArgs;
+int sdmi_rowgroup_sum(const SdmiRowGroupSumArgs* a, void* stream);
+/* y[b][y][x][c] = sum of the 2x2 block of x (backward of the nearest x2 upsample folded into a conv) */
+typedef struct { const void* x; void* y; int dtype; int B, H, W, C; } SdmiPool2x2Args;
+int sdmi_pool2x2_sum(const SdmiPool2x2Args* a, void* stream);
+/* y = x + z elementwise in `dtype` (gradient accumulation at residual / skip joins) */
+typedef struct { const void* x; const void* z; void* y; int dtype; long long n; } SdmiAddArgs;
+int sdmi_add(const SdmiAddArgs* a, void* stream);
+/* split of a channel concat: a[r][:Ca] = y[r][:Ca], b[r][:Cb] = y[r][Ca:] */
+typedef struct { const void* y; void* a; void* b; int dtype; long long rows; int Ca, Cb; } SdmiSplitArgs;
+int sdmi_split_channels(const SdmiSplitArgs* a, void* stream);
+/* dx = dy * act'(x) (SiLU on the time embedding path) */
+typedef struct { const void* x; const void* dy; void* dx; int dtype, act; long long n; } SdmiActBwdArgs;
+int sdmi_act_bwd(const SdmiActBwdArgs* a, void* stream);
+
+/* Training-mode Slot Attention (one iteration's streaming pass + its backward; the [B*N, D]
+ * mat-vecs of the iteration run on sdmi_igemm / sdmi_wgrad).  sa_diffusion.py:40-58.
+ *   attn [B][M][N] = softmax over slots;  den [B][N] = sum_m (attn+eps);  upd [B][N][D]. */
+typedef struct {
+  const void* k; const void* v; const float* q; float* attn; float* upd; float* den;
+  int dtype; int B, M, N, D, ldkv; float eps, scale;
+} SdmiSaAttendArgs;
+int sdmi_sa_attend_fwd(const SdmiSaAttendArgs* a, void* stream);
+typedef struct {
+  const void* k; const void* v; const float* q; const float* attn; const float* upd;
+  const float* den; const float* dupd; float* dq; void* dk; void* dv;
+  int dtype; int B, M, N, D, ldkv; float eps, scale;
+} SdmiSaAttendBwdArgs;
+int sdmi_sa_attend_bwd(const SdmiSaAttendBwdArgs* a, void* stream);
+/* GRUCell gate arithmetic on gi = W_ih x + b_ih, gh = W_hh h + b_hh ([R][3D], gates r,z,n). */
+typedef struct { const float* gi; const float* gh; const float* h; float* hout; int R, D; } SdmiGruGatesArgs;
+int sdmi_gru_gates(const SdmiGruGatesArgs* a, void* stream);
+typedef struct {
+  const float* gi; const float* gh; const float* h; const float* dhout;
+  float* dgi; float* dgh; float* dh; int R, D;
+} SdmiGruGatesBwdArgs;
+int sdmi_gru_gates_bwd(const SdmiGruGatesBwdArgs* a, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Optimiser: global-norm clip + Adam over a flat fp32 arena (two lr groups), and bf16 shadow

@@ -6,7 +6,8 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 OUT = os.path.join(HERE, '..', 'libsdmi.so')
-SOURCES = ['api.cpp', 'pending.cpp', 'igemm.hip', 'norm.hip', 'attention.hip', 'slot_attn.hip',
+SOURCES = ['api.cpp', 'igemm.hip', 'wgrad.hip', 'norm.hip', 'norm_bwd.hip', 'attention.hip',
+           'attention_bwd.hip', 'slot_attn.hip', 'slot_attn_train.hip', 'bwd_misc.hip',
            'elementwise.hip', 'vq.hip']
 EXTRA = {'vq.hip': ['-ffp-contract=off'], 'elementwise.hip': ['-ffp-contract=off']}
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')

@@ -1,0 +1,217 @@
+// Backward helper kernels and the fused optimiser (include/sdmi.h "Backward helpers", "Optimiser").
+#include "common.h"
+
+namespace {
+
+constexpr int TH = 256;
+static inline int nblocks(long long n) {
+  long long b = (n + TH - 1) / TH;
+  if (b > 4096) b = 4096;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+#define GRID_STRIDE(i, n)                                                         \
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < (n); \
+       i += (long long)gridDim.x * blockDim.x)
+
+template <typename T>
+__global__ void pack_dgrad_kernel(SdmiPackDgradArgs p) {
+  const long long n = (long long)p.Cout * p.KH * p.KW * p.Cin;
+  GRID_STRIDE(i, n) {                       // i indexes dst [ci][kh'][kw'][co]
+    const int co = (int)(i % p.Cout);
+    long long r = i / p.Cout;
+    const int kw = (int)(r % p.KW);
+    r /= p.KW;
+    const int kh = (int)(r % p.KH);
+    const int ci = (int)(r / p.KH);
+    const long long s = (((long long)co * p.KH + (p.KH - 1 - kh)) * p.KW + (p.KW - 1 - kw)) * p.Cin + ci;
+    ((T*)p.dst)[(i / p.Cout) * p.CoutPad + co] = ((const T*)p.src)[s];
+  }
+}
+
+// out[g][n] = sum_{r < rows_per} x[g*rows_per + r][n]; block = 256 threads over n, grid (n-blocks, groups)
+template <typename T>
+__global__ __launch_bounds__(256) void rowgroup_sum_kernel(SdmiRowGroupSumArgs p) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  const int g = blockIdx.y;
+  if (n >= p.N) return;
+  const T* x = (const T*)p.x + (long long)g * p.rows_per * p.ldx + n;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int r = 0;
+  for (; r + 3 < p.rows_per; r += 4) {
+    s0 += Elem<T>::ld(x + (long long)r * p.ldx);
+    s1 += Elem<T>::ld(x + (long long)(r + 1) * p.ldx);
+    s2 += Elem<T>::ld(x + (long long)(r + 2) * p.ldx);
+    s3 += Elem<T>::ld(x + (long long)(r + 3) * p.ldx);
+  }
+  for (; r < p.rows_per; ++r) s0 += Elem<T>::ld(x + (long long)r * p.ldx);
+  p.out[(long long)g * p.N + n] = (s0 + s1) + (s2 + s3);
+}
+
+template <typename T>
+__global__ void pool2x2_kernel(SdmiPool2x2Args p) {      // x [B,2H,2W,C] -> y [B,H,W,C]
+  constexpr int VEC = Elem<T>::VEC;
+  const int cv = p.C / VEC;
+  const long long n = (long long)p.B * p.H * p.W * cv;
+  GRID_STRIDE(i, n) {
+    const int c = (int)(i % cv) * VEC;
+    long long r = i / cv;
+    const int x = (int)(r % p.W);
+    r /= p.W;
+    const int y = (int)(r % p.H);
+    const int b = (int)(r / p.H);
+    const T* src = (const T*)p.x + ((((long long)b * 2 * p.H + 2 * y) * 2 * p.W) + 2 * x) * p.C + c;
+    float a0[VEC], a1[VEC], a2[VEC], a3[VEC];
+    unpack16<T>(*reinterpret_cast<const uint4*>(src), a0);
+    unpack16<T>(*reinterpret_cast<const uint4*>(src + p.C), a1);
+    unpack16<T>(*reinterpret_cast<const uint4*>(src + (long long)2 * p.W * p.C), a2);
+    unpack16<T>(*reinterpret_cast<const uint4*>(src + (long long)2 * p.W * p.C + p.C), a3);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) a0[j] = (a0[j] + a1[j]) + (a2[j] + a3[j]);
+    *reinterpret_cast<uint4*>((T*)p.y + (((long long)b * p.H + y) * p.W + x) * p.C + c) = pack16<T>(a0);
+  }
+}
+
+template <typename T>
+__global__ void add_kernel(SdmiAddArgs p) {
+  constexpr int VEC = Elem<T>::VEC;
+  const long long nv = p.n / VEC;
+  GRID_STRIDE(i, nv) {
+    float a[VEC], b[VEC];
+    unpack16<T>(*reinterpret_cast<const uint4*>((const T*)p.x + i * VEC), a);
+    unpack16<T>(*reinterpret_cast<const uint4*>((const T*)p.z + i * VEC), b);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) a[j] += b[j];
+    *reinterpret_cast<uint4*>((T*)p.y + i * VEC) = pack16<T>(a);
+  }
+  // tail
+  for (long long i = nv * VEC + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < p.n;
+       i += (long long)gridDim.x * blockDim.x)
+    Elem<T>::st((T*)p.y + i, Elem<T>::ld((const T*)p.x + i) + Elem<T>::ld((const T*)p.z + i));
+}
+
+template <typename T>
+__global__ void split_kernel(SdmiSplitArgs p) {
+  constexpr int VEC = Elem<T>::VEC;
+  const int cva = p.Ca / VEC, cvb = p.Cb / VEC, cv = cva + cvb;
+  const long long n = p.rows * cv;
+  GRID_STRIDE(i, n) {
+    const long long r = i / cv;
+    const int c = (int)(i - r * cv);
+    const uint4 v = *reinterpret_cast<const uint4*>((const T*)p.y + r * (p.Ca + p.Cb) + c * VEC);
+    if (c < cva) *reinterpret_cast<uint4*>((T*)p.a + r * p.Ca + c * VEC) = v;
+    else *reinterpret_cast<uint4*>((T*)p.b + r * p.Cb + (c - cva) * VEC) = v;
+  }
+}
+
+template <typename T>
+__global__ void act_bwd_kernel(SdmiActBwdArgs p) {
+  GRID_STRIDE(i, p.n) {
+    Elem<T>::st((T*)p.dx + i,
+                Elem<T>::ld((const T*)p.dy + i) * act_grad(Elem<T>::ld((const T*)p.x + i), p.act));
+  }
+}
+
+// ---- optimiser --------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sqsum_kernel(SdmiSqSumArgs p) {
+  __shared__ double red[4];
+  double acc = 0.0;
+  const long long per = (p.n + p.nblk - 1) / p.nblk;
+  const long long i0 = (long long)blockIdx.x * per;
+  long long i1 = i0 + per;
+  if (i1 > p.n) i1 = p.n;
+  for (long long i = i0 + threadIdx.x; i < i1; i += 256) {
+    const float g = p.g[i];
+    acc += (double)g * (double)g;
+  }
+  acc = wave_sum_d(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) p.partial[blockIdx.x] = (float)((red[0] + red[1]) + (red[2] + red[3]));
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(SdmiAdamArgs p) {
+  // global grad norm from the block partials (every block recomputes the same scalar)
+  __shared__ float s_coef;
+  if (threadIdx.x == 0) {
+    double s = 0.0;
+    for (int i = 0; i < p.nblk; ++i) s += (double)p.sq_partial[i];
+    const float total = (float)sqrt(s);
+    float c = p.clip > 0.f ? p.clip / (total + 1e-6f) : 1.f;
+    s_coef = c < 1.f ? c : 1.f;
+  }
+  __syncthreads();
+  const float coef = s_coef;
+  const float bc1 = 1.f - powf(p.beta1, (float)p.step);
+  const float bc2 = 1.f - powf(p.beta2, (float)p.step);
+  const float step_size = p.lr / bc1;
+  const float inv_sqrt_bc2 = 1.f / sqrtf(bc2);
+  GRID_STRIDE(i, p.n) {
+    const float g = p.g[i] * coef;
+    const float m = p.beta1 * p.m[i] + (1.f - p.beta1) * g;
+    const float v = p.beta2 * p.v[i] + (1.f - p.beta2) * g * g;
+    p.m[i] = m;
+    p.v[i] = v;
+    const float denom = sqrtf(v) * inv_sqrt_bc2 + p.eps;
+    const float w = p.p[i] - step_size * (m / denom);
+    p.p[i] = w;
+    if (p.shadow_bf16) ((bf16_t*)p.shadow_bf16)[i] = f32_to_bf16(w);
+  }
+}
+
+}  // namespace
+
+#define ST ((hipStream_t)stream)
+#define DISPATCH_T(kern, grid, args)                                                    \
+  do {                                                                                  \
+    if ((args)->dtype == SDMI_BF16)                                                     \
+      hipLaunchKernelGGL(kern<bf16_t>, grid, dim3(TH), 0, ST, *(args));                 \
+    else                                                                                \
+      hipLaunchKernelGGL(kern<float>, grid, dim3(TH), 0, ST, *(args));                  \
+  } while (0)
+
+extern "C" int sdmi_pack_dgrad(const SdmiPackDgradArgs* a, void* stream) {
+  SDMI_REQUIRE(a && a->src && a->dst && a->CoutPad >= a->Cout, "bad args");
+  DISPATCH_T(pack_dgrad_kernel, dim3(nblocks((long long)a->Cout * a->KH * a->KW * a->Cin)), a);
+  return sdmi_check_launch("pack_dgrad");
+}
+extern "C" int sdmi_rowgroup_sum(const SdmiRowGroupSumArgs* a, void* stream) {
+  SDMI_REQUIRE(a && a->x && a->out && a->groups >= 1 && a->rows_per >= 1, "bad args");
+  DISPATCH_T(rowgroup_sum_kernel, dim3((a->N + 255) / 256, a->groups), a);
+  return sdmi_check_launch("rowgroup_sum");
+}
+extern "C" int sdmi_pool2x2_sum(const SdmiPool2x2Args* a, void* stream) {
+  SDMI_REQUIRE(a && a->x && a->y, "null pointer");
+  const int vec = a->dtype == SDMI_BF16 ? 8 : 4;
+  SDMI_REQUIRE(a->C % vec == 0, "C must be a vector multiple");
+  DISPATCH_T(pool2x2_kernel, dim3(nblocks((long long)a->B * a->H * a->W * (a->C / vec))), a);
+  return sdmi_check_launch("pool2x2_sum");
+}
+extern "C" int sdmi_add(const SdmiAddArgs* a, void* stream) {
+  SDMI_REQUIRE(a && a->x && a->z && a->y, "null pointer");
+  DISPATCH_T(add_kernel, dim3(nblocks(a->n / 4 + 1)), a);
+  return sdmi_check_launch("add");
+}
+extern "C" int sdmi_split_channels(const SdmiSplitArgs* a, void* stream) {
+  SDMI_REQUIRE(a && a->y && a->a && a->b, "null pointer");
+  const int vec = a->dtype == SDMI_BF16 ? 8 : 4;
+  SDMI_REQUIRE(a->Ca % vec == 0 && a->Cb % vec == 0, "channel counts must be vector multiples");
+  DISPATCH_T(split_kernel, dim3(nblocks(a->rows * ((a->Ca + a->Cb) / vec))), a);
+  return sdmi_check_launch("split_channels");
+}
+extern "C" int sdmi_act_bwd(const SdmiActBwdArgs* a, void* stream) {
+  SDMI_REQUIRE(a && a->x && a->dy && a->dx, "null pointer");
+  DISPATCH_T(act_bwd_kernel, dim3(nblocks(a->n)), a);
+  return sdmi_check_launch("act_bwd");
+}
+extern "C" int sdmi_sqsum_partial(const SdmiSqSumArgs* a, void* stream) {
+  SDMI_REQUIRE(a && a->g && a->partial && a->nblk >= 1, "bad args");
+  hipLaunchKernelGGL(sqsum_kernel, dim3(a->nblk), dim3(256), 0, ST, *a);
+  return sdmi_check_launch("sqsum_partial");
+}
+extern "C" int sdmi_adam_clip(const SdmiAdamArgs* a, void* stream) {
+  SDMI_REQUIRE(a && a->p && a->g && a->m && a->v && a->sq_partial && a->nblk >= 1 && a->step >= 1,
+               "bad args");
+  hipLaunchKernelGGL(adam_kernel, dim3(nblocks(a->n)), dim3(256), 0, ST, *a);
+  return sdmi_check_launch("adam_clip");
+}

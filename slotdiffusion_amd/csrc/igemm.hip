@@ -134,6 +134,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(SdmiGemmArgs p, int tiles_m,
           ok = ok && iy >= 0 && iy < 2 * p.H && ix >= 0 && ix < 2 * p.W;
           iy >>= 1;
           ix >>= 1;
+        } else if (p.zins > 1) {
+          ok = ok && iy >= 0 && ix >= 0 && (iy % p.zins) == 0 && (ix % p.zins) == 0;
+          iy /= p.zins;
+          ix /= p.zins;
+          ok = ok && iy < p.H && ix < p.W;
         } else {
           ok = ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
         }
@@ -396,7 +401,7 @@ template <typename T>
 int dispatch(const SdmiGemmArgs& p, hipStream_t st) {
   constexpr int VEC = 16 / sizeof(T);
   const bool is1x1 = p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad_t == 0 && p.pad_l == 0 &&
-                     !p.ups;
+                     !p.ups && p.zins <= 1;
   int hw_shift = -1;
   {
     const int hw = p.Ho * p.Wo;
@@ -444,6 +449,7 @@ extern "C" int sdmi_igemm(const SdmiGemmArgs* a, void* stream) {
                "Cin/lda/ldw must be multiples of the 16-byte vector width");
   SDMI_REQUIRE(((uintptr_t)a->a & 15) == 0 && ((uintptr_t)a->w & 15) == 0, "unaligned operand");
   SDMI_REQUIRE(a->M == a->B * a->Ho * a->Wo, "M != B*Ho*Wo");
+  SDMI_REQUIRE(!(a->zins > 1 && (a->ups || a->stride != 1)), "zins excludes ups / stride");
   SDMI_REQUIRE(!(a->batch > 1) || (a->KH == 1 && a->KW == 1), "batched mode is 1x1 only");
   SDMI_REQUIRE(!(a->batch > 1 && a->split_k > 1), "batched split-K unsupported");
   SDMI_REQUIRE(a->sa % vec == 0 && a->sw % vec == 0, "batch strides must keep 16-byte alignment");

@@ -1,0 +1,658 @@
+"""Kernel providers used by engine.py.
+
+`Kern`      -- inference: direct libsdmi launches (no autograd bookkeeping, fused epilogues).
+`KernGrad`  -- training: the same operations as `torch.autograd.Function`s whose backward passes are
+               libsdmi kernels too (dgrad = the implicit-GEMM kernel on a flipped operand, wgrad,
+               GroupNorm/LayerNorm/attention backward ...).  Parameter gradients are written by
+               the kernels straight into the model's flat fp32 gradient arena (`p.grad` views),
+               so autograd only routes activation gradients.
+
+Both resolve weights through a WeightBank: fp32 operands are views of the master arena, bf16
+operands views of the bf16 shadow arena (same offsets); only channel-padded and non-adjacent
+fused operands are materialised.
+"""
+import torch
+
+from . import _lib, ops
+from ._lib import call
+
+_DT = {torch.float32: _lib.F32, torch.bfloat16: _lib.BF16}
+
+
+def _p(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _st():
+    return torch.cuda.current_stream().cuda_stream
+
+
+class WeightBank:
+    """name(s) -> GEMM operand [N, K] in the requested dtype (K padded to the vector width)."""
+
+    def __init__(self, model, dtype):
+        self.model = model
+        self.t = model.tensors()
+        self.dtype = dtype
+        self.cache = {}
+
+    def invalidate(self):
+        self.cache.clear()
+
+    def f(self, name):
+        return self.t[name]
+
+    def _flat(self, name, dtype):
+        """Operand view straight out of the (master | shadow) arena; None if it needs padding."""
+        p = self.t[name]
+        vec = ops.vec_of(dtype)
+        if p.dim() == 4:
+            co, ci, kh, kw = p.shape
+            if ci % vec:
+                return None
+            shape = (co, kh * kw * ci)
+        else:
+            if p.shape[-1] % vec:
+                return None
+            shape = (p.shape[0], p.shape[1]) if p.dim() == 2 else (1, p.numel())
+        if dtype == torch.float32:
+            src = self.model.arena_slice(name)
+        else:
+            src = self.model.arena_slice(name, self.model.shadow_arena())
+        return src.view(shape)
+
+    def w(self, names, dtype=None):
+        dtype = dtype or self.dtype
+        if isinstance(names, str):
+            names = (names,)
+        key = (names, dtype)
+        if key in self.cache:
+            return self.cache[key]
+        parts = [self._flat(n, dtype) for n in names]
+        out = None
+        if all(p is not None for p in parts):
+            adjacent = all(parts[i].data_ptr() + parts[i].numel() * parts[i].element_size() ==
+                           parts[i + 1].data_ptr() for i in range(len(parts) - 1))
+            if len(parts) == 1:
+                out = parts[0]
+            elif adjacent:                                 # fused operand = one arena slice
+                k = parts[0].shape[1]
+                n = sum(p.shape[0] for p in parts)
+                base = self.model.arena() if dtype == torch.float32 else self.model.shadow_arena()
+                o = self.model._offsets[names[0]][0]
+                out = base[o:o + n * k].view(n, k)
+        if out is None:
+            mats = []
+            vec = ops.vec_of(dtype)
+            for nme in names:
+                p = self.t[nme]
+                if p.dim() == 4:
+                    co, ci, kh, kw = p.shape
+                    flat = self.model.arena_slice(nme).view(co * kh * kw, ci)
+                    cpad = (ci + vec - 1) // vec * vec
+                    mats.append(ops.cast2d(flat, dtype, cols=ci, ldd=cpad).view(co, kh * kw * cpad))
+                else:
+                    k = p.shape[1]
+                    kpad = (k + vec - 1) // vec * vec
+                    mats.append(ops.cast2d(self.model.arena_slice(nme).view(p.shape[0], k), dtype,
+                                           cols=k, ldd=kpad))
+            if len(mats) == 1:
+                out = mats[0]
+            else:
+                out = torch.empty((sum(m.shape[0] for m in mats), mats[0].shape[1]), dtype=dtype,
+                                  device=mats[0].device)
+                o = 0
+                for m in mats:
+                    ops.cast2d(m, dtype, out=out[o:o + m.shape[0]])
+                    o += m.shape[0]
+        self.cache[key] = out
+        return out
+
+    def b(self, names):
+        """fp32 bias vector, fused across names (view when adjacent)."""
+        if names is None:
+            return None
+        if isinstance(names, str):
+            return self.t[names]
+        key = ('bias', names)
+        if key in self.cache:
+            return self.cache[key]
+        parts = [self.t[n] for n in names]
+        out = torch.empty((sum(p.numel() for p in parts),), dtype=torch.float32,
+                          device=parts[0].device)
+        o = 0
+        for p in parts:
+            ops.cast2d(p.view(-1, 1), torch.float32, out=out[o:o + p.numel()].view(-1, 1))
+            o += p.numel()
+        self.cache[key] = out
+        return out
+
+    def wd(self, names, dtype, kh, kw, cin_x):
+        """dgrad operand of the (fused) forward operand: [Cin][kh'][kw'][CoutPad], taps flipped."""
+        key = ('dgrad', names if not isinstance(names, str) else (names,), dtype)
+        if key in self.cache:
+            return self.cache[key]
+        w = self.w(names, dtype)
+        n = w.shape[0]
+        vec = ops.vec_of(dtype)
+        npad = (n + vec - 1) // vec * vec
+        dst = (torch.zeros if npad != n else torch.empty)((cin_x * kh * kw, npad), dtype=dtype,
+                                                          device=w.device)
+        call('sdmi_pack_dgrad', _st(), src=_p(w), dst=_p(dst), dtype=_DT[dtype], Cout=n, KH=kh,
+             KW=kw, Cin=cin_x, CoutPad=npad)
+        self.cache[key] = dst
+        return dst
+
+
+class Kern:
+    """Inference provider."""
+    training = False
+
+    def __init__(self, wb):
+        self.wb = wb
+
+    def conv(self, x, wname, bname=None, *, kh=3, kw=3, stride=1, pad=(1, 1, 1, 1), ups=False,
+             rowvec=None, residual=None, out_dtype=None, ldc=None):
+        return ops.conv2d(x, self.wb.w(wname, x.dtype), self.wb.b(bname), kh=kh, kw=kw,
+                          stride=stride, pad=pad, ups=ups, rowvec=rowvec, residual=residual,
+                          out_dtype=out_dtype, ldc=ldc)
+
+    def linear(self, x, wnames, bnames=None, *, act=None, residual=None, out_dtype=None):
+        return ops.linear(x, self.wb.w(wnames, x.dtype), self.wb.b(bnames), act=act,
+                          residual=residual, out_dtype=out_dtype)
+
+    def gn(self, x, name, *, eps, act=None, residual=None):
+        return ops.group_norm(x, self.wb.f(name + '.weight'), self.wb.f(name + '.bias'), eps=eps,
+                              act=act, residual=residual)
+
+    def ln(self, x, name):
+        return ops.layer_norm(x, self.wb.f(name + '.weight'), self.wb.f(name + '.bias'))
+
+    def attn_self(self, qkv, heads):
+        C = heads * 32
+        return ops.attention(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], heads)
+
+    def attn_cross(self, q, kv, heads):
+        C = heads * 32
+        return ops.attention(q, kv[..., :C], kv[..., C:], heads)
+
+    def geglu(self, h):
+        return ops.geglu(h)
+
+    def add_pos(self, x, pos):
+        return ops.add_pos(x, pos)
+
+    def concat(self, a, b):
+        return ops.concat_channels(a, b)
+
+    def cast(self, x, dtype):
+        return x if x.dtype == dtype else ops.act(x, None, dtype)
+
+    def slot_attention(self, kv, init, name, iters, eps):
+        wb = self.wb
+        D = kv.shape[-1] // 2
+        P = dict(lnq_g=wb.f(f'{name}.project_q.0.weight'), lnq_b=wb.f(f'{name}.project_q.0.bias'),
+                 wq=wb.f(f'{name}.project_q.1.weight'), w_ih=wb.f(f'{name}.gru.weight_ih'),
+                 w_hh=wb.f(f'{name}.gru.weight_hh'), b_ih=wb.f(f'{name}.gru.bias_ih'),
+                 b_hh=wb.f(f'{name}.gru.bias_hh'), lnm_g=wb.f(f'{name}.mlp.0.weight'),
+                 lnm_b=wb.f(f'{name}.mlp.0.bias'), w1=wb.f(f'{name}.mlp.1.weight'),
+                 b1=wb.f(f'{name}.mlp.1.bias'), w2=wb.f(f'{name}.mlp.3.weight'),
+                 b2=wb.f(f'{name}.mlp.3.bias'))
+        return ops.slot_attention(kv[..., :D], kv[..., D:], init, P, iters=iters, eps=eps)
+
+
+# ==========================================================================================
+# training provider: autograd Functions with libsdmi backward kernels
+# ==========================================================================================
+def _grads_of(wb, names):
+    """Contiguous gradient-arena destination for (fused) params, or None if not adjacent."""
+    m = wb.model
+    g = m.grad_arena()
+    if isinstance(names, str):
+        names = (names,)
+    offs = [m._offsets[n] for n in names]
+    for i in range(len(offs) - 1):
+        if offs[i][0] + offs[i][1] != offs[i + 1][0]:
+            return None
+    return g[offs[0][0]:offs[-1][0] + offs[-1][1]]
+
+
+class GemmFn(torch.autograd.Function):
+    """out = conv/linear(x, W) + bias (+ rowvec[b]) (+ residual).  Activation-free."""
+
+    @staticmethod
+    def forward(ctx, x, rowvec, residual, wb, wnames, bnames, geom, out_dtype, ldc):
+        kh, kw, stride, pad, ups = geom
+        w = wb.w(wnames, x.dtype)
+        b = wb.b(bnames)
+        if x.dim() == 4 and (kh, kw) != (0, 0):
+            out = ops.conv2d(x, w, b, kh=kh, kw=kw, stride=stride, pad=pad, ups=ups, rowvec=rowvec,
+                             residual=residual, out_dtype=out_dtype, ldc=ldc)
+        else:
+            out = ops.linear(x, w, b, residual=residual, out_dtype=out_dtype)
+        ctx.save_for_backward(x)
+        ctx.cfg = (wb, wnames, bnames, geom, rowvec is not None, residual is not None,
+                   rowvec.shape if rowvec is not None else None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        wb, wnames, bnames, geom, has_rv, has_res, rv_shape = ctx.cfg
+        kh, kw, stride, pad, ups = geom
+        is_conv = x.dim() == 4 and (kh, kw) != (0, 0)
+        if not is_conv:
+            kh = kw = 1
+            stride, pad, ups = 1, (0, 0, 0, 0), False
+        dt = x.dtype
+        vec = ops.vec_of(dt)
+        w = wb.w(wnames, dt)
+        N = w.shape[0]
+        dy = dy.contiguous()
+        # bring dY to the compute dtype with a vector-multiple row pitch
+        if dy.dtype != dt or dy.shape[-1] % vec:
+            npad = (N + vec - 1) // vec * vec
+            dy = ops.cast2d(dy, dt, cols=N, ldd=npad)
+        ldy = dy.shape[-1]
+        Cin = x.shape[-1]
+        if is_conv:
+            B, H, W_, _ = x.shape
+            Ho, Wo = dy.shape[1], dy.shape[2]
+        else:
+            B, H, W_, Ho, Wo = x.numel() // Cin, 1, 1, 1, 1
+        M = B * Ho * Wo
+        K = kh * kw * Cin
+        # ---- weight / bias gradients straight into the gradient arena
+        names = (wnames,) if isinstance(wnames, str) else tuple(wnames)
+        dst = _grads_of(wb, names)
+        k_true = wb.t[names[0]].numel() // wb.t[names[0]].shape[0]
+        direct = dst is not None and k_true == K
+        tiles = ((N + 127) // 128) * ((K + 127) // 128)
+        mt = 128 if dt == torch.bfloat16 else 32
+        splits = max(1, min((512 + tiles - 1) // tiles, max(1, M // (2 * mt)), 64))
+        ws = torch.empty((max(splits * N * K, 256 * N),), dtype=torch.float32, device=x.device)
+        dwbuf = dst if direct else torch.empty((N, K), dtype=torch.float32, device=x.device)
+        bdst = None
+        btmp = None
+        if bnames is not None:
+            bdst = _grads_of(wb, bnames)
+            btmp = bdst if bdst is not None else torch.empty((N,), dtype=torch.float32,
+                                                             device=x.device)
+        call('sdmi_wgrad', _st(), a=_p(x), dy=_p(dy), dw=_p(dwbuf), dbias=_p(btmp),
+             workspace=_p(ws), dtype=_DT[dt], M=M, N=N, K=K,
+             lda=(Cin if is_conv else x.stride(-2)), ldy=ldy, B=B, H=H, W=W_,
+             Cin=Cin, Ho=Ho, Wo=Wo, KH=kh, KW=kw, stride=stride, pad_t=pad[0], pad_l=pad[2],
+             ups=int(ups), splits=splits, accumulate=0)
+        if not direct:
+            g = wb.model.grad_arena()
+            o = 0
+            for nme in names:
+                off, cnt = wb.model._offsets[nme]
+                rows = wb.t[nme].shape[0]
+                taps = kh * kw
+                ci_true = cnt // (rows * taps)
+                # [rows*taps, Cin(pad)] -> [rows*taps, ci_true]
+                ops.cast2d(dwbuf[o:o + rows].reshape(rows * taps, Cin), torch.float32,
+                           cols=ci_true, out=g[off:off + cnt].view(rows * taps, ci_true),
+                           ldd=ci_true)
+                o += rows
+        if bnames is not None and bdst is None:
+            g = wb.model.grad_arena()
+            o = 0
+            for nme in (bnames if not isinstance(bnames, str) else (bnames,)):
+                off, cnt = wb.model._offsets[nme]
+                ops.cast2d(btmp[o:o + cnt].view(-1, 1), torch.float32,
+                           out=g[off:off + cnt].view(-1, 1))
+                o += cnt
+        # ---- data gradient: the forward kernel on the flipped operand
+        dx = None
+        if ctx.needs_input_grad[0]:
+            wd = wb.wd(wnames, dt, kh, kw, Cin)
+            if is_conv:
+                Hs, Ws = (2 * H, 2 * W_) if ups else (H, W_)
+                out = torch.empty((B, Hs, Ws, Cin), dtype=dt, device=x.device)
+                call('sdmi_igemm', _st(), a=_p(dy), w=_p(wd), out=_p(out), dtype=_DT[dt],
+                     out_dtype=_DT[dt], M=B * Hs * Ws, N=Cin, K=kh * kw * ldy, lda=ldy,
+                     ldw=kh * kw * ldy, ldc=Cin, B=B, H=Ho, W=Wo, Cin=ldy, Ho=Hs, Wo=Ws, KH=kh,
+                     KW=kw, stride=1, pad_t=kh - 1 - pad[0], pad_l=kw - 1 - pad[2], ups=0, act=0,
+                     alpha=1.0, split_k=1, batch=1, zins=(stride if stride > 1 else 0))
+                if ups:
+                    dx = torch.empty_like(x)
+                    call('sdmi_pool2x2_sum', _st(), x=_p(out), y=_p(dx), dtype=_DT[dt], B=B, H=H,
+                         W=W_, C=Cin)
+                else:
+                    dx = out
+            else:
+                dx = ops.linear(dy.view(-1, ldy), wd).view(x.shape)
+        drv = None
+        if has_rv and ctx.needs_input_grad[1]:
+            drv = torch.empty(rv_shape, dtype=torch.float32, device=x.device)
+            call('sdmi_rowgroup_sum', _st(), x=_p(dy), out=_p(drv), dtype=_DT[dt], groups=B,
+                 rows_per=Ho * Wo, N=N, ldx=ldy)
+        dres = None
+        if has_res and ctx.needs_input_grad[2]:
+            dres = dy if dy.shape[-1] == N else None
+            assert dres is not None
+        return dx, drv, dres, None, None, None, None, None, None
+
+
+class GroupNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, residual, wb, name, eps, act):
+        gamma, beta = wb.f(name + '.weight'), wb.f(name + '.bias')
+        y, stats = ops.group_norm(x, gamma, beta, eps=eps, act=act, residual=residual,
+                                  return_stats=True)
+        ctx.save_for_backward(x, stats, residual)
+        ctx.cfg = (wb, name, act)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, stats, residual = ctx.saved_tensors
+        wb, name, act = ctx.cfg
+        dy = dy.contiguous()
+        B, C = x.shape[0], x.shape[-1]
+        HW = x.numel() // (B * C)
+        G = 32
+        nsplit = max(1, min(16, HW // 64))
+        partial = torch.empty((B * nsplit * C * 2 + B * G * 2,), dtype=torch.float32,
+                              device=x.device)
+        dx = torch.empty_like(x)
+        dres = torch.empty_like(x) if residual is not None else None
+        dg = _grads_of(wb, name + '.weight')
+        db = _grads_of(wb, name + '.bias')
+        call('sdmi_groupnorm_bwd', _st(), x=_p(x), dy=_p(dy), dx=_p(dx), gamma=_p(wb.f(name + '.weight')),
+             beta=_p(wb.f(name + '.bias')), stats=_p(stats), dgamma=_p(dg), dbeta=_p(db),
+             partial=_p(partial), dtype=_DT[x.dtype], B=B, HW=HW, C=C, groups=G,
+             act=_lib.ACT[act], nsplit=nsplit, residual=_p(residual), dresidual=_p(dres))
+        return dx, dres, None, None, None, None
+
+
+class LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, wb, name):
+        C = x.shape[-1]
+        stats = torch.empty((x.numel() // C, 2), dtype=torch.float32, device=x.device)
+        y = ops.layer_norm(x, wb.f(name + '.weight'), wb.f(name + '.bias'), stats=stats)
+        ctx.save_for_backward(x, stats)
+        ctx.cfg = (wb, name)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, stats = ctx.saved_tensors
+        wb, name = ctx.cfg
+        dy = dy.contiguous()
+        C = x.shape[-1]
+        rows = x.numel() // C
+        nblk = max(1, min(512, rows // 16))
+        partial = torch.empty((nblk * C * 2,), dtype=torch.float32, device=x.device)
+        dx = torch.empty_like(x)
+        call('sdmi_layernorm_bwd', _st(), x=_p(x), dy=_p(dy), dx=_p(dx),
+             gamma=_p(wb.f(name + '.weight')), stats=_p(stats),
+             dgamma=_p(_grads_of(wb, name + '.weight')), dbeta=_p(_grads_of(wb, name + '.bias')),
+             partial=_p(partial), dtype=_DT[x.dtype], rows=rows, C=C, nblk=nblk)
+        return dx, None, None
+
+
+class AttnFn(torch.autograd.Function):
+    """self: qkv fused [B,S,3C]; cross: q [B,S,C] + kv [B,N,2C]."""
+
+    @staticmethod
+    def forward(ctx, q_or_qkv, kv, heads):
+        C = heads * 32
+        if kv is None:
+            q, k, v = q_or_qkv[..., :C], q_or_qkv[..., C:2 * C], q_or_qkv[..., 2 * C:]
+        else:
+            q, k, v = q_or_qkv, kv[..., :C], kv[..., C:]
+        B, Sq = q.shape[0], q.shape[1]
+        lse = torch.empty((B, heads, Sq), dtype=torch.float32, device=q.device)
+        out = ops.attention(q, k, v, heads, lse=lse)
+        ctx.save_for_backward(q_or_qkv, kv, out, lse)
+        ctx.heads = heads
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        a, kv, out, lse = ctx.saved_tensors
+        heads = ctx.heads
+        C = heads * 32
+        dout = dout.contiguous()
+        da = torch.empty_like(a)
+        dkv = torch.empty_like(kv) if kv is not None else None
+        if kv is None:
+            q, k, v = a[..., :C], a[..., C:2 * C], a[..., 2 * C:]
+            dq, dk, dv = da[..., :C], da[..., C:2 * C], da[..., 2 * C:]
+        else:
+            q, k, v = a, kv[..., :C], kv[..., C:]
+            dq, dk, dv = da, dkv[..., :C], dkv[..., C:]
+        B, Sq, Skv = q.shape[0], q.shape[1], k.shape[1]
+        call('sdmi_attention_bwd', _st(), q=_p(q), k=_p(k), v=_p(v), out=_p(out), dout=_p(dout),
+             lse=_p(lse), dq=_p(dq), dk=_p(dk), dv=_p(dv), dtype=_DT[q.dtype], B=B, heads=heads,
+             Sq=Sq, Skv=Skv, ldq=q.stride(1), ldk=k.stride(1), ldv=v.stride(1), ldo=out.stride(1),
+             scale=32 ** -0.5)
+        return da, dkv, None
+
+
+class GegluFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, h):
+        ctx.save_for_backward(h)
+        return ops.geglu(h)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (h,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        dh = torch.empty_like(h)
+        C = h.shape[-1] // 2
+        call('sdmi_geglu_bwd', _st(), h=_p(h), dy=_p(dy), dh=_p(dh), dtype=_DT[h.dtype],
+             rows=h.numel() // (2 * C), C=C)
+        return dh
+
+
+class ActFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, kind):
+        ctx.save_for_backward(x)
+        ctx.kind = kind
+        return ops.act(x, kind)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        call('sdmi_act_bwd', _st(), x=_p(x), dy=_p(dy), dx=_p(dx), dtype=_DT[x.dtype],
+             act=_lib.ACT[ctx.kind], n=x.numel())
+        return dx, None
+
+
+class CastFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, dtype):
+        ctx.src = x.dtype
+        return ops.act(x, None, dtype)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.act(dy.contiguous(), None, ctx.src), None
+
+
+class AddPosFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, pos):
+        ctx.pshape = pos.shape
+        return ops.add_pos(x, pos)
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        dpos = None
+        if ctx.needs_input_grad[1]:
+            B = dy.shape[0]
+            per = dy.numel() // B
+            dpos = torch.empty(ctx.pshape, dtype=torch.float32, device=dy.device)
+            call('sdmi_rowgroup_sum', _st(), x=_p(dy), out=_p(dpos), dtype=_DT[dy.dtype], groups=1,
+                 rows_per=B, N=per, ldx=per)
+        return dy, dpos
+
+
+class ConcatFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        ctx.ca, ctx.cb = a.shape[-1], b.shape[-1]
+        return ops.concat_channels(a, b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        da = torch.empty(dy.shape[:-1] + (ctx.ca,), dtype=dy.dtype, device=dy.device)
+        db = torch.empty(dy.shape[:-1] + (ctx.cb,), dtype=dy.dtype, device=dy.device)
+        call('sdmi_split_channels', _st(), y=_p(dy), a=_p(da), b=_p(db), dtype=_DT[dy.dtype],
+             rows=dy.numel() // (ctx.ca + ctx.cb), Ca=ctx.ca, Cb=ctx.cb)
+        return da, db
+
+
+class SaAttendFn(torch.autograd.Function):
+    """One Slot Attention iteration's streaming pass: (kv, q) -> (updates, attn)."""
+
+    @staticmethod
+    def forward(ctx, kv, q, eps):
+        B, M, D2 = kv.shape
+        D = D2 // 2
+        N = q.shape[1]
+        attn = torch.empty((B, M, N), dtype=torch.float32, device=kv.device)
+        upd = torch.empty((B, N, D), dtype=torch.float32, device=kv.device)
+        den = torch.empty((B, N), dtype=torch.float32, device=kv.device)
+        q = q.contiguous()
+        call('sdmi_sa_attend_fwd', _st(), k=_p(kv), v=_p(kv[..., D:]), q=_p(q), attn=_p(attn),
+             upd=_p(upd), den=_p(den), dtype=_DT[kv.dtype], B=B, M=M, N=N, D=D, ldkv=D2, eps=eps,
+             scale=D ** -0.5)
+        ctx.save_for_backward(kv, q, attn, upd, den)
+        ctx.eps = eps
+        ctx.mark_non_differentiable(attn)
+        return upd, attn
+
+    @staticmethod
+    def backward(ctx, dupd, _dattn):
+        kv, q, attn, upd, den = ctx.saved_tensors
+        B, M, D2 = kv.shape
+        D = D2 // 2
+        N = q.shape[1]
+        dupd = dupd.contiguous()
+        dq = torch.empty_like(q)
+        dkv = torch.empty_like(kv)
+        call('sdmi_sa_attend_bwd', _st(), k=_p(kv), v=_p(kv[..., D:]), q=_p(q), attn=_p(attn),
+             upd=_p(upd), den=_p(den), dupd=_p(dupd), dq=_p(dq), dk=_p(dkv), dv=_p(dkv[..., D:]),
+             dtype=_DT[kv.dtype], B=B, M=M, N=N, D=D, ldkv=D2, eps=ctx.eps, scale=D ** -0.5)
+        return dkv, dq, None
+
+
+class GruGatesFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, gi, gh, h):
+        R, D = h.shape
+        out = torch.empty_like(h)
+        call('sdmi_gru_gates', _st(), gi=_p(gi), gh=_p(gh), h=_p(h), hout=_p(out), R=R, D=D)
+        ctx.save_for_backward(gi, gh, h)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        gi, gh, h = ctx.saved_tensors
+        R, D = h.shape
+        dout = dout.contiguous()
+        dgi, dgh, dh = torch.empty_like(gi), torch.empty_like(gh), torch.empty_like(h)
+        call('sdmi_gru_gates_bwd', _st(), gi=_p(gi), gh=_p(gh), h=_p(h), dhout=_p(dout),
+             dgi=_p(dgi), dgh=_p(dgh), dh=_p(dh), R=R, D=D)
+        return dgi, dgh, dh
+
+
+class AddFn(torch.autograd.Function):
+    """y = a + b on our add kernel (both grads are dy)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        y = torch.empty_like(a)
+        call('sdmi_add', _st(), x=_p(a), z=_p(b.contiguous()), y=_p(y), dtype=_DT[a.dtype], n=a.numel())
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, dy
+
+
+class MseFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, target, scale):
+        val, dpred = ops.mse(pred, target, want_grad=True, gscale=scale)
+        ctx.save_for_backward(dpred)
+        return (val * scale).reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (dpred,) = ctx.saved_tensors
+        return dpred * g, None, None
+
+
+class KernGrad(Kern):
+    """Training provider (autograd)."""
+    training = True
+
+    def conv(self, x, wname, bname=None, *, kh=3, kw=3, stride=1, pad=(1, 1, 1, 1), ups=False,
+             rowvec=None, residual=None, out_dtype=None, ldc=None):
+        return GemmFn.apply(x, rowvec, residual, self.wb, wname, bname, (kh, kw, stride, pad, ups),
+                            out_dtype, ldc)
+
+    def linear(self, x, wnames, bnames=None, *, act=None, residual=None, out_dtype=None):
+        y = GemmFn.apply(x, None, residual, self.wb, wnames, bnames, (0, 0, 1, (0, 0, 0, 0), False),
+                         out_dtype, None)
+        return ActFn.apply(y, act) if act else y
+
+    def gn(self, x, name, *, eps, act=None, residual=None):
+        return GroupNormFn.apply(x, residual, self.wb, name, eps, act)
+
+    def ln(self, x, name):
+        return LayerNormFn.apply(x, self.wb, name)
+
+    def attn_self(self, qkv, heads):
+        return AttnFn.apply(qkv, None, heads)
+
+    def attn_cross(self, q, kv, heads):
+        return AttnFn.apply(q, kv, heads)
+
+    def geglu(self, h):
+        return GegluFn.apply(h)
+
+    def add_pos(self, x, pos):
+        return AddPosFn.apply(x, pos)
+
+    def concat(self, a, b):
+        return ConcatFn.apply(a, b)
+
+    def cast(self, x, dtype):
+        return x if x.dtype == dtype else CastFn.apply(x, dtype)
+
+    def slot_attention(self, kv, init, name, iters, eps):
+        """Unfused training form of SlotAttentionWMask.forward (sa_diffusion.py:40-68)."""
+        B, M, D2 = kv.shape
+        D = D2 // 2
+        if init.dim() == 2:
+            init = init.unsqueeze(0).expand(B, -1, -1)
+        slots = init.contiguous()
+        N = slots.shape[1]
+        seg = None
+        for _ in range(iters):
+            prev = slots.reshape(B * N, D)
+            q = self.linear(self.ln(slots, f'{name}.project_q.0'), f'{name}.project_q.1.weight')
+            upd, attn = SaAttendFn.apply(kv, q, eps)
+            seg = attn
+            gi = self.linear(upd.reshape(B * N, D), f'{name}.gru.weight_ih', f'{name}.gru.bias_ih')
+            gh = self.linear(prev, f'{name}.gru.weight_hh', f'{name}.gru.bias_hh')
+            h = GruGatesFn.apply(gi, gh, prev)
+            hid = self.linear(self.ln(h, f'{name}.mlp.0'), f'{name}.mlp.1.weight',
+                              f'{name}.mlp.1.bias', act='relu')
+            slots = self.linear(hid, f'{name}.mlp.3.weight', f'{name}.mlp.3.bias',
+                                residual=h).view(B, N, D)
+        return slots, seg

@@ -13,7 +13,7 @@ import os
 
 import torch
 
-from . import dpm, engine, ops, spec
+from . import dpm, engine, kern, ops, spec
 from .module import FlatModule, _Node
 
 _DTYPES = {'fp32': torch.float32, 'float32': torch.float32, 'bf16': torch.bfloat16,
@@ -41,13 +41,13 @@ class VQVAEWrapper(_Owned):
     @torch.no_grad()
     def encode(self, x):
         r = self.root
-        z = engine.vae_encode(r.bank(), r._to_nhwc(x), r.ed, scale_factor=r.z_scale)
+        z = engine.vae_encode(r.K(), r._to_nhwc(x), r.ed, scale_factor=r.z_scale)
         return ops.nhwc_to_nchw(z, 3)
 
     @torch.no_grad()
     def decode(self, h, quantize=True):
         r = self.root
-        img = engine.vae_decode(r.bank(), r._latent_nhwc(h), r.ed, scale_factor=r.z_scale,
+        img = engine.vae_decode(r.K(), r._latent_nhwc(h), r.ed, scale_factor=r.z_scale,
                                 quantize=quantize)
         return ops.nhwc_to_nchw(img, 3)
 
@@ -87,25 +87,31 @@ class LDM(_Owned):
 
     # -- a7/a8 ---------------------------------------------------------------------------
     def loss_function(self, data_dict, t=None, noise=None):
-        """ldm.py:59-83; t / noise may be supplied (fixtures) or are drawn like the reference."""
+        """ldm.py:59-83; t / noise may be supplied (fixtures) or are drawn like the reference.
+        Records the autograd graph (HIP backward kernels) when `slots` requires grad."""
         r = self.root
         img, slots = data_dict['img'], data_dict[self.cond_stage_key]
         B = img.shape[0]
-        bank = r.bank()
         with torch.no_grad():
-            x0 = engine.vae_encode(bank, r._to_nhwc(img), r.ed, scale_factor=r.z_scale)
-        if t is None:
-            t = torch.randint(0, self.num_timesteps, (B,), device=img.device).long()
-        if noise is None:
-            noise = torch.randn(B, 3, x0.shape[1], x0.shape[2], device=img.device)
-        nz = ops.nchw_to_nhwc(noise, torch.float32, 4)
-        ca = self.sqrt_alphas_bar[t].contiguous()
-        cb = self.sqrt_one_minus_alphas_bar[t].contiguous()
-        xt = ops.row_lincomb(x0, nz, ca, cb)
-        pred = r._unet_eps(xt, t.float(), slots)
-        loss = ops.mse(pred, nz)
-        # the 4th (zero pad) channel adds no error but is counted in n: rescale 4/3
-        return {'denoise_loss': (loss * (4.0 / 3.0)).reshape(())}
+            x0 = engine.vae_encode(r.K(), r._to_nhwc(img), r.ed, scale_factor=r.z_scale)
+            if t is None:
+                t = torch.randint(0, self.num_timesteps, (B,), device=img.device).long()
+            if noise is None:
+                noise = torch.randn(B, 3, x0.shape[1], x0.shape[2], device=img.device)
+            nz = ops.nchw_to_nhwc(noise, torch.float32, 4)
+            ca = self.sqrt_alphas_bar[t].contiguous()
+            cb = self.sqrt_one_minus_alphas_bar[t].contiguous()
+            xt = ops.row_lincomb(x0, nz, ca, cb)
+        grad = torch.is_grad_enabled() and (slots.requires_grad or r.training)
+        Kp = r.KG() if grad else r.K()
+        with torch.set_grad_enabled(grad):
+            pred = r._unet_eps(xt, t.float(), slots, Kp)
+            # the 4th (zero pad) channel adds no error but is counted in n: rescale 4/3
+            if grad:
+                loss = kern.MseFn.apply(pred, nz, 4.0 / 3.0)
+            else:
+                loss = (ops.mse(pred, nz) * (4.0 / 3.0)).reshape(())
+        return {'denoise_loss': loss}
 
     # -- a12/a13 -------------------------------------------------------------------------
     @torch.no_grad()
@@ -175,6 +181,7 @@ class SADiffusion(FlatModule):
         self._bank = None
         self._unet = None
         self._plan = None
+        self._Kinf = self._Kgrad = None
         self.use_graph = os.environ.get('SDMI_GRAPH', '1') != '0'
         self._graph_cache = {}
 
@@ -194,7 +201,6 @@ class SADiffusion(FlatModule):
 
     def invalidate_weights(self):
         self._bank = None
-        self._unet = None
         self._graph_cache = {}
 
     def load_state_dict(self, *a, **k):
@@ -213,12 +219,32 @@ class SADiffusion(FlatModule):
 
     def bank(self):
         if self._bank is None:
-            self._bank = engine.WeightBank(self.tensors(), self.compute_dtype)
+            self._bank = kern.WeightBank(self, self.compute_dtype)
+            self._Kinf = kern.Kern(self._bank)
+            self._Kgrad = kern.KernGrad(self._bank)
+            if self.compute_dtype != torch.float32:
+                self.shadow_arena(refresh=True)
         return self._bank
+
+    def K(self):
+        self.bank()
+        return self._Kinf
+
+    def KG(self):
+        self.bank()
+        return self._Kgrad
+
+    def weights_updated(self, shadow_fresh=False):
+        """Call after the master arena changed (optimizer step / checkpoint load)."""
+        if self._bank is not None:
+            self._bank.invalidate()
+            if self.compute_dtype != torch.float32 and not shadow_fresh:
+                self.shadow_arena(refresh=True)
+        self._graph_cache = {}
 
     def unet(self):
         if self._unet is None:
-            self._unet = engine.UNetRunner(self.bank(), self.unet_cfg)
+            self._unet = engine.UNetRunner(self.unet_cfg)
         return self._unet
 
     def _to_nhwc(self, img):
@@ -227,9 +253,8 @@ class SADiffusion(FlatModule):
     def _latent_nhwc(self, z):
         return ops.nchw_to_nhwc(z.float(), torch.float32, 4)
 
-    def _ctx(self, slots):
-        s = slots.contiguous().float()
-        return s if self.compute_dtype == torch.float32 else ops.act(s, None, self.compute_dtype)
+    def _ctx(self, slots, Kp=None):
+        return (Kp or self.K()).cast(slots.contiguous().float(), self.compute_dtype)
 
     def _unet_in(self, x):
         """fp32 latent state [B,h,w,4] -> UNet input in compute dtype with vector-padded channels."""
@@ -237,9 +262,11 @@ class SADiffusion(FlatModule):
             return x
         return ops.cast2d(x, self.compute_dtype, cols=3, ldd=ops.vec_of(self.compute_dtype))
 
-    def _unet_eps(self, xt, t, slots):
+    def _unet_eps(self, xt, t, slots, Kp=None):
+        Kp = Kp or self.K()
         u = self.unet()
-        return u.forward(self._unet_in(xt), u.time_rowvecs(t), u.context_kv(self._ctx(slots)))
+        return u.forward(Kp, self._unet_in(xt), u.time_rowvecs(Kp, t),
+                         u.context_kv(Kp, self._ctx(slots, Kp)))
 
     # -- sampler -------------------------------------------------------------------------
     def _dpm_sample(self, x, cond, ret_intermed=False, steps=None):
@@ -281,17 +308,17 @@ class SADiffusion(FlatModule):
     def _dpm_loop(self, x, cond, prep, ret_intermed):
         plan, tin = prep
         u = self.unet()
-        bank = self.bank()
-        ctx_kv = u.context_kv(self._ctx(cond))
-        rv_all = u.time_rowvecs(tin)                         # [NFE, sum Cout] fp32
+        Kp = self.K()
+        ctx_kv = u.context_kv(Kp, self._ctx(cond))
+        rv_all = u.time_rowvecs(Kp, tin)                     # [NFE, sum Cout] fp32
         B = x.shape[0]
-        code = bank.f(self.vq_key)
+        code = self.bank().f(self.vq_key)
         nfe = [0]
 
         def data_pred(xc, e):
             rv = rv_all[nfe[0]:nfe[0] + 1].expand(B, -1)      # pitch-0 view: same row for all b
             nfe[0] += 1
-            eps = u.forward(self._unet_in(xc), rv, ctx_kv)
+            eps = u.forward(Kp, self._unet_in(xc), rv, ctx_kv)
             x0 = ops.lincomb(1.0, xc, -e['sigma'], eps, div=e['alpha'])
             return ops.vq_nearest(x0, code, scale=self.z_scale, want_idx=False)[1]
 
@@ -318,19 +345,22 @@ class SADiffusion(FlatModule):
         return x, inter
 
     # -- a1-a4 ---------------------------------------------------------------------------
-    @torch.no_grad()
     def encode(self, img, init_slots=None):
-        """sa_diffusion.py:155-183 -> slots [B,N,D] fp32, masks [B,N,h,w] (train) / [B,N,H,W]."""
+        """sa_diffusion.py:155-183 -> slots [B,N,D] fp32, masks [B,N,h,w] (train) / [B,N,H,W].
+        In training mode with grad enabled the autograd graph (HIP backward) is recorded."""
         B, _, H, W = img.shape
-        bank = self.bank()
-        tok = engine.encoder_out(bank, self._to_nhwc(img), self.rplan)
-        init = self.init_latents[0] if init_slots is None else init_slots.contiguous().float()
-        slots, seg = engine.slot_attention(bank, tok, init, self.num_iterations, self.eps)
+        grad = self.training and torch.is_grad_enabled()
+        Kp = self.KG() if grad else self.K()
+        with torch.set_grad_enabled(grad):
+            tok = engine.encoder_out(Kp, self._to_nhwc(img), self.rplan)
+            init = self.init_latents[0] if init_slots is None else init_slots.contiguous().float()
+            slots, seg = engine.slot_attention(Kp, tok, init, self.num_iterations, self.eps)
         h, w = self.visual_resolution
-        if not self.training and (h, w) != (H, W):
-            masks, _ = ops.mask_upsample_argmax(seg, h, w, H, W)
-        else:
-            masks = seg.permute(0, 2, 1).reshape(B, self.num_slots, h, w)
+        with torch.no_grad():
+            if not self.training and (h, w) != (H, W):
+                masks, _ = ops.mask_upsample_argmax(seg, h, w, H, W)
+            else:
+                masks = seg.detach().permute(0, 2, 1).reshape(B, self.num_slots, h, w)
         return slots, masks
 
     def forward(self, data_dict, **kwargs):

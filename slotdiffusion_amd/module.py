@@ -1,24 +1,31 @@
-"""Materialise a flat parameter spec as an ``nn.Module`` tree.
+"""Materialise a flat parameter spec as an ``nn.Module`` tree backed by flat HBM arenas.
 
-The tree consists of *bare containers* (no forward code): its only job is to
-own the tensors under exactly the dotted names the reference's checkpoints
-use, so ``state_dict()``, ``load_state_dict()``, ``named_parameters()`` and
-``.to()/.cuda()`` behave like the reference modules'.  Compute lives in
-``engine.py`` and reads tensors from the flat dict returned by
-:meth:`FlatModule.tensors`.
+The tree consists of *bare containers* (no forward code): its only job is to own the tensors
+under exactly the dotted names the reference's checkpoints use, so ``state_dict()``,
+``load_state_dict()``, ``named_parameters()`` and ``.to()/.cuda()`` behave like the reference
+modules'.  Compute lives in ``engine.py`` and reads tensors from :meth:`FlatModule.tensors`.
 
-Convolution weights ``[Cout, Cin, kh, kw]`` are allocated with
-``torch.channels_last`` strides: the logical shape (and therefore the
-checkpoint format) is the reference's, while the bytes in HBM are
-``[Cout][kh][kw][Cin]`` -- the K-contiguous operand layout the implicit-GEMM
-kernels consume.  Gradients are produced in the same physical layout, so the
-fused Adam kernel walks weights, grads and moments linearly.
+MI355X-side memory design
+  * every parameter is a VIEW into one flat fp32 arena, laid out in spec order:
+        [ slot-encoder group | dm_decoder (UNet) group | frozen VQ-VAE ]
+    so the two learning-rate groups of the reference's optimiser (vb/method.py:291-341) are two
+    contiguous ranges: global-norm clip + Adam are single streaming kernels over the arena, and a
+    DDP all-reduce is a handful of large flat buckets;
+  * gradients live in a second arena with identical offsets (``p.grad`` are views of it): the
+    wgrad kernels write their fp32 results straight into it;
+  * the bf16 compute path reads a bf16 shadow arena (same offsets) refreshed by the Adam kernel;
+  * conv weights ``[Cout, Cin, kh, kw]`` keep the reference's logical shape but are stored
+    ``[Cout][kh][kw][Cin]`` (``torch.channels_last`` strides) -- the K-contiguous operand layout of
+    the implicit-GEMM kernels; q|k|v (and cross-attention k|v) projections are adjacent in the
+    arena, so their fused [3C, C] operand / gradient is one contiguous slice.
 """
 import math
 
 import numpy as np
 import torch
 import torch.nn as nn
+
+ALIGN = 8     # elements: keeps every tensor 16-byte aligned in the bf16 shadow too
 
 
 class _Node(nn.Module):
@@ -97,19 +104,54 @@ def _init_tensor(p, gen, sched):
     return t
 
 
-class FlatModule(nn.Module):
-    """nn.Module whose parameters/buffers are created from a list of spec.P."""
+def _view(arena, off, shape):
+    n = 1
+    for s in shape:
+        n *= s
+    flat = arena[off:off + n]
+    if len(shape) == 4:                      # physical [Cout][kh][kw][Cin], logical NCHW shape
+        co, ci, kh, kw = shape
+        return flat.view(co, kh, kw, ci).permute(0, 3, 1, 2)
+    return flat.view(shape)
 
-    def __init__(self, spec_list, schedule_kwargs=None, seed=0, node_classes=None):
+
+class FlatModule(nn.Module):
+    """nn.Module whose parameters/buffers are created from a list of spec.P (arena-backed)."""
+
+    def __init__(self, spec_list, schedule_kwargs=None, seed=0, node_classes=None,
+                 lr_group_of=None):
         super().__init__()
         node_classes = node_classes or {}
         self._spec = list(spec_list)
         gen = torch.Generator().manual_seed(seed)
         sched = ddpm_schedule(**schedule_kwargs) if schedule_kwargs is not None else None
+        # ---- arena layout: trainable params in spec order, then frozen ones
+        pspecs = [p for p in self._spec if not p.init.startswith('buf:')]
+        order = [p for p in pspecs if p.trainable] + [p for p in pspecs if not p.trainable]
+        self._offsets = {}
+        off = 0
+        for p in order:
+            n = int(np.prod(p.shape))
+            self._offsets[p.name] = (off, n)
+            off += (n + ALIGN - 1) // ALIGN * ALIGN
+        self._n_train = 0
+        for p in order:
+            if p.trainable:
+                o, n = self._offsets[p.name]
+                self._n_train = max(self._n_train, (o + n + ALIGN - 1) // ALIGN * ALIGN)
+        self._n_total = off
+        lr_group_of = lr_group_of or (lambda name: 1 if 'dm_decoder' in name else 0)
+        # group boundary: first trainable param of group 1 (spec order keeps groups contiguous)
+        self._group_split = self._n_train
+        for p in order:
+            if p.trainable and lr_group_of(p.name) == 1:
+                self._group_split = self._offsets[p.name][0]
+                break
+        object.__setattr__(self, '_arena', torch.zeros(self._n_total, dtype=torch.float32))
+        object.__setattr__(self, '_garena', None)
+        object.__setattr__(self, '_shadow', None)
+        self._where = {}
         for p in self._spec:
-            t = _init_tensor(p, gen, sched)
-            if t.dim() == 4:
-                t = t.contiguous(memory_format=torch.channels_last)
             parts = p.name.split('.')
             node = self
             for depth, part in enumerate(parts[:-1]):
@@ -117,22 +159,70 @@ class FlatModule(nn.Module):
                     cls = node_classes.get('.'.join(parts[:depth + 1]), _Node)
                     node.add_module(part, cls())
                 node = getattr(node, part)
+            t = _init_tensor(p, gen, sched)
             if p.init.startswith('buf:'):
                 node.register_buffer(parts[-1], t)
             else:
-                node.register_parameter(parts[-1], nn.Parameter(t, requires_grad=p.trainable))
+                v = _view(self._arena, self._offsets[p.name][0], p.shape)
+                v.copy_(t)
+                node.register_parameter(parts[-1], nn.Parameter(v, requires_grad=p.trainable))
+                self._where[p.name] = (node, parts[-1])
 
+    # ------------------------------------------------------------------------------------
     def tensors(self):
         """Flat {dotted name: tensor} view over parameters and buffers."""
         out = dict(self.named_parameters())
         out.update(dict(self.named_buffers()))
         return out
 
+    def arena(self):
+        return self._arena
+
+    def arena_ranges(self):
+        """(group0 = [0, split), group1 = [split, n_train), frozen = [n_train, n_total))."""
+        return self._group_split, self._n_train, self._n_total
+
+    def arena_slice(self, name, arena=None):
+        o, n = self._offsets[name]
+        return (self._arena if arena is None else arena)[o:o + n]
+
+    def grad_arena(self):
+        """fp32 gradient arena over the trainable range; `p.grad` are views into it."""
+        if self._garena is None or self._garena.device != self._arena.device:
+            g = torch.zeros(self._n_train, dtype=torch.float32, device=self._arena.device)
+            object.__setattr__(self, '_garena', g)
+            for p in self._spec:
+                if p.trainable and not p.init.startswith('buf:'):
+                    node, attr = self._where[p.name]
+                    getattr(node, attr).grad = _view(g, self._offsets[p.name][0], p.shape)
+        return self._garena
+
+    def shadow_arena(self, refresh=False):
+        """bf16 copy of the whole parameter arena (same offsets)."""
+        if self._shadow is None or self._shadow.device != self._arena.device:
+            object.__setattr__(self, '_shadow', torch.empty(self._n_total, dtype=torch.bfloat16,
+                                                            device=self._arena.device))
+            refresh = True
+        if refresh:
+            from . import ops
+            ops.cast2d(self._arena.view(1, -1), torch.bfloat16, out=self._shadow.view(1, -1))
+        return self._shadow
+
     def _apply(self, fn, recurse=True):
-        # keep conv weights channels_last across .to()/.cuda() (nn.Module preserves strides for
-        # dense non-overlapping tensors; assert instead of silently re-laying out)
-        r = super()._apply(fn, recurse)
-        for n, p in self.named_parameters():
-            if p.dim() == 4 and p.shape[1] > 1 and (p.shape[2] > 1 or p.shape[3] > 1):
-                assert p.is_contiguous(memory_format=torch.channels_last), n
-        return r
+        new = fn(self._arena)
+        assert new.dtype == torch.float32, 'master parameters stay fp32 (compute dtype is separate)'
+        object.__setattr__(self, '_arena', new)
+        object.__setattr__(self, '_garena', None)
+        object.__setattr__(self, '_shadow', None)
+        for p in self._spec:
+            if p.init.startswith('buf:'):
+                continue
+            node, attr = self._where[p.name]
+            param = getattr(node, attr)
+            param.data = _view(new, self._offsets[p.name][0], p.shape)
+            param.grad = None
+        for mod in self.modules():
+            for key, buf in mod._buffers.items():
+                if buf is not None:
+                    mod._buffers[key] = fn(buf)
+        return self
