@@ -126,6 +126,7 @@ typedef struct {
   int nsplit;
   const void* residual; /* forward residual (for act derivative) or NULL */
   void* dresidual;      /* optional: receives the gradient flowing to the residual branch */
+  int accumulate;       /* != 0: dgamma/dbeta += (parameter used more than once per step) */
 } SdmiGroupNormBwdArgs;
 int sdmi_groupnorm_bwd(const SdmiGroupNormBwdArgs* a, void* stream);
 
@@ -141,7 +142,7 @@ typedef struct {
   const void* x; const void* dy; void* dx; const float* gamma; const float* stats;
   float* dgamma; float* dbeta;   /* [C] fp32, accumulated via per-block partials */
   float* partial;                /* workspace [nblk][C][2] */
-  int dtype; int rows, C; int nblk;
+  int dtype; int rows, C; int nblk; int accumulate;
 } SdmiLayerNormBwdArgs;
 int sdmi_layernorm_bwd(const SdmiLayerNormBwdArgs* a, void* stream);
 

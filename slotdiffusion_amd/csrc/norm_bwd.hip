@@ -119,8 +119,8 @@ __global__ void gn_bwd_param_kernel(SdmiGroupNormBwdArgs p) {
     sa += q[0];
     sb += q[1];
   }
-  p.dbeta[c] = (float)sa;
-  p.dgamma[c] = (float)sb;
+  p.dbeta[c] = (p.accumulate ? p.dbeta[c] : 0.f) + (float)sa;
+  p.dgamma[c] = (p.accumulate ? p.dgamma[c] : 0.f) + (float)sb;
 }
 
 template <typename T>
@@ -240,8 +240,8 @@ __global__ void ln_bwd_param_kernel(SdmiLayerNormBwdArgs p) {
     sg += q[0];
     sb += q[1];
   }
-  p.dgamma[c] = (float)sg;
-  p.dbeta[c] = (float)sb;
+  p.dgamma[c] = (p.accumulate ? p.dgamma[c] : 0.f) + (float)sg;
+  p.dbeta[c] = (p.accumulate ? p.dbeta[c] : 0.f) + (float)sb;
 }
 
 }  // namespace

@@ -27,6 +27,17 @@ def _st():
     return torch.cuda.current_stream().cuda_stream
 
 
+import os as _os
+_DEBUG = _os.environ.get('SDMI_DEBUG_BWD', '') == '1'
+
+
+def _dbg(tag, **tensors):
+    if _DEBUG:
+        msg = ' '.join(f'{k}={float(v.float().norm()):.4e}' if v is not None else f'{k}=None'
+                       for k, v in tensors.items())
+        print(f'[bwd] {tag}: {msg}', flush=True)
+
+
 class WeightBank:
     """name(s) -> GEMM operand [N, K] in the requested dtype (K padded to the vector width)."""
 
@@ -35,6 +46,9 @@ class WeightBank:
         self.t = model.tensors()
         self.dtype = dtype
         self.cache = {}
+        # autograd anchor: parameters reach the kernels by name, so parameterised Functions take
+        # this requires-grad dummy to make their outputs part of the graph
+        self.anchor = torch.zeros(1, device=model.arena().device, requires_grad=True)
 
     def invalidate(self):
         self.cache.clear()
@@ -221,7 +235,7 @@ class GemmFn(torch.autograd.Function):
     """out = conv/linear(x, W) + bias (+ rowvec[b]) (+ residual).  Activation-free."""
 
     @staticmethod
-    def forward(ctx, x, rowvec, residual, wb, wnames, bnames, geom, out_dtype, ldc):
+    def forward(ctx, x, rowvec, residual, anchor, wb, wnames, bnames, geom, out_dtype, ldc):
         kh, kw, stride, pad, ups = geom
         w = wb.w(wnames, x.dtype)
         b = wb.b(bnames)
@@ -271,18 +285,18 @@ class GemmFn(torch.autograd.Function):
         mt = 128 if dt == torch.bfloat16 else 32
         splits = max(1, min((512 + tiles - 1) // tiles, max(1, M // (2 * mt)), 64))
         ws = torch.empty((max(splits * N * K, 256 * N),), dtype=torch.float32, device=x.device)
-        dwbuf = dst if direct else torch.empty((N, K), dtype=torch.float32, device=x.device)
+        dwbuf = dst if direct else torch.zeros((N, K), dtype=torch.float32, device=x.device)
         bdst = None
         btmp = None
         if bnames is not None:
             bdst = _grads_of(wb, bnames)
-            btmp = bdst if bdst is not None else torch.empty((N,), dtype=torch.float32,
+            btmp = bdst if bdst is not None else torch.zeros((N,), dtype=torch.float32,
                                                              device=x.device)
         call('sdmi_wgrad', _st(), a=_p(x), dy=_p(dy), dw=_p(dwbuf), dbias=_p(btmp),
              workspace=_p(ws), dtype=_DT[dt], M=M, N=N, K=K,
              lda=(Cin if is_conv else x.stride(-2)), ldy=ldy, B=B, H=H, W=W_,
              Cin=Cin, Ho=Ho, Wo=Wo, KH=kh, KW=kw, stride=stride, pad_t=pad[0], pad_l=pad[2],
-             ups=int(ups), splits=splits, accumulate=0)
+             ups=int(ups), splits=splits, accumulate=1)
         if not direct:
             g = wb.model.grad_arena()
             o = 0
@@ -333,12 +347,13 @@ class GemmFn(torch.autograd.Function):
         if has_res and ctx.needs_input_grad[2]:
             dres = dy if dy.shape[-1] == N else None
             assert dres is not None
-        return dx, drv, dres, None, None, None, None, None, None
+        _dbg(f'gemm {wnames if isinstance(wnames, str) else wnames[0]}', dy=dy, dx=dx, drv=drv)
+        return dx, drv, dres, None, None, None, None, None, None, None
 
 
 class GroupNormFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, residual, wb, name, eps, act):
+    def forward(ctx, x, residual, anchor, wb, name, eps, act):
         gamma, beta = wb.f(name + '.weight'), wb.f(name + '.bias')
         y, stats = ops.group_norm(x, gamma, beta, eps=eps, act=act, residual=residual,
                                   return_stats=True)
@@ -364,13 +379,14 @@ class GroupNormFn(torch.autograd.Function):
         call('sdmi_groupnorm_bwd', _st(), x=_p(x), dy=_p(dy), dx=_p(dx), gamma=_p(wb.f(name + '.weight')),
              beta=_p(wb.f(name + '.bias')), stats=_p(stats), dgamma=_p(dg), dbeta=_p(db),
              partial=_p(partial), dtype=_DT[x.dtype], B=B, HW=HW, C=C, groups=G,
-             act=_lib.ACT[act], nsplit=nsplit, residual=_p(residual), dresidual=_p(dres))
-        return dx, dres, None, None, None, None
+             act=_lib.ACT[act], nsplit=nsplit, residual=_p(residual), dresidual=_p(dres), accumulate=1)
+        _dbg(f'gn {name}', dy=dy, dx=dx, dres=dres)
+        return dx, dres, None, None, None, None, None
 
 
 class LayerNormFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, wb, name):
+    def forward(ctx, x, anchor, wb, name):
         C = x.shape[-1]
         stats = torch.empty((x.numel() // C, 2), dtype=torch.float32, device=x.device)
         y = ops.layer_norm(x, wb.f(name + '.weight'), wb.f(name + '.bias'), stats=stats)
@@ -391,8 +407,9 @@ class LayerNormFn(torch.autograd.Function):
         call('sdmi_layernorm_bwd', _st(), x=_p(x), dy=_p(dy), dx=_p(dx),
              gamma=_p(wb.f(name + '.weight')), stats=_p(stats),
              dgamma=_p(_grads_of(wb, name + '.weight')), dbeta=_p(_grads_of(wb, name + '.bias')),
-             partial=_p(partial), dtype=_DT[x.dtype], rows=rows, C=C, nblk=nblk)
-        return dx, None, None
+             partial=_p(partial), dtype=_DT[x.dtype], rows=rows, C=C, nblk=nblk, accumulate=1)
+        _dbg(f'ln {name}', dy=dy, dx=dx)
+        return dx, None, None, None
 
 
 class AttnFn(torch.autograd.Function):
@@ -431,6 +448,7 @@ class AttnFn(torch.autograd.Function):
              lse=_p(lse), dq=_p(dq), dk=_p(dk), dv=_p(dv), dtype=_DT[q.dtype], B=B, heads=heads,
              Sq=Sq, Skv=Skv, ldq=q.stride(1), ldk=k.stride(1), ldv=v.stride(1), ldo=out.stride(1),
              scale=32 ** -0.5)
+        _dbg(f'attn Sq={Sq} Skv={Skv}', dout=dout, da=da, dkv=dkv)
         return da, dkv, None
 
 
@@ -546,6 +564,7 @@ class SaAttendFn(torch.autograd.Function):
         call('sdmi_sa_attend_bwd', _st(), k=_p(kv), v=_p(kv[..., D:]), q=_p(q), attn=_p(attn),
              upd=_p(upd), den=_p(den), dupd=_p(dupd), dq=_p(dq), dk=_p(dkv), dv=_p(dkv[..., D:]),
              dtype=_DT[kv.dtype], B=B, M=M, N=N, D=D, ldkv=D2, eps=ctx.eps, scale=D ** -0.5)
+        _dbg('sa_attend', dupd=dupd, dkv=dkv, dq=dq)
         return dkv, dq, None
 
 
@@ -602,19 +621,19 @@ class KernGrad(Kern):
 
     def conv(self, x, wname, bname=None, *, kh=3, kw=3, stride=1, pad=(1, 1, 1, 1), ups=False,
              rowvec=None, residual=None, out_dtype=None, ldc=None):
-        return GemmFn.apply(x, rowvec, residual, self.wb, wname, bname, (kh, kw, stride, pad, ups),
-                            out_dtype, ldc)
+        return GemmFn.apply(x, rowvec, residual, self.wb.anchor, self.wb, wname, bname,
+                            (kh, kw, stride, pad, ups), out_dtype, ldc)
 
     def linear(self, x, wnames, bnames=None, *, act=None, residual=None, out_dtype=None):
-        y = GemmFn.apply(x, None, residual, self.wb, wnames, bnames, (0, 0, 1, (0, 0, 0, 0), False),
-                         out_dtype, None)
+        y = GemmFn.apply(x, None, residual, self.wb.anchor, self.wb, wnames, bnames,
+                         (0, 0, 1, (0, 0, 0, 0), False), out_dtype, None)
         return ActFn.apply(y, act) if act else y
 
     def gn(self, x, name, *, eps, act=None, residual=None):
-        return GroupNormFn.apply(x, residual, self.wb, name, eps, act)
+        return GroupNormFn.apply(x, residual, self.wb.anchor, self.wb, name, eps, act)
 
     def ln(self, x, name):
-        return LayerNormFn.apply(x, self.wb, name)
+        return LayerNormFn.apply(x, self.wb.anchor, self.wb, name)
 
     def attn_self(self, qkv, heads):
         return AttnFn.apply(qkv, None, heads)
