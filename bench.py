@@ -86,7 +86,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--batch', type=int, default=64)
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
-    ap.add_argument('--mode', default='sample', choices=['sample'])
+    ap.add_argument('--mode', default='train', choices=['train', 'sample'])
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
@@ -105,52 +105,96 @@ def main():
     dtype = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
 
     model, cfg = build_model(dtype)
-    model = model.to(dev).eval()
+    model = model.to(dev)
     model.use_graph = not args.no_graph
     B = args.batch
     img = synth_batch(B, rank, dev)
     from slotdiffusion_amd import ops
-    with torch.no_grad():
-        slots, _ = model.encode(img)                      # conditioning (not in the timed region)
-        g = torch.Generator(device='cpu').manual_seed(77 + rank)
-        x_T = ops.nchw_to_nhwc(torch.randn(B, 3, 32, 32, generator=g).to(dev), torch.float32, 4)
+    from slotdiffusion_amd.optim import FusedAdam
+    nfe = 20
 
-        def step():
-            return model._dpm_sample(x_T, slots)[0]
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
 
-        for _ in range(args.warmup):
-            step()
-
-        def barrier():
-            torch.cuda.synchronize()
-            if dist is not None:
-                dist.barrier()
-            torch.cuda.synchronize()
-
+    def timed(fn, steps, warmup):
+        for _ in range(warmup):
+            fn()
         barrier()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
+        for _ in range(steps):
+            fn()
         barrier()
         dt = time.perf_counter() - t0
         if dist is not None:
             tt = torch.tensor([dt], device=dev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt)
-        nfe = 20
-        value = world * B * nfe * args.steps / dt
+        return dt
 
+    # ---- sampling leg: 20-NFE DPM-Solver++ over B images' slots --------------------------
+    model.eval()
+    with torch.no_grad():
+        slots, _ = model.encode(img)
+        g = torch.Generator(device='cpu').manual_seed(77 + rank)
+        x_T = ops.nchw_to_nhwc(torch.randn(B, 3, 32, 32, generator=g).to(dev), torch.float32, 4)
+
+        def sample_step():
+            return model._dpm_sample(x_T, slots)[0]
+        dt_s = timed(sample_step, args.steps if args.mode == 'sample' else max(2, args.steps // 2),
+                     args.warmup if args.mode == 'sample' else 1)
+        n_s = args.steps if args.mode == 'sample' else max(2, args.steps // 2)
+        denoise_rate = world * B * nfe * n_s / dt_s
+
+    # ---- training leg: forward + loss + backward (+ DDP all-reduce) + clip + Adam --------
+    model.train()
+    opt = FusedAdam(model, lr=1e-4, dec_lr=2e-4, clip_grad=1.0, total_steps=100000)
+    garena = model.grad_arena()
+
+    def train_step():
+        opt.zero_grad()
+        out = model(dict(img=img))
+        loss = model.calc_train_loss(dict(img=img), out)['denoise_loss']
+        loss.backward()
+        if dist is not None:          # gradients only, flat fp32 arena in a few large buckets
+            nb = 4
+            per = (garena.numel() + nb - 1) // nb
+            for i in range(nb):
+                dist.all_reduce(garena[i * per:(i + 1) * per])
+            garena.mul_(1.0 / world)
+        opt.step()
+        return loss
+
+    train_rate = None
+    dt_t = None
+    if args.mode == 'train':
+        dt_t = timed(train_step, args.steps, args.warmup)
+        train_rate = world * B * args.steps / dt_t
+
+    if True:
+        if args.mode == 'train':
+            value, unit, ms = train_rate, 'images/s', 1e3 * dt_t / args.steps
+            metric = 'train-step images/sec, 128^2 7-slot (DPM-Solver denoise-steps/sec in `denoise`)'
+            work = ('img_based SlotDiffusion CLEVRTex 128x128 7 slots: train step = SA encoder + '
+                    'frozen VQ-VAE encode + q-sample + UNet eps + MSE, backward, clip, Adam '
+                    '(dropout 0.1)')
+        else:
+            value, unit, ms = denoise_rate, 'image-denoise-steps/s', 1e3 * dt_s / n_s
+            metric = 'DPM-Solver denoise-steps/sec, 128^2 7-slot'
+            work = ('img_based SlotDiffusion CLEVRTex 128x128 7 slots: 20-NFE DPM-Solver++ '
+                    'sampling (UNet eps + VQ per NFE)')
         out = {
-            'metric': 'DPM-Solver denoise-steps/sec, 128^2 7-slot (train-step images/sec: not yet '
-                      'native, see DESIGN.md)',
-            'value': value, 'unit': 'image-denoise-steps/s', 'n_gpus': world, 'steps': args.steps,
-            'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True,
+            'metric': metric, 'value': value, 'unit': unit, 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': ms, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
-            'config': {'workload': 'img_based SlotDiffusion CLEVRTex 128x128 7 slots: 20-NFE '
-                                   'DPM-Solver++ sampling (UNet eps + VQ per NFE)',
-                       'batch_per_gpu': B, 'nfe_per_step': nfe, 'hip_graph': model.use_graph,
+            'config': {'workload': work, 'batch_per_gpu': B, 'hip_graph_sampler': model.use_graph,
                        'parallelism': f'dp{world}'},
+            'denoise': {'value': denoise_rate, 'unit': 'image-denoise-steps/s',
+                        'ms_per_20nfe_pass': 1e3 * dt_s / n_s, 'nfe': nfe},
         }
+        step = train_step if args.mode == 'train' else sample_step
         if rank == 0 and not args.no_roofline:
             # live per-kernel timing of ONE sampling pass, eager (events around every launch)
             from slotdiffusion_amd._lib import KernelTimer
@@ -160,11 +204,14 @@ def main():
                 step()
             summ = kt.summary()
             model.use_graph = not args.no_graph
-            ig = summ['sdmi_igemm']
+            ig = dict(summ['sdmi_igemm'])
+            if 'sdmi_wgrad' in summ:        # the MFMA GEMM family = forward/dgrad igemm + wgrad
+                for k in ('calls', 'ms', 'flops'):
+                    ig[k] += summ['sdmi_wgrad'][k]
             total_ms = sum(v['ms'] for v in summ.values())
             ach = ig['flops'] / (ig['ms'] * 1e-3) / 1e12
             peak = PEAK_TFLOPS[args.dtype]
-            out['roofline'] = {'bound': 'mfma', 'kernel': 'sdmi_igemm (implicit-GEMM conv/linear)',
+            out['roofline'] = {'bound': 'mfma', 'kernel': 'sdmi_igemm + sdmi_wgrad (implicit-GEMM conv/linear fwd, dgrad, wgrad)',
                                'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak,
                                'traffic': None, 'launches_per_step': ig['calls'],
                                'avg_launch_us': 1e3 * ig['ms'] / ig['calls'],

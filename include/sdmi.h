@@ -284,6 +284,11 @@ int sdmi_pool2x2_sum(const SdmiPool2x2Args* a, void* stream);
 /* y = x + z elementwise in `dtype` (gradient accumulation at residual / skip joins) */
 typedef struct { const void* x; const void* z; void* y; int dtype; long long n; } SdmiAddArgs;
 int sdmi_add(const SdmiAddArgs* a, void* stream);
+/* inverted dropout with a counter-based generator: y[i] = keep(seed, i) ? x[i] / (1-p) : 0, keep
+ * derived from a 64-bit mix of (seed, i) so the backward pass regenerates the same mask from the
+ * seed instead of storing it (ResBlock dropout, unet.py:246; p = 0.1 in every LDM config). */
+typedef struct { const void* x; void* y; int dtype; long long n; float p; long long seed; } SdmiDropoutArgs;
+int sdmi_dropout(const SdmiDropoutArgs* a, void* stream);
 /* split of a channel concat: a[r][:Ca] = y[r][:Ca], b[r][:Cb] = y[r][Ca:] */
 typedef struct { const void* y; void* a; void* b; int dtype; long long rows; int Ca, Cb; } SdmiSplitArgs;
 int sdmi_split_channels(const SdmiSplitArgs* a, void* stream);

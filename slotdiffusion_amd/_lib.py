@@ -132,6 +132,8 @@ def _meta(fname, kw):
     if fname == 'sdmi_igemm':
         b = max(1, kw.get('batch', 1))
         return dict(flops=2.0 * kw['M'] * kw['N'] * kw['K'] * b)
+    if fname == 'sdmi_wgrad':
+        return dict(flops=2.0 * kw['M'] * kw['N'] * kw['K'])
     return {}
 
 

@@ -112,6 +112,23 @@ __global__ void act_bwd_kernel(SdmiActBwdArgs p) {
   }
 }
 
+__device__ __forceinline__ unsigned mix64(unsigned long long z) {   // splitmix64 finaliser
+  z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
+  z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
+  z = z ^ (z >> 31);
+  return (unsigned)(z >> 32);
+}
+template <typename T>
+__global__ void dropout_kernel(SdmiDropoutArgs p) {
+  const float inv = 1.f / (1.f - p.p);
+  const unsigned thr = (unsigned)((double)p.p * 4294967296.0);
+  GRID_STRIDE(i, p.n) {
+    const unsigned r = mix64((unsigned long long)p.seed + 0x9e3779b97f4a7c15ULL * (unsigned long long)(i + 1));
+    const float v = Elem<T>::ld((const T*)p.x + i);
+    Elem<T>::st((T*)p.y + i, r >= thr ? v * inv : 0.f);
+  }
+}
+
 // ---- optimiser --------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void sqsum_kernel(SdmiSqSumArgs p) {
   __shared__ double red[4];
@@ -203,6 +220,11 @@ extern "C" int sdmi_act_bwd(const SdmiActBwdArgs* a, void* stream) {
   SDMI_REQUIRE(a && a->x && a->dy && a->dx, "null pointer");
   DISPATCH_T(act_bwd_kernel, dim3(nblocks(a->n)), a);
   return sdmi_check_launch("act_bwd");
+}
+extern "C" int sdmi_dropout(const SdmiDropoutArgs* a, void* stream) {
+  SDMI_REQUIRE(a && a->x && a->y && a->p >= 0.f && a->p < 1.f, "bad args");
+  DISPATCH_T(dropout_kernel, dim3(nblocks(a->n)), a);
+  return sdmi_check_launch("dropout");
 }
 extern "C" int sdmi_sqsum_partial(const SdmiSqSumArgs* a, void* stream) {
   SDMI_REQUIRE(a && a->g && a->partial && a->nblk >= 1, "bad args");

@@ -115,7 +115,7 @@ class UNetRunner:
         rv = rowvecs[:, off:off + cout]            # strided view; the kernel takes its row pitch
         h = K.gn(x, n + '.in_layers.0', eps=1e-5, act='silu')
         h = K.conv(h, n + '.in_layers.2.weight', n + '.in_layers.2.bias', rowvec=rv)
-        h = K.gn(h, n + '.out_layers.0', eps=1e-5, act='silu')
+        h = K.dropout(K.gn(h, n + '.out_layers.0', eps=1e-5, act='silu'))   # p=0 outside training
         skip = x
         if (n + '.skip_connection.weight') in K.wb.t:
             skip = K.conv(x, n + '.skip_connection.weight', n + '.skip_connection.bias', kh=1, kw=1,

@@ -202,6 +202,9 @@ class Kern:
     def cast(self, x, dtype):
         return x if x.dtype == dtype else ops.act(x, None, dtype)
 
+    def dropout(self, x):
+        return x
+
     def slot_attention(self, kv, init, name, iters, eps):
         wb = self.wb
         D = kv.shape[-1] // 2
@@ -615,9 +618,36 @@ class MseFn(torch.autograd.Function):
         return dpred * g, None, None
 
 
+class DropoutFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p, seed):
+        ctx.p, ctx.seed = p, seed
+        y = torch.empty_like(x)
+        call('sdmi_dropout', _st(), x=_p(x), y=_p(y), dtype=_DT[x.dtype], n=x.numel(), p=p, seed=seed)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        dx = torch.empty_like(dy)
+        call('sdmi_dropout', _st(), x=_p(dy), y=_p(dx), dtype=_DT[dy.dtype], n=dy.numel(), p=ctx.p,
+             seed=ctx.seed)
+        return dx, None, None
+
+
 class KernGrad(Kern):
     """Training provider (autograd)."""
     training = True
+    dropout_p = 0.0
+    seed = 0
+    _drop_ctr = 0
+
+    def dropout(self, x):
+        p = float(getattr(self.wb.model, 'train_dropout', 0.0))
+        if p <= 0.0:
+            return x
+        KernGrad._drop_ctr += 1
+        return DropoutFn.apply(x, p, (self.seed << 20) + KernGrad._drop_ctr)
 
     def conv(self, x, wname, bname=None, *, kh=3, kw=3, stride=1, pad=(1, 1, 1, 1), ups=False,
              rowvec=None, residual=None, out_dtype=None, ldc=None):

@@ -175,6 +175,8 @@ class SADiffusion(FlatModule):
         self.rplan = spec.resnet18_plan(enc_dict['use_layer4'])
         self.unet_cfg = dec_dict['unet_dict']
         self.testing = False
+        # ResBlock dropout (unet_dict['dropout']); parity tests switch it off (RNG streams differ)
+        self.train_dropout = float(dec_dict['unet_dict'].get('dropout', 0.0))
         self.compute_dtype = compute_dtype or default_compute_dtype()
         self.dm_decoder._bind(self)
         self.dm_decoder.vae._bind(self)

@@ -28,6 +28,7 @@ def ctx(dtype=torch.float32):
         m = SADiffusion(cfg['resolution'], cfg['slot_dict'], cfg['enc_dict'], cfg['dec_dict'],
                         cfg['loss_dict'], compute_dtype=dtype)
         det_fill_(m.state_dict().items(), skip=is_buffer_name)
+        m.train_dropout = 0.0
         m = m.cuda().eval()
         m.use_graph = False
         _cache[dtype] = m
