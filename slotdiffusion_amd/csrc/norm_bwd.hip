@@ -110,17 +110,26 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(SdmiGroupNormBwdArgs
   }
 }
 
-__global__ void gn_bwd_param_kernel(SdmiGroupNormBwdArgs p) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= p.C) return;
-  double sa = 0.0, sb = 0.0;
-  for (int b = 0; b < p.B; ++b) {
-    const float* q = p.partial + (((long long)b * p.nsplit) * p.C + c) * 2;
-    sa += q[0];
-    sb += q[1];
+__global__ __launch_bounds__(256) void gn_bwd_param_kernel(SdmiGroupNormBwdArgs p) {
+  __shared__ float red[4][64][2];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), kg = threadIdx.x >> 6;
+  float sa = 0.f, sb = 0.f;
+  if (c < p.C)
+    for (int b = kg; b < p.B; b += 4) {
+      const float* q = p.partial + (((long long)b * p.nsplit) * p.C + c) * 2;
+      sa += q[0];
+      sb += q[1];
+    }
+  red[kg][threadIdx.x & 63][0] = sa;
+  red[kg][threadIdx.x & 63][1] = sb;
+  __syncthreads();
+  if (kg == 0 && c < p.C) {
+    const int l = threadIdx.x;
+    const float a = (red[0][l][0] + red[1][l][0]) + (red[2][l][0] + red[3][l][0]);
+    const float b = (red[0][l][1] + red[1][l][1]) + (red[2][l][1] + red[3][l][1]);
+    p.dbeta[c] = (p.accumulate ? p.dbeta[c] : 0.f) + a;
+    p.dgamma[c] = (p.accumulate ? p.dgamma[c] : 0.f) + b;
   }
-  p.dbeta[c] = (p.accumulate ? p.dbeta[c] : 0.f) + (float)sa;
-  p.dgamma[c] = (p.accumulate ? p.dgamma[c] : 0.f) + (float)sb;
 }
 
 template <typename T>
@@ -231,17 +240,26 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(SdmiLayerNormBwdArgs p, int
     q[1] = (red[0][c][1] + red[1][c][1]) + (red[2][c][1] + red[3][c][1]);
   }
 }
-__global__ void ln_bwd_param_kernel(SdmiLayerNormBwdArgs p) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= p.C) return;
-  double sg = 0.0, sb = 0.0;
-  for (int k = 0; k < p.nblk; ++k) {
-    const float* q = p.partial + ((long long)k * p.C + c) * 2;
-    sg += q[0];
-    sb += q[1];
+__global__ __launch_bounds__(256) void ln_bwd_param_kernel(SdmiLayerNormBwdArgs p) {
+  __shared__ float red[4][64][2];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), kg = threadIdx.x >> 6;
+  float sg = 0.f, sb = 0.f;
+  if (c < p.C)
+    for (int k = kg; k < p.nblk; k += 4) {
+      const float* q = p.partial + ((long long)k * p.C + c) * 2;
+      sg += q[0];
+      sb += q[1];
+    }
+  red[kg][threadIdx.x & 63][0] = sg;
+  red[kg][threadIdx.x & 63][1] = sb;
+  __syncthreads();
+  if (kg == 0 && c < p.C) {
+    const int l = threadIdx.x;
+    const float g = (red[0][l][0] + red[1][l][0]) + (red[2][l][0] + red[3][l][0]);
+    const float b = (red[0][l][1] + red[1][l][1]) + (red[2][l][1] + red[3][l][1]);
+    p.dgamma[c] = (p.accumulate ? p.dgamma[c] : 0.f) + g;
+    p.dbeta[c] = (p.accumulate ? p.dbeta[c] : 0.f) + b;
   }
-  p.dgamma[c] = (p.accumulate ? p.dgamma[c] : 0.f) + (float)sg;
-  p.dbeta[c] = (p.accumulate ? p.dbeta[c] : 0.f) + (float)sb;
 }
 
 }  // namespace
@@ -265,7 +283,7 @@ extern "C" int sdmi_groupnorm_bwd(const SdmiGroupNormBwdArgs* a, void* stream) {
   else
     hipLaunchKernelGGL(gn_bwd_stats_kernel<float>, g1, dim3(256), 0, st, *a);
   hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(a->B), dim3(256), 0, st, *a, gsum);
-  hipLaunchKernelGGL(gn_bwd_param_kernel, dim3((a->C + 255) / 256), dim3(256), 0, st, *a);
+  hipLaunchKernelGGL(gn_bwd_param_kernel, dim3((a->C + 63) / 64), dim3(256), 0, st, *a);
   if (a->dtype == SDMI_BF16)
     hipLaunchKernelGGL(gn_bwd_apply_kernel<bf16_t>, g3, dim3(256), 0, st, *a, gsum, rows_per);
   else
@@ -283,6 +301,6 @@ extern "C" int sdmi_layernorm_bwd(const SdmiLayerNormBwdArgs* a, void* stream) {
     hipLaunchKernelGGL(ln_bwd_kernel<bf16_t>, dim3(a->nblk), dim3(256), 0, st, *a, rows_per_blk);
   else
     hipLaunchKernelGGL(ln_bwd_kernel<float>, dim3(a->nblk), dim3(256), 0, st, *a, rows_per_blk);
-  hipLaunchKernelGGL(ln_bwd_param_kernel, dim3((a->C + 255) / 256), dim3(256), 0, st, *a);
+  hipLaunchKernelGGL(ln_bwd_param_kernel, dim3((a->C + 63) / 64), dim3(256), 0, st, *a);
   return sdmi_check_launch("layernorm_bwd");
 }

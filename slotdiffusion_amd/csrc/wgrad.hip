@@ -251,25 +251,79 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(SdmiWgradArgs p) {
   }
 }
 
-// column sums of dY (bias gradient): stage 1 partial over row chunks, stage 2 final.
+// column sums of dY (bias gradient).  Stage 1: workgroup = one row chunk; thread t owns the 16-byte
+// column vector cv = t % CVp and walks rows t / CVp, + 256/CVp, ... (whole 128-byte lines per wave,
+// several independent loads in flight); LDS reduce over the row threads -> partial[chunk][N].
+// Stage 2: 64 columns x 4 chunk-groups per workgroup.
+__device__ __forceinline__ int next_pow2_w(int v) {
+  int p = 1;
+  while (p < v) p <<= 1;
+  return p;
+}
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* y, float* part, int M, int N,
                                                              int ldy, int rows_per) {
-  const int n = blockIdx.x * 256 + threadIdx.x;
-  if (n >= N) return;
-  const int m0 = blockIdx.y * rows_per;
+  constexpr int VEC = Elem<T>::VEC;
+  __shared__ float red[256][VEC];
+  const int CVtot = (N + VEC - 1) / VEC;
+  int CVp = next_pow2_w(CVtot);
+  if (CVp > 256) CVp = 256;                    // wide N: column blocks along grid.y
+  const int R = 256 / CVp;
+  const int cv = blockIdx.y * CVp + threadIdx.x % CVp, r0 = threadIdx.x / CVp;
+  const int CV = CVtot;
+  const int m0 = blockIdx.x * rows_per;
   int m1 = m0 + rows_per;
   if (m1 > M) m1 = M;
-  float s = 0.f;
-  for (int m = m0; m < m1; ++m) s += Elem<T>::ld(y + (long long)m * ldy + n);
-  part[(long long)blockIdx.y * N + n] = s;
+  float acc[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
+  if (cv < CV) {
+    const T* base = y + cv * VEC;
+    int m = m0 + r0;
+    for (; m + 3 * R < m1; m += 4 * R) {
+      float f0[VEC], f1[VEC], f2[VEC], f3[VEC];
+      unpack16<T>(*reinterpret_cast<const uint4*>(base + (long long)m * ldy), f0);
+      unpack16<T>(*reinterpret_cast<const uint4*>(base + (long long)(m + R) * ldy), f1);
+      unpack16<T>(*reinterpret_cast<const uint4*>(base + (long long)(m + 2 * R) * ldy), f2);
+      unpack16<T>(*reinterpret_cast<const uint4*>(base + (long long)(m + 3 * R) * ldy), f3);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) acc[j] += (f0[j] + f1[j]) + (f2[j] + f3[j]);
+    }
+    for (; m < m1; m += R) {
+      float f0[VEC];
+      unpack16<T>(*reinterpret_cast<const uint4*>(base + (long long)m * ldy), f0);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) acc[j] += f0[j];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) red[threadIdx.x][j] = acc[j];
+  __syncthreads();
+  if (r0 == 0 && cv < CV) {
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      const int n = cv * VEC + j;
+      if (n < N) {
+        float s = 0.f;
+        for (int r = 0; r < R; ++r) s += red[r * CVp + (threadIdx.x % CVp)][j];
+        part[(long long)blockIdx.x * N + n] = s;
+      }
+    }
+  }
 }
-__global__ void colsum_final_kernel(const float* part, float* out, int N, int chunks, int accumulate) {
-  const int n = blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= N) return;
-  double s = accumulate ? (double)out[n] : 0.0;
-  for (int c = 0; c < chunks; ++c) s += (double)part[(long long)c * N + n];
-  out[n] = (float)s;
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* part, float* out, int N,
+                                                           int chunks, int accumulate) {
+  __shared__ float red[4][64];
+  const int n = blockIdx.x * 64 + (threadIdx.x & 63), kg = threadIdx.x >> 6;
+  float s = 0.f;
+  if (n < N)
+    for (int c = kg; c < chunks; c += 4) s += part[(long long)c * N + n];
+  red[kg][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (kg == 0 && n < N) {
+    const float t = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    out[n] = (accumulate ? out[n] : 0.f) + t;
+  }
 }
 
 template <typename T, int TN, int TK>
@@ -324,17 +378,16 @@ extern "C" int sdmi_wgrad(const SdmiWgradArgs* a, void* stream) {
   }
   if (a->dbias) {
     // reuse the (now consumed) workspace for the column-sum partials
-    int chunks = (a->M + 511) / 512;
+    int chunks = (a->M + 255) / 256;
     if (chunks > 256) chunks = 256;
     const int rows_per = (a->M + chunks - 1) / chunks;
-    dim3 grid((a->N + 255) / 256, chunks);
     if (a->dtype == SDMI_BF16)
-      hipLaunchKernelGGL(colsum_partial_kernel<bf16_t>, grid, dim3(256), 0, st,
+      hipLaunchKernelGGL(colsum_partial_kernel<bf16_t>, dim3(chunks, ((a->N + 7) / 8 + 255) / 256), dim3(256), 0, st,
                          (const bf16_t*)a->dy, a->workspace, a->M, a->N, a->ldy, rows_per);
     else
-      hipLaunchKernelGGL(colsum_partial_kernel<float>, grid, dim3(256), 0, st,
+      hipLaunchKernelGGL(colsum_partial_kernel<float>, dim3(chunks, ((a->N + 3) / 4 + 255) / 256), dim3(256), 0, st,
                          (const float*)a->dy, a->workspace, a->M, a->N, a->ldy, rows_per);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((a->N + 255) / 256), dim3(256), 0, st,
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((a->N + 63) / 64), dim3(256), 0, st,
                        a->workspace, a->dbias, a->N, chunks, a->accumulate);
     rc = sdmi_check_launch("wgrad dbias");
   }

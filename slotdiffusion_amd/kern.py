@@ -286,7 +286,7 @@ class GemmFn(torch.autograd.Function):
         direct = dst is not None and k_true == K
         tiles = ((N + 127) // 128) * ((K + 127) // 128)
         mt = 128 if dt == torch.bfloat16 else 32
-        splits = max(1, min((512 + tiles - 1) // tiles, max(1, M // (2 * mt)), 64))
+        splits = max(1, min((768 + tiles - 1) // tiles, max(1, M // (4 * mt)), 512))
         ws = torch.empty((max(splits * N * K, 256 * N),), dtype=torch.float32, device=x.device)
         dwbuf = dst if direct else torch.zeros((N, K), dtype=torch.float32, device=x.device)
         bdst = None
