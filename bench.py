@@ -51,10 +51,10 @@ def synth_batch(B, rank, device):
 
 
 def cpu_baseline(cfg, mode, quick=False):
-    """Oracle (CPU port of the reference path) timed on this box's host cores, B=4."""
+    """Oracle (CPU port of the reference path) timed on this box's host cores, B=4 (bounded sample)."""
     from oracle import slotdiff_oracle as O
     from slotdiffusion_amd import spec
-    from tests.common import oracle_weights
+    from tests.common import load_keys, oracle_weights
     cores = os.cpu_count() or 1
     threads = min(cores, 64)
     torch.set_num_threads(threads)
@@ -64,6 +64,34 @@ def cpu_baseline(cfg, mode, quick=False):
     img = (torch.randn(B, 3, 128, 128, generator=g) * 0.5).clamp(-1, 1)
     rplan = spec.resnet18_plan(False)
     uplan = spec.unet_plan(cfg['dec_dict']['unet_dict'])
+    ed = cfg['dec_dict']['vae_dict']['enc_dec_dict']
+    if mode == 'train':
+        keys = load_keys()['img_based/SADiffusion/clevrtex-7slot']
+        frozen = set(keys['frozen'])
+        names = [k for k, _ in keys['params'] if k not in frozen]
+        P = [W[k].requires_grad_(True) for k in names]
+        M = [torch.zeros_like(p) for p in P]
+        V = [torch.zeros_like(p) for p in P]
+        lrs = [2e-4 if 'dm_decoder' in n else 1e-4 for n in names]
+        t = torch.randint(0, 1000, (B,), generator=g)
+        noise = torch.randn(B, 3, 32, 32, generator=g)
+        nsteps = 1 if quick else 3
+        times = []
+        for it in range(nsteps + 1):
+            t0 = time.perf_counter()
+            for p in P:
+                p.grad = None
+            slots, _ = O.sa_encode(W, img, rplan, 3, training=True)
+            loss, _, _ = O.ldm_loss(W, uplan, ed, img, slots, t, noise)
+            loss.backward()
+            with torch.no_grad():
+                O.clip_and_adam(P, [p.grad for p in P], M, V, it + 1, lrs, clip=1.0)
+            times.append(time.perf_counter() - t0)
+        dt = sorted(times[1:])[len(times[1:]) // 2]
+        return dict(value=B / dt, unit='images/s', cores=threads, kind='port',
+                    sample=f'oracle train step (fwd+bwd+clip+Adam, no dropout), B={B}, fp32, torch-CPU '
+                           f'{threads} threads of {cores} cores, median of {nsteps} steps, '
+                           f'{dt:.2f}s/step')
     with torch.no_grad():
         slots, _ = O.sa_encode(W, img, rplan, 3, training=False)
         x_T = torch.randn(B, 3, 32, 32, generator=g)
@@ -109,7 +137,7 @@ def main():
     model.use_graph = not args.no_graph
     B = args.batch
     img = synth_batch(B, rank, dev)
-    from slotdiffusion_amd import ops
+    from slotdiffusion_amd import ops, parallel
     from slotdiffusion_amd.optim import FusedAdam
     nfe = 20
 
@@ -158,12 +186,8 @@ def main():
         out = model(dict(img=img))
         loss = model.calc_train_loss(dict(img=img), out)['denoise_loss']
         loss.backward()
-        if dist is not None:          # gradients only, flat fp32 arena in a few large buckets
-            nb = 4
-            per = (garena.numel() + nb - 1) // nb
-            for i in range(nb):
-                dist.all_reduce(garena[i * per:(i + 1) * per])
-            garena.mul_(1.0 / world)
+        if dist is not None:          # gradients only: the flat fp32 arena in a few large buckets
+            parallel.allreduce_gradients(garena, world, n_buckets=4)
         opt.step()
         return loss
 
