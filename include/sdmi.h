@@ -156,6 +156,7 @@ int sdmi_layernorm_bwd(const SdmiLayerNormBwdArgs* a, void* stream);
 typedef struct {
   const void* q; const void* k; const void* v; void* out; float* lse;
   int dtype; int B, heads, Sq, Skv; int ldq, ldk, ldv, ldo; float scale;
+  int head_dim;        /* 0 or 32: UNet; 48: SAVi transformer predictor (predictor.py:20-44) */
 } SdmiAttnArgs;
 int sdmi_attention(const SdmiAttnArgs* a, void* stream);
 
@@ -163,6 +164,7 @@ typedef struct {
   const void* q; const void* k; const void* v; const void* out; const void* dout; const float* lse;
   void* dq; void* dk; void* dv;
   int dtype; int B, heads, Sq, Skv; int ldq, ldk, ldv, ldo; float scale;
+  int head_dim;
 } SdmiAttnBwdArgs;
 int sdmi_attention_bwd(const SdmiAttnBwdArgs* a, void* stream);
 

@@ -134,6 +134,52 @@ def sa_encode(W, img, plan, num_iterations, training, eps=1e-6):
     return slots, masks
 
 
+
+# ---------------------------------------------------------------------------
+# a4/a5: video model -- transformer slot predictor + recurrence over frames
+# ---------------------------------------------------------------------------
+def transformer_predictor(W, x, num_layers, num_heads, name='predictor'):
+    """video_based/models/predictor.py:20-44: nn.TransformerEncoder, norm_first=True, ReLU FFN,
+    no final norm; dropout off (eval / parity).  x [B,N,D]."""
+    B, N, D = x.shape
+    hd = D // num_heads
+    for i in range(num_layers):
+        l = f'{name}.transformer_encoder.layers.{i}'
+        h = _ln(W, f'{l}.norm1', x)
+        qkv = F.linear(h, W[f'{l}.self_attn.in_proj_weight'], W[f'{l}.self_attn.in_proj_bias'])
+        q, k, v = qkv.chunk(3, -1)
+        sp = lambda t: t.view(B, N, num_heads, hd).permute(0, 2, 1, 3)
+        att = (torch.einsum('bhid,bhjd->bhij', sp(q), sp(k)) * hd ** -0.5).softmax(-1)
+        a = torch.einsum('bhij,bhjd->bhid', att, sp(v)).permute(0, 2, 1, 3).reshape(B, N, D)
+        x = x + _lin(W, f'{l}.self_attn.out_proj', a)
+        h = F.relu(_lin(W, f'{l}.linear1', _ln(W, f'{l}.norm2', x)))
+        x = x + _lin(W, f'{l}.linear2', h)
+    return x
+
+
+def savi_encode(W, img, plan, num_iterations, training, pred_layers, pred_heads, eps=1e-6):
+    """video_based/models/savi_diffusion.py:169-216.  img [B,T,3,H,W] ->
+    slots [B,T,N,D], masks [B,T,N,h,w] (train) / [B,T,N,H,W] (eval)."""
+    B, T, _, H, Wd = img.shape
+    x = encoder_out(W, img.flatten(0, 1), plan).unflatten(0, (B, T))
+    hw = W['encoder_pos_embedding.grid'].shape[1:3]
+    init = W['init_latents'].repeat(B, 1, 1)
+    prev, all_s, all_m = None, [], []
+    for t in range(T):
+        lat = init if prev is None else transformer_predictor(W, prev, pred_layers, pred_heads)
+        s, m = slot_attention(W, x[:, t], lat, num_iterations, eps)
+        all_s.append(s)
+        all_m.append(m)
+        prev = s
+    slots = torch.stack(all_s, 1)
+    masks = torch.stack(all_m, 1).unflatten(-1, tuple(hw))
+    N = slots.shape[2]
+    if not training and tuple(hw) != (H, Wd):
+        m = masks.flatten(0, 2).unsqueeze(1)
+        m = F.interpolate(m, (H, Wd), mode='bilinear', align_corners=False)
+        masks = m.squeeze(1).unflatten(0, (B, T, N))
+    return slots, masks
+
 # ---------------------------------------------------------------------------
 # a9-a11: LDM UNet
 # ---------------------------------------------------------------------------

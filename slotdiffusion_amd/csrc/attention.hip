@@ -6,9 +6,7 @@
 
 namespace {
 
-constexpr int HD = 32;
-
-template <typename T>
+template <typename T, int HD>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(SdmiAttnArgs p) {
   constexpr int VEC = Elem<T>::VEC;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -116,23 +114,21 @@ extern "C" int sdmi_attention(const SdmiAttnArgs* a, void* stream) {
   int threads = ((a->Sq + 63) / 64) * 64;
   if (threads > 256) threads = 256;
   dim3 grid((a->Sq + threads - 1) / threads, a->heads, a->B);
-  const int smem = 2 * a->Skv * HD * 4;
-  if (a->dtype == SDMI_BF16) {
-    static bool done = false;
-    if (!done) {
-      hipFuncSetAttribute((const void*)attn_fwd_kernel<bf16_t>,
-                          hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * HD * 4);
-      done = true;
-    }
-    hipLaunchKernelGGL(attn_fwd_kernel<bf16_t>, grid, dim3(threads), smem, st, *a);
-  } else {
-    static bool done = false;
-    if (!done) {
-      hipFuncSetAttribute((const void*)attn_fwd_kernel<float>,
-                          hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * HD * 4);
-      done = true;
-    }
-    hipLaunchKernelGGL(attn_fwd_kernel<float>, grid, dim3(threads), smem, st, *a);
-  }
+  const int hd = a->head_dim > 0 ? a->head_dim : 32;
+  SDMI_REQUIRE(hd == 32 || hd == 48, "head_dim must be 32 (UNet) or 48 (SAVi predictor)");
+  const int smem = 2 * a->Skv * hd * 4;
+#define ATTN_GO(T, HDV)                                                                      \
+  do {                                                                                       \
+    static bool done = false;                                                                \
+    if (!done) {                                                                             \
+      (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<T, HDV>,                        \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * HDV * 4); \
+      done = true;                                                                           \
+    }                                                                                        \
+    hipLaunchKernelGGL((attn_fwd_kernel<T, HDV>), grid, dim3(threads), smem, st, *a);        \
+  } while (0)
+  if (a->dtype == SDMI_BF16) { if (hd == 32) ATTN_GO(bf16_t, 32); else ATTN_GO(bf16_t, 48); }
+  else { if (hd == 32) ATTN_GO(float, 32); else ATTN_GO(float, 48); }
+#undef ATTN_GO
   return sdmi_check_launch("attention");
 }

@@ -11,22 +11,20 @@
 
 namespace {
 
-constexpr int HD = 32;
-
-template <typename T>
+template <typename T, int HD>
 __device__ __forceinline__ void load_row32(const T* p, float* f) {
   constexpr int VEC = Elem<T>::VEC;
 #pragma unroll
   for (int c = 0; c < HD; c += VEC) unpack16<T>(*reinterpret_cast<const uint4*>(p + c), f + c);
 }
-template <typename T>
+template <typename T, int HD>
 __device__ __forceinline__ void store_row32(T* p, const float* f) {
   constexpr int VEC = Elem<T>::VEC;
 #pragma unroll
   for (int c = 0; c < HD; c += VEC) *reinterpret_cast<uint4*>(p + c) = pack16<T>(f + c);
 }
 
-template <typename T>
+template <typename T, int HD>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(SdmiAttnBwdArgs p) {
   constexpr int VEC = Elem<T>::VEC;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -52,9 +50,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(SdmiAttnBwdArgs p) {
   const int qi = blockIdx.x * blockDim.x + tid;
   if (qi >= p.Sq) return;
   float q[HD], dO[HD], o[HD], dq[HD];
-  load_row32<T>((const T*)p.q + ((long long)b * p.Sq + qi) * p.ldq + h * HD, q);
-  load_row32<T>((const T*)p.dout + ((long long)b * p.Sq + qi) * p.ldo + h * HD, dO);
-  load_row32<T>((const T*)p.out + ((long long)b * p.Sq + qi) * p.ldo + h * HD, o);
+  load_row32<T, HD>((const T*)p.q + ((long long)b * p.Sq + qi) * p.ldq + h * HD, q);
+  load_row32<T, HD>((const T*)p.dout + ((long long)b * p.Sq + qi) * p.ldo + h * HD, dO);
+  load_row32<T, HD>((const T*)p.out + ((long long)b * p.Sq + qi) * p.ldo + h * HD, o);
   float D = 0.f;
 #pragma unroll
   for (int d = 0; d < HD; ++d) { D += dO[d] * o[d]; dq[d] = 0.f; q[d] *= p.scale; }
@@ -69,22 +67,22 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(SdmiAttnBwdArgs p) {
   }
 #pragma unroll
   for (int d = 0; d < HD; ++d) dq[d] *= p.scale;
-  store_row32<T>((T*)p.dq + ((long long)b * p.Sq + qi) * p.ldq + h * HD, dq);
+  store_row32<T, HD>((T*)p.dq + ((long long)b * p.Sq + qi) * p.ldq + h * HD, dq);
 }
 
 // self-attention dK/dV: lane per key; queries (q, dO, lse, D) staged in LDS in chunks.
-template <typename T>
+template <typename T, int HD>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(SdmiAttnBwdArgs p) {
   constexpr int VEC = Elem<T>::VEC;
   constexpr int QC = 64;                       // queries per staged chunk
-  __shared__ float Qs[QC][HD], Os[QC][HD], Ls[QC], Ds[QC];
+  __shared__ float Qs[QC][HD], Os[QC][HD], Ts[QC][HD], Ls[QC], Ds[QC];
   const int b = blockIdx.z, h = blockIdx.y, tid = threadIdx.x;
   const int kj = blockIdx.x * blockDim.x + tid;
   const bool act = kj < p.Skv;
   float k[HD], v[HD], dk[HD], dv[HD];
   if (act) {
-    load_row32<T>((const T*)p.k + ((long long)b * p.Skv + kj) * p.ldk + h * HD, k);
-    load_row32<T>((const T*)p.v + ((long long)b * p.Skv + kj) * p.ldv + h * HD, v);
+    load_row32<T, HD>((const T*)p.k + ((long long)b * p.Skv + kj) * p.ldk + h * HD, k);
+    load_row32<T, HD>((const T*)p.v + ((long long)b * p.Skv + kj) * p.ldv + h * HD, v);
   }
 #pragma unroll
   for (int d = 0; d < HD; ++d) { dk[d] = dv[d] = 0.f; if (!act) k[d] = v[d] = 0.f; }
@@ -104,15 +102,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(SdmiAttnBwdArgs p) {
 #pragma unroll
         for (int j = 0; j < VEC; ++j) fq[j] = fo[j] = fout[j] = 0.f;
       }
-      float part = 0.f;
 #pragma unroll
-      for (int j = 0; j < VEC; ++j) { Qs[r][c + j] = fq[j]; Os[r][c + j] = fo[j]; part += fo[j] * fout[j]; }
-      // D_r = sum over the row's vpr vectors: lanes of one row are adjacent (vpr = 4 or 8)
-      for (int o = 1; o < vpr; o <<= 1) part += __shfl_xor(part, o, 64);
-      if ((i % vpr) == 0) {
-        Ds[r] = part;
-        Ls[r] = qi < p.Sq ? p.lse[((long long)b * p.heads + h) * p.Sq + qi] : INFINITY;
-      }
+      for (int j = 0; j < VEC; ++j) { Qs[r][c + j] = fq[j]; Os[r][c + j] = fo[j]; Ts[r][c + j] = fout[j]; }
+    }
+    __syncthreads();
+    for (int r = tid; r < QC; r += blockDim.x) {       // D_r = dO_r . O_r, lse_r
+      const int qi = q0 + r;
+      float D = 0.f;
+#pragma unroll
+      for (int d = 0; d < HD; ++d) D += Os[r][d] * Ts[r][d];
+      Ds[r] = D;
+      Ls[r] = qi < p.Sq ? p.lse[((long long)b * p.heads + h) * p.Sq + qi] : INFINITY;
     }
     __syncthreads();
     const int qn = min(QC, p.Sq - q0);
@@ -129,15 +129,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(SdmiAttnBwdArgs p) {
   if (!act) return;
 #pragma unroll
   for (int d = 0; d < HD; ++d) dk[d] *= p.scale;
-  store_row32<T>((T*)p.dk + ((long long)b * p.Skv + kj) * p.ldk + h * HD, dk);
-  store_row32<T>((T*)p.dv + ((long long)b * p.Skv + kj) * p.ldv + h * HD, dv);
+  store_row32<T, HD>((T*)p.dk + ((long long)b * p.Skv + kj) * p.ldk + h * HD, dk);
+  store_row32<T, HD>((T*)p.dv + ((long long)b * p.Skv + kj) * p.ldv + h * HD, dv);
 }
 
 // cross-attention dK/dV (Skv <= 16): thread (j, d) = (tid/32, tid%32); blockDim = Skv*32.
-template <typename T>
+template <typename T, int HD>
 __global__ __launch_bounds__(512) void attn_bwd_dkv_small_kernel(SdmiAttnBwdArgs p) {
   const int b = blockIdx.y, h = blockIdx.x;
-  const int j = threadIdx.x >> 5, d = threadIdx.x & 31;
+  const int j = threadIdx.x / HD, d = threadIdx.x % HD;
   const float kd = Elem<T>::ld((const T*)p.k + ((long long)b * p.Skv + j) * p.ldk + h * HD + d);
   const float vd = Elem<T>::ld((const T*)p.v + ((long long)b * p.Skv + j) * p.ldv + h * HD + d);
   const float* lse = p.lse + ((long long)b * p.heads + h) * p.Sq;
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_small_kernel(SdmiAttnBwdArgs
   Elem<T>::st((T*)p.dv + ((long long)b * p.Skv + j) * p.ldv + h * HD + d, dv);
 }
 
-template <typename T>
+template <typename T, int HD>
 int launch_attn_bwd(const SdmiAttnBwdArgs& a, hipStream_t st) {
   int threads = ((a.Sq + 63) / 64) * 64;
   if (threads > 256) threads = 256;
@@ -170,19 +170,19 @@ int launch_attn_bwd(const SdmiAttnBwdArgs& a, hipStream_t st) {
   const int smem = 2 * a.Skv * HD * 4;
   static bool done = false;
   if (!done) {
-    hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<T>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * HD * 4);
-    (void)e;
+    (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<T, HD>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * HD * 4);
     done = true;
   }
-  hipLaunchKernelGGL(attn_bwd_dq_kernel<T>, grid, dim3(threads), smem, st, a);
-  if (a.Skv <= 16) {
-    hipLaunchKernelGGL(attn_bwd_dkv_small_kernel<T>, dim3(a.heads, a.B), dim3(a.Skv * 32), 0, st, a);
+  hipLaunchKernelGGL((attn_bwd_dq_kernel<T, HD>), grid, dim3(threads), smem, st, a);
+  if (a.Skv <= 16 && HD == 32) {
+    hipLaunchKernelGGL((attn_bwd_dkv_small_kernel<T, HD>), dim3(a.heads, a.B), dim3(a.Skv * HD), 0,
+                       st, a);
   } else {
     int kt = ((a.Skv + 63) / 64) * 64;
     if (kt > 256) kt = 256;
     dim3 g2((a.Skv + kt - 1) / kt, a.heads, a.B);
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel<T>, g2, dim3(kt), 0, st, a);
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, HD>), g2, dim3(kt), 0, st, a);
   }
   return sdmi_check_launch("attention_bwd");
 }
@@ -196,6 +196,10 @@ extern "C" int sdmi_attention_bwd(const SdmiAttnBwdArgs* a, void* stream) {
   SDMI_REQUIRE(a->ldq % vec == 0 && a->ldk % vec == 0 && a->ldv % vec == 0 && a->ldo % vec == 0,
                "row pitches must keep 16-byte alignment");
   SDMI_REQUIRE(a->Skv >= 1 && a->Skv <= 512, "Skv must be in [1, 512]");
+  const int hd = a->head_dim > 0 ? a->head_dim : 32;
+  SDMI_REQUIRE(hd == 32 || hd == 48, "head_dim must be 32 or 48");
   hipStream_t st = (hipStream_t)stream;
-  return a->dtype == SDMI_BF16 ? launch_attn_bwd<bf16_t>(*a, st) : launch_attn_bwd<float>(*a, st);
+  if (a->dtype == SDMI_BF16)
+    return hd == 32 ? launch_attn_bwd<bf16_t, 32>(*a, st) : launch_attn_bwd<bf16_t, 48>(*a, st);
+  return hd == 32 ? launch_attn_bwd<float, 32>(*a, st) : launch_attn_bwd<float, 48>(*a, st);
 }

@@ -67,6 +67,25 @@ def slot_attention(K, tokens, slots_init, iters, eps, name='slot_attention'):
 
 
 # ------------------------------------------------------------------------------------------
+# a5: SAVi slot transition = nn.TransformerEncoder, norm_first (video_based/models/predictor.py:20-44)
+# ------------------------------------------------------------------------------------------
+def transformer_predictor(K, x, num_layers, num_heads, name='predictor'):
+    """x [B,N,D] fp32 slots -> [B,N,D]; pre-LN blocks, ReLU FFN, head_dim D/heads (48)."""
+    D = x.shape[-1]
+    hd = D // num_heads
+    for i in range(num_layers):
+        l = f'{name}.transformer_encoder.layers.{i}'
+        qkv = K.linear(K.ln(x, f'{l}.norm1'), f'{l}.self_attn.in_proj_weight',
+                       f'{l}.self_attn.in_proj_bias')
+        a = K.attn_self(qkv, num_heads, hd)
+        x = K.linear_drop_res(a, f'{l}.self_attn.out_proj.weight', f'{l}.self_attn.out_proj.bias', x)
+        h = K.dropout(K.linear(K.ln(x, f'{l}.norm2'), f'{l}.linear1.weight', f'{l}.linear1.bias',
+                               act='relu'), site='pred')
+        x = K.linear_drop_res(h, f'{l}.linear2.weight', f'{l}.linear2.bias', x)
+    return x
+
+
+# ------------------------------------------------------------------------------------------
 # a9-a11: LDM UNet (unet.py:551-576, 271-285; attention.py:297-308, 247-251, 182-206)
 # ------------------------------------------------------------------------------------------
 class UNetRunner:

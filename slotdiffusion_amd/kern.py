@@ -182,9 +182,10 @@ class Kern:
     def ln(self, x, name):
         return ops.layer_norm(x, self.wb.f(name + '.weight'), self.wb.f(name + '.bias'))
 
-    def attn_self(self, qkv, heads):
-        C = heads * 32
-        return ops.attention(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], heads)
+    def attn_self(self, qkv, heads, head_dim=32):
+        C = heads * head_dim
+        return ops.attention(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], heads,
+                             head_dim=head_dim)
 
     def attn_cross(self, q, kv, heads):
         C = heads * 32
@@ -202,8 +203,12 @@ class Kern:
     def cast(self, x, dtype):
         return x if x.dtype == dtype else ops.act(x, None, dtype)
 
-    def dropout(self, x):
+    def dropout(self, x, site='unet'):
         return x
+
+    def linear_drop_res(self, x, wname, bname, res):
+        """res + dropout(linear(x)); without dropout the residual add is the GEMM epilogue."""
+        return self.linear(x, wname, bname, residual=res)
 
     def slot_attention(self, kv, init, name, iters, eps):
         wb = self.wb
@@ -419,24 +424,24 @@ class AttnFn(torch.autograd.Function):
     """self: qkv fused [B,S,3C]; cross: q [B,S,C] + kv [B,N,2C]."""
 
     @staticmethod
-    def forward(ctx, q_or_qkv, kv, heads):
-        C = heads * 32
+    def forward(ctx, q_or_qkv, kv, heads, head_dim=32):
+        C = heads * head_dim
         if kv is None:
             q, k, v = q_or_qkv[..., :C], q_or_qkv[..., C:2 * C], q_or_qkv[..., 2 * C:]
         else:
             q, k, v = q_or_qkv, kv[..., :C], kv[..., C:]
         B, Sq = q.shape[0], q.shape[1]
         lse = torch.empty((B, heads, Sq), dtype=torch.float32, device=q.device)
-        out = ops.attention(q, k, v, heads, lse=lse)
+        out = ops.attention(q, k, v, heads, lse=lse, head_dim=head_dim)
         ctx.save_for_backward(q_or_qkv, kv, out, lse)
-        ctx.heads = heads
+        ctx.heads, ctx.hd = heads, head_dim
         return out
 
     @staticmethod
     def backward(ctx, dout):
         a, kv, out, lse = ctx.saved_tensors
-        heads = ctx.heads
-        C = heads * 32
+        heads, hd = ctx.heads, ctx.hd
+        C = heads * hd
         dout = dout.contiguous()
         da = torch.empty_like(a)
         dkv = torch.empty_like(kv) if kv is not None else None
@@ -450,9 +455,9 @@ class AttnFn(torch.autograd.Function):
         call('sdmi_attention_bwd', _st(), q=_p(q), k=_p(k), v=_p(v), out=_p(out), dout=_p(dout),
              lse=_p(lse), dq=_p(dq), dk=_p(dk), dv=_p(dv), dtype=_DT[q.dtype], B=B, heads=heads,
              Sq=Sq, Skv=Skv, ldq=q.stride(1), ldk=k.stride(1), ldv=v.stride(1), ldo=out.stride(1),
-             scale=32 ** -0.5)
+             scale=hd ** -0.5, head_dim=hd)
         _dbg(f'attn Sq={Sq} Skv={Skv}', dout=dout, da=da, dkv=dkv)
-        return da, dkv, None
+        return da, dkv, None, None
 
 
 class GegluFn(torch.autograd.Function):
@@ -642,8 +647,17 @@ class KernGrad(Kern):
     seed = 0
     _drop_ctr = 0
 
-    def dropout(self, x):
-        p = float(getattr(self.wb.model, 'train_dropout', 0.0))
+    def _p_drop(self, site):
+        attr = 'train_dropout' if site == 'unet' else 'pred_dropout'
+        return float(getattr(self.wb.model, attr, 0.0))
+
+    def linear_drop_res(self, x, wname, bname, res):
+        if self._p_drop('pred') <= 0.0:
+            return self.linear(x, wname, bname, residual=res)
+        return AddFn.apply(res, self.dropout(self.linear(x, wname, bname), site='pred'))
+
+    def dropout(self, x, site='unet'):
+        p = self._p_drop(site)
         if p <= 0.0:
             return x
         KernGrad._drop_ctr += 1
@@ -665,8 +679,8 @@ class KernGrad(Kern):
     def ln(self, x, name):
         return LayerNormFn.apply(x, self.wb.anchor, self.wb, name)
 
-    def attn_self(self, qkv, heads):
-        return AttnFn.apply(qkv, None, heads)
+    def attn_self(self, qkv, heads, head_dim=32):
+        return AttnFn.apply(qkv, None, heads, head_dim)
 
     def attn_cross(self, q, kv, heads):
         return AttnFn.apply(q, kv, heads)

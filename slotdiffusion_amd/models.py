@@ -153,7 +153,7 @@ class SADiffusion(FlatModule):
                  compute_dtype=None, seed=0):
         dec_dict = copy.deepcopy(dec_dict)
         dd = dec_dict['diffusion_dict']
-        sp = spec.sa_diffusion(resolution, slot_dict, enc_dict, dec_dict)
+        sp = self._make_spec(resolution, slot_dict, enc_dict, dec_dict)
         sched = {k: dd[k] for k in ('timesteps', 'beta_schedule', 'linear_start', 'linear_end')
                  if k in dd}
         super().__init__(sp, schedule_kwargs=sched, seed=seed,
@@ -186,6 +186,9 @@ class SADiffusion(FlatModule):
         self._Kinf = self._Kgrad = None
         self.use_graph = os.environ.get('SDMI_GRAPH', '1') != '0'
         self._graph_cache = {}
+
+    def _make_spec(self, resolution, slot_dict, enc_dict, dec_dict):
+        return spec.sa_diffusion(resolution, slot_dict, enc_dict, dec_dict)
 
     # -- plumbing ------------------------------------------------------------------------
     @property
@@ -398,8 +401,81 @@ class SADiffusion(FlatModule):
         self.dm_decoder._training_step_end()
 
 
+class SAViDiffusion(SADiffusion):
+    """SlotDiffusion on videos (registry name 'SAViDiffusion', video_based/models/
+    savi_diffusion.py:74-302): per-frame Slot Attention whose initial slots are the transformer
+    predictor's output on the previous frame's slots; the LDM runs on the flattened B*T frames."""
+
+    def __init__(self, resolution, clip_len, slot_dict, enc_dict, dec_dict, pred_dict,
+                 loss_dict=None, eps=1e-6, compute_dtype=None, seed=0):
+        assert pred_dict.get('pred_type', 'transformer') == 'transformer' and \
+            not pred_dict.get('pred_rnn', False), 'hot path covers the transformer predictor'
+        self._pred_dict = dict(pred_dict)
+        self.clip_len = clip_len
+        super().__init__(resolution, slot_dict, enc_dict, dec_dict, loss_dict, eps, compute_dtype,
+                         seed)
+        self.pred_dict = dict(pred_dict)
+        self.pred_dropout = 0.1            # nn.TransformerEncoderLayer default (predictor.py:33-38)
+
+    def _make_spec(self, resolution, slot_dict, enc_dict, dec_dict):
+        return spec.savi_diffusion(resolution, slot_dict, enc_dict, dec_dict, self._pred_dict)
+
+    def encode(self, img, prev_slots=None):
+        """savi_diffusion.py:169-216: img [B,T,3,H,W] -> slots [B,T,N,D], masks [B,T,N,*,*]."""
+        B, T, _, H, W = img.shape
+        grad = self.training and torch.is_grad_enabled()
+        Kp = self.KG() if grad else self.K()
+        h, w = self.visual_resolution
+        with torch.set_grad_enabled(grad):
+            tok = engine.encoder_out(Kp, self._to_nhwc(img.flatten(0, 1)), self.rplan)
+            tok = tok.view(B, T, tok.shape[1], tok.shape[2])
+            all_s, all_seg = [], []
+            for t in range(T):
+                if prev_slots is None:
+                    lat = self.init_latents[0]
+                else:
+                    lat = engine.transformer_predictor(Kp, prev_slots.contiguous(),
+                                                       self.pred_dict['pred_num_layers'],
+                                                       self.pred_dict['pred_num_heads'])
+                tk = tok[:, t].contiguous() if T > 1 else tok[:, 0]
+                s, seg = engine.slot_attention(Kp, tk, lat, self.num_iterations, self.eps)
+                all_s.append(s)
+                all_seg.append(seg)
+                prev_slots = s
+            slots = torch.stack(all_s, 1)
+        with torch.no_grad():
+            seg = torch.stack([x.detach() for x in all_seg], 1)            # [B,T,M,N]
+            if not self.training and (h, w) != (H, W):
+                masks, _ = ops.mask_upsample_argmax(seg.flatten(0, 1).contiguous(), h, w, H, W)
+                masks = masks.view(B, T, self.num_slots, H, W)
+            else:
+                masks = seg.permute(0, 1, 3, 2).reshape(B, T, self.num_slots, h, w)
+        return slots, masks
+
+    def calc_train_loss(self, data_dict, out_dict):
+        """savi_diffusion.py:252-264: the LDM sees the B*T frames as independent images."""
+        d = {'img': data_dict['img'].flatten(0, 1), 'slots': out_dict['slots'].flatten(0, 1)}
+        return self.dm_decoder.loss_function(d, t=data_dict.get('t'), noise=data_dict.get('noise'))
+
+    @torch.no_grad()
+    def log_images(self, data_dict, **kwargs):
+        out_dict = self.forward(data_dict)
+        B, T = data_dict['img'].shape[:2]
+        log = self.dm_decoder.log_images({'img': data_dict['img'].flatten(0, 1),
+                                          'slots': out_dict['slots'].flatten(0, 1)}, **kwargs)
+        log = {k: v.unflatten(0, (B, T)) for k, v in log.items()}
+        log['masks'] = out_dict['masks']
+        return log
+
+
 def build_model(params):
-    """img_based registry (img_based/models/__init__.py:12-39) for the hot-path models."""
+    """Registry (img_based/models/__init__.py:12-39, video_based/models/__init__.py:12-33) for the
+    hot-path models."""
+    if params.model == 'SAViDiffusion':
+        return SAViDiffusion(resolution=params.resolution, clip_len=params.input_frames,
+                             slot_dict=params.slot_dict, enc_dict=params.enc_dict,
+                             dec_dict=params.dec_dict, pred_dict=params.pred_dict,
+                             loss_dict=params.loss_dict)
     if params.model == 'SADiffusion':
         return SADiffusion(resolution=params.resolution, slot_dict=params.slot_dict,
                            enc_dict=params.enc_dict, dec_dict=params.dec_dict,

@@ -141,12 +141,21 @@ class FlatModule(nn.Module):
                 self._n_train = max(self._n_train, (o + n + ALIGN - 1) // ALIGN * ALIGN)
         self._n_total = off
         lr_group_of = lr_group_of or (lambda name: 1 if 'dm_decoder' in name else 0)
-        # group boundary: first trainable param of group 1 (spec order keeps groups contiguous)
-        self._group_split = self._n_train
+        # contiguous runs of equal lr group over the trainable range (image model: 2 runs,
+        # video model: 3 -- the predictor sits after dm_decoder in checkpoint order)
+        runs = []
         for p in order:
-            if p.trainable and lr_group_of(p.name) == 1:
-                self._group_split = self._offsets[p.name][0]
-                break
+            if not p.trainable:
+                continue
+            g = lr_group_of(p.name)
+            o, n = self._offsets[p.name]
+            end = (o + n + ALIGN - 1) // ALIGN * ALIGN
+            if runs and runs[-1][2] == g:
+                runs[-1][1] = end
+            else:
+                runs.append([o, end, g])
+        self._lr_runs = [tuple(r) for r in runs]
+        self._group_split = next((r[0] for r in self._lr_runs if r[2] == 1), self._n_train)
         object.__setattr__(self, '_arena', torch.zeros(self._n_total, dtype=torch.float32))
         object.__setattr__(self, '_garena', None)
         object.__setattr__(self, '_shadow', None)
@@ -179,8 +188,12 @@ class FlatModule(nn.Module):
         return self._arena
 
     def arena_ranges(self):
-        """(group0 = [0, split), group1 = [split, n_train), frozen = [n_train, n_total))."""
+        """(first element of lr group 1, n_train, n_total); see lr_runs() for the exact ranges."""
         return self._group_split, self._n_train, self._n_total
+
+    def lr_runs(self):
+        """[(lo, hi, lr_group)] contiguous arena ranges of the trainable parameters."""
+        return list(self._lr_runs)
 
     def arena_slice(self, name, arena=None):
         o, n = self._offsets[name]

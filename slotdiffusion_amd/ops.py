@@ -153,17 +153,17 @@ def softmax_rows_(x, scale=1.0):
 # ------------------------------------------------------------------------------------------
 # attention
 # ------------------------------------------------------------------------------------------
-def attention(q, k, v, heads, *, out=None, lse=None):
+def attention(q, k, v, heads, *, out=None, lse=None, head_dim=32):
     """q [B,Sq,*] k,v [B,Skv,*] (views with last-dim stride 1; head h at channel h*32)."""
     _need_gpu(q, k, v)
     B, Sq = q.shape[0], q.shape[1]
     Skv = k.shape[1]
-    C = heads * 32
+    C = heads * head_dim
     if out is None:
         out = torch.empty((B, Sq, C), dtype=q.dtype, device=q.device)
     call('sdmi_attention', _stream(), q=_p(q), k=_p(k), v=_p(v), out=_p(out), lse=_p(lse),
          dtype=_dt(q), B=B, heads=heads, Sq=Sq, Skv=Skv, ldq=q.stride(1), ldk=k.stride(1),
-         ldv=v.stride(1), ldo=out.stride(1), scale=32 ** -0.5)
+         ldv=v.stride(1), ldo=out.stride(1), scale=head_dim ** -0.5, head_dim=head_dim)
     return out
 
 

@@ -63,9 +63,8 @@ class FusedAdam:
         arena = m.arena()
         bf16 = m.compute_dtype == torch.bfloat16
         shadow = m.shadow_arena() if bf16 else None
-        for lo, hi, lr in ((0, self.split, self.lr), (self.split, self.n_train, self.dec_lr)):
-            if hi <= lo:
-                continue
+        for lo, hi, grp in m.lr_runs():
+            lr = self.dec_lr if grp == 1 else self.lr
             call('sdmi_adam_clip', st, p=_p(arena[lo:]), g=_p(g[lo:]), m=_p(self.m[lo:]),
                  v=_p(self.v[lo:]), shadow_bf16=(_p(shadow[lo:]) if bf16 else 0),
                  sq_partial=_p(self.partial), nblk=self.nblk, n=hi - lo, lr=lr * scale,

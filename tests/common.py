@@ -68,3 +68,33 @@ def oracle_weights(cfg, seed=1234):
         else:
             W[p.name] = det_value(p.name, p.shape, i, seed)
     return W
+
+
+def movie_cfg():
+    """Restates video_based/configs/savi_ldm/savi_ldm_movie_params-res128.py (values only)."""
+    cfg = clevrtex_cfg(num_slots=15)
+    cfg['slot_dict']['num_iterations'] = 2
+    cfg['clip_len'] = 3
+    cfg['pred_dict'] = dict(pred_type='transformer', pred_rnn=False, pred_norm_first=True,
+                            pred_num_layers=2, pred_num_heads=4, pred_ffn_dim=768,
+                            pred_sg_every=None)
+    cfg['dec_dict']['vae_dict']['vqvae_ckp_path'] = './pretrained/vqvae_movie_params-res128.pth'
+    return cfg
+
+
+def oracle_weights_video(cfg, seed=1234):
+    from slotdiffusion_amd.module import build_grid, ddpm_schedule
+    sp = spec.savi_diffusion(cfg['resolution'], cfg['slot_dict'], cfg['enc_dict'], cfg['dec_dict'],
+                             cfg['pred_dict'])
+    dd = {k: v for k, v in cfg['dec_dict']['diffusion_dict'].items()
+          if k in ('timesteps', 'beta_schedule', 'linear_start', 'linear_end')}
+    sched = ddpm_schedule(**dd)
+    W = {}
+    for i, p in enumerate(sp):
+        if p.init.startswith('buf:'):
+            key = p.init[4:]
+            W[p.name] = build_grid(p.shape[1:3]) if key == 'grid' else \
+                torch.tensor(sched[key], dtype=torch.float32)
+        else:
+            W[p.name] = det_value(p.name, p.shape, i, seed)
+    return W

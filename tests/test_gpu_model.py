@@ -149,3 +149,49 @@ def test_bf16_path_deviation():
     _dump()
     assert REPORT['bf16_eps_rel_l2'] < 0.05 and REPORT['bf16_x0_rel_l2'] < 0.05
     assert REPORT['bf16_masks_eval_argmax_agree'] > 0.97
+
+
+def test_video_model_fp32():
+    """SAViDiffusion (MOVi-E config, 15 slots): predictor, per-frame Slot Attention, masks, and the
+    train-step gradients of every tensor against the reference's (tests/golden/savidiff_b1t3.npz)."""
+    from slotdiffusion_amd.models import SAViDiffusion
+    cfg = C.movie_cfg()
+    G = C.load_golden('savidiff_b1t3.npz')
+    m = SAViDiffusion(cfg['resolution'], 3, cfg['slot_dict'], cfg['enc_dict'], cfg['dec_dict'],
+                      cfg['pred_dict'], cfg['loss_dict'], compute_dtype=torch.float32)
+    det_fill_(m.state_dict().items(), skip=is_buffer_name)
+    m.train_dropout = m.pred_dropout = 0.0
+    m = m.cuda()
+    img = C.make_inputs(3, seed=11)[0].view(1, 3, 3, 128, 128).cuda()
+    m.train()
+    m.grad_arena().zero_()
+    out = m(dict(img=img))
+    R = {}
+    R['video_slots_maxerr'] = maxerr(out['slots'].detach(), G['slots'])
+    R['video_masks_argmax_agree'] = float(
+        (out['masks'].cpu().argmax(2) == G['masks_train_argmax'].long()).float().mean())
+    loss = m.calc_train_loss(dict(img=img, t=G['t'].cuda(), noise=G['noise'].cuda()), out)[
+        'denoise_loss']
+    loss.backward()
+    R['video_loss'] = float(loss.detach())
+    R['video_loss_ref'] = float(G['train_loss'])
+    named = dict(m.named_parameters())
+    names = [str(n) for n in G['grad_norms_names']]
+    mine = torch.tensor([float(named[n].grad.norm()) for n in names])
+    ref = G['grad_norms']
+    big = ref > 1e-6
+    rel = ((mine - ref).abs() / (ref.abs() + 1e-12))[big]
+    R['video_grad_norm_max_rel_vs_reference'] = float(rel.max())
+    errs = {k[5:]: float((named[k[5:]].grad.float().cpu() - G[k]).abs().max() / G[k].abs().max())
+            for k in G if k.startswith('grad:')}
+    R['video_grad_tensor_rel_err'] = errs
+    m.eval()
+    oe = m(dict(img=img))
+    R['video_masks_eval_argmax_agree'] = float(
+        (oe['masks'].cpu().argmax(2) == G['masks_eval_argmax'].long()).float().mean())
+    REPORT.update(R)
+    _dump()
+    assert R['video_slots_maxerr'] <= 1e-4 and R['video_masks_argmax_agree'] == 1.0
+    assert R['video_masks_eval_argmax_agree'] == 1.0
+    assert abs(R['video_loss'] - R['video_loss_ref']) <= 1e-4
+    assert R['video_grad_norm_max_rel_vs_reference'] <= 2e-2 and max(errs.values()) <= 2e-2

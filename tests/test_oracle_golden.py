@@ -142,3 +142,21 @@ def test_dpm_solver_trajectory():
         assert frac_bad < 0.01, frac_bad
         ps = O.psnr(samples, G['samples'])
         assert float(ps.min()) > 35., ps
+
+
+def test_video_model_oracle():
+    """SAViDiffusion (MOVi-E config): transformer predictor, recurrence over frames, masks."""
+    cfg = C.movie_cfg()
+    G = C.load_golden('savidiff_b1t3.npz')
+    W = C.oracle_weights_video(cfg)
+    img = C.make_inputs(3, seed=11)[0].view(1, 3, 3, 128, 128)
+    assert torch.equal(torch.stack([img.double().sum(), (img.double() ** 2).sum()]), G['img_checksum'])
+    rplan = spec.resnet18_plan(False)
+    with torch.no_grad():
+        close(O.transformer_predictor(W, W['init_latents'], 2, 4), G['pred_of_init'], 1e-5)
+        slots, masks = O.savi_encode(W, img, rplan, 2, True, 2, 4)
+        close(slots, G['slots'], 5e-5)
+        close(masks[:, :, :, ::2, 1::2], G['masks_train_sub'], 1e-5)
+        assert torch.equal(masks.argmax(2), G['masks_train_argmax'].long())
+        _, me = O.savi_encode(W, img, rplan, 2, False, 2, 4)
+        assert torch.equal(me.argmax(2), G['masks_eval_argmax'].long())

@@ -134,5 +134,62 @@ def main():
         print(k, v.shape, v.dtype)
 
 
+
+def main_video():
+    """video_based SAViDiffusion (MOVi-E config, 15 slots, 2 iterations), B=1 clip of T=3 frames."""
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    vm = rh.ref_models('video_based')
+    P = rh.ref_params('video_based', 'savi_ldm', 'savi_ldm_movie_params-res128')
+    model = vm.build_model(P)
+    det_fill_(model.state_dict().items(), skip=is_buffer_name)
+    B, T = 1, 3
+    img, t, noise, x_T = make_inputs(B * T, seed=11)
+    img = img.view(B, T, 3, 128, 128)
+    G = dict(t=t, noise=noise, img_checksum=torch.stack([img.double().sum(), (img.double() ** 2).sum()]))
+    model.train()
+    dm = model.dm_decoder
+    dm.model.eval()                       # UNet ResBlock dropout off
+    model.predictor.eval()                # predictor dropout off (nn.TransformerEncoderLayer p=0.1)
+    with torch.no_grad():
+        G['pred_of_init'] = model.predictor(model.init_latents.detach())
+    for p in model.parameters():
+        p.grad = None
+    out = model(dict(img=img))
+    G['slots'], G['masks_train_argmax'] = out['slots'].detach(), out['masks'].detach().argmax(2)
+    G['masks_train_sub'] = out['masks'].detach()[:, :, :, ::2, 1::2].contiguous()
+    with torch.no_grad():
+        x0 = dm.vae.encode(img.flatten(0, 1))
+    x_noisy = dm._sample_xt_from_x0(x0=x0, t=t, noise=noise)
+    pred = dm.forward(x_noisy, t, context=out['slots'].flatten(0, 1))
+    loss = torch.nn.functional.mse_loss(pred, noise)
+    loss.backward()
+    G['train_loss'] = loss.detach()
+    named = dict(model.named_parameters())
+    names = sorted(n for n, p in named.items() if p.grad is not None)
+    G['grad_norms_names'] = np.array(names)
+    G['grad_norms'] = torch.tensor([float(named[n].grad.norm()) for n in names])
+    for n in ['init_latents', 'predictor.transformer_encoder.layers.0.self_attn.in_proj_weight',
+              'predictor.transformer_encoder.layers.1.linear2.bias',
+              'predictor.transformer_encoder.layers.0.norm1.weight']:
+        G['grad:' + n] = named[n].grad.detach().clone()
+    model.eval()
+    with torch.no_grad():
+        oe = model(dict(img=img))
+    G['masks_eval_argmax'] = oe['masks'].argmax(2)
+    arrs = {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else v) for k, v in G.items()}
+    for k in list(arrs):
+        if arrs[k].dtype == np.int64 and k != 't':
+            arrs[k] = arrs[k].astype(np.int16)
+    np.savez_compressed(os.path.join(OUT, 'savidiff_b1t3.npz'), **arrs)
+    keys = {'params': [[k, list(v.shape)] for k, v in model.named_parameters()],
+            'frozen': [k for k, v in model.named_parameters() if not v.requires_grad]}
+    for k, v in arrs.items():
+        print(k, v.shape, v.dtype)
+
+
 if __name__ == '__main__':
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == 'video':
+        main_video()
+    else:
+        main()
