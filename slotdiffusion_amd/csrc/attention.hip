@@ -109,7 +109,7 @@ extern "C" int sdmi_attention(const SdmiAttnArgs* a, void* stream) {
   const int vec = a->dtype == SDMI_BF16 ? 8 : 4;
   SDMI_REQUIRE(a->ldq % vec == 0 && a->ldk % vec == 0 && a->ldv % vec == 0 && a->ldo % vec == 0,
                "row pitches must keep 16-byte alignment");
-  SDMI_REQUIRE(a->Skv >= 1 && a->Skv <= 512, "Skv must be in [1, 512] (K/V staged in LDS)");
+  SDMI_REQUIRE(a->Skv >= 1 && a->Skv <= 400, "Skv must be in [1, 400] (K/V staged in LDS)");
   hipStream_t st = (hipStream_t)stream;
   int threads = ((a->Sq + 63) / 64) * 64;
   if (threads > 256) threads = 256;
@@ -122,7 +122,8 @@ extern "C" int sdmi_attention(const SdmiAttnArgs* a, void* stream) {
     static bool done = false;                                                                \
     if (!done) {                                                                             \
       (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<T, HDV>,                        \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * HDV * 4); \
+                                hipFuncAttributeMaxDynamicSharedMemorySize,                   \
+                                (2 * 512 * HDV * 4 < 160 * 1024 ? 2 * 512 * HDV * 4 : 160 * 1024)); \
       done = true;                                                                           \
     }                                                                                        \
     hipLaunchKernelGGL((attn_fwd_kernel<T, HDV>), grid, dim3(threads), smem, st, *a);        \

@@ -171,7 +171,8 @@ int launch_attn_bwd(const SdmiAttnBwdArgs& a, hipStream_t st) {
   static bool done = false;
   if (!done) {
     (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<T, HD>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * HD * 4);
+                              hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (2 * 512 * HD * 4 < 160 * 1024 ? 2 * 512 * HD * 4 : 160 * 1024));
     done = true;
   }
   hipLaunchKernelGGL((attn_bwd_dq_kernel<T, HD>), grid, dim3(threads), smem, st, a);
@@ -195,7 +196,7 @@ extern "C" int sdmi_attention_bwd(const SdmiAttnBwdArgs* a, void* stream) {
   const int vec = a->dtype == SDMI_BF16 ? 8 : 4;
   SDMI_REQUIRE(a->ldq % vec == 0 && a->ldk % vec == 0 && a->ldv % vec == 0 && a->ldo % vec == 0,
                "row pitches must keep 16-byte alignment");
-  SDMI_REQUIRE(a->Skv >= 1 && a->Skv <= 512, "Skv must be in [1, 512]");
+  SDMI_REQUIRE(a->Skv >= 1 && a->Skv <= 400, "Skv must be in [1, 400]");
   const int hd = a->head_dim > 0 ? a->head_dim : 32;
   SDMI_REQUIRE(hd == 32 || hd == 48, "head_dim must be 32 or 48");
   hipStream_t st = (hipStream_t)stream;
