@@ -181,12 +181,12 @@ def main():
     opt = FusedAdam(model, lr=1e-4, dec_lr=2e-4, clip_grad=1.0, total_steps=100000)
     garena = model.grad_arena()
 
-    def train_step():
+    def train_step(reduce=True):
         opt.zero_grad()
         out = model(dict(img=img))
         loss = model.calc_train_loss(dict(img=img), out)['denoise_loss']
         loss.backward()
-        if dist is not None:          # gradients only: the flat fp32 arena in a few large buckets
+        if dist is not None and reduce:          # gradients only: the flat fp32 arena in a few large buckets
             parallel.allreduce_gradients(garena, world, n_buckets=4)
         opt.step()
         return loss
@@ -194,7 +194,14 @@ def main():
     train_rate = None
     dt_t = None
     if args.mode == 'train':
-        dt_t = timed(train_step, args.steps, args.warmup)
+        run_step = train_step
+        if not args.no_graph:
+            from slotdiffusion_amd.optim import GraphedTrainStep
+            ar = (lambda g: parallel.allreduce_gradients(g, world, n_buckets=4)) if dist is not None \
+                else None
+            graphed = GraphedTrainStep(model, opt, dict(img=img), allreduce=ar)
+            run_step = lambda: graphed(dict(img=img))
+        dt_t = timed(run_step, args.steps, args.warmup)
         train_rate = world * B * args.steps / dt_t
 
     if True:
@@ -213,12 +220,13 @@ def main():
             'metric': metric, 'value': value, 'unit': unit, 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': ms, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
-            'config': {'workload': work, 'batch_per_gpu': B, 'hip_graph_sampler': model.use_graph,
+            'config': {'workload': work, 'batch_per_gpu': B, 'hip_graph': not args.no_graph,
                        'parallelism': f'dp{world}'},
             'denoise': {'value': denoise_rate, 'unit': 'image-denoise-steps/s',
                         'ms_per_20nfe_pass': 1e3 * dt_s / n_s, 'nfe': nfe},
         }
-        step = train_step if args.mode == 'train' else sample_step
+        # rank-0-only instrumentation pass: no collective inside
+        step = (lambda: train_step(reduce=False)) if args.mode == 'train' else sample_step
         if rank == 0 and not args.no_roofline:
             # live per-kernel timing of ONE sampling pass, eager (events around every launch)
             from slotdiffusion_amd._lib import KernelTimer
@@ -244,7 +252,7 @@ def main():
                                'algorithmic_gflop_per_step': ig['flops'] / 1e9}
             out['kernel_breakdown_ms'] = {k: round(v['ms'], 3) for k, v in
                                           sorted(summ.items(), key=lambda kv: -kv[1]['ms'])}
-        if rank == 0 and not args.no_cpu_baseline:
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(cfg, args.mode)
     if rank == 0:
         print(json.dumps(out))

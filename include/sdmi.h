@@ -289,7 +289,10 @@ int sdmi_add(const SdmiAddArgs* a, void* stream);
 /* inverted dropout with a counter-based generator: y[i] = keep(seed, i) ? x[i] / (1-p) : 0, keep
  * derived from a 64-bit mix of (seed, i) so the backward pass regenerates the same mask from the
  * seed instead of storing it (ResBlock dropout, unet.py:246; p = 0.1 in every LDM config). */
-typedef struct { const void* x; void* y; int dtype; long long n; float p; long long seed; } SdmiDropoutArgs;
+typedef struct {
+  const void* x; void* y; int dtype; long long n; float p; long long seed;
+  const long long* seed_dev;   /* optional device word added to `seed` (HIP-graph replays advance it) */
+} SdmiDropoutArgs;
 int sdmi_dropout(const SdmiDropoutArgs* a, void* stream);
 /* split of a channel concat: a[r][:Ca] = y[r][:Ca], b[r][:Cb] = y[r][Ca:] */
 typedef struct { const void* y; void* a; void* b; int dtype; long long rows; int Ca, Cb; } SdmiSplitArgs;
@@ -331,6 +334,8 @@ typedef struct {
   float* p; const float* g; float* m; float* v; void* shadow_bf16; /* optional */
   const float* sq_partial; int nblk;     /* global norm^2 = sum(sq_partial[0..nblk)) */
   long long n; float lr, beta1, beta2, eps, clip; int step;
+  const float* lr_dev;         /* optional device scalar overriding `lr` (graph-replayable schedule) */
+  const int* step_dev;         /* optional device step counter overriding `step` */
 } SdmiAdamArgs;
 int sdmi_adam_clip(const SdmiAdamArgs* a, void* stream);
 

@@ -122,8 +122,10 @@ template <typename T>
 __global__ void dropout_kernel(SdmiDropoutArgs p) {
   const float inv = 1.f / (1.f - p.p);
   const unsigned thr = (unsigned)((double)p.p * 4294967296.0);
+  const unsigned long long seed =
+      (unsigned long long)p.seed + (p.seed_dev ? (unsigned long long)(*p.seed_dev) * 0x100000001b3ULL : 0ULL);
   GRID_STRIDE(i, p.n) {
-    const unsigned r = mix64((unsigned long long)p.seed + 0x9e3779b97f4a7c15ULL * (unsigned long long)(i + 1));
+    const unsigned r = mix64(seed + 0x9e3779b97f4a7c15ULL * (unsigned long long)(i + 1));
     const float v = Elem<T>::ld((const T*)p.x + i);
     Elem<T>::st((T*)p.y + i, r >= thr ? v * inv : 0.f);
   }
@@ -159,9 +161,11 @@ __global__ __launch_bounds__(256) void adam_kernel(SdmiAdamArgs p) {
   }
   __syncthreads();
   const float coef = s_coef;
-  const float bc1 = 1.f - powf(p.beta1, (float)p.step);
-  const float bc2 = 1.f - powf(p.beta2, (float)p.step);
-  const float step_size = p.lr / bc1;
+  const int step = p.step_dev ? *p.step_dev : p.step;
+  const float lr = p.lr_dev ? *p.lr_dev : p.lr;
+  const float bc1 = 1.f - powf(p.beta1, (float)step);
+  const float bc2 = 1.f - powf(p.beta2, (float)step);
+  const float step_size = lr / bc1;
   const float inv_sqrt_bc2 = 1.f / sqrtf(bc2);
   GRID_STRIDE(i, p.n) {
     const float g = p.g[i] * coef;
@@ -232,8 +236,8 @@ extern "C" int sdmi_sqsum_partial(const SdmiSqSumArgs* a, void* stream) {
   return sdmi_check_launch("sqsum_partial");
 }
 extern "C" int sdmi_adam_clip(const SdmiAdamArgs* a, void* stream) {
-  SDMI_REQUIRE(a && a->p && a->g && a->m && a->v && a->sq_partial && a->nblk >= 1 && a->step >= 1,
-               "bad args");
+  SDMI_REQUIRE(a && a->p && a->g && a->m && a->v && a->sq_partial && a->nblk >= 1 &&
+                   (a->step >= 1 || a->step_dev), "bad args");
   hipLaunchKernelGGL(adam_kernel, dim3(nblocks(a->n)), dim3(256), 0, ST, *a);
   return sdmi_check_launch("adam_clip");
 }

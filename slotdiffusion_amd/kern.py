@@ -625,10 +625,11 @@ class MseFn(torch.autograd.Function):
 
 class DropoutFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, p, seed):
-        ctx.p, ctx.seed = p, seed
+    def forward(ctx, x, p, seed, seed_dev):
+        ctx.p, ctx.seed, ctx.seed_dev = p, seed, seed_dev
         y = torch.empty_like(x)
-        call('sdmi_dropout', _st(), x=_p(x), y=_p(y), dtype=_DT[x.dtype], n=x.numel(), p=p, seed=seed)
+        call('sdmi_dropout', _st(), x=_p(x), y=_p(y), dtype=_DT[x.dtype], n=x.numel(), p=p, seed=seed,
+             seed_dev=_p(seed_dev))
         return y
 
     @staticmethod
@@ -636,8 +637,8 @@ class DropoutFn(torch.autograd.Function):
         dy = dy.contiguous()
         dx = torch.empty_like(dy)
         call('sdmi_dropout', _st(), x=_p(dy), y=_p(dx), dtype=_DT[dy.dtype], n=dy.numel(), p=ctx.p,
-             seed=ctx.seed)
-        return dx, None, None
+             seed=ctx.seed, seed_dev=_p(ctx.seed_dev))
+        return dx, None, None, None
 
 
 class KernGrad(Kern):
@@ -660,8 +661,14 @@ class KernGrad(Kern):
         p = self._p_drop(site)
         if p <= 0.0:
             return x
-        KernGrad._drop_ctr += 1
-        return DropoutFn.apply(x, p, (self.seed << 20) + KernGrad._drop_ctr)
+        # site counter restarts every step (`begin_step`), the per-step variation comes from the
+        # device word `model.step_seed` so that a captured HIP graph draws new masks on replay
+        self._drop_ctr += 1
+        return DropoutFn.apply(x, p, (self.seed << 20) + self._drop_ctr,
+                               getattr(self.wb.model, 'step_seed', None))
+
+    def begin_step(self):
+        self._drop_ctr = 0
 
     def conv(self, x, wname, bname=None, *, kh=3, kw=3, stride=1, pad=(1, 1, 1, 1), ups=False,
              rowvec=None, residual=None, out_dtype=None, ldc=None):

@@ -184,6 +184,7 @@ class SADiffusion(FlatModule):
         self._unet = None
         self._plan = None
         self._Kinf = self._Kgrad = None
+        self.step_seed = None      # device word mixed into dropout seeds (see optim.GraphedTrainStep)
         self.use_graph = os.environ.get('SDMI_GRAPH', '1') != '0'
         self._graph_cache = {}
 

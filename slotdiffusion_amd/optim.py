@@ -32,6 +32,12 @@ class FusedAdam:
         self.nblk = 1024
         self.partial = torch.empty(self.nblk, dtype=torch.float32, device=dev)
         self.step_count = 0
+        # device-resident step counter / learning rates so a captured HIP graph stays valid
+        self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.lr_dev = torch.tensor([self.lr, self.dec_lr], dtype=torch.float32, device=dev)
+        self._lr_ring = torch.empty(64, 2, dtype=torch.float32)
+        if dev.type == 'cuda':
+            self._lr_ring = self._lr_ring.pin_memory()
         self.total_steps, self.warmup = total_steps, (int(warmup_pct * total_steps)
                                                        if total_steps else 0)
 
@@ -51,22 +57,94 @@ class FusedAdam:
         """Global L2 norm of the last step's gradients (syncs; diagnostics only)."""
         return float(self.partial.double().sum().sqrt())
 
+    def set_lr_for_next_step(self):
+        """Host side of the schedule: refresh the device lr scalars (outside any graph)."""
+        scale = self.lr_scale(self.step_count + 1)
+        slot = self._lr_ring[self.step_count % 64]      # ring: the async copy may still be pending
+        slot[0], slot[1] = self.lr * scale, self.dec_lr * scale
+        self.lr_dev.copy_(slot, non_blocking=True)
+
     @torch.no_grad()
-    def step(self):
+    def step(self, capturable=False):
+        """clip + Adam over the arena.  capturable=True reads step / lr from device memory (the
+        caller has run set_lr_for_next_step()), so the launch sequence can live in a HIP graph."""
         m = self.model
         g = m.grad_arena()
         st = torch.cuda.current_stream().cuda_stream
-        self.step_count += 1
+        if capturable:          # host bookkeeping (step_count, lr) is the replaying caller's job
+            self.step_dev.add_(1)
+        else:
+            self.set_lr_for_next_step()
+            self.step_count += 1
+            self.step_dev.fill_(self.step_count)
         call('sdmi_sqsum_partial', st, g=_p(g), partial=_p(self.partial), n=self.n_train,
              nblk=self.nblk)
-        scale = self.lr_scale(self.step_count)
         arena = m.arena()
         bf16 = m.compute_dtype == torch.bfloat16
         shadow = m.shadow_arena() if bf16 else None
         for lo, hi, grp in m.lr_runs():
-            lr = self.dec_lr if grp == 1 else self.lr
             call('sdmi_adam_clip', st, p=_p(arena[lo:]), g=_p(g[lo:]), m=_p(self.m[lo:]),
                  v=_p(self.v[lo:]), shadow_bf16=(_p(shadow[lo:]) if bf16 else 0),
-                 sq_partial=_p(self.partial), nblk=self.nblk, n=hi - lo, lr=lr * scale,
-                 beta1=self.b1, beta2=self.b2, eps=self.eps, clip=self.clip, step=self.step_count)
+                 sq_partial=_p(self.partial), nblk=self.nblk, n=hi - lo, lr=0.0,
+                 beta1=self.b1, beta2=self.b2, eps=self.eps, clip=self.clip,
+                 step=(0 if capturable else self.step_count), lr_dev=_p(self.lr_dev[grp:]),
+                 step_dev=(_p(self.step_dev) if capturable else 0))
         m.weights_updated(shadow_fresh=True)
+
+
+class GraphedTrainStep:
+    """zero-grad -> forward -> loss -> backward -> clip+Adam captured once into a HIP graph and
+    replayed per step (about 2.5k kernel launches per replay instead of 2.5k host launches).
+    RNG (t, noise) comes from torch's graph-safe Philox generator, dropout masks from the device
+    word `model.step_seed`, Adam's step / lr from device scalars -- nothing host-side is baked in.
+    With world > 1 the gradient all-reduce runs eagerly between two graphs."""
+
+    def __init__(self, model, opt, example_batch, allreduce=None):
+        self.model, self.opt, self.allreduce = model, opt, allreduce
+        self.static = {k: v.clone() for k, v in example_batch.items()}
+        dev = model.arena().device
+        if getattr(model, 'step_seed', None) is None or model.step_seed.device != dev:
+            model.step_seed = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.loss = None
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):                      # warm-up: lazy operands, func attributes
+                opt.set_lr_for_next_step()
+                opt.step_count += 1
+                self._fwd_bwd()
+                if allreduce is not None:
+                    allreduce(model.grad_arena())
+                self._update()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.g_fb = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.g_fb):
+            self.loss = self._fwd_bwd()
+        self.g_up = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.g_up, pool=self.g_fb.pool()):
+            self._update()
+
+    def _fwd_bwd(self):
+        m = self.model
+        m.grad_arena().zero_()
+        m.step_seed.add_(1)
+        m.KG().begin_step()
+        out = m(self.static)
+        loss = m.calc_train_loss(self.static, out)['denoise_loss']
+        loss.backward()
+        return loss.detach()
+
+    def _update(self):
+        self.opt.step(capturable=True)
+
+    def __call__(self, batch):
+        for k, v in batch.items():
+            self.static[k].copy_(v, non_blocking=True)
+        self.opt.set_lr_for_next_step()
+        self.opt.step_count += 1
+        self.g_fb.replay()
+        if self.allreduce is not None:
+            self.allreduce(self.model.grad_arena())
+        self.g_up.replay()
+        return self.loss

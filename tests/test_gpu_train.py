@@ -117,6 +117,51 @@ def test_adam_clip_step_matches_oracle():
     assert worst <= 2e-6
 
 
+def test_graphed_train_step_matches_eager():
+    """The HIP-graph replay of zero-grad + fwd + bwd + clip + Adam must walk exactly the same
+    trajectory as the eager step (same kernels, same order): 4 steps, fixed t / noise, dropout
+    off; then with dropout on, two replays must draw different masks (device-side seed word)."""
+    from slotdiffusion_amd.optim import FusedAdam, GraphedTrainStep
+    G = C.load_golden()
+    img = C.make_inputs(2)[0].cuda()
+    batch = dict(img=img, t=G['t'].cuda(), noise=G['noise'].cuda())
+    finals, losses = [], []
+    for graphed in (False, True):
+        m = _model(torch.float32)
+        m.train()
+        opt = FusedAdam(m, lr=1e-4, dec_lr=2e-4, clip_grad=1.0, total_steps=50, warmup_pct=0.2)
+        ls = []
+        if graphed:
+            gs = GraphedTrainStep(m, opt, batch)       # two warm-up steps happen inside
+            for _ in range(2):
+                ls.append(float(gs(batch)))
+        else:
+            for _ in range(4):
+                opt.zero_grad()
+                out = m(batch)
+                loss = m.calc_train_loss(batch, out)['denoise_loss']
+                loss.backward()
+                opt.step()
+                ls.append(float(loss))
+        assert opt.step_count == 4 and int(opt.step_dev) == 4
+        finals.append(m.arena().detach().clone())
+        losses.append(ls)
+    diff = float((finals[0] - finals[1]).abs().max())
+    REPORT['graphed_vs_eager_param_maxdiff'] = diff
+    REPORT['graphed_losses'] = losses
+    _dump()
+    assert diff == 0.0
+    assert losses[0][2:] == losses[1]
+    # dropout on: the in-graph seed word advances, so replays differ
+    m = _model(torch.float32)
+    m.train_dropout = 0.1
+    m.train()
+    opt = FusedAdam(m, lr=0.0, dec_lr=0.0, clip_grad=1.0)
+    gs = GraphedTrainStep(m, opt, batch)
+    l1, l2 = float(gs(batch)), float(gs(batch))
+    assert l1 != l2 and abs(l1 - l2) < 0.2 * abs(l1)
+
+
 def test_train_step_bf16_gradients_close():
     G = C.load_golden()
     img = C.make_inputs(2)[0].cuda()
