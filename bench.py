@@ -231,10 +231,12 @@ def main():
             # live per-kernel timing of ONE sampling pass, eager (events around every launch)
             from slotdiffusion_amd._lib import KernelTimer
             model.use_graph = False
+            overlap, model.bank().overlap_wgrad = model.bank().overlap_wgrad, False  # clean timings
             step()
             with KernelTimer() as kt:
                 step()
             summ = kt.summary()
+            model.bank().overlap_wgrad = overlap
             model.use_graph = not args.no_graph
             ig = dict(summ['sdmi_igemm'])
             if 'sdmi_wgrad' in summ:        # the MFMA GEMM family = forward/dgrad igemm + wgrad

@@ -78,7 +78,8 @@ typedef struct {
   const void* dy;       /* [M][ldy] output gradient, `dtype` */
   float* dw;            /* [N][K] fp32 (accumulated into when accumulate != 0) */
   float* dbias;         /* [N] fp32 column sums of dy, or NULL */
-  float* workspace;     /* split partials: splits*N*K floats */
+  float* workspace;     /* split partials: splits*(N*K + N) floats (unused when splits == 1:
+                           one launch, written straight into dw / dbias) */
   int dtype;
   int M, N, K, lda, ldy;
   int B, H, W, Cin, Ho, Wo, KH, KW, stride, pad_t, pad_l, ups;

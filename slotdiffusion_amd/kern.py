@@ -11,6 +11,9 @@ Both resolve weights through a WeightBank: fp32 operands are views of the master
 operands views of the bf16 shadow arena (same offsets); only channel-padded and non-adjacent
 fused operands are materialised.
 """
+import contextlib
+import os
+
 import torch
 
 from . import _lib, ops
@@ -49,6 +52,33 @@ class WeightBank:
         # autograd anchor: parameters reach the kernels by name, so parameterised Functions take
         # this requires-grad dummy to make their outputs part of the graph
         self.anchor = torch.zeros(1, device=model.arena().device, requires_grad=True)
+        # weight-gradient GEMMs are off the backward critical path (nothing downstream reads them
+        # before the optimiser): they run on a second HIP stream, concurrently with the dgrad
+        # chain, and are joined when the autograd pass ends.  Their operands are kept alive until
+        # the join (HBM is plentiful), so no allocator stream bookkeeping is needed.
+        self.overlap_wgrad = os.environ.get('SDMI_WGRAD_STREAM', '1') != '0'
+        self._side = None
+        self._pending = []
+        self._join_queued = False
+
+    def side_stream(self):
+        if not self.overlap_wgrad:
+            return None
+        if self._side is None:
+            self._side = torch.cuda.Stream()
+        return self._side
+
+    def defer(self, *tensors):
+        self._pending.append(tensors)
+        if not self._join_queued:
+            self._join_queued = True
+            torch.autograd.Variable._execution_engine.queue_callback(self.join)
+
+    def join(self):
+        if self._side is not None:
+            torch.cuda.current_stream().wait_stream(self._side)
+        self._pending.clear()
+        self._join_queued = False
 
     def invalidate(self):
         self.cache.clear()
@@ -290,9 +320,60 @@ class GemmFn(torch.autograd.Function):
         k_true = wb.t[names[0]].numel() // wb.t[names[0]].shape[0]
         direct = dst is not None and k_true == K
         tiles = ((N + 127) // 128) * ((K + 127) // 128)
-        mt = 128 if dt == torch.bfloat16 else 32
-        splits = max(1, min((768 + tiles - 1) // tiles, max(1, M // (4 * mt)), 512))
-        ws = torch.empty((max(splits * N * K, 256 * N),), dtype=torch.float32, device=x.device)
+        # M is split so that >= ~2 workgroups per CU exist while each still walks >= 8 m-steps
+        # (64 rows per step in the bf16 kernel, 32 in the fp32 one); short contractions take one
+        # launch straight into the gradient arena
+        mt = 64 if dt == torch.bfloat16 else 32
+        splits = max(1, min((512 + tiles - 1) // tiles, M // (8 * mt), 512))
+        if M <= 16 * mt:
+            splits = 1
+        side = wb.side_stream()
+        if side is not None:
+            ev = torch.cuda.Event()
+            ev.record()
+            side.wait_event(ev)          # dy is ready
+        with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+            GemmFn._wgrad(wb, x, dy, dt, names, bnames, dst, direct, splits, M, N, K, Cin, ldy, B,
+                          H, W_, Ho, Wo, kh, kw, stride, pad, ups, is_conv)
+        if side is not None:
+            wb.defer(x, dy)
+        # ---- data gradient: the forward kernel on the flipped operand
+        dx = None
+        if ctx.needs_input_grad[0]:
+            wd = wb.wd(wnames, dt, kh, kw, Cin)
+            if is_conv:
+                Hs, Ws = (2 * H, 2 * W_) if ups else (H, W_)
+                out = torch.empty((B, Hs, Ws, Cin), dtype=dt, device=x.device)
+                call('sdmi_igemm', _st(), a=_p(dy), w=_p(wd), out=_p(out), dtype=_DT[dt],
+                     out_dtype=_DT[dt], M=B * Hs * Ws, N=Cin, K=kh * kw * ldy, lda=ldy,
+                     ldw=kh * kw * ldy, ldc=Cin, B=B, H=Ho, W=Wo, Cin=ldy, Ho=Hs, Wo=Ws, KH=kh,
+                     KW=kw, stride=1, pad_t=kh - 1 - pad[0], pad_l=kw - 1 - pad[2], ups=0, act=0,
+                     alpha=1.0, split_k=1, batch=1, zins=(stride if stride > 1 else 0))
+                if ups:
+                    dx = torch.empty_like(x)
+                    call('sdmi_pool2x2_sum', _st(), x=_p(out), y=_p(dx), dtype=_DT[dt], B=B, H=H,
+                         W=W_, C=Cin)
+                else:
+                    dx = out
+            else:
+                dx = ops.linear(dy.view(-1, ldy), wd).view(x.shape)
+        drv = None
+        if has_rv and ctx.needs_input_grad[1]:
+            drv = torch.empty(rv_shape, dtype=torch.float32, device=x.device)
+            call('sdmi_rowgroup_sum', _st(), x=_p(dy), out=_p(drv), dtype=_DT[dt], groups=B,
+                 rows_per=Ho * Wo, N=N, ldx=ldy)
+        dres = None
+        if has_res and ctx.needs_input_grad[2]:
+            dres = dy if dy.shape[-1] == N else None
+            assert dres is not None
+        _dbg(f'gemm {wnames if isinstance(wnames, str) else wnames[0]}', dy=dy, dx=dx, drv=drv)
+        return dx, drv, dres, None, None, None, None, None, None, None
+
+    @staticmethod
+    def _wgrad(wb, x, dy, dt, names, bnames, dst, direct, splits, M, N, K, Cin, ldy, B, H, W_, Ho,
+               Wo, kh, kw, stride, pad, ups, is_conv):
+        """Weight / bias gradient launches (on whatever stream is current)."""
+        ws = torch.empty((splits * (N * K + N),), dtype=torch.float32, device=x.device)
         dwbuf = dst if direct else torch.zeros((N, K), dtype=torch.float32, device=x.device)
         bdst = None
         btmp = None
@@ -326,37 +407,6 @@ class GemmFn(torch.autograd.Function):
                 ops.cast2d(btmp[o:o + cnt].view(-1, 1), torch.float32,
                            out=g[off:off + cnt].view(-1, 1))
                 o += cnt
-        # ---- data gradient: the forward kernel on the flipped operand
-        dx = None
-        if ctx.needs_input_grad[0]:
-            wd = wb.wd(wnames, dt, kh, kw, Cin)
-            if is_conv:
-                Hs, Ws = (2 * H, 2 * W_) if ups else (H, W_)
-                out = torch.empty((B, Hs, Ws, Cin), dtype=dt, device=x.device)
-                call('sdmi_igemm', _st(), a=_p(dy), w=_p(wd), out=_p(out), dtype=_DT[dt],
-                     out_dtype=_DT[dt], M=B * Hs * Ws, N=Cin, K=kh * kw * ldy, lda=ldy,
-                     ldw=kh * kw * ldy, ldc=Cin, B=B, H=Ho, W=Wo, Cin=ldy, Ho=Hs, Wo=Ws, KH=kh,
-                     KW=kw, stride=1, pad_t=kh - 1 - pad[0], pad_l=kw - 1 - pad[2], ups=0, act=0,
-                     alpha=1.0, split_k=1, batch=1, zins=(stride if stride > 1 else 0))
-                if ups:
-                    dx = torch.empty_like(x)
-                    call('sdmi_pool2x2_sum', _st(), x=_p(out), y=_p(dx), dtype=_DT[dt], B=B, H=H,
-                         W=W_, C=Cin)
-                else:
-                    dx = out
-            else:
-                dx = ops.linear(dy.view(-1, ldy), wd).view(x.shape)
-        drv = None
-        if has_rv and ctx.needs_input_grad[1]:
-            drv = torch.empty(rv_shape, dtype=torch.float32, device=x.device)
-            call('sdmi_rowgroup_sum', _st(), x=_p(dy), out=_p(drv), dtype=_DT[dt], groups=B,
-                 rows_per=Ho * Wo, N=N, ldx=ldy)
-        dres = None
-        if has_res and ctx.needs_input_grad[2]:
-            dres = dy if dy.shape[-1] == N else None
-            assert dres is not None
-        _dbg(f'gemm {wnames if isinstance(wnames, str) else wnames[0]}', dy=dy, dx=dx, drv=drv)
-        return dx, drv, dres, None, None, None, None, None, None, None
 
 
 class GroupNormFn(torch.autograd.Function):

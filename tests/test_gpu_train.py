@@ -213,15 +213,25 @@ def test_wgrad_and_dgrad_kernels(case, dtype):
     dyd = F.pad(dy.permute(0, 2, 3, 1), (0, npad - Cout)).contiguous().to(dtype).cuda()
     Ho = y.shape[2]
     M, K = B * Ho * Ho, k * k * Cin
-    splits = 4
-    ws = torch.empty(max(splits * Cout * K, 256 * Cout), device='cuda')
-    dw = torch.empty(Cout, K, device='cuda')
-    db = torch.empty(Cout, device='cuda')
-    _lib.call('sdmi_wgrad', torch.cuda.current_stream().cuda_stream, a=xd.data_ptr(),
-              dy=dyd.data_ptr(), dw=dw.data_ptr(), dbias=db.data_ptr(), workspace=ws.data_ptr(),
-              dtype=_DT[dtype], M=M, N=Cout, K=K, lda=Cin, ldy=npad, B=B, H=H, W=H, Cin=Cin, Ho=Ho,
-              Wo=Ho, KH=k, KW=k, stride=stride, pad_t=pad[0], pad_l=pad[2], ups=int(ups),
-              splits=splits, accumulate=0)
+    def run(splits, accumulate=0, init=0.0):
+        ws = torch.empty(splits * (Cout * K + Cout), device='cuda')
+        dw_ = torch.full((Cout, K), init, device='cuda')
+        db_ = torch.full((Cout,), init, device='cuda')
+        _lib.call('sdmi_wgrad', torch.cuda.current_stream().cuda_stream, a=xd.data_ptr(),
+                  dy=dyd.data_ptr(), dw=dw_.data_ptr(), dbias=db_.data_ptr(),
+                  workspace=ws.data_ptr(), dtype=_DT[dtype], M=M, N=Cout, K=K, lda=Cin, ldy=npad,
+                  B=B, H=H, W=H, Cin=Cin, Ho=Ho, Wo=Ho, KH=k, KW=k, stride=stride, pad_t=pad[0],
+                  pad_l=pad[2], ups=int(ups), splits=splits, accumulate=accumulate)
+        return dw_, db_
+
+    dw, db = run(4)
+    scale = max(1.0, float(dw.abs().max()))
+    dw1, db1 = run(1, accumulate=1, init=0.5)      # one launch, accumulating straight into dW
+    assert float((dw1 - 0.5 - dw).abs().max()) <= 1e-5 * scale + 1e-5
+    assert float((db1 - 0.5 - db).abs().max()) <= 1e-4 * max(1.0, float(db.abs().max()))
+    dwa, dba = run(3, accumulate=1, init=-1.0)
+    assert float((dwa + 1.0 - dw).abs().max()) <= 1e-5 * scale + 1e-5
+    assert float((dba + 1.0 - db).abs().max()) <= 1e-4 * max(1.0, float(db.abs().max()))
     ref_dw = w.grad.permute(0, 2, 3, 1).reshape(Cout, K)
     tol = 2e-5 if dtype == torch.float32 else 2e-2
     e = float((dw.cpu() - ref_dw).norm() / ref_dw.norm())
@@ -251,3 +261,4 @@ def test_wgrad_and_dgrad_kernels(case, dtype):
     ref_dx = x.grad.permute(0, 2, 3, 1)
     e = float((dx.float().cpu() - ref_dx).norm() / ref_dx.norm())
     assert e <= tol, f'dgrad rel err {e}'
+
