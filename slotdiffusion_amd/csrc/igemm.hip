@@ -2,9 +2,9 @@
 //
 //   out[m][n] = epi( alpha * sum_k A[m][k] * W[n][k] )      M = B*Ho*Wo, N = Cout, K = KH*KW*Cin
 //
-// Tiling (per 256-thread workgroup = 4 waves as 2x2):
-//   block tile BM x BN (128x128 or 64x64), K tile = BKB bytes of K per row (64 or 128);
-//   each wave owns (BM/2)x(BN/2) = TMxTN MFMA 32x32 tiles, fp32 accumulators in VGPR/AGPR.
+// Tiling (per 512-thread workgroup = 4 MFMA waves as 2x2 + 4 loader waves):
+//   block tile BM x BN (128x128, 128x64 or 64x64), K tile = BKB bytes of K per row (64 or
+//   128); each MFMA wave owns (BM/2)x(BN/2) = TMxTN MFMA 32x32 tiles, fp32 accumulators.
 //   bf16:  v_mfma_f32_32x32x16_bf16  -- one MFMA per 32 bytes of K per (row tile, col tile)
 //   fp32:  v_mfma_f32_32x32x2_f32 x4 -- same 32 bytes (8 floats) of K, exact fp32 (fmaf chain)
 // Both operand tiles live in LDS as [rows][BKB bytes] with a 16-byte row pad (row pitch 80/144 B:
@@ -12,9 +12,11 @@
 // 16-byte bank slots: conflict free).  Lane l reads row (l&31), K bytes [ks*32 + (l>>5)*16, +16).
 // Any consistent k permutation is valid for a contraction, so A and B use the same mapping.
 //
-// Global->LDS staging is register staged (zero fill for image borders / K tail needs predication),
-// software pipelined: the global loads of tile t+1 are issued before the MFMAs of tile t and
-// written to the other LDS buffer afterwards; one __syncthreads() per K tile.
+// Wave specialisation: the loader waves (one per SIMD, next to one MFMA wave) do the im2col
+// address arithmetic, keep two K tiles of global loads in flight in registers (zero fill for
+// image borders / K tail needs predication, so the copy is register staged) and fill a
+// double-buffered LDS image one K tile ahead; the MFMA waves only read fragments and issue
+// MFMAs, prefetching the next k-step's fragments under the current MFMAs.  One barrier per K tile.
 //
 // blockIdx.x -> tile mapping is XCD aware: the 8 XCDs (block b runs on XCD b%8) each get a
 // contiguous range of tile ids, with the n-tiles of one m-tile adjacent, so an activation tile is
@@ -28,8 +30,8 @@ struct ConvGeom {
 };
 
 template <typename T, int BM, int BN, int BKB, bool IS1X1>
-__global__ __launch_bounds__(256) void igemm_kernel(SdmiGemmArgs p, int tiles_m, int tiles_n,
-                                                    int kt_per_split, int hw_shift) {
+__device__ __forceinline__ void igemm_body(const SdmiGemmArgs& p, int tiles_m, int tiles_n,
+                                           int kt_per_split, int hw_shift) {
   constexpr int VEC = 16 / sizeof(T);
   constexpr int BK = BKB / sizeof(T);
   constexpr int VPR = BKB / 16;
@@ -43,143 +45,188 @@ __global__ __launch_bounds__(256) void igemm_kernel(SdmiGemmArgs p, int tiles_m,
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-
-  // ---- XCD-aware tile id
-  int tile_m, tile_n;
-  {
-    const int nwg = tiles_m * tiles_n;
-    const int bid = blockIdx.x;
-    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-    const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    tile_m = id / tiles_n;
-    tile_n = id - tile_m * tiles_n;
-  }
+  // ---- persistent workgroups: this one walks tiles blockIdx.x, + gridDim.x, ... (gridDim.x is a
+  // multiple of 8 whenever it is smaller than the tile count, so a virtual block id keeps its
+  // XCD).  XCD-aware id: each XCD gets a contiguous range of tile ids.
+  const int nwg = tiles_m * tiles_n;
+  auto tile_of = [&](int vb, int& m0, int& n0) __attribute__((always_inline)) {
+    const int xcd = vb & 7, q = nwg >> 3, r = nwg & 7;
+    const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (vb >> 3);
+    const int tm = id / tiles_n;
+    m0 = tm * BM;
+    n0 = (id - tm * tiles_n) * BN;
+  };
+  const int my_tiles = ((int)blockIdx.x < nwg) ? (nwg - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
   const int zb = blockIdx.y / p.split_k;
   const int ksplit = blockIdx.y - zb * p.split_k;
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
-
-  const T* __restrict__ Ag = (const T*)p.a + (long long)zb * p.sa;
-  const T* __restrict__ Wg = (const T*)p.w + (long long)zb * p.sw;
 
   const int nk_total = (p.K + BK - 1) / BK;
   const int kt_begin = ksplit * kt_per_split;
   int kt_end = kt_begin + kt_per_split;
   if (kt_end > nk_total) kt_end = nk_total;
+  const int n_kt = kt_end > kt_begin ? kt_end - kt_begin : 0;
+  const int total = my_tiles * n_kt;          // pipeline steps of this workgroup
 
-  // ---- per-thread staging coordinates
-  const int kc = tid % VPR;  // vector column inside the K tile (same for all of a thread's vectors)
-  int kk = kt_begin * BK + kc * VEC;  // this thread's k index for the current tile
-  int ci = 0, kh = 0, kw = 0;
-  if (!IS1X1) {
-    const int tap = kk / p.Cin;
-    ci = kk - tap * p.Cin;
-    kh = tap / p.KW;
-    kw = tap - kh * p.KW;
-  }
-  long long a_pix[A_VECS];   // IS1X1: m*lda ; conv: b*H*W (pixel index base)
-  int a_iy0[A_VECS], a_ix0[A_VECS];
-  bool a_ok[A_VECS];
+  if (threadIdx.x >= 256) {
+    // =============================== loader waves ===============================
+    const int tid = threadIdx.x - 256;
+    const T* __restrict__ Ag = (const T*)p.a + (long long)zb * p.sa;
+    const T* __restrict__ Wg = (const T*)p.w + (long long)zb * p.sw;
+    const int kc = tid % VPR;  // vector column inside the K tile (same for all of a thread's vectors)
+    int kk = 0, ci = 0, kh = 0, kw = 0;       // this thread's k state for the next tile to load
+    int a_pix[A_VECS];         // IS1X1: m ; conv: b*H*W (pixel index base) -- all < 2^31
+    int a_iy0[A_VECS], a_ix0[A_VECS];
+    bool a_ok[A_VECS];
+    int b_row[B_VECS];
+    bool b_ok[B_VECS];
+    int ld_tile = 0, ld_kt = 0;               // (tile, K tile) the next load_tile() fetches
+    auto begin_tile = [&]() __attribute__((always_inline)) {
+      int m0, n0;
+      tile_of((int)blockIdx.x + ld_tile * (int)gridDim.x, m0, n0);
+      kk = kt_begin * BK + kc * VEC;
+      ci = kh = kw = 0;
+      if (!IS1X1) {
+        const int tap = kk / p.Cin;
+        ci = kk - tap * p.Cin;
+        kh = tap / p.KW;
+        kw = tap - kh * p.KW;
+      }
 #pragma unroll
-  for (int i = 0; i < A_VECS; ++i) {
-    const int row = (tid + i * 256) / VPR;
-    const int m = m0 + row;
-    a_ok[i] = m < p.M;
-    if (IS1X1) {
-      a_pix[i] = (long long)m * p.lda;
-      a_iy0[i] = a_ix0[i] = 0;
-    } else {
-      const int HoWo = p.Ho * p.Wo;
-      const int b = m / HoWo;
-      const int rem = m - b * HoWo;
-      const int oy = rem / p.Wo;
-      const int ox = rem - oy * p.Wo;
-      a_pix[i] = (long long)b * p.H * p.W;
-      a_iy0[i] = oy * p.stride - p.pad_t;
-      a_ix0[i] = ox * p.stride - p.pad_l;
-    }
-  }
-  long long b_off[B_VECS];
-  bool b_ok[B_VECS];
-#pragma unroll
-  for (int i = 0; i < B_VECS; ++i) {
-    const int row = (tid + i * 256) / VPR;
-    const int n = n0 + row;
-    b_ok[i] = n < p.N;
-    b_off[i] = (long long)n * p.ldw;
-  }
-
-  u32x4 ra[A_VECS], rb[B_VECS];
-  const u32x4 zero4 = {0u, 0u, 0u, 0u};
-
-  // Loads are issued unconditionally from a clamped (always valid) address so the compiler can
-  // keep all of a tile's global loads in flight together; out-of-image / K-tail vectors are
-  // zeroed when the registers are written to LDS (mask bits travel with the tile).
-  unsigned okmask = 0;
-  auto load_tile = [&]() __attribute__((always_inline)) {
-    const bool k_ok = kk < p.K;
-    okmask = 0;
-#pragma unroll
-    for (int i = 0; i < A_VECS; ++i) {
-      bool ok = a_ok[i] && k_ok;
-      long long off;
-      if (IS1X1) {
-        off = a_pix[i] + kk;
-      } else {
-        int iy = a_iy0[i] + kh, ix = a_ix0[i] + kw;
-        if (p.ups) {
-          ok = ok && iy >= 0 && iy < 2 * p.H && ix >= 0 && ix < 2 * p.W;
-          iy >>= 1;
-          ix >>= 1;
-        } else if (p.zins > 1) {
-          ok = ok && iy >= 0 && ix >= 0 && (iy % p.zins) == 0 && (ix % p.zins) == 0;
-          iy /= p.zins;
-          ix /= p.zins;
-          ok = ok && iy < p.H && ix < p.W;
+      for (int i = 0; i < A_VECS; ++i) {
+        const int row = (tid + i * 256) / VPR;
+        const int m = m0 + row;
+        a_ok[i] = m < p.M;
+        if (IS1X1) {
+          a_pix[i] = m;
+          a_iy0[i] = a_ix0[i] = 0;
         } else {
-          ok = ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+          const int HoWo = p.Ho * p.Wo;
+          const int b = m / HoWo;
+          const int rem = m - b * HoWo;
+          const int oy = rem / p.Wo;
+          const int ox = rem - oy * p.Wo;
+          a_pix[i] = b * p.H * p.W;
+          a_iy0[i] = oy * p.stride - p.pad_t;
+          a_ix0[i] = ox * p.stride - p.pad_l;
         }
-        off = (a_pix[i] + (long long)iy * p.W + ix) * p.lda + ci;
       }
-      off = ok ? off : 0;
-      okmask |= (ok ? 1u : 0u) << i;
-      ra[i] = *reinterpret_cast<const u32x4*>(Ag + off);
-    }
 #pragma unroll
-    for (int i = 0; i < B_VECS; ++i) {
-      const bool ok = b_ok[i] && k_ok;
-      okmask |= (ok ? 1u : 0u) << (A_VECS + i);
-      rb[i] = *reinterpret_cast<const u32x4*>(Wg + (ok ? b_off[i] + kk : 0));
-    }
-    // advance k state to the next tile
-    kk += BK;
-    if (!IS1X1) {
-      ci += BK;
-      while (ci >= p.Cin) {
-        ci -= p.Cin;
-        if (++kw == p.KW) { kw = 0; ++kh; }
+      for (int i = 0; i < B_VECS; ++i) {
+        const int row = (tid + i * 256) / VPR;
+        const int n = n0 + row;
+        b_ok[i] = n < p.N;
+        b_row[i] = n;
       }
-    }
-  };
-  auto store_tile = [&](int buf) __attribute__((always_inline)) {
-    char* base = smem + buf * BUF_BYTES;
-#pragma unroll
-    for (int i = 0; i < A_VECS; ++i) {
-      const int row = (tid + i * 256) / VPR;
-      *reinterpret_cast<u32x4*>(base + row * ROWB + kc * 16) =
-          ((okmask >> i) & 1u) ? ra[i] : zero4;
-    }
-#pragma unroll
-    for (int i = 0; i < B_VECS; ++i) {
-      const int row = (tid + i * 256) / VPR;
-      *reinterpret_cast<u32x4*>(base + BM * ROWB + row * ROWB + kc * 16) =
-          ((okmask >> (A_VECS + i)) & 1u) ? rb[i] : zero4;
-    }
-  };
+    };
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
 
+    // Loads are issued unconditionally from a clamped (always valid) address so that all of a
+    // tile's global loads are in flight together; out-of-image / K-tail vectors are zeroed when
+    // the registers are written to LDS (mask bits travel with the tile).
+    auto load_tile = [&](u32x4 (&ra)[A_VECS], u32x4 (&rb)[B_VECS], unsigned& okmask)
+                         __attribute__((always_inline)) {
+      if (ld_kt == 0) begin_tile();
+      const bool k_ok = kk < p.K;
+      okmask = 0;
+#pragma unroll
+      for (int i = 0; i < A_VECS; ++i) {
+        bool ok = a_ok[i] && k_ok;
+        long long off;
+        if (IS1X1) {
+          off = (long long)a_pix[i] * p.lda + kk;
+        } else {
+          int iy = a_iy0[i] + kh, ix = a_ix0[i] + kw;
+          if (p.ups) {
+            ok = ok && iy >= 0 && iy < 2 * p.H && ix >= 0 && ix < 2 * p.W;
+            iy >>= 1;
+            ix >>= 1;
+          } else if (p.zins > 1) {
+            ok = ok && iy >= 0 && ix >= 0 && (iy % p.zins) == 0 && (ix % p.zins) == 0;
+            iy /= p.zins;
+            ix /= p.zins;
+            ok = ok && iy < p.H && ix < p.W;
+          } else {
+            ok = ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+          }
+          off = (long long)(a_pix[i] + iy * p.W + ix) * p.lda + ci;
+        }
+        off = ok ? off : 0;
+        okmask |= (ok ? 1u : 0u) << i;
+        ra[i] = *reinterpret_cast<const u32x4*>(Ag + off);
+      }
+#pragma unroll
+      for (int i = 0; i < B_VECS; ++i) {
+        const bool ok = b_ok[i] && k_ok;
+        okmask |= (ok ? 1u : 0u) << (A_VECS + i);
+        rb[i] = *reinterpret_cast<const u32x4*>(Wg + (ok ? (long long)b_row[i] * p.ldw + kk : 0));
+      }
+      // advance k state to the next K tile (or on to the workgroup's next output tile)
+      kk += BK;
+      if (!IS1X1) {
+        ci += BK;
+        while (ci >= p.Cin) {
+          ci -= p.Cin;
+          if (++kw == p.KW) { kw = 0; ++kh; }
+        }
+      }
+      if (++ld_kt == n_kt) { ld_kt = 0; ++ld_tile; }
+    };
+    auto store_tile = [&](char* base, const u32x4 (&ra)[A_VECS], const u32x4 (&rb)[B_VECS],
+                          unsigned okmask) __attribute__((always_inline)) {
+#pragma unroll
+      for (int i = 0; i < A_VECS; ++i) {
+        const int row = (tid + i * 256) / VPR;
+        *reinterpret_cast<u32x4*>(base + row * ROWB + kc * 16) =
+            ((okmask >> i) & 1u) ? ra[i] : zero4;
+      }
+#pragma unroll
+      for (int i = 0; i < B_VECS; ++i) {
+        const int row = (tid + i * 256) / VPR;
+        *reinterpret_cast<u32x4*>(base + BM * ROWB + row * ROWB + kc * 16) =
+            ((okmask >> (A_VECS + i)) & 1u) ? rb[i] : zero4;
+      }
+    };
+
+    u32x4 ra0[A_VECS], rb0[B_VECS], ra1[A_VECS], rb1[B_VECS];
+    unsigned mk0 = 0, mk1 = 0;
+    // flat pipeline over (output tile, K tile) steps: while the MFMA waves finish a tile and run
+    // its epilogue, the first K tiles of the next one are already staged / in flight
+    if (total > 0) load_tile(ra0, rb0, mk0);
+    if (total > 1) load_tile(ra1, rb1, mk1);
+    for (int g = 0; g < total; g += 2) {
+      store_tile(smem, ra0, rb0, mk0);
+      if (g + 2 < total) load_tile(ra0, rb0, mk0);
+      __syncthreads();
+      if (g + 1 < total) {
+        store_tile(smem + BUF_BYTES, ra1, rb1, mk1);
+        if (g + 3 < total) load_tile(ra1, rb1, mk1);
+        __syncthreads();
+      }
+    }
+    return;
+  }
+
+  // ================================= MFMA waves =================================
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  const int frag_row = lane & 31;
+  const int frag_kb = (lane >> 5) * 16;
+  auto read_frags = [&](const char* As, const char* Bs, int ks, u32x4 (&fa)[TM], u32x4 (&fb)[TN])
+                        __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+      fa[i] = *reinterpret_cast<const u32x4*>(As + i * 32 * ROWB + ks * 32);
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+      fb[j] = *reinterpret_cast<const u32x4*>(Bs + j * 32 * ROWB + ks * 32);
+  };
+  int g = 0;                          // pipeline step (stage = g & 1)
+  for (int ti = 0; ti < my_tiles; ++ti) {
+  int m0, n0;
+  tile_of((int)blockIdx.x + ti * (int)gridDim.x, m0, n0);
   f32x16 acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -187,52 +234,32 @@ __global__ __launch_bounds__(256) void igemm_kernel(SdmiGemmArgs p, int tiles_m,
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  const int frag_row = lane & 31;
-  const int frag_kb = (lane >> 5) * 16;
-
-  if (kt_begin < kt_end) {
-    load_tile();
-    store_tile(0);
-    __syncthreads();
-    int buf = 0;
-    for (int kt = kt_begin; kt < kt_end; ++kt) {
-      const bool more = kt + 1 < kt_end;
-      if (more) load_tile();
-      const char* As = smem + buf * BUF_BYTES + (wm * WTM + frag_row) * ROWB + frag_kb;
-      const char* Bs = smem + buf * BUF_BYTES + BM * ROWB + (wn * WTN + frag_row) * ROWB + frag_kb;
+  for (int t = 0; t < n_kt; ++t, ++g) {
+    __syncthreads();                 // stage g & 1 holds this K tile
+    const char* base = smem + (g & 1) * BUF_BYTES;
+    const char* As = base + (wm * WTM + frag_row) * ROWB + frag_kb;
+    const char* Bs = base + BM * ROWB + (wn * WTN + frag_row) * ROWB + frag_kb;
+    u32x4 fa[2][TM], fb[2][TN];
+    read_frags(As, Bs, 0, fa[0], fb[0]);
 #pragma unroll
-      for (int ks = 0; ks < KSTEPS; ++ks) {
-        u32x4 fa[TM], fb[TN];
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      if (ks + 1 < KSTEPS) read_frags(As, Bs, ks + 1, fa[(ks + 1) & 1], fb[(ks + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ahead of this k-step's MFMAs
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
-          fa[i] = *reinterpret_cast<const u32x4*>(As + i * 32 * ROWB + ks * 32);
+      for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-          fb[j] = *reinterpret_cast<const u32x4*>(Bs + j * 32 * ROWB + ks * 32);
+        for (int j = 0; j < TN; ++j) {
+          const u32x4 a4 = fa[ks & 1][i], b4 = fb[ks & 1][j];
+          if constexpr (sizeof(T) == 2) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                __builtin_bit_cast(bf16x8, a4), __builtin_bit_cast(bf16x8, b4), acc[i][j], 0, 0, 0);
+          } else {
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j) {
-            if constexpr (sizeof(T) == 2) {
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                  __builtin_bit_cast(bf16x8, fa[i]), __builtin_bit_cast(bf16x8, fb[j]), acc[i][j],
-                  0, 0, 0);
-            } else {
+            for (int c = 0; c < 4; ++c)
               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(
-                  __uint_as_float(fa[i][0]), __uint_as_float(fb[j][0]), acc[i][j], 0, 0, 0);
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(
-                  __uint_as_float(fa[i][1]), __uint_as_float(fb[j][1]), acc[i][j], 0, 0, 0);
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(
-                  __uint_as_float(fa[i][2]), __uint_as_float(fb[j][2]), acc[i][j], 0, 0, 0);
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(
-                  __uint_as_float(fa[i][3]), __uint_as_float(fb[j][3]), acc[i][j], 0, 0, 0);
-            }
+                  __uint_as_float(a4[c]), __uint_as_float(b4[c]), acc[i][j], 0, 0, 0);
           }
-      }
-      if (more) store_tile(buf ^ 1);
-      __syncthreads();
-      buf ^= 1;
+        }
     }
   }
 
@@ -252,7 +279,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(SdmiGemmArgs p, int tiles_m,
           if (m < p.M && n < p.N) ws[(long long)m * p.N + n] = acc[i][j][r];
         }
       }
-    return;
+    continue;
   }
   char* outp = (char*)p.out;
   const char* resp = (const char*)p.residual;
@@ -334,6 +361,20 @@ __global__ __launch_bounds__(256) void igemm_kernel(SdmiGemmArgs p, int tiles_m,
         }
       }
     }
+  }  // tiles of this workgroup
+}
+
+// Two entry points over the same body: <= 128 VGPRs (two workgroups per CU) for the tiles whose
+// double-buffered LDS image allows it, unconstrained for the 256-row tile (92 KB of LDS).
+template <typename T, int BM, int BN, int BKB, bool IS1X1>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void igemm_kernel(
+    SdmiGemmArgs p, int tiles_m, int tiles_n, int kt_per_split, int hw_shift) {
+  igemm_body<T, BM, BN, BKB, IS1X1>(p, tiles_m, tiles_n, kt_per_split, hw_shift);
+}
+template <typename T, int BM, int BN, int BKB, bool IS1X1>
+__global__ __launch_bounds__(512) void igemm_kernel_tall(SdmiGemmArgs p, int tiles_m, int tiles_n,
+                                                         int kt_per_split, int hw_shift) {
+  igemm_body<T, BM, BN, BKB, IS1X1>(p, tiles_m, tiles_n, kt_per_split, hw_shift);
 }
 
 // split-K second stage: sum partials, apply the same epilogue
@@ -369,7 +410,9 @@ int launch_cfg(const SdmiGemmArgs& p, int split_k, int hw_shift, hipStream_t st)
   constexpr int BK = BKB / sizeof(T);
   constexpr int smem = 2 * (BM + BN) * (BKB + 16);
   static bool attr_done = false;
-  auto kern = igemm_kernel<T, BM, BN, BKB, IS1X1>;
+  void (*kern)(SdmiGemmArgs, int, int, int, int);
+  if constexpr (BM > 128) kern = igemm_kernel_tall<T, BM, BN, BKB, IS1X1>;
+  else kern = igemm_kernel<T, BM, BN, BKB, IS1X1>;
   if (!attr_done) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem) !=
         hipSuccess) {
@@ -383,8 +426,23 @@ int launch_cfg(const SdmiGemmArgs& p, int split_k, int hw_shift, hipStream_t st)
   const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
   const int nk = (p.K + BK - 1) / BK;
   const int ktps = (nk + split_k - 1) / split_k;
-  dim3 grid(tiles_m * tiles_n, split_k * (p.batch > 0 ? p.batch : 1));
-  hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, q, tiles_m, tiles_n, ktps, hw_shift);
+  // persistent workgroups: at most what the chip holds at once (registers / LDS allow 2 workgroups
+  // per CU for the 128-row tiles, 3 for 64x64); the rest of the tiles are walked in-kernel
+  static int n_cu = 0;
+  if (!n_cu) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
+            prop.multiProcessorCount > 0)
+               ? prop.multiProcessorCount
+               : 256;
+  }
+  const int ny = split_k * (p.batch > 0 ? p.batch : 1);
+  int cap = n_cu * (BM * BN >= 128 * 64 ? 2 : 3) / ny;
+  cap = cap < 8 ? 8 : (cap & ~7);          // multiple of 8: a virtual block id keeps its XCD
+  const int nwg = tiles_m * tiles_n;
+  dim3 grid(nwg <= cap ? nwg : cap, ny);
+  hipLaunchKernelGGL(kern, grid, dim3(512), smem, st, q, tiles_m, tiles_n, ktps, hw_shift);
   int rc = sdmi_check_launch("igemm");
   if (rc) return rc;
   if (split_k > 1) {
@@ -411,8 +469,19 @@ int dispatch(const SdmiGemmArgs& p, hipStream_t st) {
     }
   }
   const int batch = p.batch > 0 ? p.batch : 1;
-  const long long t128 = (long long)((p.M + 127) / 128) * ((p.N + 127) / 128) * batch;
-  const bool big = p.N > 64 && t128 >= 192;
+  const long long tm128 = (p.M + 127) / 128;
+  const long long t128 = tm128 * ((p.N + 127) / 128) * batch;
+  // tile shape: 128x128 when that still gives >= 192 workgroups; narrow outputs (N <= 64: the
+  // 64-channel encoder convs at 128x128 pixels) 128x64; everything else 64x64 (+ split-K)
+  enum { T128x128, T128x64, T64x64 } shape = T64x64;
+  if (p.N > 64) {
+    if (t128 >= 192) shape = T128x128;
+  } else if (p.N > 32) {
+    // (a 256x64 tile was measured 1.6x slower here: 92 KB of LDS = one workgroup per CU, and
+    // with K = 576 the prologue / epilogue of each tile is no longer hidden by a neighbour)
+    if (tm128 * batch >= 192) shape = T128x64;
+  }
+  const bool big = shape != T64x64;
   // K tile: 128 bytes of K per row when K is deep enough, else 64
   const int kbytes = p.K * (int)sizeof(T);
   const bool wide = kbytes >= 512;
@@ -428,10 +497,10 @@ int dispatch(const SdmiGemmArgs& p, hipStream_t st) {
 #define SDMI_GO(BM, BN, BKB)                                                           \
   return is1x1 ? launch_cfg<T, BM, BN, BKB, true>(p, split_k, hw_shift, st)            \
                : launch_cfg<T, BM, BN, BKB, false>(p, split_k, hw_shift, st)
-  if (big) {
-    if (wide) { SDMI_GO(128, 128, 128); } else { SDMI_GO(128, 128, 64); }
-  } else {
-    if (wide) { SDMI_GO(64, 64, 128); } else { SDMI_GO(64, 64, 64); }
+  switch (shape) {
+    case T128x128: if (wide) { SDMI_GO(128, 128, 128); } else { SDMI_GO(128, 128, 64); }
+    case T128x64: if (wide) { SDMI_GO(128, 64, 128); } else { SDMI_GO(128, 64, 64); }
+    default: if (wide) { SDMI_GO(64, 64, 128); } else { SDMI_GO(64, 64, 64); }
   }
 #undef SDMI_GO
 }
