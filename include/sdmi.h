@@ -277,6 +277,16 @@ int sdmi_mse(const SdmiMseArgs* a, void* stream);
 typedef struct { const void* src; void* dst; int dtype; int Cout, KH, KW, Cin, CoutPad; } SdmiPackDgradArgs;
 /* dst row pitch CoutPad >= Cout (pad columns must be pre-zeroed by the caller) */
 int sdmi_pack_dgrad(const SdmiPackDgradArgs* a, void* stream);
+/* The same for a whole table of operands in ONE launch (every dgrad operand of the model is
+ * rebuilt after each optimiser step).  `descs` is a device array of SdmiPackDesc; workgroup b
+ * serves the descriptor with block_begin <= b < next block_begin (2048 elements per workgroup). */
+typedef struct {
+  const void* src; void* dst;
+  int Cout, KH, KW, Cin, CoutPad;
+  int block_begin;
+} SdmiPackDesc;
+typedef struct { const void* descs; int n_desc; int dtype; int total_blocks; } SdmiPackBatchArgs;
+int sdmi_pack_dgrad_batch(const SdmiPackBatchArgs* a, void* stream);
 /* out[g][n] = sum over the `rows_per` consecutive rows of group g of x[m][n] (fp32 out):
  * gradient of the per-image time-embedding row vector, bias gradients (rows_per = M). */
 typedef struct { const void* x; float* out; int dtype; int groups, rows_per, N, ldx; } SdmiRowGroupSumArgs;

@@ -29,6 +29,33 @@ __global__ void pack_dgrad_kernel(SdmiPackDgradArgs p) {
   }
 }
 
+template <typename T>
+__global__ __launch_bounds__(256) void pack_dgrad_batch_kernel(SdmiPackBatchArgs p) {
+  const SdmiPackDesc* descs = (const SdmiPackDesc*)p.descs;
+  int lo = 0, hi = p.n_desc - 1;          // last descriptor with block_begin <= blockIdx.x
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (descs[mid].block_begin <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const SdmiPackDesc d = descs[lo];
+  const long long n = (long long)d.Cout * d.KH * d.KW * d.Cin;
+  const long long base = (long long)((int)blockIdx.x - d.block_begin) * 2048;
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const long long i = base + u * 256 + threadIdx.x;      // dst [ci][kh'][kw'][co]
+    if (i >= n) break;
+    const int co = (int)(i % d.Cout);
+    long long r = i / d.Cout;
+    const int kw = (int)(r % d.KW);
+    r /= d.KW;
+    const int kh = (int)(r % d.KH);
+    const int ci = (int)(r / d.KH);
+    const long long s =
+        (((long long)co * d.KH + (d.KH - 1 - kh)) * d.KW + (d.KW - 1 - kw)) * d.Cin + ci;
+    ((T*)d.dst)[(i / d.Cout) * d.CoutPad + co] = ((const T*)d.src)[s];
+  }
+}
+
 // out[g][n] = sum_{r < rows_per} x[g*rows_per + r][n]; block = 256 threads over n, grid (n-blocks, groups)
 template <typename T>
 __global__ __launch_bounds__(256) void rowgroup_sum_kernel(SdmiRowGroupSumArgs p) {
@@ -195,6 +222,11 @@ extern "C" int sdmi_pack_dgrad(const SdmiPackDgradArgs* a, void* stream) {
   SDMI_REQUIRE(a && a->src && a->dst && a->CoutPad >= a->Cout, "bad args");
   DISPATCH_T(pack_dgrad_kernel, dim3(nblocks((long long)a->Cout * a->KH * a->KW * a->Cin)), a);
   return sdmi_check_launch("pack_dgrad");
+}
+extern "C" int sdmi_pack_dgrad_batch(const SdmiPackBatchArgs* a, void* stream) {
+  SDMI_REQUIRE(a && a->descs && a->n_desc >= 1 && a->total_blocks >= 1, "bad args");
+  DISPATCH_T(pack_dgrad_batch_kernel, dim3(a->total_blocks), a);
+  return sdmi_check_launch("pack_dgrad_batch");
 }
 extern "C" int sdmi_rowgroup_sum(const SdmiRowGroupSumArgs* a, void* stream) {
   SDMI_REQUIRE(a && a->x && a->out && a->groups >= 1 && a->rows_per >= 1, "bad args");

@@ -80,55 +80,51 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(SdmiGroupNormBwdArgs 
   }
 }
 
-// per image: channel totals over splits (written back into split 0) and the group terms
-__global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(SdmiGroupNormBwdArgs p, float* gsum) {
-  __shared__ float tot[1024][2];
-  const int b = blockIdx.x;
-  for (int c = threadIdx.x; c < p.C; c += 256) {
-    double sa = 0.0, sb = 0.0;
-    for (int k = 0; k < p.nsplit; ++k) {
-      const float* q = p.partial + ((((long long)b * p.nsplit + k) * p.C) + c) * 2;
-      sa += q[0];
-      sb += q[1];
-    }
-    tot[c][0] = (float)sa;
-    tot[c][1] = (float)sb;
-    float* q0 = p.partial + (((long long)b * p.nsplit) * p.C + c) * 2;
-    q0[0] = (float)sa;
-    q0[1] = (float)sb;
-  }
-  __syncthreads();
+// One launch turns the [B][nsplit][C][2] partials into (a) the per-(image, group) terms the
+// dx pass needs and (b) dgamma / dbeta.  A workgroup owns CB = cpg * floor(64 / cpg) channels
+// (whole groups) for all images: 4 images at a time x 64 channel lanes.
+__global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(SdmiGroupNormBwdArgs p, float* gsum,
+                                                            int CB) {
+  __shared__ float tile[4][64][2];
+  const int cl = threadIdx.x & 63, kg = threadIdx.x >> 6;
+  const int c0 = blockIdx.x * CB, c = c0 + cl;
+  const bool cok = cl < CB && c < p.C;
   const int cpg = p.C / p.groups;
-  for (int g = threadIdx.x; g < p.groups; g += 256) {
-    double s1 = 0.0, s2 = 0.0;
-    for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
-      s1 += (double)p.gamma[c] * tot[c][0];
-      s2 += (double)p.gamma[c] * tot[c][1];
+  const float gam = cok ? p.gamma[c] : 0.f;
+  float pa = 0.f, pb = 0.f;
+  for (int b0 = 0; b0 < p.B; b0 += 4) {
+    const int b = b0 + kg;
+    double sa = 0.0, sb = 0.0;
+    if (cok && b < p.B) {
+      const float2* q = reinterpret_cast<const float2*>(p.partial) + (long long)b * p.nsplit * p.C + c;
+      for (int k = 0; k < p.nsplit; ++k) {
+        const float2 v = q[(long long)k * p.C];
+        sa += v.x;
+        sb += v.y;
+      }
     }
-    gsum[(b * p.groups + g) * 2] = (float)s1;
-    gsum[(b * p.groups + g) * 2 + 1] = (float)s2;
+    pa += (float)sa;
+    pb += (float)sb;
+    tile[kg][cl][0] = gam * (float)sa;
+    tile[kg][cl][1] = gam * (float)sb;
+    __syncthreads();
+    const int g = c0 / cpg + cl;
+    if (cl < CB / cpg && g < p.groups && b < p.B) {
+      double s1 = 0.0, s2 = 0.0;
+      for (int j = 0; j < cpg; ++j) { s1 += tile[kg][cl * cpg + j][0]; s2 += tile[kg][cl * cpg + j][1]; }
+      gsum[(b * p.groups + g) * 2] = (float)s1;
+      gsum[(b * p.groups + g) * 2 + 1] = (float)s2;
+    }
+    __syncthreads();
   }
-}
-
-__global__ __launch_bounds__(256) void gn_bwd_param_kernel(SdmiGroupNormBwdArgs p) {
-  __shared__ float red[4][64][2];
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63), kg = threadIdx.x >> 6;
-  float sa = 0.f, sb = 0.f;
-  if (c < p.C)
-    for (int b = kg; b < p.B; b += 4) {
-      const float* q = p.partial + (((long long)b * p.nsplit) * p.C + c) * 2;
-      sa += q[0];
-      sb += q[1];
-    }
-  red[kg][threadIdx.x & 63][0] = sa;
-  red[kg][threadIdx.x & 63][1] = sb;
+  tile[kg][cl][0] = pa;
+  tile[kg][cl][1] = pb;
   __syncthreads();
-  if (kg == 0 && c < p.C) {
-    const int l = threadIdx.x;
-    const float a = (red[0][l][0] + red[1][l][0]) + (red[2][l][0] + red[3][l][0]);
-    const float b = (red[0][l][1] + red[1][l][1]) + (red[2][l][1] + red[3][l][1]);
+  if (kg == 0 && cok) {
+    const float a = (tile[0][cl][0] + tile[1][cl][0]) + (tile[2][cl][0] + tile[3][cl][0]);
+    const float bb = (tile[0][cl][1] + tile[1][cl][1]) + (tile[2][cl][1] + tile[3][cl][1]);
     p.dbeta[c] = (p.accumulate ? p.dbeta[c] : 0.f) + a;
-    p.dgamma[c] = (p.accumulate ? p.dgamma[c] : 0.f) + b;
+    p.dgamma[c] = (p.accumulate ? p.dgamma[c] : 0.f) + bb;
   }
 }
 
@@ -182,56 +178,100 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(SdmiGroupNormBwdArgs 
 }
 
 // ------------------------------------------------------------------------------------------
-// LayerNorm backward: one wave per row for dx; per-workgroup channel partials for dgamma/dbeta.
-template <typename T>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(SdmiLayerNormBwdArgs p, int rows_per_blk) {
+// LayerNorm backward.  A row is covered by LPR = pow2 >= C/VEC lanes (16-byte vectors, up to VPL
+// vectors per lane when C/VEC > 64), so a wave handles 64/LPR rows at once and a workgroup
+// 4*64/LPR; the two row sums are xor-butterflies inside the LPR lanes.  dgamma/dbeta accumulate
+// per lane over the workgroup's rows and leave as per-workgroup channel partials.
+template <typename T, int VPL>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(SdmiLayerNormBwdArgs p, int rows_per_blk,
+                                                     int LPR) {
+  constexpr int VEC = Elem<T>::VEC;
   __shared__ float red[4][1024][2];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane & (LPR - 1), slot = lane / LPR, RW = 64 / LPR;
+  const int CV = p.C / VEC;
   const int row0 = blockIdx.x * rows_per_blk;
   int row1 = row0 + rows_per_blk;
   if (row1 > p.rows) row1 = p.rows;
-  float ga[16], dg[16], dbt[16];
+  float ga[VPL][VEC], dg[VPL][VEC], dbt[VPL][VEC];
+  bool act[VPL];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const int c = i * 64 + lane;
-    ga[i] = c < p.C ? p.gamma[c] : 0.f;
-    dg[i] = dbt[i] = 0.f;
+  for (int i = 0; i < VPL; ++i) {
+    const int cv = sub + i * LPR;
+    act[i] = cv < CV;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      ga[i][j] = act[i] ? p.gamma[cv * VEC + j] : 0.f;
+      dg[i][j] = dbt[i][j] = 0.f;
+    }
   }
   const float invC = 1.f / (float)p.C;
-  for (int row = row0 + wave; row < row1; row += 4) {
-    const T* x = (const T*)p.x + (long long)row * p.C;
-    const T* dy = (const T*)p.dy + (long long)row * p.C;
-    T* dx = (T*)p.dx + (long long)row * p.C;
-    const float mean = p.stats[row * 2], rstd = p.stats[row * 2 + 1];
-    float xh[16], dxh[16];
+  for (int rbase = row0 + wave * RW; rbase < row1; rbase += 4 * RW) {
+    const int row = rbase + slot;
+    const bool rok = row < row1;
+    const long long ro = (long long)(rok ? row : row0) * p.C;
+    const T* x = (const T*)p.x + ro;
+    const T* dy = (const T*)p.dy + ro;
+    float xh[VPL][VEC], dxh[VPL][VEC];
     float s1 = 0.f, s2 = 0.f;
+    const float mean = p.stats[(rok ? row : row0) * 2], rstd = p.stats[(rok ? row : row0) * 2 + 1];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int c = i * 64 + lane;
-      if (c < p.C) {
-        const float d = Elem<T>::ld(dy + c);
-        xh[i] = (Elem<T>::ld(x + c) - mean) * rstd;
-        dxh[i] = d * ga[i];
-        dg[i] += d * xh[i];
-        dbt[i] += d;
-        s1 += dxh[i];
-        s2 += dxh[i] * xh[i];
-      } else {
-        xh[i] = dxh[i] = 0.f;
+    for (int i = 0; i < VPL; ++i) {
+      const int cv = sub + i * LPR;
+      float xv[VEC], dv[VEC];
+      const int cc = act[i] ? cv : 0;
+      unpack16<T>(*reinterpret_cast<const uint4*>(x + cc * VEC), xv);
+      unpack16<T>(*reinterpret_cast<const uint4*>(dy + cc * VEC), dv);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        const float d = (act[i] && rok) ? dv[j] : 0.f;
+        xh[i][j] = (xv[j] - mean) * rstd;
+        dxh[i][j] = d * ga[i][j];
+        dg[i][j] += d * xh[i][j];
+        dbt[i][j] += d;
+        s1 += dxh[i][j];
+        s2 += dxh[i][j] * xh[i][j];
       }
     }
-    s1 = wave_sum(s1) * invC;
-    s2 = wave_sum(s2) * invC;
+    for (int off = 1; off < LPR; off <<= 1) {
+      s1 += __shfl_xor(s1, off, 64);
+      s2 += __shfl_xor(s2, off, 64);
+    }
+    s1 *= invC;
+    s2 *= invC;
+    if (rok) {
+      T* dx = (T*)p.dx + ro;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int c = i * 64 + lane;
-      if (c < p.C) Elem<T>::st(dx + c, rstd * (dxh[i] - s1 - xh[i] * s2));
+      for (int i = 0; i < VPL; ++i) {
+        if (!act[i]) continue;
+        float o[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) o[j] = rstd * (dxh[i][j] - s1 - xh[i][j] * s2);
+        *reinterpret_cast<uint4*>(dx + (sub + i * LPR) * VEC) = pack16<T>(o);
+      }
     }
   }
+  // fold the wave's row slots, then the four waves
+  for (int off = LPR; off < 64; off <<= 1) {
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const int c = i * 64 + lane;
-    if (c < p.C) { red[wave][c][0] = dg[i]; red[wave][c][1] = dbt[i]; }
+    for (int i = 0; i < VPL; ++i)
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        dg[i][j] += __shfl_xor(dg[i][j], off, 64);
+        dbt[i][j] += __shfl_xor(dbt[i][j], off, 64);
+      }
+  }
+  if (slot == 0) {
+#pragma unroll
+    for (int i = 0; i < VPL; ++i)
+      if (act[i]) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          const int c = (sub + i * LPR) * VEC + j;
+          red[wave][c][0] = dg[i][j];
+          red[wave][c][1] = dbt[i][j];
+        }
+      }
   }
   __syncthreads();
   for (int c = threadIdx.x; c < p.C; c += 256) {
@@ -240,23 +280,35 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(SdmiLayerNormBwdArgs p, int
     q[1] = (red[0][c][1] + red[1][c][1]) + (red[2][c][1] + red[3][c][1]);
   }
 }
+// dgamma / dbeta from the per-workgroup partials: 16 channels x 16 partial-groups per workgroup
+// (C/16 workgroups), 4 independent loads in flight per thread, fixed-order LDS fold.
 __global__ __launch_bounds__(256) void ln_bwd_param_kernel(SdmiLayerNormBwdArgs p) {
-  __shared__ float red[4][64][2];
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63), kg = threadIdx.x >> 6;
+  __shared__ float red[16][16][2];
+  const int cl = threadIdx.x & 15, kg = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
   float sg = 0.f, sb = 0.f;
-  if (c < p.C)
-    for (int k = kg; k < p.nblk; k += 4) {
-      const float* q = p.partial + ((long long)k * p.C + c) * 2;
-      sg += q[0];
-      sb += q[1];
+  if (c < p.C) {
+    const float2* q = reinterpret_cast<const float2*>(p.partial) + c;
+    int k = kg;
+    for (; k + 48 < p.nblk; k += 64) {
+      const float2 v0 = q[(long long)k * p.C], v1 = q[(long long)(k + 16) * p.C];
+      const float2 v2 = q[(long long)(k + 32) * p.C], v3 = q[(long long)(k + 48) * p.C];
+      sg += (v0.x + v1.x) + (v2.x + v3.x);
+      sb += (v0.y + v1.y) + (v2.y + v3.y);
     }
-  red[kg][threadIdx.x & 63][0] = sg;
-  red[kg][threadIdx.x & 63][1] = sb;
+    for (; k < p.nblk; k += 16) {
+      const float2 v = q[(long long)k * p.C];
+      sg += v.x;
+      sb += v.y;
+    }
+  }
+  red[kg][cl][0] = sg;
+  red[kg][cl][1] = sb;
   __syncthreads();
   if (kg == 0 && c < p.C) {
-    const int l = threadIdx.x;
-    const float g = (red[0][l][0] + red[1][l][0]) + (red[2][l][0] + red[3][l][0]);
-    const float b = (red[0][l][1] + red[1][l][1]) + (red[2][l][1] + red[3][l][1]);
+    float g = 0.f, b = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { g += red[k][cl][0]; b += red[k][cl][1]; }
     p.dgamma[c] = (p.accumulate ? p.dgamma[c] : 0.f) + g;
     p.dbeta[c] = (p.accumulate ? p.dbeta[c] : 0.f) + b;
   }
@@ -282,8 +334,11 @@ extern "C" int sdmi_groupnorm_bwd(const SdmiGroupNormBwdArgs* a, void* stream) {
     hipLaunchKernelGGL(gn_bwd_stats_kernel<bf16_t>, g1, dim3(256), 0, st, *a);
   else
     hipLaunchKernelGGL(gn_bwd_stats_kernel<float>, g1, dim3(256), 0, st, *a);
-  hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(a->B), dim3(256), 0, st, *a, gsum);
-  hipLaunchKernelGGL(gn_bwd_param_kernel, dim3((a->C + 63) / 64), dim3(256), 0, st, *a);
+  const int cpg = a->C / a->groups;
+  SDMI_REQUIRE(cpg <= 64, "at most 64 channels per group");
+  const int CB = cpg * (64 / cpg);
+  hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3((a->C + CB - 1) / CB), dim3(256), 0, st, *a, gsum,
+                     CB);
   if (a->dtype == SDMI_BF16)
     hipLaunchKernelGGL(gn_bwd_apply_kernel<bf16_t>, g3, dim3(256), 0, st, *a, gsum, rows_per);
   else
@@ -297,10 +352,20 @@ extern "C" int sdmi_layernorm_bwd(const SdmiLayerNormBwdArgs* a, void* stream) {
   SDMI_REQUIRE(a->C > 0 && a->C <= 1024 && a->nblk >= 1, "C <= 1024");
   hipStream_t st = (hipStream_t)stream;
   const int rows_per_blk = (a->rows + a->nblk - 1) / a->nblk;
-  if (a->dtype == SDMI_BF16)
-    hipLaunchKernelGGL(ln_bwd_kernel<bf16_t>, dim3(a->nblk), dim3(256), 0, st, *a, rows_per_blk);
-  else
-    hipLaunchKernelGGL(ln_bwd_kernel<float>, dim3(a->nblk), dim3(256), 0, st, *a, rows_per_blk);
-  hipLaunchKernelGGL(ln_bwd_param_kernel, dim3((a->C + 63) / 64), dim3(256), 0, st, *a);
+  const int vec = a->dtype == SDMI_BF16 ? 8 : 4;
+  SDMI_REQUIRE(a->C % vec == 0, "C must be a multiple of the 16-byte vector width");
+  const int cv = a->C / vec;
+  int lpr = 1;
+  while (lpr < cv && lpr < 64) lpr <<= 1;
+  const int vpl = (cv + 63) / 64;
+#define LN_GO(T, V) \
+  hipLaunchKernelGGL((ln_bwd_kernel<T, V>), dim3(a->nblk), dim3(256), 0, st, *a, rows_per_blk, lpr)
+  if (a->dtype == SDMI_BF16) {
+    if (vpl <= 1) LN_GO(bf16_t, 1); else LN_GO(bf16_t, 2);
+  } else {
+    if (vpl <= 1) LN_GO(float, 1); else if (vpl == 2) LN_GO(float, 2); else LN_GO(float, 4);
+  }
+#undef LN_GO
+  hipLaunchKernelGGL(ln_bwd_param_kernel, dim3((a->C + 15) / 16), dim3(256), 0, st, *a);
   return sdmi_check_launch("layernorm_bwd");
 }

@@ -590,19 +590,34 @@ __global__ __launch_bounds__(512) void wgrad_tr_kernel(SdmiWgradArgs p, int tile
   }
 }
 
+// Fold the split partials in split order (deterministic).  One thread per 16-byte output vector
+// (N*K is a multiple of 4), 8 partial loads in flight per thread before the ordered adds.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(SdmiWgradArgs p) {
   const long long total = (long long)p.N * p.K;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total;
+  const long long total4 = total >> 2;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total4;
        i += (long long)gridDim.x * 256) {
-    float s = p.accumulate ? p.dw[i] : 0.f;
-    for (int k = 0; k < p.splits; ++k) s += p.workspace[(long long)k * total + i];
-    p.dw[i] = s;
+    const f32x4* src = reinterpret_cast<const f32x4*>(p.workspace) + i;
+    f32x4* dst = reinterpret_cast<f32x4*>(p.dw) + i;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (p.accumulate) s = *dst;
+    int k = 0;
+    for (; k + 8 <= p.splits; k += 8) {
+      f32x4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = src[(long long)(k + u) * total4];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; k < p.splits; ++k) s += src[(long long)k * total4];
+    *dst = s;
   }
   if (p.dbias)
     for (long long n = (long long)blockIdx.x * 256 + threadIdx.x; n < p.N;
          n += (long long)gridDim.x * 256) {
       float s = p.accumulate ? p.dbias[n] : 0.f;
-      for (int k = 0; k < p.splits; ++k) s += p.workspace[(long long)p.splits * total + (long long)k * p.N + n];
+      for (int k = 0; k < p.splits; ++k)
+        s += p.workspace[(long long)p.splits * total + (long long)k * p.N + n];
       p.dbias[n] = s;
     }
 }
@@ -692,8 +707,8 @@ extern "C" int sdmi_wgrad(const SdmiWgradArgs* a, void* stream) {
   int rc;
   rc = a->dtype == SDMI_BF16 ? dispatch_wgrad_bf16(*a, st) : dispatch_wgrad_f32(*a, st);
   if (rc || a->splits == 1) return rc;
-  const long long total = (long long)a->N * a->K;
-  int blocks = (int)((total + 255) / 256);
+  const long long total = (long long)a->N * a->K;     // K % 4 == 0 (Cin % vec == 0)
+  int blocks = (int)((total / 4 + 255) / 256);
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, *a);
   return sdmi_check_launch("wgrad reduce");

@@ -60,6 +60,8 @@ class WeightBank:
         self._side = None
         self._pending = []
         self._join_queued = False
+        # dgrad operands: key -> [buffer, epoch, (stable source view | None, geometry)]
+        self._wd, self._wd_epoch, self._wd_stale, self._wd_table = {}, 0, False, None
 
     def side_stream(self):
         if not self.overlap_wgrad:
@@ -82,6 +84,7 @@ class WeightBank:
 
     def invalidate(self):
         self.cache.clear()
+        self._wd_stale = True
 
     def f(self, name):
         return self.t[name]
@@ -172,20 +175,64 @@ class WeightBank:
         return out
 
     def wd(self, names, dtype, kh, kw, cin_x):
-        """dgrad operand of the (fused) forward operand: [Cin][kh'][kw'][CoutPad], taps flipped."""
+        """dgrad operand of the (fused) forward operand: [Cin][kh'][kw'][CoutPad], taps flipped.
+
+        The operands live in persistent buffers; after an optimiser step (invalidate()) the first
+        request re-packs ALL of them with one sdmi_pack_dgrad_batch launch (descriptor table on
+        the device) instead of one small launch per layer.  Operands whose forward operand is a
+        materialised copy (no fixed arena address) are packed individually."""
         key = ('dgrad', names if not isinstance(names, str) else (names,), dtype)
-        if key in self.cache:
-            return self.cache[key]
+        if self._wd_stale:
+            self._repack_all()
+        ent = self._wd.get(key)
+        if ent is not None and ent[1] == self._wd_epoch:
+            return ent[0]
         w = self.w(names, dtype)
         n = w.shape[0]
         vec = ops.vec_of(dtype)
         npad = (n + vec - 1) // vec * vec
-        dst = (torch.zeros if npad != n else torch.empty)((cin_x * kh * kw, npad), dtype=dtype,
-                                                          device=w.device)
+        dst = ent[0] if ent is not None else \
+            (torch.zeros if npad != n else torch.empty)((cin_x * kh * kw, npad), dtype=dtype,
+                                                        device=w.device)
         call('sdmi_pack_dgrad', _st(), src=_p(w), dst=_p(dst), dtype=_DT[dtype], Cout=n, KH=kh,
              KW=kw, Cin=cin_x, CoutPad=npad)
-        self.cache[key] = dst
+        stable = self._in_arena(w)
+        self._wd[key] = [dst, self._wd_epoch, (w if stable else None, n, kh, kw, cin_x, npad)]
+        if stable:
+            self._wd_table = None          # new member: rebuild the descriptor table
         return dst
+
+    def _in_arena(self, t):
+        m = self.model
+        for a in (m.arena(), m.shadow_arena() if m.compute_dtype != torch.float32 else None):
+            if a is not None and a.data_ptr() <= t.data_ptr() < a.data_ptr() + a.numel() * a.element_size():
+                return True
+        return False
+
+    def _repack_all(self):
+        self._wd_stale = False
+        self._wd_epoch += 1
+        for dtype in {k[2] for k, e in self._wd.items() if e[2][0] is not None}:
+            items = [e for k, e in self._wd.items() if k[2] == dtype and e[2][0] is not None]
+            tab = self._wd_table.get(dtype) if self._wd_table else None
+            if tab is None:
+                Desc = _lib.CSTRUCT['SdmiPackDesc']
+                arr = (Desc * len(items))()
+                blk = 0
+                for d, e in zip(arr, items):
+                    w, n, kh, kw, cin, npad = e[2]
+                    d.src, d.dst = w.data_ptr(), e[0].data_ptr()
+                    d.Cout, d.KH, d.KW, d.Cin, d.CoutPad, d.block_begin = n, kh, kw, cin, npad, blk
+                    blk += (n * kh * kw * cin + 2047) // 2048
+                dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(
+                    items[0][0].device)
+                tab = (dev, len(items), blk)
+                self._wd_table = self._wd_table or {}
+                self._wd_table[dtype] = tab
+            call('sdmi_pack_dgrad_batch', _st(), descs=_p(tab[0]), n_desc=tab[1], dtype=_DT[dtype],
+                 total_blocks=tab[2])
+            for e in items:
+                e[1] = self._wd_epoch
 
 
 class Kern:

@@ -262,3 +262,78 @@ def test_wgrad_and_dgrad_kernels(case, dtype):
     e = float((dx.float().cpu() - ref_dx).norm() / ref_dx.norm())
     assert e <= tol, f'dgrad rel err {e}'
 
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('rows,C', [(100, 192), (1000, 256), (333, 384), (64, 512), (50, 1024),
+                                    (7, 64)])
+def test_layernorm_bwd_kernel(rows, C, dtype):
+    from slotdiffusion_amd import _lib, ops
+    from slotdiffusion_amd.kern import _DT
+    g = torch.Generator().manual_seed(rows + C)
+    q = lambda t: t.to(dtype).float()
+    x = q(torch.randn(rows, C, generator=g) * 2 + 0.5).requires_grad_(True)
+    gam = (1 + 0.3 * torch.randn(C, generator=g)).requires_grad_(True)
+    bet = (0.1 * torch.randn(C, generator=g)).requires_grad_(True)
+    dy = q(torch.randn(rows, C, generator=g))
+    F.layer_norm(x, (C,), gam, bet, 1e-5).backward(dy)
+    xd, dyd = x.detach().to(dtype).cuda(), dy.to(dtype).cuda()
+    stats = torch.empty(rows, 2, device='cuda')
+    ops.layer_norm(xd, gam.detach().cuda(), bet.detach().cuda(), stats=stats)
+    nblk = max(1, min(512, rows // 16))
+    partial = torch.empty(nblk * C * 2, device='cuda')
+    dx = torch.empty_like(xd)
+    dgam, dbet = torch.full((C,), 0.5, device='cuda'), torch.full((C,), -0.5, device='cuda')
+    _lib.call('sdmi_layernorm_bwd', torch.cuda.current_stream().cuda_stream, x=xd.data_ptr(),
+              dy=dyd.data_ptr(), dx=dx.data_ptr(), gamma=gam.detach().cuda().data_ptr(),
+              stats=stats.data_ptr(), dgamma=dgam.data_ptr(), dbeta=dbet.data_ptr(),
+              partial=partial.data_ptr(), dtype=_DT[dtype], rows=rows, C=C, nblk=nblk,
+              accumulate=1)
+    tol = 2e-5 if dtype == torch.float32 else 1.5e-2
+    rel = lambda a, b: float((a.float().cpu() - b).norm() / b.norm())
+    assert rel(dx, x.grad) <= tol
+    assert rel(dgam - 0.5, gam.grad) <= tol
+    assert rel(dbet + 0.5, bet.grad) <= tol
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('B,HW,C,act,res', [(2, 256, 64, 'silu', False), (3, 64, 384, 'silu', False),
+                                            (2, 1024, 128, 'relu', True), (2, 16, 1024, None, False),
+                                            (5, 100, 96, 'silu', True)])
+def test_groupnorm_bwd_kernel(B, HW, C, act, res, dtype):
+    from slotdiffusion_amd import _lib, ops
+    from slotdiffusion_amd.kern import _DT
+    g = torch.Generator().manual_seed(B * HW + C)
+    q = lambda t: t.to(dtype).float()
+    x = q(torch.randn(B, HW, C, generator=g) * 1.5 + 0.3).requires_grad_(True)
+    r = q(torch.randn(B, HW, C, generator=g)).requires_grad_(True) if res else None
+    gam = (1 + 0.3 * torch.randn(C, generator=g)).requires_grad_(True)
+    bet = (0.1 * torch.randn(C, generator=g)).requires_grad_(True)
+    dy = q(torch.randn(B, HW, C, generator=g))
+    z = F.group_norm(x.permute(0, 2, 1), 32, gam, bet, 1e-5).permute(0, 2, 1)
+    if res:
+        z = z + r
+    y = {'silu': F.silu, 'relu': F.relu, None: (lambda t: t)}[act](z)
+    y.backward(dy)
+    xd, dyd = x.detach().to(dtype).cuda(), dy.to(dtype).cuda()
+    rd = r.detach().to(dtype).cuda() if res else None
+    gd, bd = gam.detach().cuda(), bet.detach().cuda()
+    _, stats = ops.group_norm(xd, gd, bd, eps=1e-5, act=act, residual=rd, return_stats=True)
+    nsplit = max(1, min(16, HW // 64))
+    partial = torch.empty(B * nsplit * C * 2 + B * 32 * 2, device='cuda')
+    dx = torch.empty_like(xd)
+    dres = torch.empty_like(xd) if res else None
+    dgam, dbet = torch.full((C,), 0.25, device='cuda'), torch.full((C,), -0.25, device='cuda')
+    _lib.call('sdmi_groupnorm_bwd', torch.cuda.current_stream().cuda_stream, x=xd.data_ptr(),
+              dy=dyd.data_ptr(), dx=dx.data_ptr(), gamma=gd.data_ptr(), beta=bd.data_ptr(),
+              stats=stats.data_ptr(), dgamma=dgam.data_ptr(), dbeta=dbet.data_ptr(),
+              partial=partial.data_ptr(), dtype=_DT[dtype], B=B, HW=HW, C=C, groups=32,
+              act=_lib.ACT[act], nsplit=nsplit, residual=(rd.data_ptr() if res else 0),
+              dresidual=(dres.data_ptr() if res else 0), accumulate=1)
+    tol = 3e-5 if dtype == torch.float32 else 2e-2
+    rel = lambda a, b: float((a.float().cpu() - b).norm() / b.norm())
+    assert rel(dx, x.grad) <= tol
+    assert rel(dgam - 0.25, gam.grad) <= tol
+    assert rel(dbet + 0.25, bet.grad) <= tol
+    if res:
+        assert rel(dres, r.grad) <= tol
