@@ -1,7 +1,10 @@
-// Multi-head attention with head_dim 32 (UNet self-attention over 16..256 tokens, slot
-// cross-attention over 7..15 keys).  K and V of one (image, head) are staged once in LDS as fp32
-// (Skv*32*4 B each); every lane owns one query (q and the output row live in registers) and walks
-// the keys with an online softmax, reading K/V rows as LDS broadcasts.  fp32 math throughout.
+// Multi-head attention (UNet self-attention over 16..256 tokens, slot cross-attention over 7..15
+// keys; head_dim 32, or 48 in the SAVi predictor).
+//
+// bf16, head_dim 32: matrix-core kernel `attn_fwd_mfma_kernel` (below).
+// fp32 (parity mode) and head_dim 48: `attn_fwd_kernel` -- K and V of one (image, head) staged
+// once in LDS as fp32; every lane owns one query (q and the output row live in registers) and
+// walks the keys with an online softmax, reading K/V rows as LDS broadcasts.
 #include "common.h"
 
 namespace {
@@ -102,6 +105,128 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(SdmiAttnArgs p) {
   if (p.lse) p.lse[((long long)b * p.heads + h) * p.Sq + qi] = m + __logf(l);
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Matrix-core forward (bf16, head_dim 32).  One wave owns 32 queries; everything is computed
+// TRANSPOSED so that a lane's accumulator registers all belong to one query:
+//     S^T[k][q] = K_blk Q^T      : v_mfma 32x32x16 x2, A = K rows (16-byte LDS reads), B = Q rows
+//     softmax statistics of query q = lane & 31: register reductions + one exchange with lane ^ 32
+//     O^T[d][q] += V^T_blk P^T   : B operand = the P^T accumulator registers converted to bf16 IN
+//                                  PLACE (MFMA k-slot s of lane half h  <->  key 8*(s>>2&1 ...)
+//                                  see `key of slot` below), A = V^T through ds_read_b64_tr_b16
+// so no value ever moves between lanes except the two half-wave exchanges.
+// C/D layout of the 32x32 MFMA: column = lane & 31, row(r) = (r&3) + 8*(r>>2) + 4*(lane>>5).
+// key of slot: MFMA m (keys 16m..16m+15 of the block) uses C registers r = 8m .. 8m+7 of both
+// lane halves; slot (h*8 + jj*4 + i)  <->  key 16m + 8jj + 4h + i  -- the same map is used to
+// gather the V^T operand (two transposing reads of 4 keys each).
+// ------------------------------------------------------------------------------------------
+typedef short a_s16x4 __attribute__((ext_vector_type(4)));
+typedef short a_s16x8 __attribute__((ext_vector_type(8)));
+#define ATT_LDS_V4(p) ((__attribute__((address_space(3))) a_s16x4*)(p))
+constexpr int ATT_KP = 80;   // K row pitch in LDS: 64 B + 16 (conflict-free ds_read_b128)
+constexpr int ATT_VP = 64;   // V row pitch: = 64 (mod 256), what the transposing read wants
+
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+  return (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
+}
+
+__global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(SdmiAttnArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int nkb = (p.Skv + 31) / 32, skv_pad = nkb * 32;
+  char* Ks = smem;
+  char* Vs = smem + skv_pad * ATT_KP;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  {  // stage K, V of this (image, head): 4 16-byte pieces per row each; pad rows zeroed
+    const bf16_t* kb = (const bf16_t*)p.k + (long long)b * p.Skv * p.ldk + h * 32;
+    const bf16_t* vb = (const bf16_t*)p.v + (long long)b * p.Skv * p.ldv + h * 32;
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+    for (int i = tid; i < skv_pad * 4; i += 256) {
+      const int row = i >> 2, c = i & 3;
+      const bool ok = row < p.Skv;
+      const u32x4 kv = ok ? *reinterpret_cast<const u32x4*>(kb + (long long)row * p.ldk + c * 8) : zero4;
+      const u32x4 vv = ok ? *reinterpret_cast<const u32x4*>(vb + (long long)row * p.ldv + c * 8) : zero4;
+      *reinterpret_cast<u32x4*>(Ks + row * ATT_KP + c * 16) = kv;
+      *reinterpret_cast<u32x4*>(Vs + row * ATT_VP + c * 16) = vv;
+    }
+  }
+  __syncthreads();
+  const int q0 = (blockIdx.x * 4 + wave) * 32;
+  if (q0 >= p.Sq) return;
+  const int ql = lane & 31, hh = lane >> 5;
+  const int qi = q0 + ql;
+  const int qc = qi < p.Sq ? qi : p.Sq - 1;
+  // B operand of S^T: this lane's query row, d = ks*16 + hh*8 .. +8
+  bf16x8 bq[2];
+  {
+    const bf16_t* qp = (const bf16_t*)p.q + ((long long)b * p.Sq + qc) * p.ldq + h * 32 + hh * 8;
+    bq[0] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(qp));
+    bq[1] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(qp + 16));
+  }
+  f32x16 o;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) o[r] = 0.f;
+  float m = -INFINITY, lsum = 0.f;
+  const int g = lane >> 4, t = lane & 15;
+  const char* kfrag = Ks + ql * ATT_KP + hh * 16;
+  // transposing read: lane addresses piece (row t>>2, 4 columns at (t&3)*4) of its group's block
+  const char* vfrag = Vs + (4 * hh + (t >> 2)) * ATT_VP + ((g & 1) * 16 + (t & 3) * 4) * 2;
+  for (int kb = 0; kb < nkb; ++kb) {
+    f32x16 s;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const u32x4 a = *reinterpret_cast<const u32x4*>(kfrag + kb * 32 * ATT_KP + ks * 32);
+      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), bq[ks], s, 0, 0, 0);
+    }
+    float bmax = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+      s[r] = key < p.Skv ? s[r] * p.scale : -INFINITY;
+      bmax = fmaxf(bmax, s[r]);
+    }
+    bmax = fmaxf(bmax, __shfl_xor(bmax, 32, 64));
+    const float m_new = fmaxf(m, bmax);
+    const float alpha = __expf(m - m_new);
+    float psum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      s[r] = __expf(s[r] - m_new);
+      psum += s[r];
+    }
+    psum += __shfl_xor(psum, 32, 64);
+    lsum = lsum * alpha + psum;
+    m = m_new;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] *= alpha;
+#pragma unroll
+    for (int mm = 0; mm < 2; ++mm) {
+      const u32x4 pb = {pack_bf16x2(s[8 * mm + 0], s[8 * mm + 1]), pack_bf16x2(s[8 * mm + 2], s[8 * mm + 3]),
+                        pack_bf16x2(s[8 * mm + 4], s[8 * mm + 5]), pack_bf16x2(s[8 * mm + 6], s[8 * mm + 7])};
+      const char* vp = vfrag + (kb * 32 + 16 * mm) * ATT_VP;
+      const a_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(ATT_LDS_V4(vp));
+      const a_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(ATT_LDS_V4(vp + 8 * ATT_VP));
+      const a_s16x8 av = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+      o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av),
+                                                  __builtin_bit_cast(bf16x8, pb), o, 0, 0, 0);
+    }
+  }
+  if (qi < p.Sq) {
+    const float inv = 1.f / lsum;
+    bf16_t* op = (bf16_t*)p.out + ((long long)b * p.Sq + qi) * p.ldo + h * 32 + 4 * hh;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {    // d = 8j + 4hh + (0..3)
+      uint2 w;
+      w.x = pack_bf16x2(o[4 * j] * inv, o[4 * j + 1] * inv);
+      w.y = pack_bf16x2(o[4 * j + 2] * inv, o[4 * j + 3] * inv);
+      *reinterpret_cast<uint2*>(op + 8 * j) = w;
+    }
+    if (p.lse && hh == 0) p.lse[((long long)b * p.heads + h) * p.Sq + qi] = m + __logf(lsum);
+  }
+}
+
 }  // namespace
 
 extern "C" int sdmi_attention(const SdmiAttnArgs* a, void* stream) {
@@ -116,6 +241,12 @@ extern "C" int sdmi_attention(const SdmiAttnArgs* a, void* stream) {
   dim3 grid((a->Sq + threads - 1) / threads, a->heads, a->B);
   const int hd = a->head_dim > 0 ? a->head_dim : 32;
   SDMI_REQUIRE(hd == 32 || hd == 48, "head_dim must be 32 (UNet) or 48 (SAVi predictor)");
+  if (a->dtype == SDMI_BF16 && hd == 32) {
+    const int skv_pad = (a->Skv + 31) / 32 * 32;
+    dim3 g2((a->Sq + 127) / 128, a->heads, a->B);
+    hipLaunchKernelGGL(attn_fwd_mfma_kernel, g2, dim3(256), skv_pad * (ATT_KP + ATT_VP), st, *a);
+    return sdmi_check_launch("attention (mfma)");
+  }
   const int smem = 2 * a->Skv * hd * 4;
 #define ATTN_GO(T, HDV)                                                                      \
   do {                                                                                       \
