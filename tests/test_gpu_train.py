@@ -337,3 +337,40 @@ def test_groupnorm_bwd_kernel(B, HW, C, act, res, dtype):
     assert rel(dbet + 0.25, bet.grad) <= tol
     if res:
         assert rel(dres, r.grad) <= tol
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('cfg', [(2, 8, 256, 256), (2, 12, 64, 64), (3, 16, 16, 16), (2, 8, 256, 7),
+                                 (2, 4, 50, 15), (1, 2, 130, 100)])
+def test_attention_bwd_kernel(cfg, dtype):
+    """dq/dk/dv of the attention backward (matrix-core kernels for bf16, VALU kernels for fp32)
+    against torch autograd; inputs are quantised to the compute dtype first."""
+    from slotdiffusion_amd import _lib, ops
+    from slotdiffusion_amd.kern import _DT
+    B, heads, Sq, Skv = cfg
+    C = heads * 32
+    g = torch.Generator().manual_seed(Sq * 3 + Skv)
+    qz = lambda t: t.to(dtype).float()
+    qq = qz(torch.randn(B, Sq, C, generator=g)).requires_grad_(True)
+    kk = qz(torch.randn(B, Skv, C, generator=g)).requires_grad_(True)
+    vv = qz(torch.randn(B, Skv, C, generator=g)).requires_grad_(True)
+    dout = qz(torch.randn(B, Sq, C, generator=g))
+    sp = lambda t, S: t.view(B, S, heads, 32).permute(0, 2, 1, 3)
+    sim = torch.einsum('bhid,bhjd->bhij', sp(qq, Sq), sp(kk, Skv)) * 32 ** -0.5
+    ref = torch.einsum('bhij,bhjd->bhid', sim.softmax(-1), sp(vv, Skv))
+    ref.permute(0, 2, 1, 3).reshape(B, Sq, C).backward(dout)
+    qd, kd, vd = (t.detach().to(dtype).cuda() for t in (qq, kk, vv))
+    lse = torch.empty(B, heads, Sq, device='cuda')
+    out = ops.attention(qd, kd, vd, heads, lse=lse)
+    dq, dk, dv = torch.empty_like(qd), torch.empty_like(kd), torch.empty_like(vd)
+    dod = dout.to(dtype).cuda()
+    _lib.call('sdmi_attention_bwd', torch.cuda.current_stream().cuda_stream, q=qd.data_ptr(),
+              k=kd.data_ptr(), v=vd.data_ptr(), out=out.data_ptr(), dout=dod.data_ptr(),
+              lse=lse.data_ptr(), dq=dq.data_ptr(), dk=dk.data_ptr(), dv=dv.data_ptr(),
+              dtype=_DT[dtype], B=B, heads=heads, Sq=Sq, Skv=Skv, ldq=C, ldk=C, ldv=C, ldo=C,
+              scale=32 ** -0.5, head_dim=32)
+    tol = 3e-5 if dtype == torch.float32 else 2.5e-2
+    rel = lambda a, b: float((a.float().cpu() - b).norm() / b.norm())
+    assert rel(dq, qq.grad) <= tol, ('dq', rel(dq, qq.grad))
+    assert rel(dk, kk.grad) <= tol, ('dk', rel(dk, kk.grad))
+    assert rel(dv, vv.grad) <= tol, ('dv', rel(dv, vv.grad))
