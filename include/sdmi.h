@@ -318,12 +318,15 @@ int sdmi_act_bwd(const SdmiActBwdArgs* a, void* stream);
 typedef struct {
   const void* k; const void* v; const float* q; float* attn; float* upd; float* den;
   int dtype; int B, M, N, D, ldkv; float eps, scale;
+  float* workspace;   /* optional, B*ceil(M/64)*N*(D+1) floats: enables the token-tiled kernels
+                         (one workgroup per 64/128 tokens + a finalize pass) for N <= 8 */
 } SdmiSaAttendArgs;
 int sdmi_sa_attend_fwd(const SdmiSaAttendArgs* a, void* stream);
 typedef struct {
   const void* k; const void* v; const float* q; const float* attn; const float* upd;
   const float* den; const float* dupd; float* dq; void* dk; void* dv;
   int dtype; int B, M, N, D, ldkv; float eps, scale;
+  float* workspace;   /* optional, B*ceil(M/64)*N*D floats (see SdmiSaAttendArgs) */
 } SdmiSaAttendBwdArgs;
 int sdmi_sa_attend_bwd(const SdmiSaAttendBwdArgs* a, void* stream);
 /* GRUCell gate arithmetic on gi = W_ih x + b_ih, gh = W_hh h + b_hh ([R][3D], gates r,z,n). */

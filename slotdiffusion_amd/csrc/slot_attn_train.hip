@@ -8,7 +8,14 @@
 // backward, given dupd:      c_n = dupd_n . upd_n
 //     g[m][n] = dupd_n . v_m;  dw = (g - c_n) / den_n;  dL = a * (dw - sum_n' a dw)
 //     dv_m = sum_n (w[m][n]/den_n) dupd_n;  dk_m = sum_n dL[m][n] q_n;  dq_n = sum_m dL[m][n] k_m
-// One workgroup per image; wave w owns tokens w, w+8, ...; 64 lanes split the D channels.
+// Two implementations:
+//  * token-tiled (workspace given, N <= 8): one workgroup per tile of 128 (bf16) / 64 (fp32)
+//    tokens, K and V tiles staged in LDS; phase A = per-token slot terms (a few threads per token),
+//    phase B = the per-channel contractions over the tile's tokens; per-tile partials of the
+//    token sums (upd, den, dq) are folded by a small finalize kernel.  B*M/128 workgroups fill
+//    the chip; the first version below used B workgroups and one wave reduction per (token, slot).
+//  * one workgroup per image; wave w owns tokens w, w+8, ...; 64 lanes split the D channels
+//    (N up to 16, any D <= 256).
 #include "common.h"
 
 namespace {
@@ -202,6 +209,326 @@ __global__ __launch_bounds__(SA_THREADS) void sa_attend_bwd_kernel(SdmiSaAttendB
   for (int i = tid; i < N * D; i += SA_THREADS) p.dq[(long long)b * N * D + i] = s_dq[i] * p.scale;
 }
 
+
+// ==========================================================================================
+// token-tiled kernels
+// ==========================================================================================
+constexpr int SAT_NP = 8;   // slots padded to 8
+
+template <typename T> struct SatCfg;
+template <> struct SatCfg<bf16_t> { static constexpr int TM = 128; };
+template <> struct SatCfg<float> { static constexpr int TM = 64; };
+
+template <typename T>
+__device__ __forceinline__ void sat_stage(const T* kb, const T* vb, int ldkv, int m0, int mvalid,
+                                          int D, char* Kt, char* Vt, int PK) {
+  constexpr int VEC = Elem<T>::VEC;
+  constexpr int TM = SatCfg<T>::TM;
+  const int cpr = D / VEC;                       // 16-byte pieces per row
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+  for (int i = threadIdx.x; i < TM * cpr; i += 256) {
+    const int row = i / cpr, c = i - row * cpr;
+    const bool ok = row < mvalid;
+    const long long go = (long long)(m0 + row) * ldkv + c * VEC;
+    const u32x4 kv = ok ? *reinterpret_cast<const u32x4*>(kb + go) : zero4;
+    const u32x4 vv = ok ? *reinterpret_cast<const u32x4*>(vb + go) : zero4;
+    *reinterpret_cast<u32x4*>(Kt + row * PK + c * 16) = kv;
+    *reinterpret_cast<u32x4*>(Vt + row * PK + c * 16) = vv;
+  }
+}
+
+// partial dots of one token row (LDS, this thread's channel range) with N fp32 vectors in LDS
+template <typename T>
+__device__ __forceinline__ void sat_dots(const char* row, const float* vecs, int D, int c0, int cn,
+                                         int N, float (&out)[SAT_NP]) {
+  constexpr int VEC = Elem<T>::VEC;
+#pragma unroll
+  for (int n = 0; n < SAT_NP; ++n) out[n] = 0.f;
+  for (int c = c0; c < c0 + cn; c += VEC) {
+    float x[VEC];
+    unpack16<T>(*reinterpret_cast<const uint4*>(row + c * sizeof(T)), x);
+#pragma unroll
+    for (int n = 0; n < SAT_NP; ++n) {
+      if (n < N) {
+        const float* qv = vecs + n * D + c;
+#pragma unroll
+        for (int j = 0; j < VEC; j += 4) {
+          const f32x4 q4 = *reinterpret_cast<const f32x4*>(qv + j);
+          out[n] += x[j] * q4[0] + x[j + 1] * q4[1] + x[j + 2] * q4[2] + x[j + 3] * q4[3];
+        }
+      }
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void sat_fwd_kernel(SdmiSaAttendArgs p, int tiles) {
+  constexpr int TM = SatCfg<T>::TM;
+  constexpr int TPT = 256 / TM;                  // threads per token in phase A
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int N = p.N, D = p.D;
+  const int PK = D * (int)sizeof(T) + 16;
+  char* Kt = smem;
+  char* Vt = Kt + TM * PK;
+  float* q_s = reinterpret_cast<float*>(Vt + TM * PK);     // [N][D], pre-scaled
+  float* w_s = q_s + SAT_NP * D;                           // [TM][8]
+  const int b = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
+  const int m0 = tile * TM;
+  const int mvalid = min(TM, p.M - m0);
+  const T* kb = (const T*)p.k + (long long)b * p.M * p.ldkv;
+  const T* vb = (const T*)p.v + (long long)b * p.M * p.ldkv;
+  sat_stage<T>(kb, vb, p.ldkv, m0, mvalid, D, Kt, Vt, PK);
+  for (int i = tid; i < N * D; i += 256) q_s[i] = p.q[(long long)b * N * D + i] * p.scale;
+  __syncthreads();
+  {  // phase A: logits, softmax over slots, w = a + eps
+    const int tok = tid / TPT, sub = tid % TPT;
+    const int cn = D / TPT;
+    float lg[SAT_NP];
+    sat_dots<T>(Kt + tok * PK, q_s, D, sub * cn, cn, N, lg);
+#pragma unroll
+    for (int n = 0; n < SAT_NP; ++n)
+      for (int off = 1; off < TPT; off <<= 1) lg[n] += __shfl_xor(lg[n], off, 64);
+    float mx = -INFINITY;
+#pragma unroll
+    for (int n = 0; n < SAT_NP; ++n)
+      if (n < N) mx = fmaxf(mx, lg[n]);
+    float se = 0.f;
+#pragma unroll
+    for (int n = 0; n < SAT_NP; ++n) {
+      lg[n] = n < N ? __expf(lg[n] - mx) : 0.f;
+      se += lg[n];
+    }
+    const float inv = 1.f / se;
+    if (sub == 0) {
+      const bool ok = tok < mvalid;
+      float* ap = p.attn + ((long long)b * p.M + m0 + tok) * N;
+#pragma unroll
+      for (int n = 0; n < SAT_NP; ++n) {
+        const float a = lg[n] * inv;
+        if (ok && n < N) ap[n] = a;
+        w_s[tok * SAT_NP + n] = (ok && n < N) ? a + p.eps : 0.f;
+      }
+    }
+  }
+  __syncthreads();
+  // phase B: thread d owns channel d: upd_partial[n][d] = sum_m w[m][n] v[m][d]; threads D..D+N-1: den
+  float* wsu = p.workspace + ((long long)b * tiles + tile) * N * (D + 1);
+  if (tid < D) {
+    float acc[SAT_NP];
+#pragma unroll
+    for (int n = 0; n < SAT_NP; ++n) acc[n] = 0.f;
+    const char* vcol = Vt + tid * sizeof(T);
+    for (int m = 0; m < mvalid; ++m) {
+      const float v = Elem<T>::ld(reinterpret_cast<const T*>(vcol + m * PK));
+      const f32x4 w0 = *reinterpret_cast<const f32x4*>(w_s + m * SAT_NP);
+      const f32x4 w1 = *reinterpret_cast<const f32x4*>(w_s + m * SAT_NP + 4);
+      acc[0] += w0[0] * v; acc[1] += w0[1] * v; acc[2] += w0[2] * v; acc[3] += w0[3] * v;
+      acc[4] += w1[0] * v; acc[5] += w1[1] * v; acc[6] += w1[2] * v; acc[7] += w1[3] * v;
+    }
+#pragma unroll
+    for (int n = 0; n < SAT_NP; ++n)
+      if (n < N) wsu[n * D + tid] = acc[n];
+  } else if (tid < D + N) {
+    const int n = tid - D;
+    float s = 0.f;
+    for (int m = 0; m < mvalid; ++m) s += w_s[m * SAT_NP + n];
+    wsu[N * D + n] = s;
+  }
+}
+
+__global__ __launch_bounds__(256) void sat_fwd_finalize_kernel(SdmiSaAttendArgs p, int tiles) {
+  __shared__ float den_s[SAT_NP];
+  const int b = blockIdx.x, N = p.N, D = p.D;
+  const float* ws = p.workspace + (long long)b * tiles * N * (D + 1);
+  if (threadIdx.x < N) {
+    float s = 0.f;
+    for (int t = 0; t < tiles; ++t) s += ws[(long long)t * N * (D + 1) + N * D + threadIdx.x];
+    den_s[threadIdx.x] = s;
+    p.den[b * N + threadIdx.x] = s;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < N * D; i += 256) {
+    float s = 0.f;
+    for (int t = 0; t < tiles; ++t) s += ws[(long long)t * N * (D + 1) + i];
+    p.upd[(long long)b * N * D + i] = s / den_s[i / D];
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void sat_bwd_kernel(SdmiSaAttendBwdArgs p, int tiles) {
+  constexpr int VEC = Elem<T>::VEC;
+  constexpr int TM = SatCfg<T>::TM;
+  constexpr int TPT = 256 / TM;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int N = p.N, D = p.D;
+  const int PK = D * (int)sizeof(T) + 16;
+  char* Kt = smem;
+  char* Vt = Kt + TM * PK;
+  float* q_s = reinterpret_cast<float*>(Vt + TM * PK);     // [8][D] scaled q
+  float* du_s = q_s + SAT_NP * D;                          // [8][D] dupd
+  float* dL_s = du_s + SAT_NP * D;                         // [TM][8]
+  float* wn_s = dL_s + TM * SAT_NP;                        // [TM][8]
+  float* c_s = wn_s + TM * SAT_NP;                         // [8] c_n, [8] 1/den_n
+  const int b = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
+  const int m0 = tile * TM;
+  const int mvalid = min(TM, p.M - m0);
+  const T* kb = (const T*)p.k + (long long)b * p.M * p.ldkv;
+  const T* vb = (const T*)p.v + (long long)b * p.M * p.ldkv;
+  sat_stage<T>(kb, vb, p.ldkv, m0, mvalid, D, Kt, Vt, PK);
+  for (int i = tid; i < SAT_NP * D; i += 256) {
+    const bool ok = i < N * D;
+    q_s[i] = ok ? p.q[(long long)b * N * D + i] * p.scale : 0.f;
+    du_s[i] = ok ? p.dupd[(long long)b * N * D + i] : 0.f;
+  }
+  {  // c_n = dupd_n . upd_n : 32 lanes per slot
+    const int n = tid >> 5, l = tid & 31;
+    float a = 0.f;
+    if (n < N)
+      for (int c = l; c < D; c += 32)
+        a += p.dupd[((long long)b * N + n) * D + c] * p.upd[((long long)b * N + n) * D + c];
+    for (int off = 1; off < 32; off <<= 1) a += __shfl_xor(a, off, 64);
+    if (l == 0) {
+      c_s[n] = a;
+      c_s[SAT_NP + n] = n < N ? 1.f / p.den[b * N + n] : 0.f;
+    }
+  }
+  __syncthreads();
+  {  // phase A: per-token slot terms dL[m][n], wn[m][n]
+    const int tok = tid / TPT, sub = tid % TPT;
+    const int cn = D / TPT;
+    float g[SAT_NP];
+    sat_dots<T>(Vt + tok * PK, du_s, D, sub * cn, cn, N, g);
+#pragma unroll
+    for (int n = 0; n < SAT_NP; ++n)
+      for (int off = 1; off < TPT; off <<= 1) g[n] += __shfl_xor(g[n], off, 64);
+    if (sub == 0) {
+      const bool ok = tok < mvalid;
+      const float* ap = p.attn + ((long long)b * p.M + m0 + (ok ? tok : 0)) * N;
+      float a[SAT_NP], dw[SAT_NP];
+      float dot = 0.f;
+#pragma unroll
+      for (int n = 0; n < SAT_NP; ++n) {
+        a[n] = (ok && n < N) ? ap[n] : 0.f;
+        dw[n] = (g[n] - c_s[n]) * c_s[SAT_NP + n];
+        dot += a[n] * dw[n];
+      }
+#pragma unroll
+      for (int n = 0; n < SAT_NP; ++n) {
+        dL_s[tok * SAT_NP + n] = a[n] * (dw[n] - dot);
+        wn_s[tok * SAT_NP + n] = (ok && n < N) ? (a[n] + p.eps) * c_s[SAT_NP + n] : 0.f;
+      }
+    }
+  }
+  __syncthreads();
+  // phase B: thread (chunk ch of VEC channels, token lane tl): dk, dv rows out; dq partial
+  const int CH = D / VEC, TL = 256 / CH;
+  const int ch = tid % CH, tl = tid / CH;
+  float dq[SAT_NP][VEC];
+#pragma unroll
+  for (int n = 0; n < SAT_NP; ++n)
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) dq[n][j] = 0.f;
+  if (tl < TL) {
+    float qr[SAT_NP][VEC], dur[SAT_NP][VEC];
+#pragma unroll
+    for (int n = 0; n < SAT_NP; ++n)
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        qr[n][j] = q_s[n * D + ch * VEC + j];
+        dur[n][j] = du_s[n * D + ch * VEC + j];
+      }
+    T* dkb = (T*)p.dk + (long long)b * p.M * p.ldkv;
+    T* dvb = (T*)p.dv + (long long)b * p.M * p.ldkv;
+    for (int m = tl; m < mvalid; m += TL) {
+      float kx[VEC], dkx[VEC], dvx[VEC];
+      unpack16<T>(*reinterpret_cast<const uint4*>(Kt + m * PK + ch * 16), kx);
+      float dl[SAT_NP], wn[SAT_NP];
+      *reinterpret_cast<f32x4*>(dl) = *reinterpret_cast<const f32x4*>(dL_s + m * SAT_NP);
+      *reinterpret_cast<f32x4*>(dl + 4) = *reinterpret_cast<const f32x4*>(dL_s + m * SAT_NP + 4);
+      *reinterpret_cast<f32x4*>(wn) = *reinterpret_cast<const f32x4*>(wn_s + m * SAT_NP);
+      *reinterpret_cast<f32x4*>(wn + 4) = *reinterpret_cast<const f32x4*>(wn_s + m * SAT_NP + 4);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) dkx[j] = dvx[j] = 0.f;
+#pragma unroll
+      for (int n = 0; n < SAT_NP; ++n)
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          dkx[j] += dl[n] * qr[n][j];
+          dvx[j] += wn[n] * dur[n][j];
+          dq[n][j] += dl[n] * kx[j];
+        }
+      const long long go = (long long)(m0 + m) * p.ldkv + ch * VEC;
+      *reinterpret_cast<uint4*>(dkb + go) = pack16<T>(dkx);
+      *reinterpret_cast<uint4*>(dvb + go) = pack16<T>(dvx);
+    }
+  }
+  __syncthreads();                   // K/V tiles are dead: reuse them for the dq fold
+  float* red = reinterpret_cast<float*>(smem);             // [TL][8][D]
+  if (tl < TL) {
+#pragma unroll
+    for (int n = 0; n < SAT_NP; ++n)
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) red[(tl * SAT_NP + n) * D + ch * VEC + j] = dq[n][j];
+  }
+  __syncthreads();
+  float* wsq = p.workspace + ((long long)b * tiles + tile) * N * D;
+  for (int i = tid; i < N * D; i += 256) {
+    float s = 0.f;
+    for (int l = 0; l < TL; ++l) s += red[l * SAT_NP * D + i];   // i = n*D + d, n < N <= 8
+    wsq[i] = s;
+  }
+}
+
+__global__ __launch_bounds__(256) void sat_bwd_finalize_kernel(SdmiSaAttendBwdArgs p, int tiles) {
+  const int b = blockIdx.x, N = p.N, D = p.D;
+  const float* ws = p.workspace + (long long)b * tiles * N * D;
+  for (int i = threadIdx.x; i < N * D; i += 256) {
+    float s = 0.f;
+    for (int t = 0; t < tiles; ++t) s += ws[(long long)t * N * D + i];
+    p.dq[(long long)b * N * D + i] = s * p.scale;      // wrt the UNSCALED q: L = scale * q.k
+  }
+}
+
+template <typename T>
+bool sat_ok(int N, int D, int ldkv) {
+  constexpr int VEC = Elem<T>::VEC;
+  constexpr int TPT = 256 / SatCfg<T>::TM;
+  return N <= SAT_NP && D % (TPT * VEC) == 0 && D / VEC <= 256 && ldkv % VEC == 0 && D <= 256;
+}
+template <typename T>
+int sat_launch_fwd(const SdmiSaAttendArgs& a, hipStream_t st) {
+  constexpr int TM = SatCfg<T>::TM;
+  const int tiles = (a.M + TM - 1) / TM;
+  const int smem = 2 * TM * (a.D * (int)sizeof(T) + 16) + (SAT_NP * a.D + TM * SAT_NP) * 4;
+  static bool done = false;
+  if (!done) {
+    (void)hipFuncSetAttribute((const void*)sat_fwd_kernel<T>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    done = true;
+  }
+  hipLaunchKernelGGL(sat_fwd_kernel<T>, dim3(tiles, a.B), dim3(256), smem, st, a, tiles);
+  hipLaunchKernelGGL(sat_fwd_finalize_kernel, dim3(a.B), dim3(256), 0, st, a, tiles);
+  return sdmi_check_launch("sa_attend_fwd (tiled)");
+}
+template <typename T>
+int sat_launch_bwd(const SdmiSaAttendBwdArgs& a, hipStream_t st) {
+  constexpr int TM = SatCfg<T>::TM;
+  constexpr int VEC = Elem<T>::VEC;
+  const int tiles = (a.M + TM - 1) / TM;
+  int smem = 2 * TM * (a.D * (int)sizeof(T) + 16) + (2 * SAT_NP * a.D + 2 * TM * SAT_NP + 16) * 4;
+  const int red = (256 / (a.D / VEC)) * SAT_NP * a.D * 4;
+  if (red > smem) smem = red;
+  static bool done = false;
+  if (!done) {
+    (void)hipFuncSetAttribute((const void*)sat_bwd_kernel<T>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    done = true;
+  }
+  hipLaunchKernelGGL(sat_bwd_kernel<T>, dim3(tiles, a.B), dim3(256), smem, st, a, tiles);
+  hipLaunchKernelGGL(sat_bwd_finalize_kernel, dim3(a.B), dim3(256), 0, st, a, tiles);
+  return sdmi_check_launch("sa_attend_bwd (tiled)");
+}
+
 __device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + __expf(-x)); }
 
 // GRUCell gate math on precomputed gi = W_ih x + b_ih, gh = W_hh h + b_hh ([R][3D] each, fp32)
@@ -283,6 +610,10 @@ extern "C" int sdmi_sa_attend_fwd(const SdmiSaAttendArgs* a, void* stream) {
   SDMI_REQUIRE(a && a->k && a->v && a->q && a->attn && a->upd && a->den, "null pointer");
   SDMI_REQUIRE(a->N >= 1 && a->N <= 16 && a->D <= 256, "N <= 16, D <= 256");
   hipStream_t st = (hipStream_t)stream;
+  if (a->workspace) {
+    if (a->dtype == SDMI_BF16 && sat_ok<bf16_t>(a->N, a->D, a->ldkv)) return sat_launch_fwd<bf16_t>(*a, st);
+    if (a->dtype == SDMI_F32 && sat_ok<float>(a->N, a->D, a->ldkv)) return sat_launch_fwd<float>(*a, st);
+  }
   SA_DISPATCH(launch_fwd, a, st);
 }
 extern "C" int sdmi_sa_attend_bwd(const SdmiSaAttendBwdArgs* a, void* stream) {
@@ -290,6 +621,10 @@ extern "C" int sdmi_sa_attend_bwd(const SdmiSaAttendBwdArgs* a, void* stream) {
                    a->dk && a->dv, "null pointer");
   SDMI_REQUIRE(a->N >= 1 && a->N <= 16 && a->D <= 256, "N <= 16, D <= 256");
   hipStream_t st = (hipStream_t)stream;
+  if (a->workspace) {
+    if (a->dtype == SDMI_BF16 && sat_ok<bf16_t>(a->N, a->D, a->ldkv)) return sat_launch_bwd<bf16_t>(*a, st);
+    if (a->dtype == SDMI_F32 && sat_ok<float>(a->N, a->D, a->ldkv)) return sat_launch_bwd<float>(*a, st);
+  }
   SA_DISPATCH(launch_bwd, a, st);
 }
 extern "C" int sdmi_gru_gates(const SdmiGruGatesArgs* a, void* stream) {

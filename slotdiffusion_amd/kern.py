@@ -649,9 +649,11 @@ class SaAttendFn(torch.autograd.Function):
         upd = torch.empty((B, N, D), dtype=torch.float32, device=kv.device)
         den = torch.empty((B, N), dtype=torch.float32, device=kv.device)
         q = q.contiguous()
+        ws = torch.empty((B * ((M + 63) // 64) * N * (D + 1),), dtype=torch.float32,
+                         device=kv.device)
         call('sdmi_sa_attend_fwd', _st(), k=_p(kv), v=_p(kv[..., D:]), q=_p(q), attn=_p(attn),
              upd=_p(upd), den=_p(den), dtype=_DT[kv.dtype], B=B, M=M, N=N, D=D, ldkv=D2, eps=eps,
-             scale=D ** -0.5)
+             scale=D ** -0.5, workspace=_p(ws))
         ctx.save_for_backward(kv, q, attn, upd, den)
         ctx.eps = eps
         ctx.mark_non_differentiable(attn)
@@ -666,9 +668,11 @@ class SaAttendFn(torch.autograd.Function):
         dupd = dupd.contiguous()
         dq = torch.empty_like(q)
         dkv = torch.empty_like(kv)
+        ws = torch.empty((B * ((M + 63) // 64) * N * D,), dtype=torch.float32, device=kv.device)
         call('sdmi_sa_attend_bwd', _st(), k=_p(kv), v=_p(kv[..., D:]), q=_p(q), attn=_p(attn),
              upd=_p(upd), den=_p(den), dupd=_p(dupd), dq=_p(dq), dk=_p(dkv), dv=_p(dkv[..., D:]),
-             dtype=_DT[kv.dtype], B=B, M=M, N=N, D=D, ldkv=D2, eps=ctx.eps, scale=D ** -0.5)
+             dtype=_DT[kv.dtype], B=B, M=M, N=N, D=D, ldkv=D2, eps=ctx.eps, scale=D ** -0.5,
+             workspace=_p(ws))
         _dbg('sa_attend', dupd=dupd, dkv=dkv, dq=dq)
         return dkv, dq, None
 
