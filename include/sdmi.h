@@ -279,7 +279,8 @@ typedef struct { const void* src; void* dst; int dtype; int Cout, KH, KW, Cin, C
 int sdmi_pack_dgrad(const SdmiPackDgradArgs* a, void* stream);
 /* The same for a whole table of operands in ONE launch (every dgrad operand of the model is
  * rebuilt after each optimiser step).  `descs` is a device array of SdmiPackDesc; workgroup b
- * serves the descriptor with block_begin <= b < next block_begin (2048 elements per workgroup). */
+ * serves the descriptor with block_begin <= b < next block_begin; an operand takes
+ * KH*KW * ceil(Cout/64) * ceil(Cin/64) workgroups (one 64x64 tile of one tap each). */
 typedef struct {
   const void* src; void* dst;
   int Cout, KH, KW, Cin, CoutPad;

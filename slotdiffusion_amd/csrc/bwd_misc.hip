@@ -29,8 +29,14 @@ __global__ void pack_dgrad_kernel(SdmiPackDgradArgs p) {
   }
 }
 
+// Batched version: a workgroup transposes one 64(co) x 64(ci) tile of one tap of one operand
+// through LDS -- 16-byte reads along ci, 16-byte writes along co (the per-element version above
+// gathers 2-byte elements with a stride of a whole filter).
 template <typename T>
 __global__ __launch_bounds__(256) void pack_dgrad_batch_kernel(SdmiPackBatchArgs p) {
+  constexpr int VEC = Elem<T>::VEC;
+  constexpr int VPR = 64 / VEC;                  // vectors per 64-element tile row
+  __shared__ T tile[64][64 + 2];
   const SdmiPackDesc* descs = (const SdmiPackDesc*)p.descs;
   int lo = 0, hi = p.n_desc - 1;          // last descriptor with block_begin <= blockIdx.x
   while (lo < hi) {
@@ -38,21 +44,37 @@ __global__ __launch_bounds__(256) void pack_dgrad_batch_kernel(SdmiPackBatchArgs
     if (descs[mid].block_begin <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
   }
   const SdmiPackDesc d = descs[lo];
-  const long long n = (long long)d.Cout * d.KH * d.KW * d.Cin;
-  const long long base = (long long)((int)blockIdx.x - d.block_begin) * 2048;
+  int w = (int)blockIdx.x - d.block_begin;
+  const int tci = (d.Cin + 63) / 64, tco = (d.Cout + 63) / 64;
+  const int ci0 = (w % tci) * 64;
+  w /= tci;
+  const int co0 = (w % tco) * 64;
+  const int tap = w / tco;                       // destination tap (kh', kw')
+  const int kh = tap / d.KW, kw = tap - kh * d.KW;
+  const int stap = (d.KH - 1 - kh) * d.KW + (d.KW - 1 - kw);
+  const int taps = d.KH * d.KW;
+  const T* src = (const T*)d.src;
+  T* dst = (T*)d.dst;
+  for (int i = threadIdx.x; i < 64 * VPR; i += 256) {
+    const int r = i / VPR, c = (i % VPR) * VEC;  // r: co offset, c: ci offset
+    const int co = co0 + r, ci = ci0 + c;
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (co < d.Cout && ci < d.Cin)
+      v = *reinterpret_cast<const uint4*>(src + ((long long)co * taps + stap) * d.Cin + ci);
+    const T* e = reinterpret_cast<const T*>(&v);
 #pragma unroll
-  for (int u = 0; u < 8; ++u) {
-    const long long i = base + u * 256 + threadIdx.x;      // dst [ci][kh'][kw'][co]
-    if (i >= n) break;
-    const int co = (int)(i % d.Cout);
-    long long r = i / d.Cout;
-    const int kw = (int)(r % d.KW);
-    r /= d.KW;
-    const int kh = (int)(r % d.KH);
-    const int ci = (int)(r / d.KH);
-    const long long s =
-        (((long long)co * d.KH + (d.KH - 1 - kh)) * d.KW + (d.KW - 1 - kw)) * d.Cin + ci;
-    ((T*)d.dst)[(i / d.Cout) * d.CoutPad + co] = ((const T*)d.src)[s];
+    for (int j = 0; j < VEC; ++j) tile[r][c + j] = e[j];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 64 * VPR; i += 256) {
+    const int r = i / VPR, c = (i % VPR) * VEC;  // r: ci offset, c: co offset
+    const int ci = ci0 + r, co = co0 + c;
+    if (ci >= d.Cin || co >= d.CoutPad) continue;
+    uint4 v;
+    T* e = reinterpret_cast<T*>(&v);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) e[j] = tile[c + j][r];   // rows co >= Cout hold zeros
+    *reinterpret_cast<uint4*>(dst + ((long long)ci * taps + tap) * d.CoutPad + co) = v;
   }
 }
 

@@ -5,9 +5,10 @@
 //   dx = rstd_g * ( gamma_c*dz - ( S1_g + xhat * S2_g ) / n ),
 //        S1_g = sum_{c in g} gamma_c * A_bc,  S2_g = sum_{c in g} gamma_c * B_bc,
 //        A_bc = sum_hw dz,  B_bc = sum_hw dz*xhat      (per image b, channel c)
-// so one streaming pass produces the per-(image, channel) sums, a tiny reduce turns them into the
-// group terms and the parameter gradients, and a second streaming pass writes dx (and dres).
-// Same fixed-channel thread organisation as the forward; fp64 combines, no atomics.
+// so one streaming pass produces the per-(image, split, channel) sums; the second streaming pass
+// (dx, dres) first folds them into its image's group terms in LDS, and an independent small kernel
+// folds them into dgamma / dbeta.  Same fixed-channel thread organisation as the forward; fp64
+// combines, no atomics.
 #include "common.h"
 
 namespace {
@@ -80,59 +81,71 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(SdmiGroupNormBwdArgs 
   }
 }
 
-// One launch turns the [B][nsplit][C][2] partials into (a) the per-(image, group) terms the
-// dx pass needs and (b) dgamma / dbeta.  A workgroup owns CB = cpg * floor(64 / cpg) channels
-// (whole groups) for all images: 4 images at a time x 64 channel lanes.
-__global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(SdmiGroupNormBwdArgs p, float* gsum,
-                                                            int CB) {
-  __shared__ float tile[4][64][2];
-  const int cl = threadIdx.x & 63, kg = threadIdx.x >> 6;
-  const int c0 = blockIdx.x * CB, c = c0 + cl;
-  const bool cok = cl < CB && c < p.C;
-  const int cpg = p.C / p.groups;
-  const float gam = cok ? p.gamma[c] : 0.f;
-  float pa = 0.f, pb = 0.f;
-  for (int b0 = 0; b0 < p.B; b0 += 4) {
-    const int b = b0 + kg;
-    double sa = 0.0, sb = 0.0;
-    if (cok && b < p.B) {
-      const float2* q = reinterpret_cast<const float2*>(p.partial) + (long long)b * p.nsplit * p.C + c;
-      for (int k = 0; k < p.nsplit; ++k) {
-        const float2 v = q[(long long)k * p.C];
-        sa += v.x;
-        sb += v.y;
-      }
+// out0[c] (+)= sum_e partial[e][c][0], out1[c] (+)= sum_e partial[e][c][1] over nblk entries:
+// 16 channels x 16 entry-lanes per workgroup (C/16 workgroups), 4 independent loads in flight per
+// thread, fixed-order LDS fold.  Serves dgamma/dbeta of both GroupNorm (entries = image x split)
+// and LayerNorm (entries = row blocks).
+__global__ __launch_bounds__(256) void pair_colsum_kernel(const float* partial, int nblk, int C,
+                                                          float* out0, float* out1,
+                                                          int accumulate) {
+  __shared__ float red[16][16][2];
+  const int cl = threadIdx.x & 15, kg = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
+  float s0 = 0.f, s1 = 0.f;
+  if (c < C) {
+    const float2* q = reinterpret_cast<const float2*>(partial) + c;
+    int k = kg;
+    for (; k + 48 < nblk; k += 64) {
+      const float2 v0 = q[(long long)k * C], v1 = q[(long long)(k + 16) * C];
+      const float2 v2 = q[(long long)(k + 32) * C], v3 = q[(long long)(k + 48) * C];
+      s0 += (v0.x + v1.x) + (v2.x + v3.x);
+      s1 += (v0.y + v1.y) + (v2.y + v3.y);
     }
-    pa += (float)sa;
-    pb += (float)sb;
-    tile[kg][cl][0] = gam * (float)sa;
-    tile[kg][cl][1] = gam * (float)sb;
-    __syncthreads();
-    const int g = c0 / cpg + cl;
-    if (cl < CB / cpg && g < p.groups && b < p.B) {
-      double s1 = 0.0, s2 = 0.0;
-      for (int j = 0; j < cpg; ++j) { s1 += tile[kg][cl * cpg + j][0]; s2 += tile[kg][cl * cpg + j][1]; }
-      gsum[(b * p.groups + g) * 2] = (float)s1;
-      gsum[(b * p.groups + g) * 2 + 1] = (float)s2;
+    for (; k < nblk; k += 16) {
+      const float2 v = q[(long long)k * C];
+      s0 += v.x;
+      s1 += v.y;
     }
-    __syncthreads();
   }
-  tile[kg][cl][0] = pa;
-  tile[kg][cl][1] = pb;
+  red[kg][cl][0] = s0;
+  red[kg][cl][1] = s1;
   __syncthreads();
-  if (kg == 0 && cok) {
-    const float a = (tile[0][cl][0] + tile[1][cl][0]) + (tile[2][cl][0] + tile[3][cl][0]);
-    const float bb = (tile[0][cl][1] + tile[1][cl][1]) + (tile[2][cl][1] + tile[3][cl][1]);
-    p.dbeta[c] = (p.accumulate ? p.dbeta[c] : 0.f) + a;
-    p.dgamma[c] = (p.accumulate ? p.dgamma[c] : 0.f) + bb;
+  if (kg == 0 && c < C) {
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { a += red[k][cl][0]; b += red[k][cl][1]; }
+    out0[c] = (accumulate ? out0[c] : 0.f) + a;
+    out1[c] = (accumulate ? out1[c] : 0.f) + b;
   }
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(SdmiGroupNormBwdArgs p,
-                                                           const float* gsum, int rows_per) {
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(SdmiGroupNormBwdArgs p, int rows_per) {
   constexpr int VEC = Elem<T>::VEC;
+  __shared__ float gsum[256][2];     // per-group terms of this image (groups <= 256)
   const int b = blockIdx.y;
+  const int cpg = p.C / p.groups;
+  {  // S1_g = sum_{c in g} gamma_c A_bc, S2_g likewise with B_bc: 8 lanes per group over the
+     // group's cpg * nsplit partial entries (every workgroup of the image recomputes them)
+    const int l8 = threadIdx.x & 7;
+    const int ne = cpg * p.nsplit;
+    for (int g = threadIdx.x >> 3; g < p.groups; g += 32) {
+      double s1 = 0.0, s2 = 0.0;
+      for (int e = l8; e < ne; e += 8) {
+        const int k = e / cpg, c = g * cpg + (e - k * cpg);
+        const float2 v = reinterpret_cast<const float2*>(p.partial)[((long long)b * p.nsplit + k) * p.C + c];
+        const double ga = (double)p.gamma[c];
+        s1 += ga * v.x;
+        s2 += ga * v.y;
+      }
+      for (int off = 1; off < 8; off <<= 1) {
+        s1 += __shfl_xor(s1, off, 64);
+        s2 += __shfl_xor(s2, off, 64);
+      }
+      if (l8 == 0) { gsum[g][0] = (float)s1; gsum[g][1] = (float)s2; }
+    }
+  }
+  __syncthreads();
   const int CV = p.C / VEC, CVp = next_pow2(CV);
   const int R = 256 / CVp;
   const int cv = threadIdx.x % CVp, r0 = threadIdx.x / CVp;
@@ -140,7 +153,6 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(SdmiGroupNormBwdArgs 
   const int row_begin = blockIdx.x * rows_per;
   int row_end = row_begin + rows_per;
   if (row_end > p.HW) row_end = p.HW;
-  const int cpg = p.C / p.groups;
   const float inv_n = 1.f / ((float)p.HW * (float)cpg);
   float mu[VEC], rs[VEC], ga[VEC], be[VEC], s1[VEC], s2[VEC];
 #pragma unroll
@@ -150,8 +162,8 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(SdmiGroupNormBwdArgs 
     rs[j] = p.stats[(b * p.groups + g) * 2 + 1];
     ga[j] = p.gamma[c];
     be[j] = p.beta[c];
-    s1[j] = gsum[(b * p.groups + g) * 2] * inv_n;
-    s2[j] = gsum[(b * p.groups + g) * 2 + 1] * inv_n;
+    s1[j] = gsum[g][0] * inv_n;
+    s2[j] = gsum[g][1] * inv_n;
   }
   const long long base = (long long)b * p.HW * p.C + cv * VEC;
   const T* xb = (const T*)p.x + base;
@@ -280,40 +292,6 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(SdmiLayerNormBwdArgs p, int
     q[1] = (red[0][c][1] + red[1][c][1]) + (red[2][c][1] + red[3][c][1]);
   }
 }
-// dgamma / dbeta from the per-workgroup partials: 16 channels x 16 partial-groups per workgroup
-// (C/16 workgroups), 4 independent loads in flight per thread, fixed-order LDS fold.
-__global__ __launch_bounds__(256) void ln_bwd_param_kernel(SdmiLayerNormBwdArgs p) {
-  __shared__ float red[16][16][2];
-  const int cl = threadIdx.x & 15, kg = threadIdx.x >> 4;
-  const int c = blockIdx.x * 16 + cl;
-  float sg = 0.f, sb = 0.f;
-  if (c < p.C) {
-    const float2* q = reinterpret_cast<const float2*>(p.partial) + c;
-    int k = kg;
-    for (; k + 48 < p.nblk; k += 64) {
-      const float2 v0 = q[(long long)k * p.C], v1 = q[(long long)(k + 16) * p.C];
-      const float2 v2 = q[(long long)(k + 32) * p.C], v3 = q[(long long)(k + 48) * p.C];
-      sg += (v0.x + v1.x) + (v2.x + v3.x);
-      sb += (v0.y + v1.y) + (v2.y + v3.y);
-    }
-    for (; k < p.nblk; k += 16) {
-      const float2 v = q[(long long)k * p.C];
-      sg += v.x;
-      sb += v.y;
-    }
-  }
-  red[kg][cl][0] = sg;
-  red[kg][cl][1] = sb;
-  __syncthreads();
-  if (kg == 0 && c < p.C) {
-    float g = 0.f, b = 0.f;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) { g += red[k][cl][0]; b += red[k][cl][1]; }
-    p.dgamma[c] = (p.accumulate ? p.dgamma[c] : 0.f) + g;
-    p.dbeta[c] = (p.accumulate ? p.dbeta[c] : 0.f) + b;
-  }
-}
-
 }  // namespace
 
 extern "C" int sdmi_groupnorm_bwd(const SdmiGroupNormBwdArgs* a, void* stream) {
@@ -323,7 +301,6 @@ extern "C" int sdmi_groupnorm_bwd(const SdmiGroupNormBwdArgs* a, void* stream) {
   SDMI_REQUIRE(a->C % vec == 0 && a->C <= 1024, "C must be a vector multiple <= 1024");
   SDMI_REQUIRE(a->groups > 0 && a->C % a->groups == 0 && a->nsplit >= 1, "bad groups/nsplit");
   hipStream_t st = (hipStream_t)stream;
-  float* gsum = a->partial + (long long)a->B * a->nsplit * a->C * 2;
   dim3 g1(a->nsplit, a->B);
   const long long row_bytes = (long long)a->C * (a->dtype == SDMI_BF16 ? 2 : 4);
   int rows_per = (int)((32768 + row_bytes - 1) / row_bytes);
@@ -334,15 +311,14 @@ extern "C" int sdmi_groupnorm_bwd(const SdmiGroupNormBwdArgs* a, void* stream) {
     hipLaunchKernelGGL(gn_bwd_stats_kernel<bf16_t>, g1, dim3(256), 0, st, *a);
   else
     hipLaunchKernelGGL(gn_bwd_stats_kernel<float>, g1, dim3(256), 0, st, *a);
-  const int cpg = a->C / a->groups;
-  SDMI_REQUIRE(cpg <= 64, "at most 64 channels per group");
-  const int CB = cpg * (64 / cpg);
-  hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3((a->C + CB - 1) / CB), dim3(256), 0, st, *a, gsum,
-                     CB);
+  SDMI_REQUIRE(a->groups <= 256, "at most 256 groups");
+  // dbeta = sum dz, dgamma = sum dz*xhat over all (image, split) partial entries
+  hipLaunchKernelGGL(pair_colsum_kernel, dim3((a->C + 15) / 16), dim3(256), 0, st, a->partial,
+                     a->B * a->nsplit, a->C, a->dbeta, a->dgamma, a->accumulate);
   if (a->dtype == SDMI_BF16)
-    hipLaunchKernelGGL(gn_bwd_apply_kernel<bf16_t>, g3, dim3(256), 0, st, *a, gsum, rows_per);
+    hipLaunchKernelGGL(gn_bwd_apply_kernel<bf16_t>, g3, dim3(256), 0, st, *a, rows_per);
   else
-    hipLaunchKernelGGL(gn_bwd_apply_kernel<float>, g3, dim3(256), 0, st, *a, gsum, rows_per);
+    hipLaunchKernelGGL(gn_bwd_apply_kernel<float>, g3, dim3(256), 0, st, *a, rows_per);
   return sdmi_check_launch("groupnorm_bwd");
 }
 
@@ -366,6 +342,7 @@ extern "C" int sdmi_layernorm_bwd(const SdmiLayerNormBwdArgs* a, void* stream) {
     if (vpl <= 1) LN_GO(float, 1); else if (vpl == 2) LN_GO(float, 2); else LN_GO(float, 4);
   }
 #undef LN_GO
-  hipLaunchKernelGGL(ln_bwd_param_kernel, dim3((a->C + 15) / 16), dim3(256), 0, st, *a);
+  hipLaunchKernelGGL(pair_colsum_kernel, dim3((a->C + 15) / 16), dim3(256), 0, st, a->partial,
+                     a->nblk, a->C, a->dgamma, a->dbeta, a->accumulate);
   return sdmi_check_launch("layernorm_bwd");
 }

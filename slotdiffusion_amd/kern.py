@@ -223,7 +223,7 @@ class WeightBank:
                     w, n, kh, kw, cin, npad = e[2]
                     d.src, d.dst = w.data_ptr(), e[0].data_ptr()
                     d.Cout, d.KH, d.KW, d.Cin, d.CoutPad, d.block_begin = n, kh, kw, cin, npad, blk
-                    blk += (n * kh * kw * cin + 2047) // 2048
+                    blk += kh * kw * ((n + 63) // 64) * ((cin + 63) // 64)
                 dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(
                     items[0][0].device)
                 tab = (dev, len(items), blk)

@@ -421,3 +421,34 @@ def test_sa_attend_tiled_matches_reference(B, M, N, D, dtype):
     assert rel(dq, q.grad) <= tol and rel(dkv, kv.grad) <= tol
     for x, y in zip(res[True], res[False]):
         assert rel(x, y.float().cpu()) <= (1e-5 if dtype == torch.float32 else 1e-2)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_pack_dgrad_batch_matches_single(dtype):
+    """One-launch repack of a table of dgrad operands == the per-operand kernel (bit exact)."""
+    from slotdiffusion_amd import _lib, ops
+    from slotdiffusion_amd.kern import _DT
+    vec = ops.vec_of(dtype)
+    shapes = [(3, 3, 3, 128), (64, 3, 3, 64), (200, 1, 1, 136), (384, 3, 3, 640 if dtype == torch.bfloat16 else 72),
+              (8, 1, 1, 8)]
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator(device='cuda').manual_seed(3)
+    Desc = _lib.CSTRUCT['SdmiPackDesc']
+    arr = (Desc * len(shapes))()
+    keep, blk = [], 0
+    for d, (co, kh, kw, ci) in zip(arr, shapes):
+        npad = (co + vec - 1) // vec * vec
+        src = torch.randn(co, kh * kw * ci, device='cuda', generator=g).to(dtype)
+        ref = torch.zeros(ci * kh * kw, npad, dtype=dtype, device='cuda')
+        out = torch.zeros_like(ref)
+        _lib.call('sdmi_pack_dgrad', st, src=src.data_ptr(), dst=ref.data_ptr(), dtype=_DT[dtype],
+                  Cout=co, KH=kh, KW=kw, Cin=ci, CoutPad=npad)
+        d.src, d.dst = src.data_ptr(), out.data_ptr()
+        d.Cout, d.KH, d.KW, d.Cin, d.CoutPad, d.block_begin = co, kh, kw, ci, npad, blk
+        blk += kh * kw * ((co + 63) // 64) * ((ci + 63) // 64)
+        keep.append((src, ref, out))
+    tab = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).cuda()
+    _lib.call('sdmi_pack_dgrad_batch', st, descs=tab.data_ptr(), n_desc=len(shapes), dtype=_DT[dtype],
+              total_blocks=blk)
+    for (src, ref, out), shp in zip(keep, shapes):
+        assert torch.equal(ref, out), shp
