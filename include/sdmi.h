@@ -110,6 +110,9 @@ typedef struct {
 } SdmiGroupNormArgs;
 int sdmi_groupnorm_stats(const SdmiGroupNormArgs* a, void* stream);
 int sdmi_groupnorm_apply(const SdmiGroupNormArgs* a, void* stream);
+/* Both passes in one call; images small enough to sit in one workgroup's registers
+ * (HW * C * elem <= 64 KiB, nsplit == 1) take a single fused launch (x read once). */
+int sdmi_groupnorm(const SdmiGroupNormArgs* a, void* stream);
 
 typedef struct {
   const void* x;       /* forward input */

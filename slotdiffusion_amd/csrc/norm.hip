@@ -123,6 +123,98 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(SdmiGroupNormArgs p, int 
   }
 }
 
+
+// Small images: one workgroup per image keeps its whole [HW][C] slab in registers (<= 16 vectors
+// per thread): statistics and normalisation in ONE launch, x read once.
+template <typename T>
+__global__ __launch_bounds__(256) void gn_fused_kernel(SdmiGroupNormArgs p) {
+  constexpr int VEC = Elem<T>::VEC;
+  constexpr int NV = 16;
+  __shared__ float part[256][VEC][2];
+  __shared__ float s_stats[128][2];
+  const int b = blockIdx.x;
+  const int CV = p.C / VEC, CVp = next_pow2(CV);
+  const int R = 256 / CVp;
+  const int cv = threadIdx.x % CVp, r0 = threadIdx.x / CVp;
+  const bool act_c = cv < CV;
+  const long long base = (long long)b * p.HW * p.C + (act_c ? cv : 0) * VEC;
+  const T* xb = (const T*)p.x + base;
+  uint4 xr[NV];
+  float s[VEC], ss[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) s[j] = ss[j] = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int row = r0 + i * R;
+    if (act_c && row < p.HW) xr[i] = *reinterpret_cast<const uint4*>(xb + (long long)row * p.C);
+  }
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int row = r0 + i * R;
+    if (act_c && row < p.HW) {
+      float f[VEC];
+      unpack16<T>(xr[i], f);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) { s[j] += f[j]; ss[j] += f[j] * f[j]; }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) { part[threadIdx.x][j][0] = s[j]; part[threadIdx.x][j][1] = ss[j]; }
+  __syncthreads();
+  const int cpg = p.C / p.groups;
+  if ((int)threadIdx.x < 2 * p.groups) {     // 2 threads per group: (sum | sumsq), fp64 combine
+    const int g = threadIdx.x >> 1, which = threadIdx.x & 1;
+    double acc = 0.0;
+    for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+      const int ccv = c / VEC, j = c % VEC;
+      for (int r = 0; r < R; ++r) acc += (double)part[r * CVp + ccv][j][which];
+    }
+    const double other = __shfl_xor(acc, 1, 64);
+    const double sum = which ? other : acc, sq = which ? acc : other;
+    const double n = (double)p.HW * cpg;
+    const double mean = sum / n;
+    double var = sq / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    if (which == 0) {
+      const float mf = (float)mean, rf = (float)(1.0 / sqrt(var + (double)p.eps));
+      s_stats[g][0] = mf;
+      s_stats[g][1] = rf;
+      p.stats[(b * p.groups + g) * 2 + 0] = mf;
+      p.stats[(b * p.groups + g) * 2 + 1] = rf;
+    }
+  }
+  __syncthreads();
+  if (!act_c) return;
+  float sc[VEC], sh[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    const int c = cv * VEC + j, g = c / cpg;
+    sc[j] = s_stats[g][1] * p.gamma[c];
+    sh[j] = p.beta[c] - s_stats[g][0] * sc[j];
+  }
+  T* yb = (T*)p.y + base;
+  const T* rb = p.residual ? (const T*)p.residual + base : nullptr;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int row = r0 + i * R;
+    if (row < p.HW) {
+      const long long o = (long long)row * p.C;
+      float f[VEC];
+      unpack16<T>(xr[i], f);
+      if (rb) {
+        float rr[VEC];
+        unpack16<T>(*reinterpret_cast<const uint4*>(rb + o), rr);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) f[j] = act_apply(f[j] * sc[j] + sh[j] + rr[j], p.act);
+      } else {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) f[j] = act_apply(f[j] * sc[j] + sh[j], p.act);
+      }
+      *reinterpret_cast<uint4*>(yb + o) = pack16<T>(f);
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // LayerNorm: one wave per row, two-pass in registers (C <= 1024).
 template <typename T>
@@ -213,6 +305,24 @@ extern "C" int sdmi_groupnorm_apply(const SdmiGroupNormArgs* a, void* stream) {
   else
     hipLaunchKernelGGL(gn_apply_kernel<float>, grid, dim3(256), 0, st, *a, rows_per);
   return sdmi_check_launch("groupnorm_apply");
+}
+
+extern "C" int sdmi_groupnorm(const SdmiGroupNormArgs* a, void* stream) {
+  int rc = gn_validate(a);
+  if (rc) return rc;
+  SDMI_REQUIRE(a->y, "null output");
+  const int vec = a->dtype == SDMI_BF16 ? 8 : 4;
+  int cvp = 1;
+  while (cvp < a->C / vec) cvp <<= 1;
+  const int R = 256 / cvp;
+  if ((a->HW + R - 1) / R <= 16) {          // the image fits in one workgroup's registers
+    hipStream_t st = (hipStream_t)stream;
+    if (a->dtype == SDMI_BF16) hipLaunchKernelGGL(gn_fused_kernel<bf16_t>, dim3(a->B), dim3(256), 0, st, *a);
+    else hipLaunchKernelGGL(gn_fused_kernel<float>, dim3(a->B), dim3(256), 0, st, *a);
+    return sdmi_check_launch("groupnorm (fused)");
+  }
+  rc = sdmi_groupnorm_stats(a, stream);
+  return rc ? rc : sdmi_groupnorm_apply(a, stream);
 }
 
 extern "C" int sdmi_layernorm(const SdmiLayerNormArgs* a, void* stream) {

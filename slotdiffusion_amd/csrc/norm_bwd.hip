@@ -81,6 +81,121 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(SdmiGroupNormBwdArgs 
   }
 }
 
+// Small images (the whole [HW][C] slab of x and dy fits one workgroup's registers, nsplit == 1):
+// both streaming passes in one launch.
+template <typename T>
+__global__ __launch_bounds__(256) void gn_bwd_fused_kernel(SdmiGroupNormBwdArgs p) {
+  constexpr int VEC = Elem<T>::VEC;
+  constexpr int NV = 16;
+  __shared__ float part[256][VEC][2];
+  __shared__ float gsum[256][2];
+  const int b = blockIdx.x;
+  const int CV = p.C / VEC, CVp = next_pow2(CV);
+  const int R = 256 / CVp;
+  const int cv = threadIdx.x % CVp, r0 = threadIdx.x / CVp;
+  const bool act_c = cv < CV;
+  const int cpg = p.C / p.groups;
+  float mu[VEC], rs[VEC], ga[VEC], be[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    const int c = (act_c ? cv : 0) * VEC + j, g = c / cpg;
+    mu[j] = p.stats[(b * p.groups + g) * 2];
+    rs[j] = p.stats[(b * p.groups + g) * 2 + 1];
+    ga[j] = p.gamma[c];
+    be[j] = p.beta[c];
+  }
+  const long long base = (long long)b * p.HW * p.C + (act_c ? cv : 0) * VEC;
+  const T* xb = (const T*)p.x + base;
+  const T* db = (const T*)p.dy + base;
+  const T* rb = p.residual ? (const T*)p.residual + base : nullptr;
+  uint4 xr[NV], dr[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int row = r0 + i * R;
+    if (act_c && row < p.HW) {
+      xr[i] = *reinterpret_cast<const uint4*>(xb + (long long)row * p.C);
+      dr[i] = *reinterpret_cast<const uint4*>(db + (long long)row * p.C);
+    }
+  }
+  float A[VEC], Bv[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) A[j] = Bv[j] = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int row = r0 + i * R;
+    if (act_c && row < p.HW) {
+      float x[VEC], dy[VEC], rr[VEC];
+      unpack16<T>(xr[i], x);
+      unpack16<T>(dr[i], dy);
+      if (rb) unpack16<T>(*reinterpret_cast<const uint4*>(rb + (long long)row * p.C), rr);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        const float xh = (x[j] - mu[j]) * rs[j];
+        const float z = xh * ga[j] + be[j] + (rb ? rr[j] : 0.f);
+        const float dz = dy[j] * act_grad(z, p.act);
+        dy[j] = dz;                        // keep dz for the second half
+        A[j] += dz;
+        Bv[j] += dz * xh;
+      }
+      dr[i] = pack16<T>(dy);               // (bf16: dz rounded once more, as dresidual stores it)
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) { part[threadIdx.x][j][0] = A[j]; part[threadIdx.x][j][1] = Bv[j]; }
+  __syncthreads();
+  if (r0 == 0 && act_c) {                  // channel totals -> partial[b][0][c] (for dgamma/dbeta)
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      double sa = 0.0, sb = 0.0;
+      for (int r = 0; r < R; ++r) { sa += part[r * CVp + cv][j][0]; sb += part[r * CVp + cv][j][1]; }
+      part[cv][j][0] = (float)sa;          // row 0 of the column: no other thread reads rows r>0 of it now
+      part[cv][j][1] = (float)sb;
+      float* q = p.partial + (((long long)b * p.C) + cv * VEC + j) * 2;
+      q[0] = (float)sa;
+      q[1] = (float)sb;
+    }
+  }
+  __syncthreads();
+  for (int g = threadIdx.x; g < p.groups; g += 256) {
+    double s1 = 0.0, s2 = 0.0;
+    for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+      s1 += (double)p.gamma[c] * part[c / VEC][c % VEC][0];
+      s2 += (double)p.gamma[c] * part[c / VEC][c % VEC][1];
+    }
+    gsum[g][0] = (float)s1;
+    gsum[g][1] = (float)s2;
+  }
+  __syncthreads();
+  if (!act_c) return;
+  const float inv_n = 1.f / ((float)p.HW * (float)cpg);
+  float s1[VEC], s2[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    const int g = (cv * VEC + j) / cpg;
+    s1[j] = gsum[g][0] * inv_n;
+    s2[j] = gsum[g][1] * inv_n;
+  }
+  T* dxb = (T*)p.dx + base;
+  T* drb = p.dresidual ? (T*)p.dresidual + base : nullptr;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int row = r0 + i * R;
+    if (row < p.HW) {
+      const long long o = (long long)row * p.C;
+      float x[VEC], dz[VEC], dx[VEC];
+      unpack16<T>(xr[i], x);
+      unpack16<T>(dr[i], dz);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        const float xh = (x[j] - mu[j]) * rs[j];
+        dx[j] = rs[j] * (ga[j] * dz[j] - (s1[j] + xh * s2[j]));
+      }
+      *reinterpret_cast<uint4*>(dxb + o) = pack16<T>(dx);
+      if (drb) *reinterpret_cast<uint4*>(drb + o) = dr[i];
+    }
+  }
+}
+
 // out0[c] (+)= sum_e partial[e][c][0], out1[c] (+)= sum_e partial[e][c][1] over nblk entries:
 // 16 channels x 16 entry-lanes per workgroup (C/16 workgroups), 4 independent loads in flight per
 // thread, fixed-order LDS fold.  Serves dgamma/dbeta of both GroupNorm (entries = image x split)
@@ -307,6 +422,20 @@ extern "C" int sdmi_groupnorm_bwd(const SdmiGroupNormBwdArgs* a, void* stream) {
   if (rows_per < 4) rows_per = 4;
   if (rows_per > a->HW) rows_per = a->HW;
   dim3 g3((a->HW + rows_per - 1) / rows_per, a->B);
+  {
+    int cvp = 1;
+    while (cvp < a->C / vec) cvp <<= 1;
+    const int R = 256 / cvp;
+    if (a->nsplit == 1 && (a->HW + R - 1) / R <= 16) {      // small image: one fused launch
+      if (a->dtype == SDMI_BF16)
+        hipLaunchKernelGGL(gn_bwd_fused_kernel<bf16_t>, dim3(a->B), dim3(256), 0, st, *a);
+      else
+        hipLaunchKernelGGL(gn_bwd_fused_kernel<float>, dim3(a->B), dim3(256), 0, st, *a);
+      hipLaunchKernelGGL(pair_colsum_kernel, dim3((a->C + 15) / 16), dim3(256), 0, st, a->partial,
+                         a->B, a->C, a->dbeta, a->dgamma, a->accumulate);
+      return sdmi_check_launch("groupnorm_bwd (fused)");
+    }
+  }
   if (a->dtype == SDMI_BF16)
     hipLaunchKernelGGL(gn_bwd_stats_kernel<bf16_t>, g1, dim3(256), 0, st, *a);
   else

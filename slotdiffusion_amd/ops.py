@@ -127,8 +127,7 @@ def group_norm(x, gamma, beta, *, eps, act=None, groups=32, residual=None, out=N
     kw = dict(x=_p(x), y=_p(out), gamma=_p(gamma), beta=_p(beta), stats=_p(stats),
               partial=_p(partial), dtype=_dt(x), B=B, HW=HW, C=C, groups=groups, eps=eps,
               act=ACT[act], nsplit=nsplit, residual=_p(residual))
-    call('sdmi_groupnorm_stats', _stream(), **kw)
-    call('sdmi_groupnorm_apply', _stream(), **kw)
+    call('sdmi_groupnorm', _stream(), **kw)      # one fused launch for small images, else two
     return (out, stats) if return_stats else out
 
 
