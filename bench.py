@@ -107,6 +107,31 @@ def cpu_baseline(cfg, mode, quick=False):
                        f'of {cores} cores, {dt:.1f}s')
 
 
+def pmc_traffic(which):
+    """HBM traffic / MFMA utilisation of the igemm kernels from the committed rocprofv3 PMC passes
+    (profiles/r01_<which>_pmc_by_kernel.csv; separate --pmc runs of this same command, see
+    DESIGN.md section 5).  FETCH_SIZE is doubled (gfx950 counts 128-byte requests as 64 bytes)."""
+    import csv
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles',
+                        f'r01_{which}_pmc_by_kernel.csv')
+    if not os.path.exists(path):
+        return {}
+    f = w = n = act = busy = 0.0
+    with open(path) as fh:
+        for r in csv.DictReader(fh):
+            if r['kernel'].startswith('igemm_kernel'):
+                n += float(r['dispatches'])
+                f += float(r['FETCH_SIZE'])
+                w += float(r['WRITE_SIZE'])
+                act += float(r['GRBM_GUI_ACTIVE'])
+                busy += float(r['SQ_VALU_MFMA_BUSY_CYCLES'])
+    if not n:
+        return {}
+    # GRBM_GUI_ACTIVE is summed over the 8 XCDs; 1024 SIMDs
+    return {'bytes_per_launch': (2.0 * f + w) * 1024.0 / n, 'mfma_util': busy / (act / 8.0 * 1024.0),
+            'source': os.path.relpath(path, os.path.dirname(os.path.abspath(__file__)))}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -118,6 +143,8 @@ def main():
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--only-train', action='store_true',
+                    help='profiling aid: skip the sampling leg of --mode train')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -171,6 +198,8 @@ def main():
 
         def sample_step():
             return model._dpm_sample(x_T, slots)[0]
+        if args.only_train and args.mode == 'train':
+            sample_step = lambda: None
         dt_s = timed(sample_step, args.steps if args.mode == 'sample' else max(2, args.steps // 2),
                      args.warmup if args.mode == 'sample' else 1)
         n_s = args.steps if args.mode == 'sample' else max(2, args.steps // 2)
@@ -238,20 +267,27 @@ def main():
             summ = kt.summary()
             model.bank().overlap_wgrad = overlap
             model.use_graph = not args.no_graph
-            ig = dict(summ['sdmi_igemm'])
-            if 'sdmi_wgrad' in summ:        # the MFMA GEMM family = forward/dgrad igemm + wgrad
+            ig = dict(summ['sdmi_igemm'])       # dominant kernel: the implicit-GEMM conv/linear
+            fam = dict(ig)
+            if 'sdmi_wgrad' in summ:            # MFMA GEMM family = forward/dgrad igemm + wgrad
                 for k in ('calls', 'ms', 'flops'):
-                    ig[k] += summ['sdmi_wgrad'][k]
+                    fam[k] += summ['sdmi_wgrad'][k]
             total_ms = sum(v['ms'] for v in summ.values())
             ach = ig['flops'] / (ig['ms'] * 1e-3) / 1e12
             peak = PEAK_TFLOPS[args.dtype]
-            out['roofline'] = {'bound': 'mfma', 'kernel': 'sdmi_igemm + sdmi_wgrad (implicit-GEMM conv/linear fwd, dgrad, wgrad)',
+            pmc = pmc_traffic('train' if args.mode == 'train' else 'sample')
+            out['roofline'] = {'bound': 'mfma', 'kernel': 'igemm_kernel (sdmi_igemm: implicit-GEMM conv/linear fwd + dgrad)',
                                'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak,
-                               'traffic': None, 'launches_per_step': ig['calls'],
+                               'traffic': pmc.get('bytes_per_launch'), 'traffic_unit': 'HBM bytes per launch',
+                               'traffic_source': pmc.get('source'),
+                               'mfma_util_pmc': pmc.get('mfma_util'),
+                               'algorithmic_gflop_per_launch': ig['flops'] / ig['calls'] / 1e9,
+                               'launches_per_step': ig['calls'],
                                'avg_launch_us': 1e3 * ig['ms'] / ig['calls'],
                                'igemm_ms_per_step': ig['ms'],
+                               'gemm_family_tflops_incl_wgrad': fam['flops'] / (fam['ms'] * 1e-3) / 1e12,
                                'all_kernels_ms_per_step_eager': total_ms,
-                               'algorithmic_gflop_per_step': ig['flops'] / 1e9}
+                               'algorithmic_gflop_per_step': fam['flops'] / 1e9}
             out['kernel_breakdown_ms'] = {k: round(v['ms'], 3) for k, v in
                                           sorted(summ.items(), key=lambda kv: -kv[1]['ms'])}
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
