@@ -254,6 +254,20 @@ int sdmi_geglu_bwd(const SdmiGegluBwdArgs* a, void* stream);
 /* y[b][p][c] = x[b][p][c] + pos[p][c] (SoftPositionEmbed, models/utils.py:60-63) */
 typedef struct { const void* x; const float* pos; void* y; int dtype; int B; long long per; } SdmiAddPosArgs;
 int sdmi_add_pos(const SdmiAddPosArgs* a, void* stream);
+/* Plain-SA spatial-broadcast decoder (img_based/models/slot_attention.py:343-364):
+ * y[g][r][c] = x[g][c] + pos[r][c]: every slot vector broadcast over the R decoder positions plus
+ * the decoder position embedding (x, pos fp32; y in `dtype`). */
+typedef struct { const float* x; const float* pos; void* y; int dtype; int G, R, C; } SdmiBroadcastPosArgs;
+int sdmi_broadcast_pos(const SdmiBroadcastPosArgs* a, void* stream);
+/* o [B*N][HW][ldo] (channels 0..2 rgb, 3 alpha logit) -> masks[b][n][p] = softmax_n(alpha),
+ * recon[b][p][0..2] = sum_n rgb*mask (fp32, pitch 4, channel 3 = 0).  slot_attention.py:357-363. */
+typedef struct { const void* o; float* recon; float* masks; int dtype; int B, N, HW, ldo; } SdmiSaCombineArgs;
+int sdmi_sa_combine(const SdmiSaCombineArgs* a, void* stream);
+/* backward: dout[bn][p][0..2] = mask*drecon, [3] = mask*(s_n - sum_m mask_m s_m), s_n = rgb_n.drecon */
+typedef struct {
+  const void* o; const float* masks; const float* drecon; void* dout; int dtype; int B, N, HW, ldo;
+} SdmiSaCombineBwdArgs;
+int sdmi_sa_combine_bwd(const SdmiSaCombineBwdArgs* a, void* stream);
 /* channel concat of two NHWC tensors (skip connections, unet.py:572) */
 typedef struct { const void* a; const void* b; void* y; int dtype; long long rows; int Ca, Cb; } SdmiConcatArgs;
 int sdmi_concat_channels(const SdmiConcatArgs* a, void* stream);

@@ -379,6 +379,38 @@ def ldm_loss(W, plan, ed, img, slots, t, noise, mc=128):
 
 
 # ---------------------------------------------------------------------------
+# a16: plain-SA spatial-broadcast CNN decoder + reconstruction loss
+# ---------------------------------------------------------------------------
+def sa_decode(W, slots, dec_plan, dec_resolution):
+    """img_based/models/slot_attention.py:343-364.  dec_plan = spec.sa_decoder_plan(...).
+    -> recon [B,3,H,W], recons [B,N,3,H,W], masks [B,N,1,H,W].  The transposed convs follow nerv's
+    deconv_norm_act (padding k//2, output_padding stride-1, ReLU; tools/ref_harness.py)."""
+    B, N, D = slots.shape
+    h, w = dec_resolution
+    x = slots.reshape(B * N, D, 1, 1).repeat(1, 1, h, w)
+    pos = _lin(W, 'decoder_pos_embedding.dense', W['decoder_pos_embedding.grid'])
+    x = x + pos.permute(0, 3, 1, 2)
+    for i, (kind, cin, cout, k, stride) in enumerate(dec_plan):
+        if kind == 'deconv':
+            x = F.relu(F.conv_transpose2d(x, W[f'decoder.{i}.0.weight'], W[f'decoder.{i}.0.bias'],
+                                          stride=stride, padding=k // 2, output_padding=stride - 1))
+        else:
+            x = F.conv2d(x, W[f'decoder.{i}.weight'], W[f'decoder.{i}.bias'])
+    H, Wd = x.shape[-2:]
+    out = x.view(B, N, 4, H, Wd)
+    recons = out[:, :, :3]
+    masks = F.softmax(out[:, :, 3:], dim=1)
+    return (recons * masks).sum(1), recons, masks
+
+
+def sa_forward_loss(W, img, plan, dec_plan, dec_resolution, num_iterations, eps=1e-6):
+    """SA.forward + calc_train_loss (slot_attention.py:318-375): -> loss, recon, masks, slots."""
+    slots, _ = sa_encode(W, img, plan, num_iterations, training=True, eps=eps)
+    recon, recons, masks = sa_decode(W, slots, dec_plan, dec_resolution)
+    return F.mse_loss(recon, img), recon, masks, slots
+
+
+# ---------------------------------------------------------------------------
 # a12/a13: DPM-Solver++ (singlestep, order 3, time_uniform) on the discrete schedule
 # ---------------------------------------------------------------------------
 class NoiseScheduleDiscrete:

@@ -152,6 +152,80 @@ __global__ void add_pos_kernel(SdmiAddPosArgs p) {
   }
 }
 
+
+template <typename T>
+__global__ void broadcast_pos_kernel(SdmiBroadcastPosArgs p) {
+  constexpr int VEC = Elem<T>::VEC;
+  const int cv = p.C / VEC;
+  const long long n = (long long)p.G * p.R * cv;
+  GRID_STRIDE(i, n) {
+    const int c = (int)(i % cv) * VEC;
+    const long long gr = i / cv;
+    const int r = (int)(gr % p.R);
+    const long long g = gr / p.R;
+    float v[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) v[j] = p.x[g * p.C + c + j] + p.pos[(long long)r * p.C + c + j];
+    *reinterpret_cast<uint4*>((T*)p.y + i * VEC) = pack16<T>(v);
+  }
+}
+
+template <typename T>
+__global__ void sa_combine_kernel(SdmiSaCombineArgs p) {
+  const long long n = (long long)p.B * p.HW;
+  GRID_STRIDE(i, n) {
+    const long long b = i / p.HW;
+    const int px = (int)(i - b * p.HW);
+    const T* o = (const T*)p.o + ((b * p.N) * p.HW + px) * p.ldo;
+    const long long sn = (long long)p.HW * p.ldo;       // slot stride
+    float mx = -INFINITY;
+    for (int s = 0; s < p.N; ++s) mx = fmaxf(mx, Elem<T>::ld(o + s * sn + 3));
+    float den = 0.f, r0 = 0.f, r1 = 0.f, r2 = 0.f;
+    for (int s = 0; s < p.N; ++s) {
+      const float e = __expf(Elem<T>::ld(o + s * sn + 3) - mx);
+      den += e;
+      r0 += e * Elem<T>::ld(o + s * sn);
+      r1 += e * Elem<T>::ld(o + s * sn + 1);
+      r2 += e * Elem<T>::ld(o + s * sn + 2);
+    }
+    const float inv = 1.f / den;
+    for (int s = 0; s < p.N; ++s)
+      p.masks[(b * p.N + s) * p.HW + px] = __expf(Elem<T>::ld(o + s * sn + 3) - mx) * inv;
+    float4 w = make_float4(r0 * inv, r1 * inv, r2 * inv, 0.f);
+    reinterpret_cast<float4*>(p.recon)[i] = w;
+  }
+}
+
+template <typename T>
+__global__ void sa_combine_bwd_kernel(SdmiSaCombineBwdArgs p) {
+  const long long n = (long long)p.B * p.HW;
+  GRID_STRIDE(i, n) {
+    const long long b = i / p.HW;
+    const int px = (int)(i - b * p.HW);
+    const long long sn = (long long)p.HW * p.ldo;
+    const T* o = (const T*)p.o + ((b * p.N) * p.HW + px) * p.ldo;
+    T* d = (T*)p.dout + ((b * p.N) * p.HW + px) * p.ldo;
+    const float4 dr = reinterpret_cast<const float4*>(p.drecon)[i];
+    float t = 0.f;
+    for (int s = 0; s < p.N; ++s) {
+      const float m = p.masks[(b * p.N + s) * p.HW + px];
+      const float sdot = Elem<T>::ld(o + s * sn) * dr.x + Elem<T>::ld(o + s * sn + 1) * dr.y +
+                         Elem<T>::ld(o + s * sn + 2) * dr.z;
+      t += m * sdot;
+    }
+    for (int s = 0; s < p.N; ++s) {
+      const float m = p.masks[(b * p.N + s) * p.HW + px];
+      const float sdot = Elem<T>::ld(o + s * sn) * dr.x + Elem<T>::ld(o + s * sn + 1) * dr.y +
+                         Elem<T>::ld(o + s * sn + 2) * dr.z;
+      Elem<T>::st(d + s * sn, m * dr.x);
+      Elem<T>::st(d + s * sn + 1, m * dr.y);
+      Elem<T>::st(d + s * sn + 2, m * dr.z);
+      Elem<T>::st(d + s * sn + 3, m * (sdot - t));
+      for (int c = 4; c < p.ldo; ++c) Elem<T>::st(d + s * sn + c, 0.f);
+    }
+  }
+}
+
 template <typename T>
 __global__ void concat_kernel(SdmiConcatArgs p) {
   constexpr int VEC = Elem<T>::VEC;
@@ -308,6 +382,29 @@ extern "C" int sdmi_add_pos(const SdmiAddPosArgs* a, void* stream) {
   if (a->dtype == SDMI_BF16) hipLaunchKernelGGL(add_pos_kernel<bf16_t>, dim3(g), dim3(EW_THREADS), 0, ST, *a);
   else hipLaunchKernelGGL(add_pos_kernel<float>, dim3(g), dim3(EW_THREADS), 0, ST, *a);
   return sdmi_check_launch("add_pos");
+}
+extern "C" int sdmi_broadcast_pos(const SdmiBroadcastPosArgs* a, void* stream) {
+  SDMI_REQUIRE(a && a->x && a->pos && a->y, "null pointer");
+  const int vec = a->dtype == SDMI_BF16 ? 8 : 4;
+  SDMI_REQUIRE(a->C % vec == 0, "C must be a multiple of the vector width");
+  const int g = ew_blocks((long long)a->G * a->R * (a->C / vec));
+  if (a->dtype == SDMI_BF16) hipLaunchKernelGGL(broadcast_pos_kernel<bf16_t>, dim3(g), dim3(EW_THREADS), 0, ST, *a);
+  else hipLaunchKernelGGL(broadcast_pos_kernel<float>, dim3(g), dim3(EW_THREADS), 0, ST, *a);
+  return sdmi_check_launch("broadcast_pos");
+}
+extern "C" int sdmi_sa_combine(const SdmiSaCombineArgs* a, void* stream) {
+  SDMI_REQUIRE(a && a->o && a->recon && a->masks && a->ldo >= 4 && a->N >= 1, "bad args");
+  const int g = ew_blocks((long long)a->B * a->HW);
+  if (a->dtype == SDMI_BF16) hipLaunchKernelGGL(sa_combine_kernel<bf16_t>, dim3(g), dim3(EW_THREADS), 0, ST, *a);
+  else hipLaunchKernelGGL(sa_combine_kernel<float>, dim3(g), dim3(EW_THREADS), 0, ST, *a);
+  return sdmi_check_launch("sa_combine");
+}
+extern "C" int sdmi_sa_combine_bwd(const SdmiSaCombineBwdArgs* a, void* stream) {
+  SDMI_REQUIRE(a && a->o && a->masks && a->drecon && a->dout && a->ldo >= 4, "bad args");
+  const int g = ew_blocks((long long)a->B * a->HW);
+  if (a->dtype == SDMI_BF16) hipLaunchKernelGGL(sa_combine_bwd_kernel<bf16_t>, dim3(g), dim3(EW_THREADS), 0, ST, *a);
+  else hipLaunchKernelGGL(sa_combine_bwd_kernel<float>, dim3(g), dim3(EW_THREADS), 0, ST, *a);
+  return sdmi_check_launch("sa_combine_bwd");
 }
 extern "C" int sdmi_concat_channels(const SdmiConcatArgs* a, void* stream) {
   SDMI_REQUIRE(a && a->a && a->b && a->y, "null pointer");

@@ -282,3 +282,25 @@ def vae_decode(K, z, ed, prefix='dm_decoder.vae.vqvae', scale_factor=1.0, quanti
                        ups=True)
     h = K.gn(h, d + '.norm_out', eps=1e-6, act='silu')
     return K.conv(h, d + '.conv_out.weight', d + '.conv_out.bias', out_dtype=torch.float32, ldc=4)
+
+
+# ------------------------------------------------------------------------------------------
+# a16: plain-SA spatial-broadcast decoder (img_based/models/slot_attention.py:343-364)
+# ------------------------------------------------------------------------------------------
+def sa_decode(K, slots, dec_plan, dec_resolution, dtype):
+    """slots [B,N,D] fp32 -> recon [B,H,W,4] fp32 (channel 3 = 0), masks [B,N,H*W] fp32,
+    o [B*N,H,W,ld] (per-slot rgb + alpha logit, compute dtype)."""
+    B, N, D = slots.shape
+    h, w = dec_resolution
+    pos = position_embedding(K, 'decoder_pos_embedding')                 # [h*w, D] fp32
+    x = K.broadcast_pos(slots.reshape(B * N, D), pos, dtype).view(B * N, h, w, D)
+    for i, (kind, cin, cout, k, stride) in enumerate(dec_plan):
+        if kind == 'deconv':
+            x = K.deconv(x, f'decoder.{i}.0.weight', f'decoder.{i}.0.bias', k=k, stride=stride,
+                         pad=k // 2, act='relu')
+        else:
+            vec = 8 if dtype == torch.bfloat16 else 4
+            x = K.conv(x, f'decoder.{i}.weight', f'decoder.{i}.bias', kh=k, kw=k, stride=1,
+                       pad=(k // 2,) * 4, ldc=(cout + vec - 1) // vec * vec)
+    recon, masks = K.sa_combine(x, B, N)
+    return recon, masks, x

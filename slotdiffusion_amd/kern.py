@@ -256,6 +256,20 @@ class Kern:
         return ops.group_norm(x, self.wb.f(name + '.weight'), self.wb.f(name + '.bias'), eps=eps,
                               act=act, residual=residual)
 
+    def deconv(self, x, wname, bname, *, k, stride, pad, act='relu'):
+        return deconv_forward(self.wb, x, wname, bname, k, stride, pad, act)
+
+    def broadcast_pos(self, x, pos, dtype):
+        return BroadcastPosFn.forward(None, x, pos, dtype)
+
+    def sa_combine(self, o, B, N):
+        BN, H, W_, ld = o.shape
+        recon = torch.empty((B, H, W_, 4), dtype=torch.float32, device=o.device)
+        masks = torch.empty((B, N, H * W_), dtype=torch.float32, device=o.device)
+        call('sdmi_sa_combine', _st(), o=_p(o), recon=_p(recon), masks=_p(masks), dtype=_DT[o.dtype],
+             B=B, N=N, HW=H * W_, ldo=ld)
+        return recon, masks
+
     def ln(self, x, name):
         return ops.layer_norm(x, self.wb.f(name + '.weight'), self.wb.f(name + '.bias'))
 
@@ -742,6 +756,147 @@ class DropoutFn(torch.autograd.Function):
         return dx, None, None, None
 
 
+
+# ------------------------------------------------------------------------------------------
+# plain-SA decoder pieces (img_based/models/slot_attention.py:343-364)
+# ------------------------------------------------------------------------------------------
+def _deconv_geom(x, w, k, stride, pad):
+    B, H, W_, Cin = x.shape
+    Cout = w.shape[1] // (k * k)
+    Ho = (H - 1) * stride - 2 * pad + k + (stride - 1)
+    Wo = (W_ - 1) * stride - 2 * pad + k + (stride - 1)
+    return B, H, W_, Cin, Cout, Ho, Wo
+
+
+def deconv_forward(wb, x, wname, bname, k, stride, pad, act):
+    """ConvTranspose2d(k, stride, padding=pad, output_padding=stride-1) on NHWC.  The parameter
+    [Cin, Cout, k, k] lies in the arena as [Cin][k][k][Cout] = the weight of the stride-`stride`
+    convolution this layer is the data gradient of, so the forward pass is sdmi_igemm on the
+    flipped/transposed operand with virtual zero insertion (exactly GemmFn's dgrad launch)."""
+    dt = x.dtype
+    w = wb.w(wname, dt)                           # [Cin][k*k*Cout]
+    B, H, W_, Cin, Cout, Ho, Wo = _deconv_geom(x, w, k, stride, pad)
+    wd = wb.wd(wname, dt, k, k, Cout)             # [Cout][k'][k'][Cin]
+    y = torch.empty((B, Ho, Wo, Cout), dtype=dt, device=x.device)
+    call('sdmi_igemm', _st(), a=_p(x), w=_p(wd), out=_p(y), bias=_p(wb.b(bname)), dtype=_DT[dt],
+         out_dtype=_DT[dt], M=B * Ho * Wo, N=Cout, K=k * k * Cin, lda=Cin, ldw=k * k * Cin, ldc=Cout,
+         B=B, H=H, W=W_, Cin=Cin, Ho=Ho, Wo=Wo, KH=k, KW=k, stride=1, pad_t=k - 1 - pad,
+         pad_l=k - 1 - pad, ups=0, act=_lib.ACT[act], alpha=1.0, split_k=1, batch=1,
+         zins=(stride if stride > 1 else 0))
+    return y
+
+
+class DeconvFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, anchor, wb, wname, bname, k, stride, pad, act):
+        y = deconv_forward(wb, x, wname, bname, k, stride, pad, act)
+        ctx.save_for_backward(x, y)
+        ctx.cfg = (wb, wname, bname, k, stride, pad, act)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y = ctx.saved_tensors
+        wb, wname, bname, k, stride, pad, act = ctx.cfg
+        dt = x.dtype
+        dy = dy.contiguous()
+        w = wb.w(wname, dt)
+        B, H, W_, Cin, Cout, Ho, Wo = _deconv_geom(x, w, k, stride, pad)
+        if act:                                   # relu: act'(z) from the output
+            dz = torch.empty_like(dy)
+            call('sdmi_act_bwd', _st(), x=_p(y), dy=_p(dy), dx=_p(dz), dtype=_DT[dt],
+                 act=_lib.ACT[act], n=dy.numel())
+        else:
+            dz = dy
+        # data gradient = the strided convolution itself
+        dx = ops.conv2d(dz, w, None, kh=k, kw=k, stride=stride, pad=(pad, pad, pad, pad)) \
+            if ctx.needs_input_grad[0] else None
+        # weight gradient: roles swapped (A = dz gathered with the stride, "dY" = x)
+        M, N, K = B * H * W_, Cin, k * k * Cout
+        mt = 64 if dt == torch.bfloat16 else 32
+        tiles = ((N + 127) // 128) * ((K + 127) // 128)
+        splits = max(1, min((512 + tiles - 1) // tiles, M // (8 * mt), 512))
+        ws = torch.empty((splits * (N * K + N),), dtype=torch.float32, device=x.device)
+        call('sdmi_wgrad', _st(), a=_p(dz), dy=_p(x), dw=_p(_grads_of(wb, wname)), dbias=0,
+             workspace=_p(ws), dtype=_DT[dt], M=M, N=N, K=K, lda=Cout, ldy=Cin, B=B, H=Ho, W=Wo,
+             Cin=Cout, Ho=H, Wo=W_, KH=k, KW=k, stride=stride, pad_t=pad, pad_l=pad, ups=0,
+             splits=splits, accumulate=1)
+        # bias gradient: column sums of dz in 1024-row chunks, folded into the arena
+        rows = B * Ho * Wo
+        chunk = 1024 if rows % 1024 == 0 else rows
+        part = torch.empty((rows // chunk, Cout), dtype=torch.float32, device=x.device)
+        call('sdmi_rowgroup_sum', _st(), x=_p(dz), out=_p(part), dtype=_DT[dt], groups=rows // chunk,
+             rows_per=chunk, N=Cout, ldx=Cout)
+        gb = _grads_of(wb, bname)
+        tot = torch.empty((1, Cout), dtype=torch.float32, device=x.device)
+        call('sdmi_rowgroup_sum', _st(), x=_p(part), out=_p(tot), dtype=_lib.F32, groups=1,
+             rows_per=rows // chunk, N=Cout, ldx=Cout)
+        call('sdmi_add', _st(), x=_p(gb), z=_p(tot), y=_p(gb), dtype=_lib.F32, n=Cout)
+        return dx, None, None, None, None, None, None, None, None
+
+
+class BroadcastPosFn(torch.autograd.Function):
+    """[G, C] slot vectors -> [G, R, C] (+ position embedding [R, C])."""
+
+    @staticmethod
+    def forward(ctx, x, pos, dtype):
+        G, C = x.shape
+        R = pos.shape[0]
+        y = torch.empty((G, R, C), dtype=dtype, device=x.device)
+        call('sdmi_broadcast_pos', _st(), x=_p(x.contiguous()), pos=_p(pos.contiguous()), y=_p(y),
+             dtype=_DT[dtype], G=G, R=R, C=C)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        G, R, C = dy.shape
+        dx = torch.empty((G, C), dtype=torch.float32, device=dy.device)
+        call('sdmi_rowgroup_sum', _st(), x=_p(dy), out=_p(dx), dtype=_DT[dy.dtype], groups=G,
+             rows_per=R, N=C, ldx=C)
+        dpos = torch.empty((R, C), dtype=torch.float32, device=dy.device)
+        call('sdmi_rowgroup_sum', _st(), x=_p(dy), out=_p(dpos), dtype=_DT[dy.dtype], groups=1,
+             rows_per=G, N=R * C, ldx=R * C)
+        return dx, dpos, None
+
+
+class SaCombineFn(torch.autograd.Function):
+    """o [B*N, H, W, ld] (rgb + alpha logit) -> recon [B, H, W, 4] fp32, masks [B, N, H*W] fp32."""
+
+    @staticmethod
+    def forward(ctx, o, B, N):
+        BN, H, W_, ld = o.shape
+        recon = torch.empty((B, H, W_, 4), dtype=torch.float32, device=o.device)
+        masks = torch.empty((B, N, H * W_), dtype=torch.float32, device=o.device)
+        call('sdmi_sa_combine', _st(), o=_p(o), recon=_p(recon), masks=_p(masks), dtype=_DT[o.dtype],
+             B=B, N=N, HW=H * W_, ldo=ld)
+        ctx.save_for_backward(o, masks)
+        ctx.mark_non_differentiable(masks)
+        return recon, masks
+
+    @staticmethod
+    def backward(ctx, drecon, _dm):
+        o, masks = ctx.saved_tensors
+        B, N = masks.shape[0], masks.shape[1]
+        dout = torch.empty_like(o)
+        call('sdmi_sa_combine_bwd', _st(), o=_p(o), masks=_p(masks), drecon=_p(drecon.contiguous()),
+             dout=_p(dout), dtype=_DT[o.dtype], B=B, N=N, HW=masks.shape[2], ldo=o.shape[-1])
+        return dout, None, None
+
+
+class NhwcToNchwFn(torch.autograd.Function):
+    """fp32 [B, H, W, Cpad] -> [B, C, H, W] with gradient (user-facing recon_img)."""
+
+    @staticmethod
+    def forward(ctx, x, C):
+        ctx.cpad = x.shape[-1]
+        return ops.nhwc_to_nchw(x, C)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.nchw_to_nhwc(dy.contiguous(), torch.float32, ctx.cpad), None
+
+
 class KernGrad(Kern):
     """Training provider (autograd)."""
     training = True
@@ -783,6 +938,15 @@ class KernGrad(Kern):
 
     def gn(self, x, name, *, eps, act=None, residual=None):
         return GroupNormFn.apply(x, residual, self.wb.anchor, self.wb, name, eps, act)
+
+    def deconv(self, x, wname, bname, *, k, stride, pad, act='relu'):
+        return DeconvFn.apply(x, self.wb.anchor, self.wb, wname, bname, k, stride, pad, act)
+
+    def broadcast_pos(self, x, pos, dtype):
+        return BroadcastPosFn.apply(x, pos, dtype)
+
+    def sa_combine(self, o, B, N):
+        return SaCombineFn.apply(o, B, N)
 
     def ln(self, x, name):
         return LayerNormFn.apply(x, self.wb.anchor, self.wb, name)

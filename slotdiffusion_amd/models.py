@@ -146,50 +146,12 @@ class LDM(_Owned):
         return {'samples': self.vae.decode(ret)}
 
 
-class SADiffusion(FlatModule):
-    """SlotDiffusion on images (registry name 'SADiffusion')."""
-
-    def __init__(self, resolution, slot_dict, enc_dict, dec_dict, loss_dict=None, eps=1e-6,
-                 compute_dtype=None, seed=0):
-        dec_dict = copy.deepcopy(dec_dict)
-        dd = dec_dict['diffusion_dict']
-        sp = self._make_spec(resolution, slot_dict, enc_dict, dec_dict)
-        sched = {k: dd[k] for k in ('timesteps', 'beta_schedule', 'linear_start', 'linear_end')
-                 if k in dd}
-        super().__init__(sp, schedule_kwargs=sched, seed=seed,
-                         node_classes={'dm_decoder': LDM, 'dm_decoder.vae': VQVAEWrapper})
-        assert dd.get('pred_target', 'eps') == 'eps', 'hot path covers eps-prediction'
-        self.resolution = tuple(resolution)
-        self.eps = eps
-        self.slot_dict, self.enc_dict, self.dec_dict = dict(slot_dict), dict(enc_dict), dec_dict
-        self.loss_dict = dict(loss_dict or {'use_denoise_loss': True})
-        self.num_slots = slot_dict['num_slots']
-        self.slot_size = slot_dict['slot_size']
-        self.num_iterations = slot_dict['num_iterations']
-        div = 8 if enc_dict['use_layer4'] else 4
-        self.visual_resolution = tuple(r // div for r in self.resolution)
-        self.latent_res = tuple(dec_dict['resolution'])
-        self.ed = dec_dict['vae_dict']['enc_dec_dict']
-        self.z_scale = float(dd.get('z_scale_factor', 1.))
-        self.vq_key = 'dm_decoder.vae.vqvae.quantize.embedding.weight'
-        self.rplan = spec.resnet18_plan(enc_dict['use_layer4'])
-        self.unet_cfg = dec_dict['unet_dict']
-        self.testing = False
-        # ResBlock dropout (unet_dict['dropout']); parity tests switch it off (RNG streams differ)
-        self.train_dropout = float(dec_dict['unet_dict'].get('dropout', 0.0))
-        self.compute_dtype = compute_dtype or default_compute_dtype()
-        self.dm_decoder._bind(self)
-        self.dm_decoder.vae._bind(self)
-        self._bank = None
-        self._unet = None
-        self._plan = None
-        self._Kinf = self._Kgrad = None
-        self.step_seed = None      # device word mixed into dropout seeds (see optim.GraphedTrainStep)
-        self.use_graph = os.environ.get('SDMI_GRAPH', '1') != '0'
-        self._graph_cache = {}
-
-    def _make_spec(self, resolution, slot_dict, enc_dict, dec_dict):
-        return spec.sa_diffusion(resolution, slot_dict, enc_dict, dec_dict)
+class SlotModelBase(FlatModule):
+    """Plumbing shared by the slot models: compute dtype, weight bank / kernel providers,
+    checkpoint loading (nerv BaseModel surface: load_weight, device, dtype)."""
+    _bank = None
+    _Kinf = _Kgrad = None
+    compute_dtype = None
 
     # -- plumbing ------------------------------------------------------------------------
     @property
@@ -248,13 +210,59 @@ class SADiffusion(FlatModule):
                 self.shadow_arena(refresh=True)
         self._graph_cache = {}
 
+    def _to_nhwc(self, img):
+        return ops.nchw_to_nhwc(img.float(), self.compute_dtype, ops.vec_of(self.compute_dtype))
+
+
+class SADiffusion(SlotModelBase):
+    """SlotDiffusion on images (registry name 'SADiffusion')."""
+
+    def __init__(self, resolution, slot_dict, enc_dict, dec_dict, loss_dict=None, eps=1e-6,
+                 compute_dtype=None, seed=0):
+        dec_dict = copy.deepcopy(dec_dict)
+        dd = dec_dict['diffusion_dict']
+        sp = self._make_spec(resolution, slot_dict, enc_dict, dec_dict)
+        sched = {k: dd[k] for k in ('timesteps', 'beta_schedule', 'linear_start', 'linear_end')
+                 if k in dd}
+        super().__init__(sp, schedule_kwargs=sched, seed=seed,
+                         node_classes={'dm_decoder': LDM, 'dm_decoder.vae': VQVAEWrapper})
+        assert dd.get('pred_target', 'eps') == 'eps', 'hot path covers eps-prediction'
+        self.resolution = tuple(resolution)
+        self.eps = eps
+        self.slot_dict, self.enc_dict, self.dec_dict = dict(slot_dict), dict(enc_dict), dec_dict
+        self.loss_dict = dict(loss_dict or {'use_denoise_loss': True})
+        self.num_slots = slot_dict['num_slots']
+        self.slot_size = slot_dict['slot_size']
+        self.num_iterations = slot_dict['num_iterations']
+        div = 8 if enc_dict['use_layer4'] else 4
+        self.visual_resolution = tuple(r // div for r in self.resolution)
+        self.latent_res = tuple(dec_dict['resolution'])
+        self.ed = dec_dict['vae_dict']['enc_dec_dict']
+        self.z_scale = float(dd.get('z_scale_factor', 1.))
+        self.vq_key = 'dm_decoder.vae.vqvae.quantize.embedding.weight'
+        self.rplan = spec.resnet18_plan(enc_dict['use_layer4'])
+        self.unet_cfg = dec_dict['unet_dict']
+        self.testing = False
+        # ResBlock dropout (unet_dict['dropout']); parity tests switch it off (RNG streams differ)
+        self.train_dropout = float(dec_dict['unet_dict'].get('dropout', 0.0))
+        self.compute_dtype = compute_dtype or default_compute_dtype()
+        self.dm_decoder._bind(self)
+        self.dm_decoder.vae._bind(self)
+        self._bank = None
+        self._unet = None
+        self._plan = None
+        self._Kinf = self._Kgrad = None
+        self.step_seed = None      # device word mixed into dropout seeds (see optim.GraphedTrainStep)
+        self.use_graph = os.environ.get('SDMI_GRAPH', '1') != '0'
+        self._graph_cache = {}
+
+    def _make_spec(self, resolution, slot_dict, enc_dict, dec_dict):
+        return spec.sa_diffusion(resolution, slot_dict, enc_dict, dec_dict)
+
     def unet(self):
         if self._unet is None:
             self._unet = engine.UNetRunner(self.unet_cfg)
         return self._unet
-
-    def _to_nhwc(self, img):
-        return ops.nchw_to_nhwc(img.float(), self.compute_dtype, ops.vec_of(self.compute_dtype))
 
     def _latent_nhwc(self, z):
         return ops.nchw_to_nhwc(z.float(), torch.float32, 4)
@@ -469,9 +477,89 @@ class SAViDiffusion(SADiffusion):
         return log
 
 
+class SA(SlotModelBase):
+    """Plain Slot Attention auto-encoder (registry name 'SA', BASELINE config 0):
+    img_based/models/slot_attention.py:126-420 -- ResNet-18 encoder + Slot Attention + the
+    spatial-broadcast transposed-conv decoder, trained with an image reconstruction loss."""
+
+    def __init__(self, resolution, slot_dict, enc_dict, dec_dict, loss_dict=None, eps=1e-6,
+                 compute_dtype=None, seed=0):
+        sp = spec.sa_model(resolution, slot_dict, enc_dict, dec_dict)
+        super().__init__(sp, seed=seed)
+        self.resolution = tuple(resolution)
+        self.eps = eps
+        self.slot_dict, self.enc_dict, self.dec_dict = dict(slot_dict), dict(enc_dict), dict(dec_dict)
+        self.loss_dict = dict(loss_dict or {'use_img_recon_loss': True})
+        assert self.loss_dict.get('use_img_recon_loss', True)
+        self.num_slots = slot_dict['num_slots']
+        self.slot_size = slot_dict['slot_size']
+        self.num_iterations = slot_dict['num_iterations']
+        div = 8 if enc_dict['use_layer4'] else 4
+        self.visual_resolution = tuple(r // div for r in self.resolution)
+        self.dec_resolution = tuple(dec_dict['dec_resolution'])
+        self.rplan = spec.resnet18_plan(enc_dict['use_layer4'])
+        self.dplan = spec.sa_decoder_plan(self.resolution, dec_dict)
+        self.testing = False
+        self.compute_dtype = compute_dtype or default_compute_dtype()
+        self.step_seed = None
+        self._graph_cache = {}
+
+    def encode(self, img, init_slots=None):
+        """slot_attention.py:318-334 -> slots [B,N,D] fp32."""
+        grad = self.training and torch.is_grad_enabled()
+        Kp = self.KG() if grad else self.K()
+        with torch.set_grad_enabled(grad):
+            tok = engine.encoder_out(Kp, self._to_nhwc(img), self.rplan)
+            init = self.init_latents[0] if init_slots is None else init_slots.contiguous().float()
+            slots, _ = engine.slot_attention(Kp, tok, init, self.num_iterations, self.eps)
+        return slots
+
+    def decode(self, slots):
+        """slot_attention.py:343-364 -> recon [B,3,H,W], recons [B,N,3,H,W], masks [B,N,1,H,W],
+        slots."""
+        B, N, _ = slots.shape
+        H, W = self.resolution
+        grad = self.training and torch.is_grad_enabled() and slots.requires_grad
+        Kp = self.KG() if grad else self.K()
+        with torch.set_grad_enabled(grad):
+            recon, masks, o = engine.sa_decode(Kp, slots.float(), self.dplan, self.dec_resolution,
+                                               self.compute_dtype)
+            recon_img = kern.NhwcToNchwFn.apply(recon, 3) if grad else ops.nhwc_to_nchw(recon, 3)
+        with torch.no_grad():
+            recons = ops.nhwc_to_nchw(o.detach(), 3).view(B, N, 3, H, W)
+        self._last_recon_nhwc = recon
+        return recon_img, recons, masks.detach().view(B, N, 1, H, W), slots
+
+    def forward(self, data_dict):
+        slots = self.encode(data_dict['img'])
+        if self.testing:
+            return {'slots': slots}
+        recon_img, recons, masks, _ = self.decode(slots)
+        return {'recon_img': recon_img, 'recons': recons, 'masks': masks, 'slots': slots}
+
+    def calc_train_loss(self, data_dict, out_dict):
+        """slot_attention.py:366-375: {'img_recon_loss': mse(recon_img, img)}."""
+        recon, img = out_dict['recon_img'], data_dict['img']
+        if recon.requires_grad:
+            # NHWC pair (4th channel zero in both): mean over the 3 real channels -> scale 4/3
+            tgt = ops.nchw_to_nhwc(img.float(), torch.float32, 4)
+            return {'img_recon_loss': kern.MseFn.apply(self._last_recon_nhwc, tgt, 4.0 / 3.0)}
+        tgt = ops.nchw_to_nhwc(img.float(), torch.float32, 4)
+        val = ops.mse(ops.nchw_to_nhwc(recon, torch.float32, 4), tgt) * (4.0 / 3.0)
+        return {'img_recon_loss': val.reshape(())}
+
+    @torch.no_grad()
+    def calc_eval_loss(self, data_dict, out_dict):
+        return self.calc_train_loss(data_dict, {k: (v.detach() if torch.is_tensor(v) else v)
+                                                for k, v in out_dict.items()})
+
+
 def build_model(params):
     """Registry (img_based/models/__init__.py:12-39, video_based/models/__init__.py:12-33) for the
     hot-path models."""
+    if params.model == 'SA':
+        return SA(resolution=params.resolution, slot_dict=params.slot_dict, enc_dict=params.enc_dict,
+                  dec_dict=params.dec_dict, loss_dict=params.loss_dict)
     if params.model == 'SAViDiffusion':
         return SAViDiffusion(resolution=params.resolution, clip_len=params.input_frames,
                              slot_dict=params.slot_dict, enc_dict=params.enc_dict,

@@ -345,6 +345,42 @@ def sa_encoder_side(resolution, slot_dict, enc_dict):
     return out, vis_ch, vis_res
 
 
+def deconv(name, cin, cout, k):
+    """nn.ConvTranspose2d(cin, cout, k): weight [cin, cout, k, k] (torch fan_in = cout*k*k)."""
+    fi = cout * k * k
+    return [_p(f'{name}.weight', (cin, cout, k, k), 'lin', fi), _p(f'{name}.bias', (cout,), 'lin', fi)]
+
+
+def sa_decoder_plan(resolution, dec_dict):
+    """[(kind, cin, cout, k, stride)] of the plain-SA CNN decoder (img_based/models/
+    slot_attention.py:251-292): stride-2 transposed convs until the image resolution is reached,
+    then stride 1; final 1x1 conv to rgb + alpha."""
+    ch = list(dec_dict['dec_channels'])
+    k = dec_dict['dec_ks']
+    size = tuple(dec_dict['dec_resolution'])
+    plan, stride = [], 2
+    for i in range(len(ch) - 1):
+        if size == tuple(resolution):
+            stride = 1
+        plan.append(('deconv', ch[i], ch[i + 1], k, stride))
+        size = tuple((v - 1) * stride - 2 * (k // 2) + (k - 1) + (stride - 1) + 1 for v in size)
+    assert size == tuple(resolution), 'decoder output does not match the image resolution'
+    plan.append(('conv', ch[-1], 4, 1, 1))
+    return plan
+
+
+def sa_model(resolution, slot_dict, enc_dict, dec_dict):
+    """Plain Slot Attention auto-encoder (registry name 'SA'), key order of the reference
+    constructor (slot_attention.py:153-156)."""
+    out, _, _ = sa_encoder_side(resolution, slot_dict, enc_dict)
+    assert dec_dict.get('dec_norm', '') == '', 'decoder norm layers are not part of the path'
+    assert dec_dict['dec_channels'][0] == slot_dict['slot_size']
+    for i, (kind, cin, cout, k, _) in enumerate(sa_decoder_plan(resolution, dec_dict)):
+        out += deconv(f'decoder.{i}.0', cin, cout, k) if kind == 'deconv' else conv(f'decoder.{i}', cin, cout, k)
+    out += soft_pos_embed('decoder_pos_embedding', slot_dict['slot_size'], dec_dict['dec_resolution'])
+    return out
+
+
 def sa_diffusion(resolution, slot_dict, enc_dict, dec_dict):
     out, _, _ = sa_encoder_side(resolution, slot_dict, enc_dict)
     return out + ldm('dm_decoder', dec_dict)

@@ -42,6 +42,27 @@ def clevrtex_cfg(num_slots=7):
         loss_dict=dict(use_denoise_loss=True))
 
 
+def sa_plain_cfg(num_slots=7):
+    """Restates img_based/configs/sa/sa_clevrtex_params-res128.py (values only; BASELINE.json
+    config 0 asks 7 slots)."""
+    d = 192
+    return dict(resolution=(128, 128),
+                slot_dict=dict(num_slots=num_slots, slot_size=d, slot_mlp_size=2 * d, num_iterations=3),
+                enc_dict=dict(resnet='resnet18', use_layer4=False, enc_out_channels=d),
+                dec_dict=dict(dec_channels=(d, 128, 128, 128, 128), dec_resolution=(8, 8), dec_ks=5,
+                              dec_norm=''),
+                loss_dict=dict(use_img_recon_loss=True))
+
+
+def oracle_weights_sa(cfg):
+    from slotdiffusion_amd.module import build_grid
+    sp = spec.sa_model(cfg['resolution'], cfg['slot_dict'], cfg['enc_dict'], cfg['dec_dict'])
+    W = {}
+    for i, p in enumerate(sp):
+        W[p.name] = build_grid(p.shape[1:3]) if p.init == 'buf:grid' else det_value(p.name, p.shape, i)
+    return W
+
+
 def load_golden(name='sadiff_b2.npz'):
     z = np.load(os.path.join(GOLD, name))
     return {k: (torch.from_numpy(z[k]) if z[k].dtype.kind in 'fiu' else z[k]) for k in z.files}

@@ -195,3 +195,72 @@ def test_video_model_fp32():
     assert R['video_masks_eval_argmax_agree'] == 1.0
     assert abs(R['video_loss'] - R['video_loss_ref']) <= 1e-4
     assert R['video_grad_norm_max_rel_vs_reference'] <= 2e-2 and max(errs.values()) <= 2e-2
+
+
+def _plain_sa(dtype):
+    from slotdiffusion_amd.models import SA
+    cfg = C.sa_plain_cfg()
+    m = SA(cfg['resolution'], cfg['slot_dict'], cfg['enc_dict'], cfg['dec_dict'], cfg['loss_dict'],
+           compute_dtype=dtype)
+    det_fill_(m.state_dict().items(), skip=is_buffer_name)
+    return m.cuda().train()
+
+
+def test_plain_sa_autoencoder_fp32():
+    """Row a16 / BASELINE config 0: plain Slot Attention auto-encoder (transposed-conv decoder,
+    slot softmax compositing, reconstruction loss) forward + backward against the reference run
+    in tests/golden/sa_b2.npz."""
+    G = C.load_golden('sa_b2.npz')
+    img = C.make_inputs(2)[0].cuda()
+    m = _plain_sa(torch.float32)
+    m.grad_arena().zero_()
+    out = m(dict(img=img))
+    loss = m.calc_train_loss(dict(img=img), out)['img_recon_loss']
+    loss.backward()
+    torch.cuda.synchronize()
+    REPORT['sa_slots'] = maxerr(out['slots'], G['slots'])
+    REPORT['sa_recon'] = maxerr(out['recon_img'][:, :, 1::2, ::2], G['recon_img_sub2'])
+    REPORT['sa_masks'] = maxerr(out['masks'][:, :, 0, ::4, 1::4], G['masks_sub4'])
+    REPORT['sa_recons'] = maxerr(out['recons'][:, :, :, 1::4, ::4], G['recons_sub4'])
+    REPORT['sa_loss_rel'] = abs(float(loss) - float(G['img_recon_loss'])) / float(G['img_recon_loss'])
+    agree = float((out['masks'][:, :, 0].argmax(1).cpu() == G['masks_argmax']).float().mean())
+    REPORT['sa_mask_argmax_agree'] = agree
+    names = [str(n) for n in G['param_names']]
+    named = dict(m.named_parameters())
+    gn = torch.stack([named[n].grad.double().norm().cpu() for n in names]).float()
+    rel = (gn - G['grad_norms']).abs() / (G['grad_norms'].abs() + 1e-9)
+    REPORT['sa_gradnorm_rel_max'] = float(rel.max())
+    g0 = named['decoder.0.0.weight'].grad.cpu()[::4, ::4]
+    REPORT['sa_deconv_wgrad_rel'] = float((g0 - G['grad/decoder.0.0.weight']).abs().max() /
+                                          G['grad/decoder.0.0.weight'].abs().max())
+    for k in ('decoder.3.0.bias', 'decoder.4.weight', 'decoder_pos_embedding.dense.weight', 'init_latents'):
+        ref = G['grad/' + k]
+        REPORT['sa_grad/' + k] = float((named[k].grad.cpu() - ref).abs().max() / ref.abs().max())
+    _dump()
+    assert REPORT['sa_slots'] <= 1e-4 and REPORT['sa_recon'] <= 1e-4 and REPORT['sa_masks'] <= 1e-4
+    assert REPORT['sa_recons'] <= 1e-4 and REPORT['sa_loss_rel'] <= 1e-5
+    assert agree == 1.0
+    assert REPORT['sa_gradnorm_rel_max'] <= 1e-2
+    assert REPORT['sa_deconv_wgrad_rel'] <= 5e-3
+    for k in ('decoder.3.0.bias', 'decoder.4.weight', 'decoder_pos_embedding.dense.weight', 'init_latents'):
+        assert REPORT['sa_grad/' + k] <= 1e-2, k
+
+
+def test_plain_sa_autoencoder_bf16_close():
+    G = C.load_golden('sa_b2.npz')
+    img = C.make_inputs(2)[0].cuda()
+    m = _plain_sa(torch.bfloat16)
+    m.grad_arena().zero_()
+    out = m(dict(img=img))
+    loss = m.calc_train_loss(dict(img=img), out)['img_recon_loss']
+    loss.backward()
+    REPORT['sa_bf16_loss_rel'] = abs(float(loss) - float(G['img_recon_loss'])) / float(G['img_recon_loss'])
+    named = dict(m.named_parameters())
+    names = [str(n) for n in G['param_names']]
+    gn = torch.stack([named[n].grad.double().norm().cpu() for n in names]).float()
+    big = G['grad_norms'] > 1e-6 * G['grad_norms'].max()
+    rel = ((gn - G['grad_norms']).abs() / G['grad_norms'].abs())[big]
+    REPORT['sa_bf16_gradnorm_rel_median'] = float(rel.median())
+    _dump()
+    assert REPORT['sa_bf16_loss_rel'] <= 2e-2
+    assert float(rel.median()) <= 5e-2

@@ -160,3 +160,35 @@ def test_video_model_oracle():
         assert torch.equal(masks.argmax(2), G['masks_train_argmax'].long())
         _, me = O.savi_encode(W, img, rplan, 2, False, 2, 4)
         assert torch.equal(me.argmax(2), G['masks_eval_argmax'].long())
+
+
+def test_plain_sa_oracle_matches_reference():
+    """Row a16 (SA.decode, config 0): the oracle's spatial-broadcast decoder + reconstruction loss
+    and their gradients against the reference run captured in tests/golden/sa_b2.npz; the spec's
+    key order must equal the reference state_dict."""
+    from slotdiffusion_amd import spec
+    cfg = C.sa_plain_cfg()
+    G = C.load_golden('sa_b2.npz')
+    sp = spec.sa_model(cfg['resolution'], cfg['slot_dict'], cfg['enc_dict'], cfg['dec_dict'])
+    assert [p.name for p in sp] == [str(k) for k in G['state_dict_keys']]
+    W = C.oracle_weights_sa(cfg)
+    names = [str(n) for n in G['param_names']]
+    for n in names:
+        W[n].requires_grad_(True)
+    img = C.make_inputs(2)[0]
+    plan = spec.resnet18_plan(False)
+    dplan = spec.sa_decoder_plan(cfg['resolution'], cfg['dec_dict'])
+    loss, recon, masks, slots = O.sa_forward_loss(W, img, plan, dplan, cfg['dec_dict']['dec_resolution'],
+                                                  cfg['slot_dict']['num_iterations'])
+    loss.backward()
+    assert float((slots - G['slots']).abs().max()) <= 2e-5
+    assert float((recon[:, :, 1::2, ::2] - G['recon_img_sub2']).abs().max()) <= 2e-5
+    assert float((masks[:, :, 0, ::4, 1::4] - G['masks_sub4']).abs().max()) <= 2e-5
+    assert torch.equal(masks[:, :, 0].argmax(1), G['masks_argmax'])
+    assert abs(float(loss) - float(G['img_recon_loss'])) <= 1e-6 * max(1.0, float(G['img_recon_loss']))
+    gn = torch.stack([W[n].grad.double().norm() for n in names]).float()
+    # (project_q.0.bias has a mathematically zero gradient: softmax over slots is shift invariant)
+    rel = ((gn - G['grad_norms']).abs() / (G['grad_norms'].abs() + 1e-9))
+    assert float(rel.max()) <= 5e-3, float(rel.max())
+    g0 = W['decoder.0.0.weight'].grad[::4, ::4]
+    assert float((g0 - G['grad/decoder.0.0.weight']).abs().max()) <= 2e-3 * float(G['grad/decoder.0.0.weight'].abs().max())

@@ -135,6 +135,41 @@ def main():
 
 
 
+def main_sa():
+    """tests/golden/sa_b2.npz: plain Slot Attention auto-encoder (registry 'SA', BASELINE config 0;
+    SURVEY 8(a) row a16): slots, recon, masks, loss and parameter-gradient norms at B=2."""
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    im = rh.ref_models('img_based')
+    P = rh.ref_params('img_based', 'sa', 'sa_clevrtex_params-res128')
+    P.slot_dict['num_slots'] = 7
+    model = im.build_model(P)
+    keys = list(model.state_dict().keys())
+    det_fill_(model.state_dict().items(), skip=is_buffer_name)
+    img = make_inputs(2)[0]
+    model.train()
+    out = model(dict(img=img))
+    loss = model.calc_train_loss(dict(img=img), out)['img_recon_loss']
+    loss.backward()
+    G = dict(slots=out['slots'].detach(), recon_img_sub2=out['recon_img'].detach()[:, :, 1::2, ::2].contiguous(),
+             recon_checksum=torch.stack([out['recon_img'].detach().double().sum(),
+                                         (out['recon_img'].detach().double() ** 2).sum()]),
+             masks_sub4=out['masks'].detach()[:, :, 0, ::4, 1::4].contiguous(),
+             masks_argmax=out['masks'].detach()[:, :, 0].argmax(1),
+             recons_sub4=out['recons'].detach()[:, :, :, 1::4, ::4].contiguous(),
+             img_recon_loss=loss.detach())
+    names = [n for n, p in model.named_parameters()]
+    G['grad_norms'] = torch.stack([p.grad.double().norm() for _, p in model.named_parameters()]).float()
+    for n, p in model.named_parameters():
+        if n in ('decoder.0.0.weight', 'decoder.3.0.bias', 'decoder.4.weight', 'decoder_pos_embedding.dense.weight',
+                 'init_latents', 'slot_attention.project_q.1.weight'):
+            G['grad/' + n] = (p.grad.detach()[::4, ::4] if n == 'decoder.0.0.weight' else p.grad.detach()).clone()
+    os.makedirs(OUT, exist_ok=True)
+    np.savez_compressed(os.path.join(OUT, 'sa_b2.npz'), **{k: v.numpy() for k, v in G.items()},
+                        state_dict_keys=np.array(keys), param_names=np.array(names))
+    print('wrote sa_b2.npz', {k: tuple(v.shape) for k, v in G.items()})
+
+
 def main_video():
     """video_based SAViDiffusion (MOVi-E config, 15 slots, 2 iterations), B=1 clip of T=3 frames."""
     torch.manual_seed(0)
@@ -189,6 +224,9 @@ def main_video():
 
 
 if __name__ == '__main__':
+    if len(sys.argv) > 1 and sys.argv[1] == 'sa':
+        main_sa()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'video':
         main_video()
     else:
