@@ -315,6 +315,10 @@ int sdmi_pool2x2_sum(const SdmiPool2x2Args* a, void* stream);
 /* y = x + z elementwise in `dtype` (gradient accumulation at residual / skip joins) */
 typedef struct { const void* x; const void* z; void* y; int dtype; long long n; } SdmiAddArgs;
 int sdmi_add(const SdmiAddArgs* a, void* stream);
+/* EMA of the denoiser weights (LitEma.forward, ddpm/ema.py:29-52):
+ * shadow[i] -= one_minus_decay * (shadow[i] - p[i]) over a contiguous fp32 arena range. */
+typedef struct { float* shadow; const float* p; long long n; float one_minus_decay; } SdmiEmaArgs;
+int sdmi_ema_update(const SdmiEmaArgs* a, void* stream);
 /* inverted dropout with a counter-based generator: y[i] = keep(seed, i) ? x[i] / (1-p) : 0, keep
  * derived from a 64-bit mix of (seed, i) so the backward pass regenerates the same mask from the
  * seed instead of storing it (ResBlock dropout, unet.py:246; p = 0.1 in every LDM config). */

@@ -563,6 +563,17 @@ def clip_and_adam(params, grads, m, v, step, lrs, clip, b1=0.9, b2=0.999, eps=1e
 # ---------------------------------------------------------------------------
 # metrics used by the acceptance checks
 # ---------------------------------------------------------------------------
+def ema_update(shadow, params, num_updates, decay=0.9999):
+    """LitEma.forward (ddpm/ema.py:29-52): returns the new num_updates; shadows updated in place."""
+    if num_updates >= 0:
+        num_updates += 1
+        decay = min(decay, (1 + num_updates) / (10 + num_updates))
+    omd = 1.0 - decay
+    for s, p in zip(shadow, params):
+        s.sub_(omd * (s - p))
+    return num_updates
+
+
 def psnr(a, b):
     """10*log10(1/mse) on [0,1]-mapped images (eval_utils.py:95-101 via skimage, data_range=1)."""
     a01, b01 = (a * 0.5 + 0.5).clamp(0, 1), (b * 0.5 + 0.5).clamp(0, 1)

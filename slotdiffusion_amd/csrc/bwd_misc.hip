@@ -198,6 +198,14 @@ __global__ __launch_bounds__(256) void sqsum_kernel(SdmiSqSumArgs p) {
   if (threadIdx.x == 0) p.partial[blockIdx.x] = (float)((red[0] + red[1]) + (red[2] + red[3]));
 }
 
+__global__ __launch_bounds__(256) void ema_kernel(SdmiEmaArgs p) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < p.n;
+       i += (long long)gridDim.x * 256) {
+    const float s = p.shadow[i];
+    p.shadow[i] = s - p.one_minus_decay * (s - p.p[i]);
+  }
+}
+
 __global__ __launch_bounds__(256) void adam_kernel(SdmiAdamArgs p) {
   // global grad norm from the block partials (every block recomputes the same scalar)
   __shared__ float s_coef;
@@ -249,6 +257,14 @@ extern "C" int sdmi_pack_dgrad_batch(const SdmiPackBatchArgs* a, void* stream) {
   SDMI_REQUIRE(a && a->descs && a->n_desc >= 1 && a->total_blocks >= 1, "bad args");
   DISPATCH_T(pack_dgrad_batch_kernel, dim3(a->total_blocks), a);
   return sdmi_check_launch("pack_dgrad_batch");
+}
+extern "C" int sdmi_ema_update(const SdmiEmaArgs* a, void* stream) {
+  SDMI_REQUIRE(a && a->shadow && a->p && a->n >= 0, "bad args");
+  long long nb = (a->n + 255) / 256;
+  if (nb > 4096) nb = 4096;
+  if (nb < 1) nb = 1;
+  hipLaunchKernelGGL(ema_kernel, dim3((int)nb), dim3(256), 0, (hipStream_t)stream, *a);
+  return sdmi_check_launch("ema_update");
 }
 extern "C" int sdmi_rowgroup_sum(const SdmiRowGroupSumArgs* a, void* stream) {
   SDMI_REQUIRE(a && a->x && a->out && a->groups >= 1 && a->rows_per >= 1, "bad args");

@@ -8,6 +8,7 @@ evaluation scripts can switch packages:
 Tensors cross this boundary in the reference's layout (NCHW fp32 images / latents, [B,N,D] slots);
 inside, everything is NHWC in the compute dtype (fp32 for parity runs, bf16 for throughput).
 """
+import contextlib
 import copy
 import os
 
@@ -78,12 +79,56 @@ class LDM(_Owned):
     def num_timesteps(self):
         return self.betas.shape[0]
 
+    # -- a18: EMA of the denoiser (ddpm/ema.py:29-85, ddpm.py:134-147, 275-278) ---------------
+    # The shipped configs have use_ema=False; `enable_ema()` switches the hook on.  The shadow is
+    # one flat fp32 copy of the UNet's arena range, updated by a single streaming kernel.
+    def _ema_range(self):
+        r = self.root
+        offs = [r._offsets[n] for n, _ in r.named_parameters() if n.startswith('dm_decoder.model.')]
+        lo = min(o for o, _ in offs)
+        hi = max(o + c for o, c in offs)
+        return lo, hi
+
+    def enable_ema(self, decay=0.9999, use_num_updates=True):
+        lo, hi = self._ema_range()
+        self.use_ema = True
+        self.ema_decay = float(decay)
+        self.ema_num_updates = 0 if use_num_updates else -1
+        self._ema_shadow = self.root.arena()[lo:hi].detach().clone()
+        self._ema_stored = None
+        return self
+
+    @contextlib.contextmanager
     def ema_scope(self, context=None):
-        import contextlib
-        return contextlib.nullcontext()        # use_ema=False in every shipped LDM config
+        """Temporarily run with the EMA weights (store -> copy_to ... restore)."""
+        if not self.use_ema:
+            yield None
+            return
+        lo, hi = self._ema_range()
+        arena = self.root.arena()
+        self._ema_stored = arena[lo:hi].clone()
+        with torch.no_grad():
+            arena[lo:hi].copy_(self._ema_shadow)
+        self.root.weights_updated()
+        try:
+            yield None
+        finally:
+            with torch.no_grad():
+                arena[lo:hi].copy_(self._ema_stored)
+            self._ema_stored = None
+            self.root.weights_updated()
 
     def _training_step_end(self, *a, **k):
-        pass
+        if not self.use_ema:
+            return
+        decay = self.ema_decay
+        if self.ema_num_updates >= 0:
+            self.ema_num_updates += 1
+            decay = min(decay, (1 + self.ema_num_updates) / (10 + self.ema_num_updates))
+        lo, hi = self._ema_range()
+        kern.call('sdmi_ema_update', torch.cuda.current_stream().cuda_stream,
+                  shadow=self._ema_shadow.data_ptr(), p=self.root.arena()[lo:hi].data_ptr(),
+                  n=hi - lo, one_minus_decay=1.0 - decay)
 
     # -- a7/a8 ---------------------------------------------------------------------------
     def loss_function(self, data_dict, t=None, noise=None):

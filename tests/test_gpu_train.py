@@ -452,3 +452,34 @@ def test_pack_dgrad_batch_matches_single(dtype):
               total_blocks=blk)
     for (src, ref, out), shp in zip(keep, shapes):
         assert torch.equal(ref, out), shp
+
+
+def test_ema_hook_matches_reference_formula():
+    """Row a18: LitEma semantics (ddpm/ema.py:29-85) on the flat arena -- decay warm-up
+    min(decay, (1+n)/(10+n)), in-place shadow update, ema_scope store / copy_to / restore."""
+    from oracle import slotdiff_oracle as O
+    m = _model(torch.float32)
+    dm = m.dm_decoder
+    assert dm.use_ema is False
+    with dm.ema_scope():          # disabled: a no-op context
+        pass
+    dm.enable_ema(decay=0.9999)
+    lo, hi = dm._ema_range()
+    names = [n for n, _ in m.named_parameters() if n.startswith('dm_decoder.model.')]
+    assert sum(dict(m.named_parameters())[n].numel() for n in names) <= hi - lo
+    shadow_ref = [m.arena()[lo:hi].detach().cpu().clone()]
+    nupd = 0
+    g = torch.Generator(device='cuda').manual_seed(11)
+    for it in range(3):
+        with torch.no_grad():
+            m.arena()[lo:hi].add_(0.01 * torch.randn(hi - lo, device='cuda', generator=g))
+        m._training_step_end()
+        nupd = O.ema_update(shadow_ref, [m.arena()[lo:hi].detach().cpu()], nupd, 0.9999)
+    assert dm.ema_num_updates == nupd == 3
+    err = float((dm._ema_shadow.cpu() - shadow_ref[0]).abs().max())
+    assert err <= 1e-6, err
+    before = m.arena().detach().clone()
+    with dm.ema_scope('eval'):
+        assert torch.equal(m.arena()[lo:hi], dm._ema_shadow)
+        assert torch.equal(m.arena()[:lo], before[:lo])
+    assert torch.equal(m.arena(), before)
