@@ -1,0 +1,130 @@
+"""Training-method stand-in behind the reference's plugin API
+(`task.build_method(model=, datamodule=, params=, ckp_path=, local_rank=, use_ddp=, use_fp16=)`,
+scripts/train.py:65-76; optimiser groups and schedule of img_based/method.py:235-285 /
+video_based/method.py:291-341; loss weighting `params.<loss>_w`, clipping, AMP switch and the
+per-step hook as nerv's BaseMethod does them).
+
+The reference delegates the loop to nerv's trainer (logging, wandb, Slurm requeue ...), which is out
+of scope; this class keeps the part of it that IS the hot path: one process per
+GPU, fused clip+Adam over the flat arena, gradient all-reduce of the arena over RCCL, optional HIP
+graph replay of the whole step.
+"""
+import os
+
+import torch
+
+from . import parallel
+from .optim import FusedAdam, GraphedTrainStep
+
+
+class SyntheticDataModule:
+    """`build_dataset` stand-in: seeded random images in [-1, 1] of the configured shape
+    (datasets themselves are out of scope; SURVEY section 8(d) defines this synthetic input)."""
+
+    def __init__(self, params, steps_per_epoch=8, frames=None, device='cuda', seed=1234):
+        self.params = params
+        self.steps_per_epoch = steps_per_epoch
+        self.frames = frames
+        self.device = device
+        self.seed = seed
+        self.rank = int(os.environ.get('RANK', 0))
+
+    def __len__(self):
+        return self.steps_per_epoch
+
+    def train_loader(self, epoch=0):
+        B = self.params.train_batch_size
+        H, W = self.params.resolution
+        g = torch.Generator().manual_seed(self.seed + 1000 * epoch + self.rank)
+        for _ in range(self.steps_per_epoch):
+            shape = (B, 3, H, W) if self.frames is None else (B, self.frames, 3, H, W)
+            yield {'img': (torch.randn(shape, generator=g) * 0.5).clamp_(-1, 1).to(self.device)}
+
+
+class Method:
+    """fit() = epochs x steps of {forward, weighted loss, backward, (all-reduce), clip+Adam, hook}."""
+
+    def __init__(self, model, datamodule, params, ckp_path=None, local_rank=0, use_ddp=False,
+                 use_fp16=False):
+        self.model, self.datamodule, self.params = model, datamodule, params
+        self.ckp_path, self.local_rank, self.use_ddp = ckp_path, local_rank, use_ddp
+        if use_fp16:                      # the reference's --fp16 switch = our bf16 compute path
+            model.set_compute_dtype('bf16')
+        self.world = torch.distributed.get_world_size() if use_ddp else 1
+        self.it = 0
+        self.use_graph = os.environ.get('SDMI_GRAPH', '1') != '0'
+        self.optimizer = None
+        self.history = []
+
+    def _get(self, key, default=None):
+        p = self.params
+        return p.get(key, default) if hasattr(p, 'get') else getattr(p, key, default)
+
+    # img_based/method.py:235-285 (SA / SADiffusion), video_based/method.py:291-341
+    def _configure_optimizers(self):
+        p = self.params
+        assert p.optimizer.lower() in ('adam', 'adamw') and p.weight_decay == 0., \
+            'the path covers Adam without weight decay (every shipped config)'
+        total = p.max_epochs * len(self.datamodule)
+        clip = p.clip_grad if getattr(p, 'clip_grad', -1) and p.clip_grad > 0 else 0.0
+        return FusedAdam(self.model, lr=p.lr, dec_lr=self._get('dec_lr', p.lr), clip_grad=clip,
+                         total_steps=total, warmup_pct=p.warmup_steps_pct)
+
+    def _loss(self, batch):
+        out = self.model(batch)
+        losses = self.model.calc_train_loss(batch, out)
+        total = None
+        for k, v in losses.items():
+            w = self._get(f'{k}_w', 1.0)
+            total = v * w if total is None else total + v * w
+        return total, losses
+
+    def _eager_step(self, batch):
+        self.optimizer.zero_grad()
+        if hasattr(self.model, 'KG'):
+            self.model.KG().begin_step()
+        total, losses = self._loss(batch)
+        total.backward()
+        if self.world > 1:
+            parallel.allreduce_gradients(self.model.grad_arena(), self.world)
+        self.optimizer.step()
+        return total.detach()
+
+    def fit(self, resume_from='', san_check_val_step=0, max_steps=None):
+        if resume_from:
+            self.model.load_weight(resume_from)
+        self.model.train()
+        if self.use_ddp:
+            parallel.broadcast_parameters(self.model.arena())
+        self.optimizer = self._configure_optimizers()
+        graphed = None
+        for epoch in range(self.params.max_epochs):
+            for batch in self.datamodule.train_loader(epoch):
+                if self.use_graph and graphed is None and len(self._loss_names()) == 1:
+                    ar = (lambda g: parallel.allreduce_gradients(g, self.world)) \
+                        if self.world > 1 else None
+                    key = self._loss_names()[0]
+                    # capturing the step runs two (real) warm-up steps on this first batch
+                    graphed = GraphedTrainStep(self.model, self.optimizer, batch, allreduce=ar,
+                                               loss_key=key, loss_weight=self._get(f'{key}_w', 1.0))
+                    self.it += 2
+                else:
+                    loss = graphed(batch) if graphed is not None else self._eager_step(batch)
+                    self.it += 1
+                    self.history.append(loss)
+                self.model._training_step_end(self)
+                if max_steps is not None and self.it >= max_steps:
+                    return self
+        return self
+
+    def _loss_names(self):
+        from .models import SA
+        return ['img_recon_loss'] if isinstance(self.model, SA) else ['denoise_loss']
+
+    def save(self, path):
+        torch.save({'state_dict': self.model.state_dict(), 'it': self.it}, path)
+
+
+def build_method(**kwargs):
+    """Same call signature as the reference's task.build_method."""
+    return Method(**kwargs)

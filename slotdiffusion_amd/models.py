@@ -258,6 +258,9 @@ class SlotModelBase(FlatModule):
     def _to_nhwc(self, img):
         return ops.nchw_to_nhwc(img.float(), self.compute_dtype, ops.vec_of(self.compute_dtype))
 
+    def _training_step_end(self, method=None):
+        pass
+
 
 class SADiffusion(SlotModelBase):
     """SlotDiffusion on images (registry name 'SADiffusion')."""
@@ -588,7 +591,8 @@ class SA(SlotModelBase):
         if recon.requires_grad:
             # NHWC pair (4th channel zero in both): mean over the 3 real channels -> scale 4/3
             tgt = ops.nchw_to_nhwc(img.float(), torch.float32, 4)
-            return {'img_recon_loss': kern.MseFn.apply(self._last_recon_nhwc, tgt, 4.0 / 3.0)}
+            pred, self._last_recon_nhwc = self._last_recon_nhwc, None    # do not pin the graph
+            return {'img_recon_loss': kern.MseFn.apply(pred, tgt, 4.0 / 3.0)}
         tgt = ops.nchw_to_nhwc(img.float(), torch.float32, 4)
         val = ops.mse(ops.nchw_to_nhwc(recon, torch.float32, 4), tgt) * (4.0 / 3.0)
         return {'img_recon_loss': val.reshape(())}

@@ -99,8 +99,10 @@ class GraphedTrainStep:
     word `model.step_seed`, Adam's step / lr from device scalars -- nothing host-side is baked in.
     With world > 1 the gradient all-reduce runs eagerly between two graphs."""
 
-    def __init__(self, model, opt, example_batch, allreduce=None):
+    def __init__(self, model, opt, example_batch, allreduce=None, loss_key='denoise_loss',
+                 loss_weight=1.0):
         self.model, self.opt, self.allreduce = model, opt, allreduce
+        self.loss_key, self.loss_weight = loss_key, loss_weight
         self.static = {k: v.clone() for k, v in example_batch.items()}
         dev = model.arena().device
         if getattr(model, 'step_seed', None) is None or model.step_seed.device != dev:
@@ -131,7 +133,9 @@ class GraphedTrainStep:
         m.step_seed.add_(1)
         m.KG().begin_step()
         out = m(self.static)
-        loss = m.calc_train_loss(self.static, out)['denoise_loss']
+        loss = m.calc_train_loss(self.static, out)[self.loss_key]
+        if self.loss_weight != 1.0:
+            loss = loss * self.loss_weight
         loss.backward()
         return loss.detach()
 

@@ -119,3 +119,21 @@ def oracle_weights_video(cfg, seed=1234):
         else:
             W[p.name] = det_value(p.name, p.shape, i, seed)
     return W
+
+
+class Params:
+    """Config object with the attribute surface of the reference's *_params.py classes."""
+
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+    def get(self, key, default=None):
+        return getattr(self, key, default)
+
+
+def make_params(model='SADiffusion', batch=2):
+    cfg = sa_plain_cfg() if model == 'SA' else clevrtex_cfg()
+    extra = dict(lr=4e-4, clip_grad=-1, warmup_steps_pct=0.025, img_recon_loss_w=1.) if model == 'SA' \
+        else dict(lr=1e-4, dec_lr=2e-4, clip_grad=1.0, warmup_steps_pct=0.05, denoise_loss_w=1.)
+    return Params(model=model, optimizer='Adam', weight_decay=0.0, max_epochs=1,
+                  train_batch_size=batch, dataset='clevrtex', san_check_val_step=0, **cfg, **extra)

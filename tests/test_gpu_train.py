@@ -483,3 +483,25 @@ def test_ema_hook_matches_reference_formula():
         assert torch.equal(m.arena()[lo:hi], dm._ema_shadow)
         assert torch.equal(m.arena()[:lo], before[:lo])
     assert torch.equal(m.arena(), before)
+
+
+@pytest.mark.parametrize('name', ['SADiffusion', 'SA'])
+def test_method_fit_through_the_registry(name):
+    """build_model -> build_dataset -> build_method -> fit(): the plugin path of scripts/train.py,
+    3 optimiser steps on synthetic data (graph replay on), losses finite, weights move."""
+    from slotdiffusion_amd import img_based as task
+    P = C.make_params(name)
+    model = task.build_model(P)
+    det_fill_(model.state_dict().items(), skip=is_buffer_name)
+    model = model.cuda()
+    model.set_compute_dtype('fp32')
+    before = model.arena().detach().clone()
+    dm = task.build_dataset(P)
+    dm.steps_per_epoch = 5
+    method = task.build_method(model=model, datamodule=dm, params=P, ckp_path=None, local_rank=0,
+                               use_ddp=False, use_fp16=False)
+    method.fit(resume_from='', san_check_val_step=0, max_steps=5)
+    losses = [float(l) for l in method.history]
+    assert len(losses) == 3 and all(math.isfinite(l) for l in losses), losses   # 2 warm-up + 3 replays
+    assert method.optimizer.step_count == 5
+    assert float((model.arena() - before).abs().max()) > 0

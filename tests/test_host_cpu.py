@@ -90,3 +90,23 @@ def test_model_registry_and_checkpoint_keys():
         'encoder.conv1.weight'].is_contiguous(memory_format=torch.channels_last)
     # schedule buffers equal the oracle's recipe
     assert torch.equal(m.dm_decoder.betas, C.oracle_weights(cfg)['dm_decoder.betas'])
+
+
+def test_registry_modules_expose_the_plugin_api():
+    """scripts/train.py:97-100 imports `slotdiffusion.<task>` and uses build_dataset / build_model /
+    build_method; our registry modules keep that surface."""
+    import importlib
+    import inspect
+    for task in ('img_based', 'video_based'):
+        mod = importlib.import_module(f'slotdiffusion_amd.{task}')
+        for fn in ('build_dataset', 'build_model', 'build_method'):
+            assert callable(getattr(mod, fn))
+        sig = inspect.signature(mod.build_method)
+        assert any(p.kind == p.VAR_KEYWORD for p in sig.parameters.values())
+    from slotdiffusion_amd.method import Method
+    assert list(inspect.signature(Method.__init__).parameters)[1:] == [
+        'model', 'datamodule', 'params', 'ckp_path', 'local_rank', 'use_ddp', 'use_fp16']
+    from tests import common as C
+    from slotdiffusion_amd.img_based import build_model
+    m = build_model(C.make_params('SA'))
+    assert type(m).__name__ == 'SA' and len(list(m.parameters())) == 83
