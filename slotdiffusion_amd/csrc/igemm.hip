@@ -29,9 +29,15 @@ struct ConvGeom {
   int H, W, Cin, HoWo, Wo, KH, KW, stride, pad_t, pad_l, ups;
 };
 
-template <typename T, int BM, int BN, int BKB, bool IS1X1>
+template <typename T, int BM, int BN, int BKB, int MODE>
 __device__ __forceinline__ void igemm_body(const SdmiGemmArgs& p, int tiles_m, int tiles_n,
                                            int kt_per_split, int hw_shift) {
+  // MODE: 0 = general gather (nearest-x2 fold, zero insertion, K tiles that straddle filter taps),
+  //       1 = 1x1 / linear, 2 = plain convolution whose K tiles lie inside one filter tap
+  //       (Cin % BK == 0): the tap (kh, kw) is wave-uniform, so the per-vector work shrinks to two
+  //       adds, two compares and one 64-bit multiply-add
+  constexpr bool IS1X1 = MODE == 1;
+  constexpr bool TAPU = MODE == 2;
   constexpr int VEC = 16 / sizeof(T);
   constexpr int BK = BKB / sizeof(T);
   constexpr int VPR = BKB / 16;
@@ -85,7 +91,13 @@ __device__ __forceinline__ void igemm_body(const SdmiGemmArgs& p, int tiles_m, i
       tile_of((int)blockIdx.x + ld_tile * (int)gridDim.x, m0, n0);
       kk = kt_begin * BK + kc * VEC;
       ci = kh = kw = 0;
-      if (!IS1X1) {
+      if (TAPU) {               // uniform: derived from the K tile index only
+        const int k0 = kt_begin * BK;
+        const int tap = k0 / p.Cin;
+        ci = k0 - tap * p.Cin;  // channel base of the K tile (this thread adds kc * VEC)
+        kh = tap / p.KW;
+        kw = tap - kh * p.KW;
+      } else if (!IS1X1) {
         const int tap = kk / p.Cin;
         ci = kk - tap * p.Cin;
         kh = tap / p.KW;
@@ -105,9 +117,9 @@ __device__ __forceinline__ void igemm_body(const SdmiGemmArgs& p, int tiles_m, i
           const int rem = m - b * HoWo;
           const int oy = rem / p.Wo;
           const int ox = rem - oy * p.Wo;
-          a_pix[i] = b * p.H * p.W;
           a_iy0[i] = oy * p.stride - p.pad_t;
           a_ix0[i] = ox * p.stride - p.pad_l;
+          a_pix[i] = b * p.H * p.W + (TAPU ? a_iy0[i] * p.W + a_ix0[i] : 0);
         }
       }
 #pragma unroll
@@ -134,6 +146,10 @@ __device__ __forceinline__ void igemm_body(const SdmiGemmArgs& p, int tiles_m, i
         long long off;
         if (IS1X1) {
           off = (long long)a_pix[i] * p.lda + kk;
+        } else if (TAPU) {
+          const int iy = a_iy0[i] + kh, ix = a_ix0[i] + kw;
+          ok = ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+          off = (long long)(a_pix[i] + kh * p.W + kw) * p.lda + (ci + kc * VEC);
         } else {
           int iy = a_iy0[i] + kh, ix = a_ix0[i] + kw;
           if (p.ups) {
@@ -162,7 +178,13 @@ __device__ __forceinline__ void igemm_body(const SdmiGemmArgs& p, int tiles_m, i
       }
       // advance k state to the next K tile (or on to the workgroup's next output tile)
       kk += BK;
-      if (!IS1X1) {
+      if (TAPU) {
+        ci += BK;
+        if (ci == p.Cin) {
+          ci = 0;
+          if (++kw == p.KW) { kw = 0; ++kh; }
+        }
+      } else if (!IS1X1) {
         ci += BK;
         while (ci >= p.Cin) {
           ci -= p.Cin;
@@ -366,15 +388,15 @@ __device__ __forceinline__ void igemm_body(const SdmiGemmArgs& p, int tiles_m, i
 
 // Two entry points over the same body: <= 128 VGPRs (two workgroups per CU) for the tiles whose
 // double-buffered LDS image allows it, unconstrained for the 256-row tile (92 KB of LDS).
-template <typename T, int BM, int BN, int BKB, bool IS1X1>
+template <typename T, int BM, int BN, int BKB, int MODE>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void igemm_kernel(
     SdmiGemmArgs p, int tiles_m, int tiles_n, int kt_per_split, int hw_shift) {
-  igemm_body<T, BM, BN, BKB, IS1X1>(p, tiles_m, tiles_n, kt_per_split, hw_shift);
+  igemm_body<T, BM, BN, BKB, MODE>(p, tiles_m, tiles_n, kt_per_split, hw_shift);
 }
-template <typename T, int BM, int BN, int BKB, bool IS1X1>
+template <typename T, int BM, int BN, int BKB, int MODE>
 __global__ __launch_bounds__(512) void igemm_kernel_tall(SdmiGemmArgs p, int tiles_m, int tiles_n,
                                                          int kt_per_split, int hw_shift) {
-  igemm_body<T, BM, BN, BKB, IS1X1>(p, tiles_m, tiles_n, kt_per_split, hw_shift);
+  igemm_body<T, BM, BN, BKB, MODE>(p, tiles_m, tiles_n, kt_per_split, hw_shift);
 }
 
 // split-K second stage: sum partials, apply the same epilogue
@@ -405,14 +427,14 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(SdmiGemmArgs p, in
   }
 }
 
-template <typename T, int BM, int BN, int BKB, bool IS1X1>
+template <typename T, int BM, int BN, int BKB, int MODE>
 int launch_cfg(const SdmiGemmArgs& p, int split_k, int hw_shift, hipStream_t st) {
   constexpr int BK = BKB / sizeof(T);
   constexpr int smem = 2 * (BM + BN) * (BKB + 16);
   static bool attr_done = false;
   void (*kern)(SdmiGemmArgs, int, int, int, int);
-  if constexpr (BM > 128) kern = igemm_kernel_tall<T, BM, BN, BKB, IS1X1>;
-  else kern = igemm_kernel<T, BM, BN, BKB, IS1X1>;
+  if constexpr (BM > 128) kern = igemm_kernel_tall<T, BM, BN, BKB, MODE>;
+  else kern = igemm_kernel<T, BM, BN, BKB, MODE>;
   if (!attr_done) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem) !=
         hipSuccess) {
@@ -494,9 +516,14 @@ int dispatch(const SdmiGemmArgs& p, hipStream_t st) {
   }
   if (split_k > 1 && !p.workspace) split_k = 1;
   (void)VEC;
-#define SDMI_GO(BM, BN, BKB)                                                           \
-  return is1x1 ? launch_cfg<T, BM, BN, BKB, true>(p, split_k, hw_shift, st)            \
-               : launch_cfg<T, BM, BN, BKB, false>(p, split_k, hw_shift, st)
+  const bool plain = !is1x1 && !p.ups && p.zins <= 1;
+#define SDMI_GO(BM, BN, BKB)                                                                    \
+  do {                                                                                          \
+    if (is1x1) return launch_cfg<T, BM, BN, BKB, 1>(p, split_k, hw_shift, st);                  \
+    if (plain && p.Cin % (BKB / (int)sizeof(T)) == 0)                                           \
+      return launch_cfg<T, BM, BN, BKB, 2>(p, split_k, hw_shift, st);                           \
+    return launch_cfg<T, BM, BN, BKB, 0>(p, split_k, hw_shift, st);                             \
+  } while (0)
   switch (shape) {
     case T128x128: if (wide) { SDMI_GO(128, 128, 128); } else { SDMI_GO(128, 128, 64); }
     case T128x64: if (wide) { SDMI_GO(128, 64, 128); } else { SDMI_GO(128, 64, 64); }
