@@ -18,6 +18,8 @@ the launch stream) and cpu_baseline (the CPU oracle on this box's host cores, bo
 import argparse
 import json
 import os
+
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')   # dmabuf IPC (RCCL across processes)
 import sys
 import time
 
@@ -151,12 +153,13 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     dist = None
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+        os.environ.setdefault('MASTER_PORT', '29511')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
     dtype = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
 
     model, cfg = build_model(dtype)

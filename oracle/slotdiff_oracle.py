@@ -544,6 +544,41 @@ def ldm_sample(W, plan, ed, slots, x_T, steps=20, mc=128, trace=None):
 
 
 # ---------------------------------------------------------------------------
+# 8(f) row 2: DDIM sampler (video_based/models/ddpm/ddim.py:90-218; utils.py:50-97)
+# ---------------------------------------------------------------------------
+def ddim_schedule(alphas_bar, steps, eta=0.):
+    """uniform discretisation: timesteps = range(0, T, T // steps) + 1; a_t, a_prev, sigma_t."""
+    T = alphas_bar.shape[0]
+    ts = torch.arange(0, T, T // steps) + 1
+    a = alphas_bar[ts]
+    a_prev = torch.cat([alphas_bar[:1], alphas_bar[ts[:-1]]])
+    sig = eta * torch.sqrt((1 - a_prev) / (1 - a) * (1 - a / a_prev))
+    return ts, a, a_prev, sig
+
+
+def ddim_sample(eps_fn, quantize_fn, alphas_bar, x, steps, eta=0., log_every_t=100, noise_fn=None):
+    """DDIMSampler._sample_x0_from_noise / _p_sample_ddim for pred_target='eps', vq_denoised.
+    Returns (x_0, intermediates as the reference logs them)."""
+    ts, a, a_prev, sig = ddim_schedule(alphas_bar, steps, eta)
+    som = torch.sqrt(1. - a)
+    B = x.shape[0]
+    n = ts.shape[0]
+    inter = [x]
+    for i, step in enumerate(torch.flip(ts, (0,))):
+        index = n - i - 1
+        t = torch.full((B,), int(step), dtype=torch.long)
+        e_t = eps_fn(x, t)
+        pred_x0 = (x - som[index] * e_t) / a[index].sqrt()
+        pred_x0 = quantize_fn(pred_x0)
+        dir_xt = (1. - a_prev[index] - sig[index] ** 2).sqrt() * e_t
+        noise = sig[index] * (noise_fn(x.shape) if noise_fn is not None else torch.zeros_like(x))
+        x = a_prev[index].sqrt() * pred_x0 + dir_xt + noise
+        if index % log_every_t == 0 or index == n - 1:
+            inter.append(x)
+    return x, torch.stack(inter, 0)
+
+
+# ---------------------------------------------------------------------------
 # a17: optimiser step restated (Adam, two groups, global-norm clip)
 # ---------------------------------------------------------------------------
 def clip_and_adam(params, grads, m, v, step, lrs, clip, b1=0.9, b2=0.999, eps=1e-8):

@@ -135,3 +135,25 @@ def build_plan(betas, steps=20, order=3):
 
 def plan_t_inputs(plan):
     return [e['t_input'] for st in plan['steps'] for e in st['evals']]
+
+
+def ddim_plan(alphas_bar, steps, eta=0.):
+    """Per-step scalars of the reference's DDIM sampler (video_based/models/ddpm/ddim.py:36-218,
+    utils.py:50-97; uniform discretisation), computed with the same fp32 torch-CPU expressions.
+    Steps are listed in sampling order (largest timestep first)."""
+    ab = torch.as_tensor(alphas_bar, dtype=torch.float32).cpu()
+    T = ab.shape[0]
+    ts = torch.arange(0, T, T // steps) + 1
+    a = ab[ts]
+    a_prev = torch.cat([ab[:1], ab[ts[:-1]]])
+    sig = eta * torch.sqrt((1 - a_prev) / (1 - a) * (1 - a / a_prev))
+    som = torch.sqrt(1. - a)
+    out = []
+    n = ts.shape[0]
+    for i in range(n):
+        index = n - i - 1
+        out.append(dict(index=index, t=int(ts[index]), som=float(som[index]),
+                        sqrt_a=float(a[index].sqrt()), sqrt_a_prev=float(a_prev[index].sqrt()),
+                        dir=float((1. - a_prev[index] - sig[index] ** 2).sqrt()),
+                        sigma=float(sig[index])))
+    return out

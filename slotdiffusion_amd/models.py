@@ -163,8 +163,9 @@ class LDM(_Owned):
     def generate_imgs(self, cond, batch_size=16, ret_intermed=False, verbose=False,
                       use_ddim=False, use_dpm=True, x_T=None, same_noise=False, **kwargs):
         """cond_ddpm.py:134-212 (DPM-Solver branch). Returns latents [B,3,h,w] (NCHW fp32)."""
-        if not use_dpm or use_ddim:
-            raise NotImplementedError('hot path covers the DPM-Solver++ sampler (use_dpm=True)')
+        if not use_dpm and not use_ddim:
+            raise NotImplementedError('ancestral 1000-step sampling is not part of the path: use '
+                                      'use_dpm=True (DPM-Solver++) or use_ddim=True (DDIM)')
         r = self.root
         if cond.dim() == 2:
             cond = cond.unsqueeze(0).expand(batch_size, -1, -1)
@@ -176,7 +177,12 @@ class LDM(_Owned):
             else:
                 x_T = torch.randn(batch_size, 3, h, w, device=cond.device)
         x = ops.nchw_to_nhwc(x_T, torch.float32, 4)
-        x, inter = r._dpm_sample(x, cond, ret_intermed)
+        if use_dpm:            # cond_ddpm.py:155-178 (takes precedence, as in the reference)
+            x, inter = r._dpm_sample(x, cond, ret_intermed)
+        else:                  # cond_ddpm.py:180-190: DDIM, max(200, T // 5) steps, eta = 0
+            steps = kwargs.get('ddim_steps') or max(200, self.num_timesteps // 5)
+            x, inter = r._ddim_sample(x, cond, steps, kwargs.get('eta', 0.), ret_intermed,
+                                      kwargs.get('log_every_t', 100))
         out = ops.nhwc_to_nchw(x, 3)
         if ret_intermed:
             return out, torch.stack([ops.nhwc_to_nchw(i, 3) for i in inter], 0)
@@ -358,6 +364,39 @@ class SADiffusion(SlotModelBase):
         sc.copy_(cond)
         graph.replay()
         return out, []
+
+    def _ddim_sample(self, x, cond, steps, eta=0., ret_intermed=False, log_every_t=100):
+        """DDIMSampler._sample_x0_from_noise (ddim.py:128-218) for eps-prediction with the VQ
+        denoiser: per step  eps -> x0 = (x - sqrt(1-a_t) eps)/sqrt(a_t) -> VQ ->
+        x = sqrt(a_prev) x0 + sqrt(1 - a_prev - sigma^2) eps (+ sigma * noise)."""
+        plan = dpm.ddim_plan(self.dm_decoder.alphas_bar.detach().float().cpu(), steps, eta)
+        inter = [x]
+        for x, st in self._ddim_steps(x, cond, plan):
+            if st['index'] % log_every_t == 0 or st['index'] == len(plan) - 1:
+                inter.append(x)
+        return x, (inter if ret_intermed else [])
+
+    def _ddim_steps(self, x, cond, plan):
+        """Generator over the DDIM updates of `plan` (a list of dpm.ddim_plan entries, any subset in
+        sampling order): yields (x after the step, step)."""
+        u = self.unet()
+        Kp = self.K()
+        tin = torch.tensor([float(st['t']) for st in plan], dtype=torch.float32, device=x.device)
+        ctx_kv = u.context_kv(Kp, self._ctx(cond))
+        rv_all = u.time_rowvecs(Kp, tin)
+        B = x.shape[0]
+        code = self.bank().f(self.vq_key)
+        for i, st in enumerate(plan):
+            rv = rv_all[i:i + 1].expand(B, -1)
+            eps = u.forward(Kp, self._unet_in(x), rv, ctx_kv)
+            x0 = ops.lincomb(1.0, x, -st['som'], eps, div=st['sqrt_a'])
+            x0 = ops.vq_nearest(x0, code, scale=self.z_scale, want_idx=False)[1]
+            x = ops.lincomb(st['sqrt_a_prev'], x0, st['dir'], eps)
+            if st['sigma'] != 0.0:
+                nz = ops.nchw_to_nhwc(torch.randn(B, 3, x.shape[1], x.shape[2], device=x.device),
+                                      torch.float32, 4)
+                x = ops.lincomb(1.0, x, st['sigma'], nz)
+            yield x, st
 
     def _dpm_prepare(self, steps, device):
         if self._plan is None or self._plan[0] != steps:

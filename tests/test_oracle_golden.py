@@ -192,3 +192,26 @@ def test_plain_sa_oracle_matches_reference():
     assert float(rel.max()) <= 5e-3, float(rel.max())
     g0 = W['decoder.0.0.weight'].grad[::4, ::4]
     assert float((g0 - G['grad/decoder.0.0.weight']).abs().max()) <= 2e-3 * float(G['grad/decoder.0.0.weight'].abs().max())
+
+
+def test_ddim_oracle_matches_reference():
+    """DDIM (eta = 0, 50 steps, VQ-denoised) trajectory of the oracle against the
+    reference sampler's (tests/golden/ddim_b2.npz); schedule tables exact."""
+    cfg = C.clevrtex_cfg()
+    G, D = C.load_golden(), C.load_golden('ddim_b2.npz')
+    W = C.oracle_weights(cfg)
+    ab = W['dm_decoder.alphas_bar']
+    ts, a, a_prev, sig = O.ddim_schedule(ab, int(D['steps']))
+    assert torch.equal(ts, D['ddim_timesteps'].long())
+    assert torch.equal(a, D['ddim_alphas']) and torch.equal(a_prev, D['ddim_alphas_prev'])
+    plan = spec.unet_plan(cfg['dec_dict']['unet_dict'])
+    slots = G['slots']
+    eps_fn = lambda xc, t: O.unet_forward(W, plan, xc, t, slots)
+    q_fn = lambda x0: O.vq_quantize(W, x0)[0]
+    with torch.no_grad():
+        x, inter = O.ddim_sample(eps_fn, q_fn, ab, G['x_T'], int(D['steps']), log_every_t=10)
+    assert inter.shape == D['ddim_inter'].shape
+    assert float((inter - D['ddim_inter']).abs().max()) <= 1e-4
+    assert float((x - D['ddim_final']).abs().max()) <= 1e-4
+    idx = O.vq_quantize(W, x)[1]
+    assert float((idx == D['ddim_final_idx'].long()).float().mean()) >= 0.999

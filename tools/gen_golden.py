@@ -135,6 +135,42 @@ def main():
 
 
 
+def main_ddim():
+    """tests/golden/ddim_b2.npz: the reference's DDIM sampler (ddim.py:90-218, eta = 0, VQ-denoised)
+    driven exactly as CondDDPM.generate_imgs(use_ddim=True) does (cond_ddpm.py:180-190) but with 50
+    steps, B = 2, from the slots / x_T of sadiff_b2.npz."""
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    im = rh.ref_models('img_based')
+    P = rh.ref_params('img_based', 'sa_ldm', 'sa_ldm_clevrtex_params-res128')
+    P.slot_dict['num_slots'] = 7
+    model = im.build_model(P)
+    det_fill_(model.state_dict().items(), skip=is_buffer_name)
+    model.eval()
+    img, t, noise, x_T = make_inputs(2)
+    with torch.no_grad():
+        slots, _ = model.encode(img)
+    dm = model.dm_decoder
+    from slotdiffusion.video_based.models.ddpm import ddim as dd
+    # the reference class moves every buffer to 'cuda' (ddim.py:31-35); keep them on the CPU here
+    dd.DDIMSampler.register_buffer = lambda self, name, attr: setattr(self, name, attr)
+    sampler = dd.DDIMSampler(dm, schedule=dm.beta_schedule)
+    steps = 50
+    import slotdiffusion.video_based.models.ddpm.ddim as ddmod
+    ddmod.noise_like = lambda shape, device, repeat=False: x_T.clone()      # fixed x_T, eta = 0
+    with torch.no_grad():
+        x, inter = sampler.generate_imgs(steps, tuple(x_T.shape), conditioning=slots, eta=0.,
+                                         verbose=False, log_every_t=10, ret_intermed=True)
+    G = dict(ddim_timesteps=torch.tensor(sampler.ddim_timesteps), ddim_alphas=torch.as_tensor(sampler.ddim_alphas),
+             ddim_alphas_prev=torch.as_tensor(sampler.ddim_alphas_prev), ddim_final=x, ddim_inter=inter,
+             steps=torch.tensor(steps))
+    with torch.no_grad():
+        _, _, (_, _, idx) = dm.vae.vqvae.quantize(x)
+        G['ddim_final_idx'] = idx
+    np.savez_compressed(os.path.join(OUT, 'ddim_b2.npz'), **{k: np.asarray(v.numpy() if torch.is_tensor(v) else v) for k, v in G.items()})
+    print('wrote ddim_b2.npz', {k: tuple(np.asarray(v).shape) for k, v in G.items()})
+
+
 def main_sa():
     """tests/golden/sa_b2.npz: plain Slot Attention auto-encoder (registry 'SA', BASELINE config 0;
     SURVEY 8(a) row a16): slots, recon, masks, loss and parameter-gradient norms at B=2."""
@@ -224,6 +260,9 @@ def main_video():
 
 
 if __name__ == '__main__':
+    if len(sys.argv) > 1 and sys.argv[1] == 'ddim':
+        main_ddim()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'sa':
         main_sa()
         sys.exit(0)
