@@ -25,6 +25,10 @@
 
 namespace {
 
+// Out-of-image / K-tail / out-of-range operand vectors are FETCHED from this zero line instead of
+// being zeroed with per-dword selects after the load (pointer select = 2 VALU ops per vector).
+__device__ uint4 g_zero_line[8];
+
 struct ConvGeom {
   int H, W, Cin, HoWo, Wo, KH, KW, stride, pad_t, pad_l, ups;
 };
@@ -48,6 +52,7 @@ __device__ __forceinline__ void igemm_body(const SdmiGemmArgs& p, int tiles_m, i
   constexpr int TM = WTM / 32, TN = WTN / 32;
   constexpr int KSTEPS = BKB / 32;
   constexpr int BUF_BYTES = (BM + BN) * ROWB;
+  constexpr int MTH_ROWS = 256 / VPR;         // rows covered by one pass of the 256 loader threads
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -79,25 +84,34 @@ __device__ __forceinline__ void igemm_body(const SdmiGemmArgs& p, int tiles_m, i
     const T* __restrict__ Ag = (const T*)p.a + (long long)zb * p.sa;
     const T* __restrict__ Wg = (const T*)p.w + (long long)zb * p.sw;
     const int kc = tid % VPR;  // vector column inside the K tile (same for all of a thread's vectors)
-    int kk = 0, ci = 0, kh = 0, kw = 0;       // this thread's k state for the next tile to load
-    int a_pix[A_VECS];         // IS1X1: m ; conv: b*H*W (pixel index base) -- all < 2^31
-    int a_iy0[A_VECS], a_ix0[A_VECS];
-    bool a_ok[A_VECS];
-    int b_row[B_VECS];
-    bool b_ok[B_VECS];
+    const T* zero_src = reinterpret_cast<const T*>(g_zero_line);
     int ld_tile = 0, ld_kt = 0;               // (tile, K tile) the next load_tile() fetches
+    // Rows m >= M / n >= N only feed output rows / columns that are never stored, so they are
+    // CLAMPED to the last valid row instead of being zero-filled.
+    //
+    // MODE 1 / 2 ("pointer" loaders): a 64-bit base pointer per vector is set up once per output
+    // tile; a K tile then costs one wave-uniform offset add and (conv) a 3-op border test per
+    // vector.  Border validity of a 3x3-type filter factorises into row bits (kh) x column bits
+    // (kw), computed once per tile.
+    const T* a_ptr[A_VECS];
+    const T* b_ptr[B_VECS];
+    unsigned a_rb[A_VECS], a_cb[A_VECS];
+    int k0 = 0, ci = 0, kh = 0, kw = 0;       // wave-uniform k state of the next K tile (MODE 1/2)
+    // MODE 0 (general gather) state
+    int kk = 0;
+    int a_pix[A_VECS], a_iy0[A_VECS], a_ix0[A_VECS];
+    int b_row[B_VECS];
     auto begin_tile = [&]() __attribute__((always_inline)) {
       int m0, n0;
       tile_of((int)blockIdx.x + ld_tile * (int)gridDim.x, m0, n0);
-      kk = kt_begin * BK + kc * VEC;
-      ci = kh = kw = 0;
+      k0 = kt_begin * BK;
       if (TAPU) {               // uniform: derived from the K tile index only
-        const int k0 = kt_begin * BK;
         const int tap = k0 / p.Cin;
-        ci = k0 - tap * p.Cin;  // channel base of the K tile (this thread adds kc * VEC)
+        ci = k0 - tap * p.Cin;  // channel base of the K tile
         kh = tap / p.KW;
         kw = tap - kh * p.KW;
       } else if (!IS1X1) {
+        kk = k0 + kc * VEC;
         const int tap = kk / p.Cin;
         ci = kk - tap * p.Cin;
         kh = tap / p.KW;
@@ -106,51 +120,71 @@ __device__ __forceinline__ void igemm_body(const SdmiGemmArgs& p, int tiles_m, i
 #pragma unroll
       for (int i = 0; i < A_VECS; ++i) {
         const int row = (tid + i * 256) / VPR;
-        const int m = m0 + row;
-        a_ok[i] = m < p.M;
+        const int m = min(m0 + row, p.M - 1);
         if (IS1X1) {
-          a_pix[i] = m;
-          a_iy0[i] = a_ix0[i] = 0;
+          a_ptr[i] = Ag + (long long)m * p.lda + kc * VEC;
         } else {
           const int HoWo = p.Ho * p.Wo;
           const int b = m / HoWo;
           const int rem = m - b * HoWo;
           const int oy = rem / p.Wo;
           const int ox = rem - oy * p.Wo;
-          a_iy0[i] = oy * p.stride - p.pad_t;
-          a_ix0[i] = ox * p.stride - p.pad_l;
-          a_pix[i] = b * p.H * p.W + (TAPU ? a_iy0[i] * p.W + a_ix0[i] : 0);
+          const int iy0 = oy * p.stride - p.pad_t, ix0 = ox * p.stride - p.pad_l;
+          if (TAPU) {
+            a_ptr[i] = Ag + (long long)(b * p.H * p.W + iy0 * p.W + ix0) * p.lda + kc * VEC;
+            unsigned rb = 0, cb = 0;
+            for (int q = 0; q < p.KH; ++q) rb |= ((unsigned)(iy0 + q) < (unsigned)p.H ? 1u : 0u) << q;
+            for (int q = 0; q < p.KW; ++q) cb |= ((unsigned)(ix0 + q) < (unsigned)p.W ? 1u : 0u) << q;
+            a_rb[i] = rb;
+            a_cb[i] = cb;
+          } else {
+            a_iy0[i] = iy0;
+            a_ix0[i] = ix0;
+            a_pix[i] = b * p.H * p.W;
+          }
         }
       }
 #pragma unroll
       for (int i = 0; i < B_VECS; ++i) {
         const int row = (tid + i * 256) / VPR;
-        const int n = n0 + row;
-        b_ok[i] = n < p.N;
+        const int n = min(n0 + row, p.N - 1);
         b_row[i] = n;
+        b_ptr[i] = Wg + (long long)n * p.ldw + kc * VEC;
       }
     };
-    const u32x4 zero4 = {0u, 0u, 0u, 0u};
-
-    // Loads are issued unconditionally from a clamped (always valid) address so that all of a
-    // tile's global loads are in flight together; out-of-image / K-tail vectors are zeroed when
-    // the registers are written to LDS (mask bits travel with the tile).
-    auto load_tile = [&](u32x4 (&ra)[A_VECS], u32x4 (&rb)[B_VECS], unsigned& okmask)
+    // Loads are unconditional (all of a tile's global loads in flight together): border / K-tail
+    // vectors read the zero line.
+    auto load_tile = [&](u32x4 (&ra)[A_VECS], u32x4 (&rb)[B_VECS])
                          __attribute__((always_inline)) {
       if (ld_kt == 0) begin_tile();
-      const bool k_ok = kk < p.K;
-      okmask = 0;
+      if constexpr (TAPU) {
+        const long long aoff = (long long)(kh * p.W + kw) * p.lda + ci;     // wave-uniform
 #pragma unroll
-      for (int i = 0; i < A_VECS; ++i) {
-        bool ok = a_ok[i] && k_ok;
-        long long off;
-        if (IS1X1) {
-          off = (long long)a_pix[i] * p.lda + kk;
-        } else if (TAPU) {
-          const int iy = a_iy0[i] + kh, ix = a_ix0[i] + kw;
-          ok = ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-          off = (long long)(a_pix[i] + kh * p.W + kw) * p.lda + (ci + kc * VEC);
-        } else {
+        for (int i = 0; i < A_VECS; ++i) {
+          const bool ok = ((a_rb[i] >> kh) & (a_cb[i] >> kw) & 1u) != 0;
+          ra[i] = *reinterpret_cast<const u32x4*>(ok ? a_ptr[i] + aoff : zero_src);
+        }
+#pragma unroll
+        for (int i = 0; i < B_VECS; ++i)                  // K % BK == 0 here: no K tail
+          rb[i] = *reinterpret_cast<const u32x4*>(b_ptr[i] + k0);
+        ci += BK;
+        if (ci == p.Cin) {
+          ci = 0;
+          if (++kw == p.KW) { kw = 0; ++kh; }
+        }
+      } else if constexpr (IS1X1) {
+        const bool k_ok = k0 + kc * VEC < p.K;
+#pragma unroll
+        for (int i = 0; i < A_VECS; ++i)
+          ra[i] = *reinterpret_cast<const u32x4*>(k_ok ? a_ptr[i] + k0 : zero_src);
+#pragma unroll
+        for (int i = 0; i < B_VECS; ++i)
+          rb[i] = *reinterpret_cast<const u32x4*>(k_ok ? b_ptr[i] + k0 : zero_src);
+      } else {
+        const bool k_ok = kk < p.K;
+#pragma unroll
+        for (int i = 0; i < A_VECS; ++i) {
+          bool ok = k_ok;
           int iy = a_iy0[i] + kh, ix = a_ix0[i] + kw;
           if (p.ups) {
             ok = ok && iy >= 0 && iy < 2 * p.H && ix >= 0 && ix < 2 * p.W;
@@ -164,64 +198,49 @@ __device__ __forceinline__ void igemm_body(const SdmiGemmArgs& p, int tiles_m, i
           } else {
             ok = ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
           }
-          off = (long long)(a_pix[i] + iy * p.W + ix) * p.lda + ci;
+          const long long off = (long long)(a_pix[i] + iy * p.W + ix) * p.lda + ci;
+          ra[i] = *reinterpret_cast<const u32x4*>(ok ? Ag + off : zero_src);
         }
-        off = ok ? off : 0;
-        okmask |= (ok ? 1u : 0u) << i;
-        ra[i] = *reinterpret_cast<const u32x4*>(Ag + off);
-      }
 #pragma unroll
-      for (int i = 0; i < B_VECS; ++i) {
-        const bool ok = b_ok[i] && k_ok;
-        okmask |= (ok ? 1u : 0u) << (A_VECS + i);
-        rb[i] = *reinterpret_cast<const u32x4*>(Wg + (ok ? (long long)b_row[i] * p.ldw + kk : 0));
-      }
-      // advance k state to the next K tile (or on to the workgroup's next output tile)
-      kk += BK;
-      if (TAPU) {
-        ci += BK;
-        if (ci == p.Cin) {
-          ci = 0;
-          if (++kw == p.KW) { kw = 0; ++kh; }
-        }
-      } else if (!IS1X1) {
+        for (int i = 0; i < B_VECS; ++i)
+          rb[i] = *reinterpret_cast<const u32x4*>(
+              k_ok ? Wg + ((long long)b_row[i] * p.ldw + kk) : zero_src);
+        kk += BK;
         ci += BK;
         while (ci >= p.Cin) {
           ci -= p.Cin;
           if (++kw == p.KW) { kw = 0; ++kh; }
         }
       }
+      k0 += BK;
       if (++ld_kt == n_kt) { ld_kt = 0; ++ld_tile; }
     };
-    auto store_tile = [&](char* base, const u32x4 (&ra)[A_VECS], const u32x4 (&rb)[B_VECS],
-                          unsigned okmask) __attribute__((always_inline)) {
+    // LDS destinations: this thread's first row + compile-time row strides (immediate offsets)
+    constexpr int RSTEP = MTH_ROWS;
+    char* const st_a = smem + (tid / VPR) * ROWB + kc * 16;
+    char* const st_b = st_a + BM * ROWB;
+    auto store_tile = [&](int stage_off, const u32x4 (&ra)[A_VECS], const u32x4 (&rb)[B_VECS])
+                          __attribute__((always_inline)) {
 #pragma unroll
-      for (int i = 0; i < A_VECS; ++i) {
-        const int row = (tid + i * 256) / VPR;
-        *reinterpret_cast<u32x4*>(base + row * ROWB + kc * 16) =
-            ((okmask >> i) & 1u) ? ra[i] : zero4;
-      }
+      for (int i = 0; i < A_VECS; ++i)
+        *reinterpret_cast<u32x4*>(st_a + stage_off + i * RSTEP * ROWB) = ra[i];
 #pragma unroll
-      for (int i = 0; i < B_VECS; ++i) {
-        const int row = (tid + i * 256) / VPR;
-        *reinterpret_cast<u32x4*>(base + BM * ROWB + row * ROWB + kc * 16) =
-            ((okmask >> (A_VECS + i)) & 1u) ? rb[i] : zero4;
-      }
+      for (int i = 0; i < B_VECS; ++i)
+        *reinterpret_cast<u32x4*>(st_b + stage_off + i * RSTEP * ROWB) = rb[i];
     };
 
     u32x4 ra0[A_VECS], rb0[B_VECS], ra1[A_VECS], rb1[B_VECS];
-    unsigned mk0 = 0, mk1 = 0;
     // flat pipeline over (output tile, K tile) steps: while the MFMA waves finish a tile and run
     // its epilogue, the first K tiles of the next one are already staged / in flight
-    if (total > 0) load_tile(ra0, rb0, mk0);
-    if (total > 1) load_tile(ra1, rb1, mk1);
+    if (total > 0) load_tile(ra0, rb0);
+    if (total > 1) load_tile(ra1, rb1);
     for (int g = 0; g < total; g += 2) {
-      store_tile(smem, ra0, rb0, mk0);
-      if (g + 2 < total) load_tile(ra0, rb0, mk0);
+      store_tile(0, ra0, rb0);
+      if (g + 2 < total) load_tile(ra0, rb0);
       __syncthreads();
       if (g + 1 < total) {
-        store_tile(smem + BUF_BYTES, ra1, rb1, mk1);
-        if (g + 3 < total) load_tile(ra1, rb1, mk1);
+        store_tile(BUF_BYTES, ra1, rb1);
+        if (g + 3 < total) load_tile(ra1, rb1);
         __syncthreads();
       }
     }
