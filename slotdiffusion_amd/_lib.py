@@ -10,7 +10,7 @@ import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(_HERE, '..', 'include', 'sdmi.h')
-LIBPATH = os.path.join(_HERE, 'libsdmi.so')
+LIBPATH = os.environ.get('SDMI_LIBPATH') or os.path.join(_HERE, 'libsdmi.so')   # override: kernel experiments
 
 _CT = {
     'int': ctypes.c_int, 'float': ctypes.c_float, 'long long': ctypes.c_longlong,
