@@ -145,6 +145,9 @@ def main():
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--big-batch', type=int, default=256,
+                    help='extra sampling measurement at this batch (0 = off): the chip is far from '
+                         'full at the configured B = 64')
     ap.add_argument('--only-train', action='store_true',
                     help='profiling aid: skip the sampling leg of --mode train')
     args = ap.parse_args()
@@ -207,6 +210,18 @@ def main():
                      args.warmup if args.mode == 'sample' else 1)
         n_s = args.steps if args.mode == 'sample' else max(2, args.steps // 2)
         denoise_rate = world * B * nfe * n_s / dt_s
+        big_rate = None
+        if args.big_batch and args.big_batch != B and world == 1 and not args.only_train:
+            # informational: the same sampler at a batch that fills the chip better
+            Bb = args.big_batch
+            slots_b = slots[:1].expand(Bb, -1, -1).contiguous() + 0.01 * torch.randn(
+                Bb, slots.shape[1], slots.shape[2], device=dev)
+            xT_b = ops.nchw_to_nhwc(torch.randn(Bb, 3, 32, 32, device=dev), torch.float32, 4)
+            big = lambda: model._dpm_sample(xT_b, slots_b)[0]
+            dt_b = timed(big, 2, 1)
+            big_rate = Bb * nfe * 2 / dt_b
+            model._graph_cache.clear()
+            del slots_b, xT_b
 
     # ---- training leg: forward + loss + backward (+ DDP all-reduce) + clip + Adam --------
     model.train()
@@ -254,6 +269,8 @@ def main():
             'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
             'config': {'workload': work, 'batch_per_gpu': B, 'hip_graph': not args.no_graph,
                        'parallelism': f'dp{world}'},
+            'denoise_big_batch': ({'value': big_rate, 'unit': 'image-denoise-steps/s',
+                                   'batch': args.big_batch} if big_rate else None),
             'denoise': {'value': denoise_rate, 'unit': 'image-denoise-steps/s',
                         'ms_per_20nfe_pass': 1e3 * dt_s / n_s, 'nfe': nfe},
         }
