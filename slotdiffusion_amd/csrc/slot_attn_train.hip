@@ -213,7 +213,7 @@ __global__ __launch_bounds__(SA_THREADS) void sa_attend_bwd_kernel(SdmiSaAttendB
 // ==========================================================================================
 // token-tiled kernels
 // ==========================================================================================
-constexpr int SAT_NP = 8;   // slots padded to 8
+// slots are padded to NP = 8 or 16 (template parameter)
 
 template <typename T> struct SatCfg;
 template <> struct SatCfg<bf16_t> { static constexpr int TM = 128; };
@@ -238,17 +238,17 @@ __device__ __forceinline__ void sat_stage(const T* kb, const T* vb, int ldkv, in
 }
 
 // partial dots of one token row (LDS, this thread's channel range) with N fp32 vectors in LDS
-template <typename T>
+template <typename T, int NP>
 __device__ __forceinline__ void sat_dots(const char* row, const float* vecs, int D, int c0, int cn,
-                                         int N, float (&out)[SAT_NP]) {
+                                         int N, float (&out)[NP]) {
   constexpr int VEC = Elem<T>::VEC;
 #pragma unroll
-  for (int n = 0; n < SAT_NP; ++n) out[n] = 0.f;
+  for (int n = 0; n < NP; ++n) out[n] = 0.f;
   for (int c = c0; c < c0 + cn; c += VEC) {
     float x[VEC];
     unpack16<T>(*reinterpret_cast<const uint4*>(row + c * sizeof(T)), x);
 #pragma unroll
-    for (int n = 0; n < SAT_NP; ++n) {
+    for (int n = 0; n < NP; ++n) {
       if (n < N) {
         const float* qv = vecs + n * D + c;
 #pragma unroll
@@ -261,7 +261,7 @@ __device__ __forceinline__ void sat_dots(const char* row, const float* vecs, int
   }
 }
 
-template <typename T>
+template <typename T, int NP>
 __global__ __launch_bounds__(256) void sat_fwd_kernel(SdmiSaAttendArgs p, int tiles) {
   constexpr int TM = SatCfg<T>::TM;
   constexpr int TPT = 256 / TM;                  // threads per token in phase A
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(256) void sat_fwd_kernel(SdmiSaAttendArgs p, int ti
   char* Kt = smem;
   char* Vt = Kt + TM * PK;
   float* q_s = reinterpret_cast<float*>(Vt + TM * PK);     // [N][D], pre-scaled
-  float* w_s = q_s + SAT_NP * D;                           // [TM][8]
+  float* w_s = q_s + NP * D;                           // [TM][NP]
   const int b = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
   const int m0 = tile * TM;
   const int mvalid = min(TM, p.M - m0);
@@ -283,18 +283,18 @@ __global__ __launch_bounds__(256) void sat_fwd_kernel(SdmiSaAttendArgs p, int ti
   {  // phase A: logits, softmax over slots, w = a + eps
     const int tok = tid / TPT, sub = tid % TPT;
     const int cn = D / TPT;
-    float lg[SAT_NP];
-    sat_dots<T>(Kt + tok * PK, q_s, D, sub * cn, cn, N, lg);
+    float lg[NP];
+    sat_dots<T, NP>(Kt + tok * PK, q_s, D, sub * cn, cn, N, lg);
 #pragma unroll
-    for (int n = 0; n < SAT_NP; ++n)
+    for (int n = 0; n < NP; ++n)
       for (int off = 1; off < TPT; off <<= 1) lg[n] += __shfl_xor(lg[n], off, 64);
     float mx = -INFINITY;
 #pragma unroll
-    for (int n = 0; n < SAT_NP; ++n)
+    for (int n = 0; n < NP; ++n)
       if (n < N) mx = fmaxf(mx, lg[n]);
     float se = 0.f;
 #pragma unroll
-    for (int n = 0; n < SAT_NP; ++n) {
+    for (int n = 0; n < NP; ++n) {
       lg[n] = n < N ? __expf(lg[n] - mx) : 0.f;
       se += lg[n];
     }
@@ -303,10 +303,10 @@ __global__ __launch_bounds__(256) void sat_fwd_kernel(SdmiSaAttendArgs p, int ti
       const bool ok = tok < mvalid;
       float* ap = p.attn + ((long long)b * p.M + m0 + tok) * N;
 #pragma unroll
-      for (int n = 0; n < SAT_NP; ++n) {
+      for (int n = 0; n < NP; ++n) {
         const float a = lg[n] * inv;
         if (ok && n < N) ap[n] = a;
-        w_s[tok * SAT_NP + n] = (ok && n < N) ? a + p.eps : 0.f;
+        w_s[tok * NP + n] = (ok && n < N) ? a + p.eps : 0.f;
       }
     }
   }
@@ -314,30 +314,32 @@ __global__ __launch_bounds__(256) void sat_fwd_kernel(SdmiSaAttendArgs p, int ti
   // phase B: thread d owns channel d: upd_partial[n][d] = sum_m w[m][n] v[m][d]; threads D..D+N-1: den
   float* wsu = p.workspace + ((long long)b * tiles + tile) * N * (D + 1);
   if (tid < D) {
-    float acc[SAT_NP];
+    float acc[NP];
 #pragma unroll
-    for (int n = 0; n < SAT_NP; ++n) acc[n] = 0.f;
+    for (int n = 0; n < NP; ++n) acc[n] = 0.f;
     const char* vcol = Vt + tid * sizeof(T);
     for (int m = 0; m < mvalid; ++m) {
       const float v = Elem<T>::ld(reinterpret_cast<const T*>(vcol + m * PK));
-      const f32x4 w0 = *reinterpret_cast<const f32x4*>(w_s + m * SAT_NP);
-      const f32x4 w1 = *reinterpret_cast<const f32x4*>(w_s + m * SAT_NP + 4);
-      acc[0] += w0[0] * v; acc[1] += w0[1] * v; acc[2] += w0[2] * v; acc[3] += w0[3] * v;
-      acc[4] += w1[0] * v; acc[5] += w1[1] * v; acc[6] += w1[2] * v; acc[7] += w1[3] * v;
+#pragma unroll
+      for (int q = 0; q < NP / 4; ++q) {
+        const f32x4 w4 = *reinterpret_cast<const f32x4*>(w_s + m * NP + 4 * q);
+        acc[4 * q] += w4[0] * v; acc[4 * q + 1] += w4[1] * v;
+        acc[4 * q + 2] += w4[2] * v; acc[4 * q + 3] += w4[3] * v;
+      }
     }
 #pragma unroll
-    for (int n = 0; n < SAT_NP; ++n)
+    for (int n = 0; n < NP; ++n)
       if (n < N) wsu[n * D + tid] = acc[n];
   } else if (tid < D + N) {
     const int n = tid - D;
     float s = 0.f;
-    for (int m = 0; m < mvalid; ++m) s += w_s[m * SAT_NP + n];
+    for (int m = 0; m < mvalid; ++m) s += w_s[m * NP + n];
     wsu[N * D + n] = s;
   }
 }
 
 __global__ __launch_bounds__(256) void sat_fwd_finalize_kernel(SdmiSaAttendArgs p, int tiles) {
-  __shared__ float den_s[SAT_NP];
+  __shared__ float den_s[16];
   const int b = blockIdx.x, N = p.N, D = p.D;
   const float* ws = p.workspace + (long long)b * tiles * N * (D + 1);
   if (threadIdx.x < N) {
@@ -354,7 +356,7 @@ __global__ __launch_bounds__(256) void sat_fwd_finalize_kernel(SdmiSaAttendArgs 
   }
 }
 
-template <typename T>
+template <typename T, int NP>
 __global__ __launch_bounds__(256) void sat_bwd_kernel(SdmiSaAttendBwdArgs p, int tiles) {
   constexpr int VEC = Elem<T>::VEC;
   constexpr int TM = SatCfg<T>::TM;
@@ -364,24 +366,25 @@ __global__ __launch_bounds__(256) void sat_bwd_kernel(SdmiSaAttendBwdArgs p, int
   const int PK = D * (int)sizeof(T) + 16;
   char* Kt = smem;
   char* Vt = Kt + TM * PK;
-  float* q_s = reinterpret_cast<float*>(Vt + TM * PK);     // [8][D] scaled q
-  float* du_s = q_s + SAT_NP * D;                          // [8][D] dupd
-  float* dL_s = du_s + SAT_NP * D;                         // [TM][8]
-  float* wn_s = dL_s + TM * SAT_NP;                        // [TM][8]
-  float* c_s = wn_s + TM * SAT_NP;                         // [8] c_n, [8] 1/den_n
+  float* q_s = reinterpret_cast<float*>(Vt + TM * PK);     // [NP][D] scaled q
+  float* du_s = q_s + NP * D;                          // [NP][D] dupd
+  float* dL_s = du_s + NP * D;                         // [TM][NP]
+  float* wn_s = dL_s + TM * NP;                        // [TM][NP]
+  float* c_s = wn_s + TM * NP;                         // [NP] c_n, [NP] 1/den_n
   const int b = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
   const int m0 = tile * TM;
   const int mvalid = min(TM, p.M - m0);
   const T* kb = (const T*)p.k + (long long)b * p.M * p.ldkv;
   const T* vb = (const T*)p.v + (long long)b * p.M * p.ldkv;
   sat_stage<T>(kb, vb, p.ldkv, m0, mvalid, D, Kt, Vt, PK);
-  for (int i = tid; i < SAT_NP * D; i += 256) {
+  for (int i = tid; i < NP * D; i += 256) {
     const bool ok = i < N * D;
     q_s[i] = ok ? p.q[(long long)b * N * D + i] * p.scale : 0.f;
     du_s[i] = ok ? p.dupd[(long long)b * N * D + i] : 0.f;
   }
-  {  // c_n = dupd_n . upd_n : 32 lanes per slot
-    const int n = tid >> 5, l = tid & 31;
+  // c_n = dupd_n . upd_n : 32 lanes per slot, 8 slots per round
+  for (int n = tid >> 5; n < NP; n += 8) {
+    const int l = tid & 31;
     float a = 0.f;
     if (n < N)
       for (int c = l; c < D; c += 32)
@@ -389,92 +392,102 @@ __global__ __launch_bounds__(256) void sat_bwd_kernel(SdmiSaAttendBwdArgs p, int
     for (int off = 1; off < 32; off <<= 1) a += __shfl_xor(a, off, 64);
     if (l == 0) {
       c_s[n] = a;
-      c_s[SAT_NP + n] = n < N ? 1.f / p.den[b * N + n] : 0.f;
+      c_s[NP + n] = n < N ? 1.f / p.den[b * N + n] : 0.f;
     }
   }
   __syncthreads();
   {  // phase A: per-token slot terms dL[m][n], wn[m][n]
     const int tok = tid / TPT, sub = tid % TPT;
     const int cn = D / TPT;
-    float g[SAT_NP];
-    sat_dots<T>(Vt + tok * PK, du_s, D, sub * cn, cn, N, g);
+    float g[NP];
+    sat_dots<T, NP>(Vt + tok * PK, du_s, D, sub * cn, cn, N, g);
 #pragma unroll
-    for (int n = 0; n < SAT_NP; ++n)
+    for (int n = 0; n < NP; ++n)
       for (int off = 1; off < TPT; off <<= 1) g[n] += __shfl_xor(g[n], off, 64);
     if (sub == 0) {
       const bool ok = tok < mvalid;
       const float* ap = p.attn + ((long long)b * p.M + m0 + (ok ? tok : 0)) * N;
-      float a[SAT_NP], dw[SAT_NP];
+      float a[NP], dw[NP];
       float dot = 0.f;
 #pragma unroll
-      for (int n = 0; n < SAT_NP; ++n) {
+      for (int n = 0; n < NP; ++n) {
         a[n] = (ok && n < N) ? ap[n] : 0.f;
-        dw[n] = (g[n] - c_s[n]) * c_s[SAT_NP + n];
+        dw[n] = (g[n] - c_s[n]) * c_s[NP + n];
         dot += a[n] * dw[n];
       }
 #pragma unroll
-      for (int n = 0; n < SAT_NP; ++n) {
-        dL_s[tok * SAT_NP + n] = a[n] * (dw[n] - dot);
-        wn_s[tok * SAT_NP + n] = (ok && n < N) ? (a[n] + p.eps) * c_s[SAT_NP + n] : 0.f;
+      for (int n = 0; n < NP; ++n) {
+        dL_s[tok * NP + n] = a[n] * (dw[n] - dot);
+        wn_s[tok * NP + n] = (ok && n < N) ? (a[n] + p.eps) * c_s[NP + n] : 0.f;
       }
     }
   }
   __syncthreads();
-  // phase B: thread (chunk ch of VEC channels, token lane tl): dk, dv rows out; dq partial
-  const int CH = D / VEC, TL = 256 / CH;
+  // phase B: thread (chunk ch of CW channels, token lane tl): dk, dv rows out; dq partial.
+  // CW = the 16-byte vector, or half of it for 16 padded slots in bf16 (register budget:
+  // 3 * NP * CW values per thread)
+  constexpr int CW = (NP == 16 && VEC == 8) ? 4 : VEC;
+  const int CH = D / CW, TL = 256 / CH;
   const int ch = tid % CH, tl = tid / CH;
-  float dq[SAT_NP][VEC];
+  float dq[NP][CW];
 #pragma unroll
-  for (int n = 0; n < SAT_NP; ++n)
+  for (int n = 0; n < NP; ++n)
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) dq[n][j] = 0.f;
+    for (int j = 0; j < CW; ++j) dq[n][j] = 0.f;
   if (tl < TL) {
-    float qr[SAT_NP][VEC], dur[SAT_NP][VEC];
+    float qr[NP][CW], dur[NP][CW];
 #pragma unroll
-    for (int n = 0; n < SAT_NP; ++n)
+    for (int n = 0; n < NP; ++n)
 #pragma unroll
-      for (int j = 0; j < VEC; ++j) {
-        qr[n][j] = q_s[n * D + ch * VEC + j];
-        dur[n][j] = du_s[n * D + ch * VEC + j];
+      for (int j = 0; j < CW; ++j) {
+        qr[n][j] = q_s[n * D + ch * CW + j];
+        dur[n][j] = du_s[n * D + ch * CW + j];
       }
     T* dkb = (T*)p.dk + (long long)b * p.M * p.ldkv;
     T* dvb = (T*)p.dv + (long long)b * p.M * p.ldkv;
     for (int m = tl; m < mvalid; m += TL) {
-      float kx[VEC], dkx[VEC], dvx[VEC];
-      unpack16<T>(*reinterpret_cast<const uint4*>(Kt + m * PK + ch * 16), kx);
-      float dl[SAT_NP], wn[SAT_NP];
-      *reinterpret_cast<f32x4*>(dl) = *reinterpret_cast<const f32x4*>(dL_s + m * SAT_NP);
-      *reinterpret_cast<f32x4*>(dl + 4) = *reinterpret_cast<const f32x4*>(dL_s + m * SAT_NP + 4);
-      *reinterpret_cast<f32x4*>(wn) = *reinterpret_cast<const f32x4*>(wn_s + m * SAT_NP);
-      *reinterpret_cast<f32x4*>(wn + 4) = *reinterpret_cast<const f32x4*>(wn_s + m * SAT_NP + 4);
+      float kx[CW], dkx[CW], dvx[CW];
+      const T* kp = reinterpret_cast<const T*>(Kt + m * PK) + ch * CW;
 #pragma unroll
-      for (int j = 0; j < VEC; ++j) dkx[j] = dvx[j] = 0.f;
+      for (int j = 0; j < CW; ++j) kx[j] = Elem<T>::ld(kp + j);
+      float dl[NP], wn[NP];
 #pragma unroll
-      for (int n = 0; n < SAT_NP; ++n)
+      for (int q = 0; q < NP / 4; ++q) {
+        *reinterpret_cast<f32x4*>(dl + 4 * q) = *reinterpret_cast<const f32x4*>(dL_s + m * NP + 4 * q);
+        *reinterpret_cast<f32x4*>(wn + 4 * q) = *reinterpret_cast<const f32x4*>(wn_s + m * NP + 4 * q);
+      }
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) {
+      for (int j = 0; j < CW; ++j) dkx[j] = dvx[j] = 0.f;
+#pragma unroll
+      for (int n = 0; n < NP; ++n)
+#pragma unroll
+        for (int j = 0; j < CW; ++j) {
           dkx[j] += dl[n] * qr[n][j];
           dvx[j] += wn[n] * dur[n][j];
           dq[n][j] += dl[n] * kx[j];
         }
-      const long long go = (long long)(m0 + m) * p.ldkv + ch * VEC;
-      *reinterpret_cast<uint4*>(dkb + go) = pack16<T>(dkx);
-      *reinterpret_cast<uint4*>(dvb + go) = pack16<T>(dvx);
+      T* dkp = dkb + (long long)(m0 + m) * p.ldkv + ch * CW;
+      T* dvp = dvb + (long long)(m0 + m) * p.ldkv + ch * CW;
+#pragma unroll
+      for (int j = 0; j < CW; ++j) {
+        Elem<T>::st(dkp + j, dkx[j]);
+        Elem<T>::st(dvp + j, dvx[j]);
+      }
     }
   }
   __syncthreads();                   // K/V tiles are dead: reuse them for the dq fold
-  float* red = reinterpret_cast<float*>(smem);             // [TL][8][D]
+  float* red = reinterpret_cast<float*>(smem);             // [TL][NP][D]
   if (tl < TL) {
 #pragma unroll
-    for (int n = 0; n < SAT_NP; ++n)
+    for (int n = 0; n < NP; ++n)
 #pragma unroll
-      for (int j = 0; j < VEC; ++j) red[(tl * SAT_NP + n) * D + ch * VEC + j] = dq[n][j];
+      for (int j = 0; j < CW; ++j) red[(tl * NP + n) * D + ch * CW + j] = dq[n][j];
   }
   __syncthreads();
   float* wsq = p.workspace + ((long long)b * tiles + tile) * N * D;
   for (int i = tid; i < N * D; i += 256) {
     float s = 0.f;
-    for (int l = 0; l < TL; ++l) s += red[l * SAT_NP * D + i];   // i = n*D + d, n < N <= 8
+    for (int l = 0; l < TL; ++l) s += red[l * NP * D + i];       // i = n*D + d, n < N <= NP
     wsq[i] = s;
   }
 }
@@ -493,38 +506,44 @@ template <typename T>
 bool sat_ok(int N, int D, int ldkv) {
   constexpr int VEC = Elem<T>::VEC;
   constexpr int TPT = 256 / SatCfg<T>::TM;
-  return N <= SAT_NP && D % (TPT * VEC) == 0 && D / VEC <= 256 && ldkv % VEC == 0 && D <= 256;
+  const int np = N <= 8 ? 8 : 16;
+  const int tm = SatCfg<T>::TM;
+  // LDS of the (larger) backward kernel must fit the 160 KB of a CU
+  const int smem_bwd = 2 * tm * (D * (int)sizeof(T) + 16) + (2 * np * D + 2 * tm * np + 2 * np) * 4;
+  return N <= 16 && D % (TPT * VEC) == 0 && D / VEC <= 256 && ldkv % VEC == 0 && D <= 256 &&
+         smem_bwd <= 160 * 1024;
 }
-template <typename T>
+template <typename T, int NP>
 int sat_launch_fwd(const SdmiSaAttendArgs& a, hipStream_t st) {
   constexpr int TM = SatCfg<T>::TM;
   const int tiles = (a.M + TM - 1) / TM;
-  const int smem = 2 * TM * (a.D * (int)sizeof(T) + 16) + (SAT_NP * a.D + TM * SAT_NP) * 4;
+  const int smem = 2 * TM * (a.D * (int)sizeof(T) + 16) + (NP * a.D + TM * NP) * 4;
   static bool done = false;
   if (!done) {
-    (void)hipFuncSetAttribute((const void*)sat_fwd_kernel<T>,
+    (void)hipFuncSetAttribute((const void*)sat_fwd_kernel<T, NP>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     done = true;
   }
-  hipLaunchKernelGGL(sat_fwd_kernel<T>, dim3(tiles, a.B), dim3(256), smem, st, a, tiles);
+  hipLaunchKernelGGL((sat_fwd_kernel<T, NP>), dim3(tiles, a.B), dim3(256), smem, st, a, tiles);
   hipLaunchKernelGGL(sat_fwd_finalize_kernel, dim3(a.B), dim3(256), 0, st, a, tiles);
   return sdmi_check_launch("sa_attend_fwd (tiled)");
 }
-template <typename T>
+template <typename T, int NP>
 int sat_launch_bwd(const SdmiSaAttendBwdArgs& a, hipStream_t st) {
   constexpr int TM = SatCfg<T>::TM;
   constexpr int VEC = Elem<T>::VEC;
   const int tiles = (a.M + TM - 1) / TM;
-  int smem = 2 * TM * (a.D * (int)sizeof(T) + 16) + (2 * SAT_NP * a.D + 2 * TM * SAT_NP + 16) * 4;
-  const int red = (256 / (a.D / VEC)) * SAT_NP * a.D * 4;
+  int smem = 2 * TM * (a.D * (int)sizeof(T) + 16) + (2 * NP * a.D + 2 * TM * NP + 2 * NP) * 4;
+  const int cw = (NP == 16 && VEC == 8) ? 4 : VEC;
+  const int red = (256 / (a.D / cw)) * NP * a.D * 4;
   if (red > smem) smem = red;
   static bool done = false;
   if (!done) {
-    (void)hipFuncSetAttribute((const void*)sat_bwd_kernel<T>,
+    (void)hipFuncSetAttribute((const void*)sat_bwd_kernel<T, NP>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     done = true;
   }
-  hipLaunchKernelGGL(sat_bwd_kernel<T>, dim3(tiles, a.B), dim3(256), smem, st, a, tiles);
+  hipLaunchKernelGGL((sat_bwd_kernel<T, NP>), dim3(tiles, a.B), dim3(256), smem, st, a, tiles);
   hipLaunchKernelGGL(sat_bwd_finalize_kernel, dim3(a.B), dim3(256), 0, st, a, tiles);
   return sdmi_check_launch("sa_attend_bwd (tiled)");
 }
@@ -611,8 +630,8 @@ extern "C" int sdmi_sa_attend_fwd(const SdmiSaAttendArgs* a, void* stream) {
   SDMI_REQUIRE(a->N >= 1 && a->N <= 16 && a->D <= 256, "N <= 16, D <= 256");
   hipStream_t st = (hipStream_t)stream;
   if (a->workspace) {
-    if (a->dtype == SDMI_BF16 && sat_ok<bf16_t>(a->N, a->D, a->ldkv)) return sat_launch_fwd<bf16_t>(*a, st);
-    if (a->dtype == SDMI_F32 && sat_ok<float>(a->N, a->D, a->ldkv)) return sat_launch_fwd<float>(*a, st);
+    if (a->dtype == SDMI_BF16 && sat_ok<bf16_t>(a->N, a->D, a->ldkv)) return a->N <= 8 ? sat_launch_fwd<bf16_t, 8>(*a, st) : sat_launch_fwd<bf16_t, 16>(*a, st);
+    if (a->dtype == SDMI_F32 && sat_ok<float>(a->N, a->D, a->ldkv)) return a->N <= 8 ? sat_launch_fwd<float, 8>(*a, st) : sat_launch_fwd<float, 16>(*a, st);
   }
   SA_DISPATCH(launch_fwd, a, st);
 }
@@ -622,8 +641,8 @@ extern "C" int sdmi_sa_attend_bwd(const SdmiSaAttendBwdArgs* a, void* stream) {
   SDMI_REQUIRE(a->N >= 1 && a->N <= 16 && a->D <= 256, "N <= 16, D <= 256");
   hipStream_t st = (hipStream_t)stream;
   if (a->workspace) {
-    if (a->dtype == SDMI_BF16 && sat_ok<bf16_t>(a->N, a->D, a->ldkv)) return sat_launch_bwd<bf16_t>(*a, st);
-    if (a->dtype == SDMI_F32 && sat_ok<float>(a->N, a->D, a->ldkv)) return sat_launch_bwd<float>(*a, st);
+    if (a->dtype == SDMI_BF16 && sat_ok<bf16_t>(a->N, a->D, a->ldkv)) return a->N <= 8 ? sat_launch_bwd<bf16_t, 8>(*a, st) : sat_launch_bwd<bf16_t, 16>(*a, st);
+    if (a->dtype == SDMI_F32 && sat_ok<float>(a->N, a->D, a->ldkv)) return a->N <= 8 ? sat_launch_bwd<float, 8>(*a, st) : sat_launch_bwd<float, 16>(*a, st);
   }
   SA_DISPATCH(launch_bwd, a, st);
 }

@@ -377,7 +377,8 @@ def test_attention_bwd_kernel(cfg, dtype):
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize('B,M,N,D', [(2, 1024, 7, 192), (3, 200, 5, 192), (2, 130, 8, 128)])
+@pytest.mark.parametrize('B,M,N,D', [(2, 1024, 7, 192), (3, 200, 5, 192), (2, 130, 8, 128),
+                                     (2, 1024, 15, 192), (2, 300, 11, 192), (1, 784, 16, 256)])
 def test_sa_attend_tiled_matches_reference(B, M, N, D, dtype):
     """Token-tiled Slot-Attention pass (forward and backward) against torch autograd of the
     reference formula (sa_diffusion.py:40-58) and against the one-workgroup-per-image kernels."""
