@@ -244,9 +244,10 @@ def main():
         run_step = train_step
         if not args.no_graph:
             from slotdiffusion_amd.optim import GraphedTrainStep
-            ar = (lambda g: parallel.allreduce_gradients(g, world, n_buckets=4)) if dist is not None \
-                else None
-            graphed = GraphedTrainStep(model, opt, dict(img=img), allreduce=ar)
+            # world > 1: backward split at the slots, denoiser gradients all-reduced under the
+            # encoder's backward (optim.GraphedTrainStep)
+            graphed = GraphedTrainStep(model, opt, dict(img=img),
+                                       allreduce=(True if dist is not None else None), world=world)
             run_step = lambda: graphed(dict(img=img))
         dt_t = timed(run_step, args.steps, args.warmup)
         train_rate = world * B * args.steps / dt_t

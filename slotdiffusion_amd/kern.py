@@ -52,6 +52,10 @@ class WeightBank:
         # autograd anchor: parameters reach the kernels by name, so parameterised Functions take
         # this requires-grad dummy to make their outputs part of the graph
         self.anchor = torch.zeros(1, device=model.arena().device, requires_grad=True)
+        # a second anchor for the denoiser's Functions: `autograd.grad(loss, [slots, anchor_dec])`
+        # then runs exactly the denoiser's backward (and stops at the slots), so that its gradient
+        # range can be all-reduced while the slot encoder's backward is still running
+        self.anchor_dec = torch.zeros(1, device=model.arena().device, requires_grad=True)
         # weight-gradient GEMMs are off the backward critical path (nothing downstream reads them
         # before the optimiser): they run on a second HIP stream, concurrently with the dgrad
         # chain, and are joined when the autograd pass ends.  Their operands are kept alive until
@@ -62,6 +66,10 @@ class WeightBank:
         self._join_queued = False
         # dgrad operands: key -> [buffer, epoch, (stable source view | None, geometry)]
         self._wd, self._wd_epoch, self._wd_stale, self._wd_table = {}, 0, False, None
+
+    def anchor_for(self, names):
+        n = names if isinstance(names, str) else names[0]
+        return self.anchor_dec if n.startswith('dm_decoder') else self.anchor
 
     def side_stream(self):
         if not self.overlap_wgrad:
@@ -928,19 +936,19 @@ class KernGrad(Kern):
 
     def conv(self, x, wname, bname=None, *, kh=3, kw=3, stride=1, pad=(1, 1, 1, 1), ups=False,
              rowvec=None, residual=None, out_dtype=None, ldc=None):
-        return GemmFn.apply(x, rowvec, residual, self.wb.anchor, self.wb, wname, bname,
+        return GemmFn.apply(x, rowvec, residual, self.wb.anchor_for(wname), self.wb, wname, bname,
                             (kh, kw, stride, pad, ups), out_dtype, ldc)
 
     def linear(self, x, wnames, bnames=None, *, act=None, residual=None, out_dtype=None):
-        y = GemmFn.apply(x, None, residual, self.wb.anchor, self.wb, wnames, bnames,
+        y = GemmFn.apply(x, None, residual, self.wb.anchor_for(wnames), self.wb, wnames, bnames,
                          (0, 0, 1, (0, 0, 0, 0), False), out_dtype, None)
         return ActFn.apply(y, act) if act else y
 
     def gn(self, x, name, *, eps, act=None, residual=None):
-        return GroupNormFn.apply(x, residual, self.wb.anchor, self.wb, name, eps, act)
+        return GroupNormFn.apply(x, residual, self.wb.anchor_for(name), self.wb, name, eps, act)
 
     def deconv(self, x, wname, bname, *, k, stride, pad, act='relu'):
-        return DeconvFn.apply(x, self.wb.anchor, self.wb, wname, bname, k, stride, pad, act)
+        return DeconvFn.apply(x, self.wb.anchor_for(wname), self.wb, wname, bname, k, stride, pad, act)
 
     def broadcast_pos(self, x, pos, dtype):
         return BroadcastPosFn.apply(x, pos, dtype)
@@ -949,7 +957,7 @@ class KernGrad(Kern):
         return SaCombineFn.apply(o, B, N)
 
     def ln(self, x, name):
-        return LayerNormFn.apply(x, self.wb.anchor, self.wb, name)
+        return LayerNormFn.apply(x, self.wb.anchor_for(name), self.wb, name)
 
     def attn_self(self, qkv, heads, head_dim=32):
         return AttnFn.apply(qkv, None, heads, head_dim)

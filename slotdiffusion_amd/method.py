@@ -101,12 +101,12 @@ class Method:
         for epoch in range(self.params.max_epochs):
             for batch in self.datamodule.train_loader(epoch):
                 if self.use_graph and graphed is None and len(self._loss_names()) == 1:
-                    ar = (lambda g: parallel.allreduce_gradients(g, self.world)) \
-                        if self.world > 1 else None
+                    ar = True if self.world > 1 else None      # overlapped gradient all-reduce
                     key = self._loss_names()[0]
                     # capturing the step runs two (real) warm-up steps on this first batch
                     graphed = GraphedTrainStep(self.model, self.optimizer, batch, allreduce=ar,
-                                               loss_key=key, loss_weight=self._get(f'{key}_w', 1.0))
+                                               loss_key=key, loss_weight=self._get(f'{key}_w', 1.0),
+                                               world=self.world)
                     self.it += 2
                 else:
                     loss = graphed(batch) if graphed is not None else self._eager_step(batch)

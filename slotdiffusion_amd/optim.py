@@ -93,41 +93,76 @@ class FusedAdam:
 
 
 class GraphedTrainStep:
-    """zero-grad -> forward -> loss -> backward -> clip+Adam captured once into a HIP graph and
-    replayed per step (about 2.5k kernel launches per replay instead of 2.5k host launches).
+    """zero-grad -> forward -> loss -> backward -> clip+Adam captured once into HIP graphs and
+    replayed per step (about 2.2k kernel launches per replay instead of 2.2k host launches).
     RNG (t, noise) comes from torch's graph-safe Philox generator, dropout masks from the device
     word `model.step_seed`, Adam's step / lr from device scalars -- nothing host-side is baked in.
-    With world > 1 the gradient all-reduce runs eagerly between two graphs."""
+
+    world == 1: one graph for forward + backward, one for the update.
+    world  > 1 (`allreduce` given): the backward is split at the slots -- graph A = forward + loss +
+    the denoiser's backward (97 % of the gradient bytes), then the all-reduce of that gradient
+    range starts on the collective stream while graph B (the slot encoder's backward: the
+    64-channel convolutions at full resolution) runs; the small encoder range follows, then the
+    update graph.  `allreduce` may be the legacy callable (whole arena, no overlap) or True."""
 
     def __init__(self, model, opt, example_batch, allreduce=None, loss_key='denoise_loss',
-                 loss_weight=1.0):
+                 loss_weight=1.0, world=None):
         self.model, self.opt, self.allreduce = model, opt, allreduce
         self.loss_key, self.loss_weight = loss_key, loss_weight
         self.static = {k: v.clone() for k, v in example_batch.items()}
         dev = model.arena().device
         if getattr(model, 'step_seed', None) is None or model.step_seed.device != dev:
             model.step_seed = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.world = world
+        if allreduce is not None and world is None:
+            import torch.distributed as dist
+            self.world = dist.get_world_size()
+        # overlap mode needs the denoiser / encoder split of the arena (lr group 1 = dm_decoder)
+        runs = model.lr_runs()
+        self.dec_runs = [(lo, hi) for lo, hi, grp in runs if grp == 1]
+        self.enc_runs = [(lo, hi) for lo, hi, grp in runs if grp != 1]
+        self.overlap = allreduce is True and len(self.dec_runs) > 0 and len(self.enc_runs) > 0
+        if allreduce is True and not self.overlap:        # no denoiser range to split at
+            from . import parallel
+            self.allreduce = allreduce = lambda g: parallel.allreduce_gradients(g, self.world)
         self.loss = None
+        self._slots = self._dslots = None
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(2):                      # warm-up: lazy operands, func attributes
                 opt.set_lr_for_next_step()
                 opt.step_count += 1
-                self._fwd_bwd()
-                if allreduce is not None:
-                    allreduce(model.grad_arena())
+                if self.overlap:
+                    self._fwd_bwd_denoiser()
+                    works = self._start_reduce(self.dec_runs)
+                    self._bwd_encoder()
+                    works += self._start_reduce(self.enc_runs)
+                    self._finish_reduce(works)
+                else:
+                    self._fwd_bwd()
+                    if allreduce is not None:
+                        allreduce(model.grad_arena())
                 self._update()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.g_fb = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g_fb):
-            self.loss = self._fwd_bwd()
+        self.g_enc = None
+        if self.overlap:
+            with torch.cuda.graph(self.g_fb):
+                self.loss = self._fwd_bwd_denoiser()
+            self.g_enc = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g_enc, pool=self.g_fb.pool()):
+                self._bwd_encoder()
+        else:
+            with torch.cuda.graph(self.g_fb):
+                self.loss = self._fwd_bwd()
         self.g_up = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.g_up, pool=self.g_fb.pool()):
             self._update()
 
-    def _fwd_bwd(self):
+    # -- pieces ---------------------------------------------------------------------------
+    def _forward_loss(self):
         m = self.model
         m.grad_arena().zero_()
         m.step_seed.add_(1)
@@ -136,8 +171,36 @@ class GraphedTrainStep:
         loss = m.calc_train_loss(self.static, out)[self.loss_key]
         if self.loss_weight != 1.0:
             loss = loss * self.loss_weight
+        return out, loss
+
+    def _fwd_bwd(self):
+        _, loss = self._forward_loss()
         loss.backward()
         return loss.detach()
+
+    def _fwd_bwd_denoiser(self):
+        out, loss = self._forward_loss()
+        slots = out['slots']
+        dslots, _ = torch.autograd.grad(loss, [slots, self.model.bank().anchor_dec], allow_unused=True)
+        self._slots, self._dslots = slots, dslots
+        return loss.detach()
+
+    def _bwd_encoder(self):
+        torch.autograd.backward([self._slots], [self._dslots])
+        self._slots = self._dslots = None
+
+    def _start_reduce(self, runs):
+        from . import parallel
+        g = self.model.grad_arena()
+        works = []
+        for lo, hi in runs:
+            works += parallel.allreduce_range_async(g, lo, hi)
+        return works
+
+    def _finish_reduce(self, works):
+        for w in works:
+            w.wait()
+        self.model.grad_arena().mul_(1.0 / self.world)
 
     def _update(self):
         self.opt.step(capturable=True)
@@ -148,7 +211,12 @@ class GraphedTrainStep:
         self.opt.set_lr_for_next_step()
         self.opt.step_count += 1
         self.g_fb.replay()
-        if self.allreduce is not None:
+        if self.overlap:
+            works = self._start_reduce(self.dec_runs)
+            self.g_enc.replay()
+            works += self._start_reduce(self.enc_runs)
+            self._finish_reduce(works)
+        elif self.allreduce is not None:
             self.allreduce(self.model.grad_arena())
         self.g_up.replay()
         return self.loss

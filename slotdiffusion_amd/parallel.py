@@ -41,6 +41,25 @@ def allreduce_gradients(arena, world=None, n_buckets=4, group=None):
     return arena
 
 
+def allreduce_range_async(arena, lo, hi, n_buckets=2, group=None):
+    """Start the sum-all-reduce of arena[lo:hi] (a few large buckets); returns the work handles.
+    The caller overlaps other GPU work, then calls finish_allreduce()."""
+    works = []
+    if hi <= lo:
+        return works
+    view = arena[lo:hi]
+    for a, b in reversed(bucket_bounds(hi - lo, n_buckets)):
+        works.append(dist.all_reduce(view[a:b], op=dist.ReduceOp.SUM, group=group, async_op=True))
+    return works
+
+
+def finish_allreduce(arena, works, world):
+    for w in works:
+        w.wait()
+    arena.mul_(1.0 / world)
+    return arena
+
+
 def broadcast_parameters(arena, src=0, group=None):
     """Make every rank start from rank `src`'s parameters (one flat broadcast)."""
     dist.broadcast(arena, src=src, group=group)

@@ -52,14 +52,15 @@ def _worker(rank, world, port, out_dir):
         parallel.broadcast_parameters(m.arena())
         opt = FusedAdam(m, lr=1e-4, dec_lr=2e-4, clip_grad=1.0)
         batch = _batch(2 * rank, 2 * rank + 2)
-        # gradients of the first step at the common initial weights (eager), all-reduced
-        opt.zero_grad()
-        m.calc_train_loss(batch, m(batch))['denoise_loss'].backward()
-        parallel.allreduce_gradients(m.grad_arena(), world)
+        # gradients of the first step at the common initial weights, through the same split
+        # backward + range-wise all-reduce the graphed step uses (zero learning rate: weights stay)
+        opt0 = FusedAdam(m, lr=0.0, dec_lr=0.0, clip_grad=1.0)
+        s0 = GraphedTrainStep(m, opt0, batch, allreduce=True, world=world)
+        s0(batch)
         torch.cuda.synchronize()
         torch.save(m.grad_arena().detach().cpu(), os.path.join(out_dir, f'grad{rank}.pt'))
-        step = GraphedTrainStep(m, opt, batch,
-                                allreduce=lambda g: parallel.allreduce_gradients(g, world))
+        step = GraphedTrainStep(m, opt, batch, allreduce=True, world=world)   # split backward,
+        assert step.overlap                                                  # overlapped all-reduce
         step(batch)                                   # 2 warm-up steps inside + 1 replay
         torch.cuda.synchronize()
         torch.save(m.arena().detach().cpu(), os.path.join(out_dir, f'arena{rank}.pt'))
