@@ -23,6 +23,10 @@
 // fetched into one L2 and re-used by its n-tiles there.
 #include "common.h"
 
+#ifndef SDMI_IGEMM_DMA
+#define SDMI_IGEMM_DMA 0
+#endif
+
 namespace {
 
 // Out-of-image / K-tail / out-of-range operand vectors are FETCHED from this zero line instead of
@@ -32,6 +36,112 @@ __device__ uint4 g_zero_line[8];
 struct ConvGeom {
   int H, W, Cin, HoWo, Wo, KH, KW, stride, pad_t, pad_l, ups;
 };
+
+// Epilogue of one MFMA wave's (TM*32)x(TN*32) accumulator block whose top-left output element is
+// (mw0, nw0): split-K partial store, or alpha / bias / per-image row vector / residual / activation
+// and the typed store.
+template <int TM, int TN>
+__device__ __forceinline__ void wave_epilogue(const SdmiGemmArgs& p, f32x16 (&acc)[TM][TN], int mw0,
+                                              int nw0, int zb, int hw_shift, int lane) {
+  // ---- epilogue. C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  const int col_l = lane & 31;
+  const int row_l = (lane >> 5) * 4;
+  if (p.split_k > 1) {
+    float* ws = p.workspace + ((long long)blockIdx.y) * p.M * p.N;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int n = nw0 + j * 32 + col_l;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = mw0 + i * 32 + (r & 3) + 8 * (r >> 2) + row_l;
+          if (m < p.M && n < p.N) ws[(long long)m * p.N + n] = acc[i][j][r];
+        }
+      }
+    return;
+  }
+  char* outp = (char*)p.out;
+  const char* resp = (const char*)p.residual;
+  const long long zc = (long long)zb * p.sc, zr = (long long)zb * p.sr;
+  const int HoWo = p.Ho * p.Wo;
+  const bool out_bf16 = p.out_dtype == SDMI_BF16;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = nw0 + j * 32 + col_l;
+      const bool n_ok = n < p.N;
+      const float bn = (p.bias && !p.bias_m && n_ok) ? p.bias[n] : 0.f;
+      const int mbase = mw0 + i * 32 + row_l;
+      // phase 1: gather every epilogue operand of this 32x32 tile.  Indices are clamped into
+      // range so all loads are unconditional and in flight together (`out` may alias
+      // `residual`, so no load may be interleaved with the stores of phase 2).
+      const int nc = n_ok ? n : p.N - 1;
+      float add[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) add[r] = bn;
+      if (p.bias && p.bias_m) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = min(mbase + (r & 3) + 8 * (r >> 2), p.M - 1);
+          add[r] += p.bias[m];
+        }
+      }
+      if (p.rowvec) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = min(mbase + (r & 3) + 8 * (r >> 2), p.M - 1);
+          const int b = hw_shift >= 0 ? (m >> hw_shift) : (m / HoWo);
+          add[r] += p.rowvec[(long long)b * p.ldrv + nc];
+        }
+      }
+      if (resp) {
+        if (out_bf16) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int m = min(mbase + (r & 3) + 8 * (r >> 2), p.M - 1);
+            add[r] += bf16_to_f32(((const bf16_t*)resp)[zr + (long long)m * p.ldr + nc]);
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int m = min(mbase + (r & 3) + 8 * (r >> 2), p.M - 1);
+            add[r] += ((const float*)resp)[zr + (long long)m * p.ldr + nc];
+          }
+        }
+      }
+      // phase 2: finish and store (uniform switches hoisted out of the element loops)
+      float v[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] = acc[i][j][r] * p.alpha + add[r];
+      if (p.act == SDMI_ACT_SILU) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = act_apply(v[r], SDMI_ACT_SILU);
+      } else if (p.act == SDMI_ACT_RELU) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.f);
+      } else if (p.act == SDMI_ACT_GELU) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = act_apply(v[r], SDMI_ACT_GELU);
+      }
+      if (out_bf16) {
+        bf16_t* o = (bf16_t*)outp + zc + n;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = mbase + (r & 3) + 8 * (r >> 2);
+          if (n_ok && m < p.M) o[(long long)m * p.ldc] = f32_to_bf16(v[r]);
+        }
+      } else {
+        float* o = (float*)outp + zc + n;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = mbase + (r & 3) + 8 * (r >> 2);
+          if (n_ok && m < p.M) o[(long long)m * p.ldc] = v[r];
+        }
+      }
+    }
+}
 
 template <typename T, int BM, int BN, int BKB, int MODE>
 __device__ __forceinline__ void igemm_body(const SdmiGemmArgs& p, int tiles_m, int tiles_n,
@@ -89,13 +199,18 @@ __device__ __forceinline__ void igemm_body(const SdmiGemmArgs& p, int tiles_m, i
     // Rows m >= M / n >= N only feed output rows / columns that are never stored, so they are
     // CLAMPED to the last valid row instead of being zero-filled.
     //
-    // MODE 1 / 2 ("pointer" loaders): a 64-bit base pointer per vector is set up once per output
-    // tile; a K tile then costs one wave-uniform offset add and (conv) a 3-op border test per
-    // vector.  Border validity of a 3x3-type filter factorises into row bits (kh) x column bits
-    // (kw), computed once per tile.
-    const T* a_ptr[A_VECS];
-    const T* b_ptr[B_VECS];
-    unsigned a_rb[A_VECS], a_cb[A_VECS];
+    // MODE 1 / 2 loaders are scalar-only in the steady state (VALU work of a loader wave and the
+    // MFMAs of the wave next to it on the SIMD serialise -- tools/probes/ldsdma.hip): operands are
+    // fetched with buffer loads whose per-lane byte offset (voffset) is computed once per output
+    // tile, the walk over K is a wave-uniform SGPR offset; image borders / the K tail are
+    // out-of-range voffsets (the buffer returns zeros), a filter tap's validity mask is applied
+    // once per tap.  The activation base is biased by -(pad_t*W + pad_l) pixels: offsets >= 0.
+    constexpr unsigned OOB = 0x80000000u;       // == num_records
+    const T* Abase = Ag;
+    if (TAPU) Abase -= (long long)(p.pad_t * p.W + p.pad_l) * p.lda;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)Abase, 0, (int)OOB, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)Wg, 0, (int)OOB, 0x00020000);
+    unsigned a_vo[A_VECS], a_cur[A_VECS], a_inv[A_VECS], b_vo[B_VECS], b_cur[B_VECS];
     int k0 = 0, ci = 0, kh = 0, kw = 0;       // wave-uniform k state of the next K tile (MODE 1/2)
     // MODE 0 (general gather) state
     int kk = 0;
@@ -122,7 +237,9 @@ __device__ __forceinline__ void igemm_body(const SdmiGemmArgs& p, int tiles_m, i
         const int row = (tid + i * 256) / VPR;
         const int m = min(m0 + row, p.M - 1);
         if (IS1X1) {
-          a_ptr[i] = Ag + (long long)m * p.lda + kc * VEC;
+          a_vo[i] = ((unsigned)m * (unsigned)p.lda + kc * VEC) * (unsigned)sizeof(T);
+          a_inv[i] = 0;
+          a_cur[i] = a_vo[i];
         } else {
           const int HoWo = p.Ho * p.Wo;
           const int b = m / HoWo;
@@ -131,12 +248,15 @@ __device__ __forceinline__ void igemm_body(const SdmiGemmArgs& p, int tiles_m, i
           const int ox = rem - oy * p.Wo;
           const int iy0 = oy * p.stride - p.pad_t, ix0 = ox * p.stride - p.pad_l;
           if (TAPU) {
-            a_ptr[i] = Ag + (long long)(b * p.H * p.W + iy0 * p.W + ix0) * p.lda + kc * VEC;
-            unsigned rb = 0, cb = 0;
-            for (int q = 0; q < p.KH; ++q) rb |= ((unsigned)(iy0 + q) < (unsigned)p.H ? 1u : 0u) << q;
-            for (int q = 0; q < p.KW; ++q) cb |= ((unsigned)(ix0 + q) < (unsigned)p.W ? 1u : 0u) << q;
-            a_rb[i] = rb;
-            a_cb[i] = cb;
+            a_vo[i] = ((unsigned)((b * p.H + oy * p.stride) * p.W + ox * p.stride) * (unsigned)p.lda +
+                       kc * VEC) * (unsigned)sizeof(T);
+            unsigned rb = 0, cb = 0, inv = 0;   // bad rows / columns of the filter window
+            for (int q = 0; q < p.KH; ++q) rb |= ((unsigned)(iy0 + q) < (unsigned)p.H ? 0u : 1u) << q;
+            for (int q = 0; q < p.KW; ++q) cb |= ((unsigned)(ix0 + q) < (unsigned)p.W ? 0u : 1u) << q;
+            for (int q = 0; q < p.KH; ++q)
+              inv |= (((rb >> q) & 1u) ? ((1u << p.KW) - 1u) : cb) << (q * p.KW);
+            a_inv[i] = inv;
+            a_cur[i] = a_vo[i];
           } else {
             a_iy0[i] = iy0;
             a_ix0[i] = ix0;
@@ -149,37 +269,48 @@ __device__ __forceinline__ void igemm_body(const SdmiGemmArgs& p, int tiles_m, i
         const int row = (tid + i * 256) / VPR;
         const int n = min(n0 + row, p.N - 1);
         b_row[i] = n;
-        b_ptr[i] = Wg + (long long)n * p.ldw + kc * VEC;
+        b_vo[i] = ((unsigned)n * (unsigned)p.ldw + kc * VEC) * (unsigned)sizeof(T);
+        b_cur[i] = b_vo[i];
       }
     };
     // Loads are unconditional (all of a tile's global loads in flight together): border / K-tail
-    // vectors read the zero line.
+    // vectors read zeros (out-of-range buffer offset, or the zero line in MODE 0).
     auto load_tile = [&](u32x4 (&ra)[A_VECS], u32x4 (&rb)[B_VECS])
                          __attribute__((always_inline)) {
       if (ld_kt == 0) begin_tile();
-      if constexpr (TAPU) {
-        const long long aoff = (long long)(kh * p.W + kw) * p.lda + ci;     // wave-uniform
+      if constexpr (TAPU || IS1X1) {
+        unsigned so_a;
+        if constexpr (TAPU) {
+          if (ci == 0 || ld_kt == 0) {             // new filter tap: apply its validity mask
+            const int tap = kh * p.KW + kw;
 #pragma unroll
-        for (int i = 0; i < A_VECS; ++i) {
-          const bool ok = ((a_rb[i] >> kh) & (a_cb[i] >> kw) & 1u) != 0;
-          ra[i] = *reinterpret_cast<const u32x4*>(ok ? a_ptr[i] + aoff : zero_src);
-        }
+            for (int i = 0; i < A_VECS; ++i) a_cur[i] = ((a_inv[i] >> tap) & 1u) ? OOB : a_vo[i];
+          }
+          so_a = (unsigned)((kh * p.W + kw) * p.lda + ci) * (unsigned)sizeof(T);
+        } else {
+          if (k0 + BK > p.K) {                     // K tail (last K tile of an output tile only)
+            const bool k_ok = k0 + kc * VEC < p.K;
 #pragma unroll
-        for (int i = 0; i < B_VECS; ++i)                  // K % BK == 0 here: no K tail
-          rb[i] = *reinterpret_cast<const u32x4*>(b_ptr[i] + k0);
-        ci += BK;
-        if (ci == p.Cin) {
-          ci = 0;
-          if (++kw == p.KW) { kw = 0; ++kh; }
+            for (int i = 0; i < A_VECS; ++i) a_cur[i] = k_ok ? a_vo[i] : OOB;
+#pragma unroll
+            for (int i = 0; i < B_VECS; ++i) b_cur[i] = k_ok ? b_vo[i] : OOB;
+          }
+          so_a = (unsigned)k0 * (unsigned)sizeof(T);
         }
-      } else if constexpr (IS1X1) {
-        const bool k_ok = k0 + kc * VEC < p.K;
+        const unsigned so_b = (unsigned)k0 * (unsigned)sizeof(T);
 #pragma unroll
         for (int i = 0; i < A_VECS; ++i)
-          ra[i] = *reinterpret_cast<const u32x4*>(k_ok ? a_ptr[i] + k0 : zero_src);
+          ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)a_cur[i], (int)so_a, 0);
 #pragma unroll
         for (int i = 0; i < B_VECS; ++i)
-          rb[i] = *reinterpret_cast<const u32x4*>(k_ok ? b_ptr[i] + k0 : zero_src);
+          rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rsW, (int)b_cur[i], (int)so_b, 0);
+        if constexpr (TAPU) {
+          ci += BK;
+          if (ci == p.Cin) {
+            ci = 0;
+            if (++kw == p.KW) { kw = 0; ++kh; }
+          }
+        }
       } else {
         const bool k_ok = kk < p.K;
 #pragma unroll
@@ -304,105 +435,232 @@ __device__ __forceinline__ void igemm_body(const SdmiGemmArgs& p, int tiles_m, i
     }
   }
 
-  // ---- epilogue. C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-  const int col_l = lane & 31;
-  const int row_l = (lane >> 5) * 4;
-  if (p.split_k > 1) {
-    float* ws = p.workspace + ((long long)blockIdx.y) * p.M * p.N;
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn * WTN + j * 32 + col_l;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + row_l;
-          if (m < p.M && n < p.N) ws[(long long)m * p.N + n] = acc[i][j][r];
-        }
+  wave_epilogue<TM, TN>(p, acc, m0 + wm * WTM, n0 + wn * WTN, zb, hw_shift, lane);
+  }  // tiles of this workgroup
+}
+
+// ------------------------------------------------------------------------------------------
+// LDS-DMA variant (MODE 1 = 1x1 / linear, MODE 2 = plain convolution with Cin % BK == 0; K tile =
+// 128 bytes of K per row).  Measured on MI355X (tools/probes/ldsdma.hip): VALU instructions of a
+// loader wave and the MFMAs of the wave next to it on the SIMD serialise -- a loader that computes
+// 64-bit addresses per K tile makes fill time and MFMA time ADD UP instead of overlapping.  So the
+// loaders here are scalar-only in the steady state:
+//   * operands are fetched with `buffer_load_dwordx4 ... lds` (global -> LDS, no VGPR staging, no
+//     ds_write): the per-lane byte offset (voffset) is computed once per output tile, the walk over
+//     K is a wave-uniform SGPR offset (soffset);
+//   * image borders / the K tail are out-of-range voffsets (the buffer returns zeros); a filter
+//     tap's validity mask is applied once per tap, not per K tile;
+//   * the activation base pointer is biased by -(pad_t*W + pad_l) pixels so every offset is >= 0.
+// One DMA instruction writes 64 lanes x 16 B = 1 KB of LDS contiguously = 8 rows of 128 B, so the
+// tile rows are unpadded and bank conflicts are avoided by an XOR swizzle instead: logical 16-byte
+// chunk c of row r lives at chunk c ^ ((r >> 1) & 7); each lane simply FETCHES the chunk that
+// belongs at its position.  The 16 rows of every ds_read_b128 lane group then cover all 64 banks.
+// Prefetch depth comes from NSTAGE LDS stages (NSTAGE-1 K tiles in flight), one s_barrier per K
+// tile: before barrier g the loaders have waited for K tile g to land; after it they refill the
+// stage that K tile g-1 just vacated.
+template <typename T, int BM, int BN, int NSTAGE, int MODE>
+__global__ __launch_bounds__((BM / 64) * (BN / 64) * 64 + 256) void igemm_dma_kernel(
+    SdmiGemmArgs p, int tiles_m, int tiles_n, int kt_per_split, int hw_shift) {
+  constexpr int VEC = 16 / sizeof(T);
+  constexpr int BK = 128 / sizeof(T);
+  constexpr int WGN = BN / 64;
+  constexpr int NMFMA = (BM / 64) * WGN * 64;        // MFMA threads; 256 loader threads follow
+  constexpr int STAGE = (BM + BN) * 128;
+  constexpr int A_PC = BM / 32, B_PC = BN / 32;      // 1 KB pieces per loader wave per K tile
+  constexpr int NLOAD = A_PC + B_PC;
+  constexpr unsigned OOB = 0x80000000u;              // == num_records: always out of range
+  static_assert((NSTAGE - 2) * NLOAD <= 63, "vmcnt field");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int nwg = tiles_m * tiles_n;
+  auto tile_of = [&](int vb, int& m0, int& n0) __attribute__((always_inline)) {
+    const int xcd = vb & 7, q = nwg >> 3, r = nwg & 7;
+    const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (vb >> 3);
+    const int tm = id / tiles_n;
+    m0 = tm * BM;
+    n0 = (id - tm * tiles_n) * BN;
+  };
+  const int my_tiles = ((int)blockIdx.x < nwg) ? (nwg - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+  const int zb = blockIdx.y / p.split_k;
+  const int ksplit = blockIdx.y - zb * p.split_k;
+  const int nk_total = (p.K + BK - 1) / BK;
+  const int kt_begin = ksplit * kt_per_split;
+  int kt_end = kt_begin + kt_per_split;
+  if (kt_end > nk_total) kt_end = nk_total;
+  const int n_kt = kt_end > kt_begin ? kt_end - kt_begin : 0;
+  const int total = my_tiles * n_kt;
+  if (total == 0) return;
+
+  if (threadIdx.x >= NMFMA) {
+    // =============================== loader waves ===============================
+    const int lt = threadIdx.x - NMFMA, l = lt & 63;
+    const int lw = __builtin_amdgcn_readfirstlane(lt >> 6);      // scalar: LDS piece addresses stay in SGPRs
+    const int kc = (l & 7) ^ ((4 * (lw & 1) + (l >> 4)) & 7);   // logical chunk fetched by this lane
+    const T* Ag = (const T*)p.a + (long long)zb * p.sa;
+    if (MODE == 2) Ag -= (long long)(p.pad_t * p.W + p.pad_l) * p.lda;
+    const T* Wg = (const T*)p.w + (long long)zb * p.sw;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)Ag, 0, (int)OOB, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)Wg, 0, (int)OOB, 0x00020000);
+    unsigned a_vo[A_PC], a_cur[A_PC], a_inv[A_PC], b_vo[B_PC], b_cur[B_PC];
+    int ld_tile = 0, ld_kt = 0, k0 = 0, ci = 0, kh = 0, kw = 0;   // wave-uniform
+    auto begin_tile = [&]() __attribute__((always_inline)) {
+      int m0, n0;
+      tile_of((int)blockIdx.x + ld_tile * (int)gridDim.x, m0, n0);
+      k0 = kt_begin * BK;
+      if (MODE == 2) {
+        const int tap = k0 / p.Cin;
+        ci = k0 - tap * p.Cin;
+        kh = tap / p.KW;
+        kw = tap - kh * p.KW;
       }
-    continue;
-  }
-  char* outp = (char*)p.out;
-  const char* resp = (const char*)p.residual;
-  const long long zc = (long long)zb * p.sc, zr = (long long)zb * p.sr;
-  const int HoWo = p.Ho * p.Wo;
-  const bool out_bf16 = p.out_dtype == SDMI_BF16;
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int n = n0 + wn * WTN + j * 32 + col_l;
-      const bool n_ok = n < p.N;
-      const float bn = (p.bias && !p.bias_m && n_ok) ? p.bias[n] : 0.f;
-      const int mbase = m0 + wm * WTM + i * 32 + row_l;
-      // phase 1: gather every epilogue operand of this 32x32 tile.  Indices are clamped into
-      // range so all loads are unconditional and in flight together (`out` may alias
-      // `residual`, so no load may be interleaved with the stores of phase 2).
-      const int nc = n_ok ? n : p.N - 1;
-      float add[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) add[r] = bn;
-      if (p.bias && p.bias_m) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = min(mbase + (r & 3) + 8 * (r >> 2), p.M - 1);
-          add[r] += p.bias[m];
-        }
-      }
-      if (p.rowvec) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = min(mbase + (r & 3) + 8 * (r >> 2), p.M - 1);
-          const int b = hw_shift >= 0 ? (m >> hw_shift) : (m / HoWo);
-          add[r] += p.rowvec[(long long)b * p.ldrv + nc];
-        }
-      }
-      if (resp) {
-        if (out_bf16) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int m = min(mbase + (r & 3) + 8 * (r >> 2), p.M - 1);
-            add[r] += bf16_to_f32(((const bf16_t*)resp)[zr + (long long)m * p.ldr + nc]);
-          }
+      for (int i = 0; i < A_PC; ++i) {
+        const int row = (lw + 4 * i) * 8 + (l >> 3);
+        const int m = min(m0 + row, p.M - 1);
+        if (MODE == 1) {
+          a_vo[i] = ((unsigned)m * (unsigned)p.lda + kc * VEC) * (unsigned)sizeof(T);
+          a_inv[i] = 0;
         } else {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int m = min(mbase + (r & 3) + 8 * (r >> 2), p.M - 1);
-            add[r] += ((const float*)resp)[zr + (long long)m * p.ldr + nc];
-          }
+          const int HoWo = p.Ho * p.Wo;
+          const int b = hw_shift >= 0 ? (m >> hw_shift) : (m / HoWo);
+          const int rem = m - b * HoWo;
+          const int oy = rem / p.Wo;
+          const int ox = rem - oy * p.Wo;
+          const int iy0 = oy * p.stride - p.pad_t, ix0 = ox * p.stride - p.pad_l;
+          a_vo[i] = ((unsigned)((b * p.H + oy * p.stride) * p.W + ox * p.stride) * (unsigned)p.lda +
+                     kc * VEC) * (unsigned)sizeof(T);
+          unsigned rb = 0, cb = 0, inv = 0;   // bad rows / columns of the filter window
+          for (int q = 0; q < p.KH; ++q) rb |= ((unsigned)(iy0 + q) < (unsigned)p.H ? 0u : 1u) << q;
+          for (int q = 0; q < p.KW; ++q) cb |= ((unsigned)(ix0 + q) < (unsigned)p.W ? 0u : 1u) << q;
+          for (int q = 0; q < p.KH; ++q) inv |= (((rb >> q) & 1u) ? ((1u << p.KW) - 1u) : cb) << (q * p.KW);
+          a_inv[i] = inv;
         }
+        a_cur[i] = a_vo[i];
       }
-      // phase 2: finish and store (uniform switches hoisted out of the element loops)
-      float v[16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) v[r] = acc[i][j][r] * p.alpha + add[r];
-      if (p.act == SDMI_ACT_SILU) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] = act_apply(v[r], SDMI_ACT_SILU);
-      } else if (p.act == SDMI_ACT_RELU) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.f);
-      } else if (p.act == SDMI_ACT_GELU) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] = act_apply(v[r], SDMI_ACT_GELU);
+      for (int i = 0; i < B_PC; ++i) {
+        const int row = (lw + 4 * i) * 8 + (l >> 3);
+        const int n = min(n0 + row, p.N - 1);
+        b_vo[i] = ((unsigned)n * (unsigned)p.ldw + kc * VEC) * (unsigned)sizeof(T);
+        b_cur[i] = b_vo[i];
       }
-      if (out_bf16) {
-        bf16_t* o = (bf16_t*)outp + zc + n;
+    };
+    int ld_stage = 0;
+    auto issue = [&]() __attribute__((always_inline)) {
+      if (ld_kt == 0) begin_tile();
+      unsigned so_a;
+      if (MODE == 2) {
+        if (ci == 0 || ld_kt == 0) {               // new filter tap: apply its validity mask
+          const int tap = kh * p.KW + kw;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = mbase + (r & 3) + 8 * (r >> 2);
-          if (n_ok && m < p.M) o[(long long)m * p.ldc] = f32_to_bf16(v[r]);
+          for (int i = 0; i < A_PC; ++i) a_cur[i] = ((a_inv[i] >> tap) & 1u) ? OOB : a_vo[i];
         }
+        so_a = (unsigned)((kh * p.W + kw) * p.lda + ci) * (unsigned)sizeof(T);
       } else {
-        float* o = (float*)outp + zc + n;
+        if (k0 + BK > p.K) {                       // K tail (last K tile of a tile only)
+          const bool k_ok = k0 + kc * VEC < p.K;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = mbase + (r & 3) + 8 * (r >> 2);
-          if (n_ok && m < p.M) o[(long long)m * p.ldc] = v[r];
+          for (int i = 0; i < A_PC; ++i) a_cur[i] = k_ok ? a_vo[i] : OOB;
+#pragma unroll
+          for (int i = 0; i < B_PC; ++i) b_cur[i] = k_ok ? b_vo[i] : OOB;
         }
+        so_a = (unsigned)k0 * (unsigned)sizeof(T);
+      }
+      const unsigned so_b = (unsigned)k0 * (unsigned)sizeof(T);
+      char* st = smem + ld_stage * STAGE + lw * 1024;
+#pragma unroll
+      for (int i = 0; i < A_PC; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void*)(st + i * 4096), 16, (int)a_cur[i],
+                                                 (int)so_a, 0, 0);
+#pragma unroll
+      for (int i = 0; i < B_PC; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_void*)(st + BM * 128 + i * 4096), 16,
+                                                 (int)b_cur[i], (int)so_b, 0, 0);
+      if (MODE == 2) {
+        ci += BK;
+        if (ci == p.Cin) {
+          ci = 0;
+          if (++kw == p.KW) { kw = 0; ++kh; }
+        }
+      }
+      k0 += BK;
+      if (++ld_kt == n_kt) { ld_kt = 0; ++ld_tile; }
+      if (++ld_stage == NSTAGE) ld_stage = 0;
+    };
+    // Steps past the last one re-fetch clamped rows of a non-existent tile into a stage nobody
+    // reads any more: the number of DMA groups in flight stays static, so a fixed vmcnt works.
+#pragma unroll
+    for (int s = 0; s < NSTAGE - 1; ++s) issue();
+    for (int g = 0; g < total; ++g) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTAGE - 2) * NLOAD) : "memory");   // K tile g landed
+      __builtin_amdgcn_s_barrier();
+      issue();                                     // K tile g + NSTAGE - 1 -> stage of K tile g - 1
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no DMA may outlive the workgroup's LDS
+    return;
+  }
+
+  // ================================= MFMA waves =================================
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WGN, wn = wave - wm * WGN;
+  const int R = lane & 31;
+  int swz[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) swz[ks] = ((2 * ks + (lane >> 5)) ^ ((R >> 1) & 7)) * 16;
+  const int a_off = (wm * 64 + R) * 128;
+  const int b_off = BM * 128 + (wn * 64 + R) * 128;
+  auto read_frags = [&](const char* base, int ks, u32x4 (&fa)[2], u32x4 (&fb)[2])
+                        __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      fa[i] = *reinterpret_cast<const u32x4*>(base + a_off + i * 4096 + swz[ks]);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      fb[j] = *reinterpret_cast<const u32x4*>(base + b_off + j * 4096 + swz[ks]);
+  };
+  int stage = 0;
+  for (int ti = 0; ti < my_tiles; ++ti) {
+    int m0, n0;
+    tile_of((int)blockIdx.x + ti * (int)gridDim.x, m0, n0);
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    for (int t = 0; t < n_kt; ++t) {
+      __builtin_amdgcn_s_barrier();               // K tile landed; previous stage may be refilled
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      const char* base = smem + stage * STAGE;
+      if (++stage == NSTAGE) stage = 0;
+      u32x4 fa[2][2], fb[2][2];
+      read_frags(base, 0, fa[0], fb[0]);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        if (ks + 1 < 4) read_frags(base, ks + 1, fa[(ks + 1) & 1], fb[(ks + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const u32x4 a4 = fa[ks & 1][i], b4 = fb[ks & 1][j];
+            if constexpr (sizeof(T) == 2) {
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                  __builtin_bit_cast(bf16x8, a4), __builtin_bit_cast(bf16x8, b4), acc[i][j], 0, 0, 0);
+            } else {
+#pragma unroll
+              for (int c = 0; c < 4; ++c)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                    __uint_as_float(a4[c]), __uint_as_float(b4[c]), acc[i][j], 0, 0, 0);
+            }
+          }
       }
     }
-  }  // tiles of this workgroup
+    wave_epilogue<2, 2>(p, acc, m0 + wm * 64, n0 + wn * 64, zb, hw_shift, lane);
+  }
 }
 
 // Two entry points over the same body: <= 128 VGPRs (two workgroups per CU) for the tiles whose
@@ -446,6 +704,8 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(SdmiGemmArgs p, in
   }
 }
 
+static int device_cus();
+
 template <typename T, int BM, int BN, int BKB, int MODE>
 int launch_cfg(const SdmiGemmArgs& p, int split_k, int hw_shift, hipStream_t st) {
   constexpr int BK = BKB / sizeof(T);
@@ -469,15 +729,7 @@ int launch_cfg(const SdmiGemmArgs& p, int split_k, int hw_shift, hipStream_t st)
   const int ktps = (nk + split_k - 1) / split_k;
   // persistent workgroups: at most what the chip holds at once (registers / LDS allow 2 workgroups
   // per CU for the 128-row tiles, 3 for 64x64); the rest of the tiles are walked in-kernel
-  static int n_cu = 0;
-  if (!n_cu) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
-            prop.multiProcessorCount > 0)
-               ? prop.multiProcessorCount
-               : 256;
-  }
+  const int n_cu = device_cus();
   const int ny = split_k * (p.batch > 0 ? p.batch : 1);
   int cap = n_cu * (BM * BN >= 128 * 64 ? 2 : 3) / ny;
   cap = cap < 8 ? 8 : (cap & ~7);          // multiple of 8: a virtual block id keeps its XCD
@@ -494,6 +746,47 @@ int launch_cfg(const SdmiGemmArgs& p, int split_k, int hw_shift, hipStream_t st)
     rc = sdmi_check_launch("igemm splitk epilogue");
   }
   return rc;
+}
+
+static int device_cus() {
+  static int n_cu = 0;
+  if (!n_cu) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
+            prop.multiProcessorCount > 0)
+               ? prop.multiProcessorCount
+               : 256;
+  }
+  return n_cu;
+}
+
+template <typename T, int BM, int BN, int NSTAGE, int MODE>
+int launch_dma(const SdmiGemmArgs& p, int hw_shift, hipStream_t st) {
+  constexpr int BK = 128 / sizeof(T);
+  constexpr int smem = NSTAGE * (BM + BN) * 128;
+  constexpr int threads = (BM / 64) * (BN / 64) * 64 + 256;
+  static bool attr_done = false;
+  auto kern = igemm_dma_kernel<T, BM, BN, NSTAGE, MODE>;
+  if (!attr_done) {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem) !=
+        hipSuccess) {
+      sdmi_set_error("igemm: hipFuncSetAttribute failed");
+      return SDMI_ELAUNCH;
+    }
+    attr_done = true;
+  }
+  SdmiGemmArgs q = p;
+  q.split_k = 1;
+  const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+  const int nk = (p.K + BK - 1) / BK;
+  const int ny = p.batch > 0 ? p.batch : 1;
+  int cap = device_cus() / ny;               // one workgroup per CU (its LDS stages fill the CU)
+  cap = cap < 8 ? 8 : (cap & ~7);
+  const int nwg = tiles_m * tiles_n;
+  dim3 grid(nwg <= cap ? nwg : cap, ny);
+  hipLaunchKernelGGL(kern, grid, dim3(threads), smem, st, q, tiles_m, tiles_n, nk, hw_shift);
+  return sdmi_check_launch("igemm (lds-dma)");
 }
 
 template <typename T>
@@ -536,10 +829,32 @@ int dispatch(const SdmiGemmArgs& p, hipStream_t st) {
   if (split_k > 1 && !p.workspace) split_k = 1;
   (void)VEC;
   const bool plain = !is1x1 && !p.ups && p.zins <= 1;
+  // the scalar-offset loaders (MODE 1 / 2) address operands with 31-bit byte offsets
+  const long long a_bytes =
+      ((long long)p.B * p.H * p.W + (long long)(p.KH + 1) * p.W) * p.lda * (long long)sizeof(T);
+  const long long w_bytes = (long long)p.N * p.ldw * (long long)sizeof(T);
+  const bool fits31 = a_bytes < (1ll << 31) && w_bytes < (1ll << 31);
+  // LDS-DMA kernels (one workgroup per CU, 3-4 LDS stages): deep-K 1x1 / plain convolutions with
+  // wide outputs, no split-K
+  {
+    const bool dma_ok = SDMI_IGEMM_DMA && wide && kbytes >= 8 * 128 && split_k == 1 && p.N > 64 && fits31 &&
+                        (is1x1 || (plain && p.Cin % (128 / (int)sizeof(T)) == 0)) && p.KH * p.KW <= 32;
+    if (dma_ok) {
+      const long long t256 = ((p.M + 255) / 256) * ((p.N + 127) / 128) * batch;
+      if (t256 >= 192) {
+        if (is1x1) return launch_dma<T, 256, 128, 3, 1>(p, hw_shift, st);
+        return launch_dma<T, 256, 128, 3, 2>(p, hw_shift, st);
+      }
+      if (t128 >= 192) {
+        if (is1x1) return launch_dma<T, 128, 128, 4, 1>(p, hw_shift, st);
+        return launch_dma<T, 128, 128, 4, 2>(p, hw_shift, st);
+      }
+    }
+  }
 #define SDMI_GO(BM, BN, BKB)                                                                    \
   do {                                                                                          \
-    if (is1x1) return launch_cfg<T, BM, BN, BKB, 1>(p, split_k, hw_shift, st);                  \
-    if (plain && p.Cin % (BKB / (int)sizeof(T)) == 0)                                           \
+    if (is1x1 && fits31) return launch_cfg<T, BM, BN, BKB, 1>(p, split_k, hw_shift, st);        \
+    if (plain && fits31 && p.KH * p.KW <= 32 && p.Cin % (BKB / (int)sizeof(T)) == 0)            \
       return launch_cfg<T, BM, BN, BKB, 2>(p, split_k, hw_shift, st);                           \
     return launch_cfg<T, BM, BN, BKB, 0>(p, split_k, hw_shift, st);                             \
   } while (0)

@@ -69,6 +69,12 @@ CONV_CASES = [
     (2, 64, 128, 16, 1, 2, (0, 0, 0, 0), False, ''),                 # ResNet downsample 1x1 s2
     (4, 512, 512, 4, 3, 1, (1, 1, 1, 1), False, 'bias,rowvec'),      # skinny: split-K path
     (1, 896, 384, 8, 3, 1, (1, 1, 1, 1), False, 'bias'),             # non power-of-two Cin
+    # LDS-DMA kernels (>= 192 tiles of 256x128, or of 128x128 when M is too small for that)
+    (48, 64, 128, 32, 3, 1, (1, 1, 1, 1), False, 'bias,rowvec,res,silu'),   # 256x128, 3 stages
+    (25, 128, 192, 30, 3, 1, (1, 1, 1, 1), False, 'bias'),           # 128x128 x4 stages, ragged M / N
+    (48, 64, 128, 32, 5, 1, (2, 2, 2, 2), False, 'bias'),            # 5x5 taps
+    (48, 64, 136, 64, 3, 2, (1, 1, 1, 1), False, 'bias,res'),        # stride 2, ragged N
+    (48, 328, 128, 32, 1, 1, (0, 0, 0, 0), False, 'bias,res'),       # 1x1 with a K tail
 ]
 
 
@@ -105,7 +111,7 @@ def test_igemm_conv(case, dtype):
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize('mnk', [(70, 50, 24), (448, 512, 192), (1024, 4096, 512), (64, 1536, 512),
-                                 (4, 2944, 512), (8192, 192, 256)])
+                                 (4, 2944, 512), (8192, 192, 256), (50000, 130, 264)])
 def test_igemm_linear(mnk, dtype):
     ops = _ops()
     M, N, K = mnk

@@ -5,6 +5,8 @@
 
   exp1  igemm loaders skip their global loads (LDS stores, barriers and MFMAs kept)
   exp2  igemm MFMA waves skip the MFMAs (loaders unchanged)
+  exp4  exp2 + no fragment reads (loaders + barriers only)
+  dma   -DSDMI_IGEMM_DMA=1: big deep-K shapes go to the LDS-DMA kernels (igemm_dma_kernel)
   exp3  s_memtime stamps of workgroup 0 into the `workspace` argument (tools/exp/timeline.py)
 
 The variants are produced by patching a COPY of slotdiffusion_amd/csrc/igemm.hip; if a pattern no
@@ -28,12 +30,14 @@ def main():
     from slotdiffusion_amd.csrc import build
     build.build()
     src = open(os.path.join(CSRC, 'igemm.hip')).read()
-    v = patch(src, "      if (ld_kt == 0) begin_tile();\n      if constexpr (TAPU) {",
+    v = patch(src, "      if (ld_kt == 0) begin_tile();\n      if constexpr (TAPU || IS1X1) {",
               "      if (ld_kt == 0) begin_tile();\n#ifdef SDMI_EXP1\n      k0 += BK; "
-              "if (++ld_kt == n_kt) { ld_kt = 0; ++ld_tile; } return;\n#endif\n      if constexpr (TAPU) {")
+              "if (++ld_kt == n_kt) { ld_kt = 0; ++ld_tile; } return;\n#endif\n      if constexpr (TAPU || IS1X1) {")
     v = patch(v, "          if constexpr (sizeof(T) == 2) {\n            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(",
               "#ifdef SDMI_EXP2\n          acc[i][j][0] += __uint_as_float(a4[0] ^ b4[0]);\n          continue;\n#endif\n"
               "          if constexpr (sizeof(T) == 2) {\n            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(")
+    v = patch(v, "    read_frags(As, Bs, 0, fa[0], fb[0]);",
+              "#ifdef SDMI_EXP4\n    continue;\n#endif\n    read_frags(As, Bs, 0, fa[0], fb[0]);")
     t = patch(src, """    for (int g = 0; g < total; g += 2) {
       store_tile(0, ra0, rb0);
       if (g + 2 < total) load_tile(ra0, rb0);
@@ -78,16 +82,16 @@ def main():
     }
   }
 
-  // ---- epilogue""", """          }
+  wave_epilogue<TM, TN>(""", """          }
         }
     }
     if (rec && g < 64) dbg[g * 8 + 6] = __builtin_amdgcn_s_memtime();
   }
-
-  // ---- epilogue""")
+  wave_epilogue<TM, TN>(""")
     objs = [os.path.join(CSRC, '_build', o) for o in os.listdir(os.path.join(CSRC, '_build'))
             if o.endswith('.o') and o != 'igemm.o']
-    for tag, text, defs in (('exp1', v, ['-DSDMI_EXP1']), ('exp2', v, ['-DSDMI_EXP2']), ('exp3', t, [])):
+    for tag, text, defs in (('exp1', v, ['-DSDMI_EXP1']), ('exp2', v, ['-DSDMI_EXP2']), ('exp3', t, []),
+                            ('exp4', v, ['-DSDMI_EXP2', '-DSDMI_EXP4']), ('dma', src, ['-DSDMI_IGEMM_DMA=1'])):
         cpy = f'/tmp/igemm_{tag}.hip'
         open(cpy, 'w').write(text)
         obj = f'/tmp/igemm_{tag}.o'
