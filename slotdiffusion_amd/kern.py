@@ -61,7 +61,8 @@ class WeightBank:
         # chain, and are joined when the autograd pass ends.  Their operands are kept alive until
         # the join (HBM is plentiful), so no allocator stream bookkeeping is needed.
         self.overlap_wgrad = os.environ.get('SDMI_WGRAD_STREAM', '1') != '0'
-        self._side = None
+        self.n_side = max(1, int(os.environ.get('SDMI_WGRAD_STREAMS', '4')))
+        self._sides, self._side_i = [], 0
         self._pending = []
         self._join_queued = False
         # dgrad operands: key -> [buffer, epoch, (stable source view | None, geometry)]
@@ -74,9 +75,12 @@ class WeightBank:
     def side_stream(self):
         if not self.overlap_wgrad:
             return None
-        if self._side is None:
-            self._side = torch.cuda.Stream()
-        return self._side
+        # round-robin over a few streams: most weight-gradient launches are small (<= 128
+        # workgroups + their reduction) and two of them fit the chip next to the dgrad chain
+        if not self._sides:
+            self._sides = [torch.cuda.Stream() for _ in range(self.n_side)]
+        self._side_i = (self._side_i + 1) % len(self._sides)
+        return self._sides[self._side_i]
 
     def defer(self, *tensors):
         self._pending.append(tensors)
@@ -85,8 +89,8 @@ class WeightBank:
             torch.autograd.Variable._execution_engine.queue_callback(self.join)
 
     def join(self):
-        if self._side is not None:
-            torch.cuda.current_stream().wait_stream(self._side)
+        for side in self._sides:
+            torch.cuda.current_stream().wait_stream(side)
         self._pending.clear()
         self._join_queued = False
 
