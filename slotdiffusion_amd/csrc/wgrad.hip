@@ -369,10 +369,20 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 #define SDMI_LDS_V4(p) ((__attribute__((address_space(3))) s16x4*)(p))
 
-template <int TN, int TK, bool IS1X1>
+// MODE 0: general convolution (stride, nearest-x2 fold, any image size): per-step address
+//         arithmetic in the loaders.
+// MODE 1 (1x1 / linear) and MODE 2 (stride-1 "same" convolution on a power-of-two image, where the
+// input pixel of output row m is m + const): scalar-only loaders -- buffer loads whose per-lane
+// byte offset is fixed for the whole launch, the walk over m in an SGPR offset, out-of-range
+// offsets (zeros) for inactive columns, the split's tail and image borders.  A loader wave's VALU
+// work serialises with the MFMAs of the wave next to it (tools/probes/ldsdma.hip), so MODE 2
+// keeps only the border test (~10 VALU per vector and step) and MODE 1 none.
+template <int TN, int TK, int MODE>
 __global__ __launch_bounds__(512) void wgrad_tr_kernel(SdmiWgradArgs p, int tiles_n, int tiles_k,
                                                        int m_per_split) {
   typedef bf16_t T;
+  constexpr bool IS1X1 = MODE == 1;
+  constexpr bool FAST = MODE != 0;
   constexpr int MT = 64;                        // m rows per step
   constexpr int PY = TN * 2 + 64, PA = TK * 2 + 64;   // row pitches (bytes)
   constexpr int STAGE = MT * (PY + PA);
@@ -432,10 +442,56 @@ __global__ __launch_bounds__(512) void wgrad_tr_kernel(SdmiWgradArgs p, int tile
       adv_x = rr - adv_y * p.Wo;
     }
     const u32x4 zero4 = {0u, 0u, 0u, 0u};
+    // ---- scalar-only loaders (MODE 1 / 2): offsets relative to the split's first row
+    constexpr unsigned OOB = 0x80000000u;       // == num_records
+    const long long a_bias = MODE == 2 ? (long long)p.pad_t * p.W + p.pad_l : 0;   // offsets >= 0
+    const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(Yg + (long long)m_begin * p.ldy), 0, (int)OOB, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(Ag + ((long long)m_begin - a_bias) * p.lda), 0, (int)OOB, 0x00020000);
+    unsigned y_vo[Y_PER], a_vo[A_PER];
+    int lw_sh = 0;
+    if constexpr (FAST) {
+#pragma unroll
+      for (int i = 0; i < Y_PER; ++i)
+        y_vo[i] = y_act ? ((unsigned)(yr0 + i * RSY) * (unsigned)p.ldy + yn) * 2u : OOB;
+#pragma unroll
+      for (int i = 0; i < A_PER; ++i) {
+        const unsigned r = ar0 + i * RSA + (MODE == 2 ? a_kh * p.W + a_kw : 0);
+        a_vo[i] = a_act ? (r * (unsigned)p.lda + a_ci) * 2u : OOB;
+      }
+      while ((1 << lw_sh) < p.W) ++lw_sh;
+    }
 
     auto issue = [&](int mt, u32x4 (&ry)[Y_PER], u32x4 (&ra)[A_PER], unsigned& mask)
                      __attribute__((always_inline)) {
       mask = 0;
+      if constexpr (FAST) {
+        const int rel = mt - m_begin;            // wave-uniform
+        const bool tail = mt + MT > m_end;
+        const unsigned so_y = (unsigned)rel * (unsigned)p.ldy * 2u;
+        const unsigned so_a = (unsigned)rel * (unsigned)p.lda * 2u;
+#pragma unroll
+        for (int i = 0; i < Y_PER; ++i) {
+          unsigned vo = y_vo[i];
+          if (tail && mt + yr0 + i * RSY >= m_end) vo = OOB;
+          ry[i] = __builtin_amdgcn_raw_buffer_load_b128(rsY, (int)vo, (int)so_y, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i) {
+          unsigned vo = a_vo[i];
+          const int m = mt + ar0 + i * RSA;
+          if constexpr (MODE == 2) {
+            const int ox = m & (p.W - 1), oy = (m >> lw_sh) & (p.H - 1);
+            const bool bad = (unsigned)(oy + a_kh - p.pad_t) >= (unsigned)p.H ||
+                             (unsigned)(ox + a_kw - p.pad_l) >= (unsigned)p.W;
+            vo = bad ? OOB : vo;
+          }
+          if (tail && m >= m_end) vo = OOB;
+          ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)vo, (int)so_a, 0);
+        }
+        return;
+      }
 #pragma unroll
       for (int i = 0; i < Y_PER; ++i) {
         const int m = mt + yr0 + i * RSY;
@@ -477,11 +533,11 @@ __global__ __launch_bounds__(512) void wgrad_tr_kernel(SdmiWgradArgs p, int tile
 #pragma unroll
       for (int i = 0; i < Y_PER; ++i)
         *reinterpret_cast<u32x4*>(Ys + (yr0 + i * RSY) * PY + ycc * 16) =
-            ((mask >> i) & 1u) ? ry[i] : zero4;
+            (FAST || ((mask >> i) & 1u)) ? ry[i] : zero4;
 #pragma unroll
       for (int i = 0; i < A_PER; ++i)
         *reinterpret_cast<u32x4*>(As + (ar0 + i * RSA) * PA + acc_ * 16) =
-            ((mask >> (16 + i)) & 1u) ? ra[i] : zero4;
+            (FAST || ((mask >> (16 + i)) & 1u)) ? ra[i] : zero4;
     };
 
     u32x4 ry0[Y_PER], ra0[A_PER], ry1[Y_PER], ra1[A_PER];
@@ -645,11 +701,11 @@ int launch_wgrad(const SdmiWgradArgs& a, hipStream_t st) {
   return sdmi_check_launch("wgrad");
 }
 
-template <int TN, int TK, bool IS1X1>
+template <int TN, int TK, int MODE>
 int launch_wgrad_tr(const SdmiWgradArgs& a, hipStream_t st) {
   constexpr int MT = 64;
   constexpr int smem = 2 * MT * (TN * 2 + 64 + TK * 2 + 64);
-  auto kern = wgrad_tr_kernel<TN, TK, IS1X1>;
+  auto kern = wgrad_tr_kernel<TN, TK, MODE>;
   static bool done = false;
   if (!done) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem) !=
@@ -685,8 +741,16 @@ int dispatch_wgrad_f32(const SdmiWgradArgs& a, hipStream_t st) {
 int dispatch_wgrad_bf16(const SdmiWgradArgs& a, hipStream_t st) {
   const bool is1x1 = wgrad_is1x1(a);
   const bool n64 = a.N <= 64, k64 = a.K <= 64;
-#define WG_TR(TN, TK) \
-  (is1x1 ? launch_wgrad_tr<TN, TK, true>(a, st) : launch_wgrad_tr<TN, TK, false>(a, st))
+  // "same" stride-1 convolution on a power-of-two image: the input pixel is linear in m
+  const bool lin = !is1x1 && !a.ups && a.stride == 1 && a.H == a.Ho && a.W == a.Wo &&
+                   (a.H & (a.H - 1)) == 0 && (a.W & (a.W - 1)) == 0;
+  // the scalar-only loaders address a split's rows with 31-bit byte offsets
+  const long long mps = ((long long)a.M + a.splits - 1) / a.splits + 64;
+  const long long ld = a.lda > a.ldy ? a.lda : a.ldy;
+  const bool fits = (mps + (long long)(a.KH + 1) * a.W + 64) * ld * 2 < (1ll << 31);
+#define WG_TR(TN, TK)                                                              \
+  (is1x1 && fits ? launch_wgrad_tr<TN, TK, 1>(a, st)                               \
+   : lin && fits ? launch_wgrad_tr<TN, TK, 2>(a, st) : launch_wgrad_tr<TN, TK, 0>(a, st))
   if (n64) return k64 ? WG_TR(64, 64) : WG_TR(64, 128);
   return k64 ? WG_TR(128, 64) : WG_TR(128, 128);
 #undef WG_TR

@@ -194,7 +194,11 @@ def test_train_step_bf16_gradients_close():
                                   (2, 32, 64, 8, 3, 1, (1, 1, 1, 1), True),
                                   (2, 64, 128, 16, 1, 2, (0, 0, 0, 0), False),
                                   (3, 128, 3, 16, 3, 1, (1, 1, 1, 1), False),
-                                  (2, 96, 192, 8, 1, 1, (0, 0, 0, 0), False)])
+                                  (2, 96, 192, 8, 1, 1, (0, 0, 0, 0), False),
+                                  (2, 64, 64, 32, 5, 1, (2, 2, 2, 2), False),     # 5x5 "same"
+                                  (1, 16, 32, 128, 3, 1, (1, 1, 1, 1), False),    # W > m step
+                                  (2, 32, 64, 12, 3, 1, (1, 1, 1, 1), False),     # not 2^n
+                                  (5, 72, 200, 8, 1, 1, (0, 0, 0, 0), False)])    # 1x1 tails
 def test_wgrad_and_dgrad_kernels(case, dtype):
     from slotdiffusion_amd import _lib, ops
     from slotdiffusion_amd.kern import _DT
