@@ -119,18 +119,23 @@ def pmc_traffic(which):
     if not os.path.exists(path):
         return {}
     f = w = n = act = busy = 0.0
+    have_tcc = True
     with open(path) as fh:
         for r in csv.DictReader(fh):
             if r['kernel'].startswith('igemm_kernel'):
                 n += float(r['dispatches'])
-                f += float(r['FETCH_SIZE'])
-                w += float(r['WRITE_SIZE'])
+                have_tcc = have_tcc and 'FETCH_SIZE' in r and 'WRITE_SIZE' in r
+                if have_tcc:
+                    f += float(r['FETCH_SIZE'])
+                    w += float(r['WRITE_SIZE'])
                 act += float(r['GRBM_GUI_ACTIVE'])
                 busy += float(r['SQ_VALU_MFMA_BUSY_CYCLES'])
     if not n:
         return {}
-    # GRBM_GUI_ACTIVE is summed over the 8 XCDs; 1024 SIMDs
-    return {'bytes_per_launch': (2.0 * f + w) * 1024.0 / n, 'mfma_util': busy / (act / 8.0 * 1024.0),
+    # GRBM_GUI_ACTIVE is summed over the 8 XCDs; 1024 SIMDs.  (The TCC passes of the sampling
+    # command abort inside rocprofv3 on this image: traffic is then reported as null.)
+    return {'bytes_per_launch': (2.0 * f + w) * 1024.0 / n if have_tcc else None,
+            'mfma_util': busy / (act / 8.0 * 1024.0),
             'source': os.path.relpath(path, os.path.dirname(os.path.abspath(__file__)))}
 
 

@@ -1,0 +1,27 @@
+#!/bin/bash
+# Round profile collection on the GPU box (outputs under gpurun_out/prof_<tag>/, copy the summaries
+# into profiles/).  usage: bash tools/collect_profiles.sh r01
+TAG=${1:-r01}
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/prof_$TAG
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+# 1. kernel-trace + stats of the bench command (graph replay), train and sampling
+timeout 600 rocprofv3 --kernel-trace --stats -d $O/train -o train --output-format csv -- python $R/bench.py --only-train --no-cpu-baseline --no-roofline --steps 5 --warmup 2 > $O/train_trace.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -d $O/sample -o sample --output-format csv -- python $R/bench.py --mode sample --big-batch 0 --no-cpu-baseline --no-roofline --steps 3 --warmup 1 > $O/sample_trace.log 2>&1
+# 2. PMC passes (separate runs, kernel-trace only), eager mode so that kernels are attributable
+for mode in train sample; do
+  if [ $mode = train ]; then ARGS="--only-train --no-graph --no-cpu-baseline --no-roofline --steps 2 --warmup 1"; else ARGS="--mode sample --big-batch 0 --no-graph --no-cpu-baseline --no-roofline --steps 1 --warmup 1"; fi
+  timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_BF16 -d $O/pmc_${mode}_1 -o p --output-format csv -- python $R/bench.py $ARGS > $O/pmc_${mode}_1.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_${mode}_2 -o p --output-format csv -- python $R/bench.py $ARGS > $O/pmc_${mode}_2.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_${mode}_3 -o p --output-format csv -- python $R/bench.py $ARGS > $O/pmc_${mode}_3.log 2>&1
+done
+cd $R
+cp $O/train/train_kernel_stats.csv $O/${TAG}_train_b64_bf16_kernel_stats.csv 2>/dev/null
+cp $O/sample/sample_kernel_stats.csv $O/${TAG}_sample_b64_bf16_kernel_stats.csv 2>/dev/null
+python tools/trace_step.py $O/train/train_kernel_trace.csv 60 > $O/${TAG}_train_step_breakdown.txt 2>&1
+for mode in train sample; do
+  python tools/pmc_summary.py "$O/pmc_${mode}_*/**/*counter_collection.csv" > $O/${TAG}_${mode}_pmc_by_kernel.csv 2>&1
+done
+rm -rf $O/train/*trace.csv $O/sample/*trace.csv $O/pmc_*/*counter_collection.csv $O/pmc_*/*kernel_trace.csv
+ls -la $O | head -40
