@@ -369,13 +369,13 @@ def q_sample(W, x0, t, noise, prefix='dm_decoder'):
     return a * x0 + s * noise
 
 
-def ldm_loss(W, plan, ed, img, slots, t, noise, mc=128):
-    """ldm.py:59-83 with t / noise supplied by the caller (pred_target='eps')."""
+def ldm_loss(W, plan, ed, img, slots, t, noise, mc=128, pred_target='eps'):
+    """ldm.py:59-83 with t / noise supplied by the caller; target = noise ('eps') or x0 ('x0')."""
     with torch.no_grad():
         x0 = vae_encode(W, img, ed)
     xt = q_sample(W, x0, t, noise)
     pred = unet_forward(W, plan, xt, t, slots, mc=mc)
-    return F.mse_loss(pred, noise), pred, x0
+    return F.mse_loss(pred, noise if pred_target == 'eps' else x0), pred, x0
 
 
 # ---------------------------------------------------------------------------
@@ -493,7 +493,8 @@ def dpm_step_coeffs(ns, s, t, order):
     return c
 
 
-def dpm_solver_sample(eps_fn, quantize_fn, betas, x, steps=20, order=3, trace=None):
+def dpm_solver_sample(eps_fn, quantize_fn, betas, x, steps=20, order=3, trace=None,
+                      model_type='noise'):
     """DPM_Solver.sample(method='singlestep', skip 'time_uniform') (dpm_solver.py:1310-1328).
 
     eps_fn(x, t_input[B]) -> eps prediction with t_input = (t - 1/N) * 1000 (345-346);
@@ -507,6 +508,8 @@ def dpm_solver_sample(eps_fn, quantize_fn, betas, x, steps=20, order=3, trace=No
     def data_pred(xc, tc):
         t_in = (tc.expand(B) - 1. / ns.total_N) * 1000.
         eps = eps_fn(xc, t_in)
+        if model_type == 'x_start':          # model_wrapper.noise_pred_fn (dpm_solver.py:358-361)
+            eps = (xc - ns.alpha(tc) * eps) / ns.std(tc)
         x0 = (xc - ns.std(tc) * eps) / ns.alpha(tc)
         return quantize_fn(x0)
 
@@ -541,6 +544,47 @@ def ldm_sample(W, plan, ed, slots, x_T, steps=20, mc=128, trace=None):
     q_fn = lambda x0: vq_quantize(W, x0)[0]
     x = dpm_solver_sample(eps_fn, q_fn, betas, x_T, steps=steps, order=3, trace=trace)
     return x, vae_decode(W, x, ed)
+
+
+# ---------------------------------------------------------------------------
+# 8(f) row 2: ancestral sampler (img_based/models/ddpm/cond_ddpm.py:55-132, ddpm.py:167-180)
+# ---------------------------------------------------------------------------
+def p_mean(W, model_out, x, t, quantize_fn, pred_target='eps', clip_denoised=False,
+           prefix='dm_decoder'):
+    """_p_mean_variance: x0 estimate (from eps, or the model output itself for 'x0'), optional
+    clamp, VQ denoising, then the posterior mean / log-variance of q(x_{t-1} | x_t, x0)."""
+    g = lambda k: W[f'{prefix}.{k}'][t].view(-1, 1, 1, 1)
+    if pred_target == 'eps':
+        x0 = g('sqrt_recip_alphas_bar') * x - g('sqrt_recipm1_alphas_bar') * model_out
+    else:
+        x0 = model_out
+    if clip_denoised:
+        x0 = x0.clamp(-1., 1.)
+    if quantize_fn is not None:
+        x0 = quantize_fn(x0)
+    mean = g('posterior_mean_coef1') * x0 + g('posterior_mean_coef2') * x
+    return mean, g('posterior_log_variance_clipped')
+
+
+def p_sample(W, model_fn, x, t, noise, quantize_fn, pred_target='eps', clip_denoised=False):
+    """_p_sample: x_{t-1} = mean + [t > 0] * exp(0.5 * logvar) * noise."""
+    mean, logvar = p_mean(W, model_fn(x, t), x, t, quantize_fn, pred_target, clip_denoised)
+    mask = (1 - (t == 0).float()).view(-1, 1, 1, 1)
+    return mean + mask * (0.5 * logvar).exp() * noise
+
+
+def ancestral_sample(W, model_fn, quantize_fn, x, noise_fn, num_timesteps, log_every_t=100,
+                     pred_target='eps'):
+    """_sample_x0_from_noise: t = T-1 .. 0; intermediates = [x_T] + states at i % log_every_t == 0
+    or i == T-1."""
+    inter = [x]
+    B = x.shape[0]
+    for i in reversed(range(num_timesteps)):
+        t = torch.full((B,), i, dtype=torch.long)
+        x = p_sample(W, model_fn, x, t, noise_fn(x.shape), quantize_fn, pred_target)
+        if i % log_every_t == 0 or i == num_timesteps - 1:
+            inter.append(x)
+    return x, torch.stack(inter, 0)
 
 
 # ---------------------------------------------------------------------------

@@ -152,20 +152,19 @@ class LDM(_Owned):
         with torch.set_grad_enabled(grad):
             pred = r._unet_eps(xt, t.float(), slots, Kp)
             # the 4th (zero pad) channel adds no error but is counted in n: rescale 4/3
+            gt = nz if self.pred_target == 'eps' else x0       # ldm.py:76-79
             if grad:
-                loss = kern.MseFn.apply(pred, nz, 4.0 / 3.0)
+                loss = kern.MseFn.apply(pred, gt, 4.0 / 3.0)
             else:
-                loss = (ops.mse(pred, nz) * (4.0 / 3.0)).reshape(())
+                loss = (ops.mse(pred, gt) * (4.0 / 3.0)).reshape(())
         return {'denoise_loss': loss}
 
     # -- a12/a13 -------------------------------------------------------------------------
     @torch.no_grad()
     def generate_imgs(self, cond, batch_size=16, ret_intermed=False, verbose=False,
                       use_ddim=False, use_dpm=True, x_T=None, same_noise=False, **kwargs):
-        """cond_ddpm.py:134-212 (DPM-Solver branch). Returns latents [B,3,h,w] (NCHW fp32)."""
-        if not use_dpm and not use_ddim:
-            raise NotImplementedError('ancestral 1000-step sampling is not part of the path: use '
-                                      'use_dpm=True (DPM-Solver++) or use_ddim=True (DDIM)')
+        """cond_ddpm.py:134-212: DPM-Solver++ (use_dpm, takes precedence), DDIM (use_ddim) or the
+        T-step ancestral sampler.  Returns latents [B,3,h,w] (NCHW fp32)."""
         r = self.root
         if cond.dim() == 2:
             cond = cond.unsqueeze(0).expand(batch_size, -1, -1)
@@ -179,10 +178,12 @@ class LDM(_Owned):
         x = ops.nchw_to_nhwc(x_T, torch.float32, 4)
         if use_dpm:            # cond_ddpm.py:155-178 (takes precedence, as in the reference)
             x, inter = r._dpm_sample(x, cond, ret_intermed)
-        else:                  # cond_ddpm.py:180-190: DDIM, max(200, T // 5) steps, eta = 0
+        elif use_ddim:         # cond_ddpm.py:180-190: DDIM, max(200, T // 5) steps, eta = 0
             steps = kwargs.get('ddim_steps') or max(200, self.num_timesteps // 5)
             x, inter = r._ddim_sample(x, cond, steps, kwargs.get('eta', 0.), ret_intermed,
                                       kwargs.get('log_every_t', 100))
+        else:                  # cond_ddpm.py:191-196: ancestral sampling over all T timesteps
+            x, inter = r._ancestral_sample(x, cond, ret_intermed, kwargs.get('log_every_t', 100))
         out = ops.nhwc_to_nchw(x, 3)
         if ret_intermed:
             return out, torch.stack([ops.nhwc_to_nchw(i, 3) for i in inter], 0)
@@ -280,7 +281,8 @@ class SADiffusion(SlotModelBase):
                  if k in dd}
         super().__init__(sp, schedule_kwargs=sched, seed=seed,
                          node_classes={'dm_decoder': LDM, 'dm_decoder.vae': VQVAEWrapper})
-        assert dd.get('pred_target', 'eps') == 'eps', 'hot path covers eps-prediction'
+        assert dd.get('pred_target', 'eps') in ('eps', 'x0')          # ddpm.py:79
+        self.dm_decoder.pred_target = dd.get('pred_target', 'eps')
         self.resolution = tuple(resolution)
         self.eps = eps
         self.slot_dict, self.enc_dict, self.dec_dict = dict(slot_dict), dict(enc_dict), dec_dict
@@ -376,9 +378,55 @@ class SADiffusion(SlotModelBase):
                 inter.append(x)
         return x, (inter if ret_intermed else [])
 
+    def _ancestral_sample(self, x, cond, ret_intermed=False, log_every_t=100):
+        """_sample_x0_from_noise (cond_ddpm.py:88-120): t = T-1 .. 0."""
+        T = self.dm_decoder.num_timesteps
+        inter = [x]
+        for x, i in self._ancestral_steps(x, cond, list(reversed(range(T)))):
+            if i % log_every_t == 0 or i == T - 1:
+                inter.append(x)
+        return x, (inter if ret_intermed else [])
+
+    def _ancestral_steps(self, x, cond, ts, noises=None):
+        """Generator over ancestral updates x_t -> x_{t-1} for the integer timesteps `ts` (any
+        list, in sampling order): _p_mean_variance + _p_sample (cond_ddpm.py:55-86, ddpm.py:167-180)
+        with the VQ denoiser.  `noises` (list of [B,3,h,w] or None) replaces the random draws."""
+        dm = self.dm_decoder
+        u = self.unet()
+        Kp = self.K()
+        tab = {k: getattr(dm, k).detach().double().cpu() for k in
+               ('sqrt_recip_alphas_bar', 'sqrt_recipm1_alphas_bar', 'posterior_mean_coef1',
+                'posterior_mean_coef2', 'posterior_log_variance_clipped')}
+        ctx_kv = u.context_kv(Kp, self._ctx(cond))
+        B = x.shape[0]
+        code = self.bank().f(self.vq_key)
+        CH = 50                                   # time-embedding rows are prepared 50 steps at a time
+        for c0 in range(0, len(ts), CH):
+            chunk = ts[c0:c0 + CH]
+            tin = torch.tensor([float(t) for t in chunk], dtype=torch.float32, device=x.device)
+            rv_all = u.time_rowvecs(Kp, tin)
+            for j, t in enumerate(chunk):
+                out = u.forward(Kp, self._unet_in(x), rv_all[j:j + 1].expand(B, -1), ctx_kv)
+                if dm.pred_target == 'eps':
+                    x0 = ops.lincomb(float(tab['sqrt_recip_alphas_bar'][t]), x,
+                                     -float(tab['sqrt_recipm1_alphas_bar'][t]), out)
+                else:
+                    x0 = out
+                x0 = ops.vq_nearest(x0, code, scale=self.z_scale, want_idx=False)[1]
+                x = ops.lincomb(float(tab['posterior_mean_coef1'][t]), x0,
+                                float(tab['posterior_mean_coef2'][t]), x)
+                if t != 0:
+                    nz = noises[c0 + j] if noises is not None else torch.randn(
+                        B, 3, x.shape[1], x.shape[2], device=x.device)
+                    nz = ops.nchw_to_nhwc(nz, torch.float32, 4)
+                    sd = float(torch.exp(0.5 * tab['posterior_log_variance_clipped'][t].float()))
+                    x = ops.lincomb(1.0, x, sd, nz)
+                yield x, t
+
     def _ddim_steps(self, x, cond, plan):
         """Generator over the DDIM updates of `plan` (a list of dpm.ddim_plan entries, any subset in
         sampling order): yields (x after the step, step)."""
+        assert self.dm_decoder.pred_target == 'eps', 'the DDIM sampler is defined for eps models'
         u = self.unet()
         Kp = self.K()
         tin = torch.tensor([float(st['t']) for st in plan], dtype=torch.float32, device=x.device)
@@ -415,11 +463,14 @@ class SADiffusion(SlotModelBase):
         B = x.shape[0]
         code = self.bank().f(self.vq_key)
         nfe = [0]
+        x_start = self.dm_decoder.pred_target == 'x0'
 
         def data_pred(xc, e):
             rv = rv_all[nfe[0]:nfe[0] + 1].expand(B, -1)      # pitch-0 view: same row for all b
             nfe[0] += 1
             eps = u.forward(Kp, self._unet_in(xc), rv, ctx_kv)
+            if x_start:        # model_wrapper 'x_start' (dpm_solver.py:358-361): output -> noise
+                eps = ops.lincomb(1.0, xc, -e['alpha'], eps, div=e['sigma'])
             x0 = ops.lincomb(1.0, xc, -e['sigma'], eps, div=e['alpha'])
             return ops.vq_nearest(x0, code, scale=self.z_scale, want_idx=False)[1]
 

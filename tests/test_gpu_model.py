@@ -306,3 +306,75 @@ def test_ddim_sampler_fp32():
     REPORT['ddim_single_step_agree'] = worst
     _dump()
     assert worst >= 0.995
+
+
+def test_ancestral_sampler_and_x0_target_fp32():
+    """ancestral sampling steps (generate_imgs(use_dpm=False, use_ddim=False)
+    path) and the x0-prediction variant (loss target, ancestral step, DPM-Solver 'x_start') against
+    the reference run in tests/golden/anc_x0_b2.npz.  Single steps with the fixture's explicit
+    noise are the parity points (each step is restarted from the reference state: the VQ denoiser
+    makes long trajectories chaotic)."""
+    from slotdiffusion_amd import ops
+    from slotdiffusion_amd.models import SADiffusion
+    m, G, img = ctx()
+    A = C.load_golden('anc_x0_b2.npz')
+    slots = G['slots'].cuda()
+    ts = [int(v) for v in A['anc_t'].tolist()]
+    nz = A['anc_noise'].cuda()
+
+    def steps_of(model, key):
+        agree = 1.0
+        x_in = G['x_T']
+        for j, tv in enumerate(ts):
+            x = ops.nchw_to_nhwc(x_in.cuda(), torch.float32, 4)
+            x_dev = next(model._ancestral_steps(x, slots, [tv], noises=[nz]))[0]
+            ok = ((ops.nhwc_to_nchw(x_dev, 3).cpu() - A[key][j]).abs() <= 1e-4).float().mean()
+            agree = min(agree, float(ok))
+            x_in = A[key][j]
+        return agree
+
+    REPORT['ancestral_eps_step_agree'] = steps_of(m, 'eps_anc_x')
+    # the full sampler API on a 12-timestep schedule (same weights): runs, logs T//4-spaced states
+    cfg = C.clevrtex_cfg()
+    cfg['dec_dict']['diffusion_dict']['timesteps'] = 12
+    ms = SADiffusion(cfg['resolution'], cfg['slot_dict'], cfg['enc_dict'], cfg['dec_dict'],
+                     cfg['loss_dict'], compute_dtype=torch.float32)
+    det_fill_(ms.state_dict().items(), skip=is_buffer_name)
+    ms = ms.cuda().eval()
+    ms.use_graph = False
+    out, inter = ms.dm_decoder.generate_imgs(slots, batch_size=2, ret_intermed=True, use_dpm=False,
+                                             use_ddim=False, x_T=G['x_T'].cuda(), log_every_t=4)
+    assert out.shape == (2, 3, 32, 32) and inter.shape[0] == 1 + 4 and bool(torch.isfinite(out).all())
+    assert maxerr(inter[0], G['x_T']) == 0.0 and maxerr(inter[-1], out.cpu()) == 0.0
+    del ms
+    # ---- x0-prediction model
+    cfg = C.clevrtex_cfg()
+    cfg['dec_dict']['diffusion_dict']['pred_target'] = 'x0'
+    mx = SADiffusion(cfg['resolution'], cfg['slot_dict'], cfg['enc_dict'], cfg['dec_dict'],
+                     cfg['loss_dict'], compute_dtype=torch.float32)
+    det_fill_(mx.state_dict().items(), skip=is_buffer_name)
+    mx.train_dropout = 0.0
+    mx = mx.cuda().eval()
+    mx.use_graph = False
+    REPORT['ancestral_x0_step_agree'] = steps_of(mx, 'x0_anc_x')
+    x, tr = mx.dm_decoder.generate_imgs(cond=slots, batch_size=2, x_T=G['x_T'].cuda(), ret_intermed=True)
+    REPORT['x0_dpm_step0_maxerr'] = maxerr(tr[0], A['x0_dpm_trace'][0])
+    REPORT['x0_dpm_final_frac_gt_1e-3'] = float(((x.cpu() - A['x0_dpm_final']).abs() > 1e-3).float().mean())
+    # training loss with the x0 target + gradient norms
+    mx.train()
+    for p in mx.parameters():
+        p.grad = None
+    data = dict(img=img, t=G['t'].long().cuda(), noise=G['noise'].cuda())
+    loss = mx.calc_train_loss(data, mx(data))['denoise_loss']
+    loss.backward()
+    named = dict(mx.named_parameters())
+    names = [str(n) for n in A['x0_grad_norms_names']]
+    mine = torch.tensor([float(named[n].grad.norm()) for n in names])
+    rel = (mine - A['x0_grad_norms']).abs() / (A['x0_grad_norms'].abs() + 1e-12)
+    REPORT['x0_train_loss_err'] = abs(float(loss.detach()) - float(A['x0_train_loss']))
+    REPORT['x0_grad_norm_max_rel'] = float(rel.max())
+    _dump()
+    assert REPORT['ancestral_eps_step_agree'] >= 0.995 and REPORT['ancestral_x0_step_agree'] >= 0.995
+    assert REPORT['x0_dpm_step0_maxerr'] <= 1e-4 and REPORT['x0_dpm_final_frac_gt_1e-3'] <= 0.02
+    assert REPORT['x0_train_loss_err'] <= 1e-5 * max(1.0, float(A['x0_train_loss']))
+    assert REPORT['x0_grad_norm_max_rel'] <= 2e-3

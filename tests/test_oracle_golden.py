@@ -215,3 +215,46 @@ def test_ddim_oracle_matches_reference():
     assert float((x - D['ddim_final']).abs().max()) <= 1e-4
     idx = O.vq_quantize(W, x)[1]
     assert float((idx == D['ddim_final_idx'].long()).float().mean()) >= 0.999
+
+
+def test_ancestral_and_x0_oracle_matches_reference():
+    """ancestral sampler steps (eps and x0 prediction), posterior tables, the x0
+    training target and the 'x_start' DPM-Solver wrapper of the oracle against the reference
+    (tests/golden/anc_x0_b2.npz)."""
+    cfg = C.clevrtex_cfg()
+    G, A = C.load_golden(), C.load_golden('anc_x0_b2.npz')
+    W = C.oracle_weights(cfg)
+    sel = torch.tensor([0, 1, 2, 250, 500, 998, 999])
+    for k in ('posterior_mean_coef1', 'posterior_mean_coef2', 'posterior_log_variance_clipped',
+              'sqrt_recip_alphas_bar', 'sqrt_recipm1_alphas_bar'):
+        assert torch.equal(W['dm_decoder.' + k][sel], A['tab_' + k]), k
+    plan = spec.unet_plan(cfg['dec_dict']['unet_dict'])
+    slots = G['slots']
+    fn = lambda xc, t: O.unet_forward(W, plan, xc, t, slots)
+    q_fn = lambda x0: O.vq_quantize(W, x0)[0]
+    for target in ('eps', 'x0'):
+        x = G['x_T']
+        with torch.no_grad():
+            for j, tv in enumerate(A['anc_t'].tolist()):
+                t = torch.full((2,), int(tv), dtype=torch.long)
+                mean, _ = O.p_mean(W, fn(x, t), x, t, q_fn, target)
+                assert float((mean - A[target + '_anc_mean'][j]).abs().max()) <= 2e-4, (target, tv)
+                x = O.p_sample(W, fn, x, t, A['anc_noise'], q_fn, target)
+                assert float((x - A[target + '_anc_x'][j]).abs().max()) <= 2e-4, (target, tv)
+                x = A[target + '_anc_x'][j]          # continue from the reference state
+    # x0 target of the loss
+    ed = cfg['dec_dict']['vae_dict']['enc_dec_dict']
+    with torch.no_grad():
+        loss, pred, _ = O.ldm_loss(W, plan, ed, C.make_inputs(2)[0], slots, G['t'].long(), G['noise'],
+                                   pred_target='x0')
+    assert float((pred - A['x0_pred']).abs().max()) <= 2e-4
+    assert abs(float(loss) - float(A['x0_train_loss'])) <= 1e-5 * max(1.0, float(A['x0_train_loss']))
+    # DPM-Solver++ with an x_start model: first outer step tight, whole trace loose (VQ ties)
+    tr = []
+    with torch.no_grad():
+        O.dpm_solver_sample(fn, q_fn, W['dm_decoder.betas'], G['x_T'], steps=20, order=3, trace=tr,
+                            model_type='x_start')
+    tr = torch.stack(tr, 0)
+    assert tr.shape == A['x0_dpm_trace'].shape
+    assert float((tr[0] - A['x0_dpm_trace'][0]).abs().max()) <= 2e-4
+    assert float((tr - A['x0_dpm_trace']).abs().mean()) <= 1e-2

@@ -171,6 +171,88 @@ def main_ddim():
     print('wrote ddim_b2.npz', {k: tuple(np.asarray(v).shape) for k, v in G.items()})
 
 
+def main_anc():
+    """tests/golden/anc_x0_b2.npz: the reference's ancestral sampler
+    (cond_ddpm.py:55-132: _p_mean_variance / _p_sample / _sample_x0_from_noise, VQ-denoised LDM
+    branch) as single steps with explicit x, t and noise, the posterior tables it reads, and the
+    x0-prediction variant (pred_target='x0': loss target, _p_sample, DPM-Solver 'x_start')."""
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    im = rh.ref_models('img_based')
+    import slotdiffusion.img_based.models.ddpm.cond_ddpm as cd
+    G = {}
+    for target in ('eps', 'x0'):
+        P = rh.ref_params('img_based', 'sa_ldm', 'sa_ldm_clevrtex_params-res128')
+        P.slot_dict['num_slots'] = 7
+        P.dec_dict['diffusion_dict']['pred_target'] = target
+        model = im.build_model(P)
+        det_fill_(model.state_dict().items(), skip=is_buffer_name)
+        model.eval()
+        img, t, noise, x_T = make_inputs(2)
+        with torch.no_grad():
+            slots, _ = model.encode(img)
+        dm = model.dm_decoder
+        assert dm.pred_target == target and dm.vq_denoised and not dm.clip_denoised
+        pre = target + '_'
+        if target == 'eps':
+            for k in ('posterior_mean_coef1', 'posterior_mean_coef2', 'posterior_log_variance_clipped',
+                      'sqrt_recip_alphas_bar', 'sqrt_recipm1_alphas_bar'):
+                G['tab_' + k] = getattr(dm, k)[[0, 1, 2, 250, 500, 998, 999]].clone()
+        # single ancestral steps with explicit noise (x_{t-1} | x_t = x_T-like state)
+        nz = torch.randn(x_T.shape, generator=torch.Generator().manual_seed(77))
+        G['anc_noise'] = nz
+        cd.noise_like = lambda shape, device, repeat=False: nz.clone()
+        ts = [999, 500, 1, 0]
+        G['anc_t'] = torch.tensor(ts)
+        outs, means = [], []
+        x = x_T.clone()
+        with torch.no_grad():
+            for tv in ts:
+                tt = torch.full((2,), tv, dtype=torch.long)
+                mean, _, logvar = dm._p_mean_variance(x.clone(), tt, slots, clip_denoised=False,
+                                                      vq_denoised=True)
+                means.append(mean)
+                x = dm._p_sample(x, tt, slots, clip_denoised=False, vq_denoised=True)
+                outs.append(x)
+        G[pre + 'anc_mean'] = torch.stack(means, 0)
+        G[pre + 'anc_x'] = torch.stack(outs, 0)
+        if target == 'x0':
+            # loss with the x0 target (ldm.py:59-83) at explicit t / noise, a few gradient norms
+            model.train()
+            dm.model.eval()
+            with torch.no_grad():
+                x0 = dm.vae.encode(img)
+            out = model(dict(img=img))
+            xt = dm._sample_xt_from_x0(x0=x0, t=t, noise=noise)
+            pred = dm.forward(xt, t, context=out['slots'])
+            loss = torch.nn.functional.mse_loss(pred, x0)
+            loss.backward()
+            G['x0_train_loss'] = loss.detach()
+            named = dict(model.named_parameters())
+            names = sorted(n for n, p in named.items() if p.grad is not None)[::16]
+            G['x0_grad_norms_names'] = np.array(names)
+            G['x0_grad_norms'] = torch.tensor([float(named[n].grad.norm()) for n in names])
+            G['x0_pred'] = pred.detach()
+            # DPM-Solver++ with model_type 'x_start' (cond_ddpm.py:160-166)
+            model.eval()
+            from slotdiffusion.img_based.models.ddpm import dpm_solver as ds
+            ns = ds.NoiseScheduleVP(betas=dm.betas)
+            with torch.no_grad():
+                dm.model.vae = dm.vae
+                model_fn = ds.model_wrapper(model=dm.model, noise_schedule=ns, model_type='x_start',
+                                            guidance_type='classifier-free', condition=slots)
+                sampler = ds.DPM_Solver(model_fn, ns, algorithm_type='dpmsolver++',
+                                        correcting_x0_fn=False, vq_denoised=True)
+                xx, inter = sampler.sample(x_T.clone(), steps=20, order=3, method='singlestep',
+                                           return_intermediate=True)
+                dm.model.vae = None
+            G['x0_dpm_trace'] = torch.stack(inter, 0)
+            G['x0_dpm_final'] = xx
+    arrs = {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else v) for k, v in G.items()}
+    np.savez_compressed(os.path.join(OUT, 'anc_x0_b2.npz'), **arrs)
+    print('wrote anc_x0_b2.npz', {k: tuple(np.asarray(v).shape) for k, v in arrs.items()})
+
+
 def main_sa():
     """tests/golden/sa_b2.npz: plain Slot Attention auto-encoder (registry 'SA', BASELINE config 0;
     SURVEY 8(a) row a16): slots, recon, masks, loss and parameter-gradient norms at B=2."""
@@ -265,6 +347,9 @@ if __name__ == '__main__':
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'sa':
         main_sa()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'anc':
+        main_anc()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'video':
         main_video()
