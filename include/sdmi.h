@@ -375,6 +375,29 @@ typedef struct {
 } SdmiAdamArgs;
 int sdmi_adam_clip(const SdmiAdamArgs* a, void* stream);
 
+
+/* ------------------------------------------------------------------------------------------
+ * Evaluation metrics on device (video_based/models/eval_utils.py:119-320).
+ * The segmentation scores (ARI / FG-ARI, Hungarian mIoU, mBO) are all functions of the per-image
+ * contingency table of (ground-truth id, predicted id) pairs, which is exact integer work:
+ *   counts[b][c][k] = #{p : gt[b][p] == c and pred[b][p] == k}     (ids outside the table are skipped)
+ * replaces the one_hot + einsum("bthwc,bthwk->bck") of adjusted_rand_index (eval_utils.py:148-157)
+ * and the one_hot products of hungarian_miou / mean_best_overlap (238-290).  `counts` must be
+ * zeroed by the caller.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  const int* gt; const int* pred; int* counts;     /* [B][P], [B][P], [B][Kg][Kp] */
+  int B; long long P; int Kg, Kp;                   /* Kg * Kp <= 8192 */
+} SdmiContingencyArgs;
+int sdmi_contingency(const SdmiContingencyArgs* a, void* stream);
+/* Per-image squared error for mse_metric / psnr_metric (eval_utils.py:75-92):
+ *   partial[b][j] = sum over the j-th of `nchunk` equal slices of (x[b][i] - y[b][i])^2, in fp64
+ * (the caller adds the nchunk partials of an image in index order). */
+typedef struct {
+  const float* x; const float* y; double* partial; int B; long long n; int nchunk;
+} SdmiSqErrArgs;
+int sdmi_sqerr_rows(const SdmiSqErrArgs* a, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

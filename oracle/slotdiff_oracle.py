@@ -658,3 +658,87 @@ def psnr(a, b):
     a01, b01 = (a * 0.5 + 0.5).clamp(0, 1), (b * 0.5 + 0.5).clamp(0, 1)
     mse = ((a01 - b01) ** 2).flatten(1).mean(1)
     return 10. * torch.log10(1. / mse)
+
+
+# ---------------------------------------------------------------------------
+# 8(f) row 3: evaluation metrics (video_based/models/eval_utils.py:75-92, 119-333)
+# ---------------------------------------------------------------------------
+def adjusted_rand_index(true_ids, pred_ids, ignore_background=False):
+    """eval_utils.py:119-176 (one_hot + einsum form): ARI per batch element, float32 [B]."""
+    if true_ids.dim() == 3:
+        true_ids = true_ids.unsqueeze(1)
+    if pred_ids.dim() == 3:
+        pred_ids = pred_ids.unsqueeze(1)
+    true_oh = F.one_hot(true_ids).float()
+    pred_oh = F.one_hot(pred_ids).float()
+    if ignore_background:
+        true_oh = true_oh[..., 1:]
+    N = torch.einsum('bthwc,bthwk->bck', true_oh, pred_oh)
+    A = N.sum(-1)
+    Bc = N.sum(-2)
+    num_points = A.sum(1)
+    rindex = torch.sum(N * (N - 1), dim=[1, 2])
+    aindex = torch.sum(A * (A - 1), dim=1)
+    bindex = torch.sum(Bc * (Bc - 1), dim=1)
+    expected = aindex * bindex / torch.clamp(num_points * (num_points - 1), min=1)
+    max_r = (aindex + bindex) / 2
+    den = max_r - expected
+    ari = (rindex - expected) / den
+    return torch.where(den != 0, ari, torch.tensor(1.).type_as(ari))
+
+
+def _pair_iou(gt_mask, pred_mask, ignore_background):
+    true_oh = F.one_hot(gt_mask).float()
+    if ignore_background:
+        true_oh = true_oh[..., 1:]
+    pred_oh = F.one_hot(pred_mask).float()
+    inter = (true_oh[:, :, None] * pred_oh[:, None, :]).sum(0)
+    union = true_oh.sum(0)[:, None] + pred_oh.sum(0)[None] - inter
+    return (inter / (union + 1e-8)).numpy()
+
+
+def hungarian_miou(gt_mask, pred_mask, ignore_background=True):
+    """eval_utils.py:238-263, masks [H*W] after argmax."""
+    import numpy as np
+    from scipy.optimize import linear_sum_assignment
+    if gt_mask.max().item() == 0 and ignore_background:
+        return np.nan
+    iou = _pair_iou(gt_mask, pred_mask, ignore_background)
+    N, M = iou.shape
+    r, c = linear_sum_assignment(iou, maximize=True)
+    return iou[r, c].mean() if M >= N else iou[r, c].sum() / float(N)
+
+
+def mean_best_overlap(gt_mask, pred_mask):
+    """eval_utils.py:266-290."""
+    import numpy as np
+    if gt_mask.max().item() == 0:
+        return np.nan
+    return _pair_iou(gt_mask, pred_mask, True).max(1).mean()
+
+
+def seg_metrics(gt, pred):
+    """ARI / FG-ARI / mIoU / FG-mIoU / mBO of [B,H,W] id maps, as the *_metric wrappers
+    (eval_utils.py:179-190, 293-333)."""
+    import numpy as np
+    g, q = gt.flatten(1, 2), pred.flatten(1, 2)
+    B = gt.shape[0]
+    return dict(
+        ari=adjusted_rand_index(gt, pred, False).mean().item(),
+        fari=adjusted_rand_index(gt, pred, True).mean().item(),
+        miou=np.nanmean([hungarian_miou(g[i], q[i], False) for i in range(B)]),
+        fmiou=np.nanmean([hungarian_miou(g[i], q[i], True) for i in range(B)]),
+        mbo=np.nanmean([mean_best_overlap(g[i], q[i]) for i in range(B)]))
+
+
+def mse_metric(x, y):
+    """eval_utils.py:75-78 (numpy arrays or tensors in [0,1], [B,3,H,W])."""
+    d = (x.double() - y.double()) ** 2
+    return float(d.sum((-1, -2, -3)).mean())
+
+
+def psnr_metric(x, y):
+    """eval_utils.py:81-92 with skimage's definition restated (skimage is absent here):
+    peak_signal_noise_ratio(a, b, data_range=1) = 10 log10(1 / mean((a-b)^2)), float64."""
+    d = ((x.double() - y.double()) ** 2).flatten(1).mean(1)
+    return float((10.0 * torch.log10(1.0 / d)).mean())

@@ -1,0 +1,158 @@
+"""Evaluation metrics with the pixel work on the GPU.
+
+Host-side mirror of video_based/models/eval_utils.py (img_based twin identical): ARI / FG-ARI
+(119-186), Hungarian mIoU (238-263, 293-320), mBO (266-290, 323-333), MSE / PSNR (75-92).  The
+per-pixel part -- the (gt id, pred id) contingency table of every image, the per-image squared
+error -- runs in HIP kernels (sdmi_contingency, sdmi_sqerr_rows); what is left is arithmetic on a
+[B, C, K] table of exact integers, done with the reference's own float32 formulas on the host, and
+scipy's linear_sum_assignment for the matching, exactly as the reference does.
+
+Not covered: SSIM / LPIPS (skimage / lpips networks), bounding-box AP/AR (torchvision ops),
+postproc_mask.
+"""
+import numpy as np
+import torch
+
+from . import _lib
+
+__all__ = ['contingency', 'adjusted_rand_index', 'ARI_metric', 'fARI_metric', 'miou_metric',
+           'fmiou_metric', 'mbo_metric', 'mse_metric', 'psnr_metric']
+
+
+def _need_gpu(t):
+    if not t.is_cuda:
+        raise RuntimeError('slotdiffusion_amd.metrics runs on the GPU (libsdmi); got a CPU tensor')
+
+
+def contingency(true_ids, pred_ids, num_true=None, num_pred=None):
+    """Integer ids [B, ...] (any trailing shape, e.g. [B,H,W] or [B,T,H,W]) -> int32 table
+    [B, C, K] on the device; C / K default to max id + 1 over the batch (the one_hot widths)."""
+    _need_gpu(true_ids)
+    _need_gpu(pred_ids)
+    assert true_ids.shape == pred_ids.shape
+    assert 'int' in str(true_ids.dtype) and 'int' in str(pred_ids.dtype)
+    B = true_ids.shape[0]
+    g = true_ids.reshape(B, -1).to(torch.int32).contiguous()
+    q = pred_ids.reshape(B, -1).to(torch.int32).contiguous()
+    C = int(num_true if num_true is not None else int(g.max()) + 1)
+    K = int(num_pred if num_pred is not None else int(q.max()) + 1)
+    counts = torch.zeros((B, C, K), dtype=torch.int32, device=g.device)
+    _lib.call('sdmi_contingency', torch.cuda.current_stream().cuda_stream, gt=g.data_ptr(),
+              pred=q.data_ptr(), counts=counts.data_ptr(), B=B, P=g.shape[1], Kg=C, Kp=K)
+    return counts
+
+
+def _ari_from_table(N):
+    """eval_utils.py:157-176 on the [B, C, K] float32 table."""
+    A = torch.sum(N, dim=-1)
+    Bc = torch.sum(N, dim=-2)
+    num_points = torch.sum(A, dim=1)
+    rindex = torch.sum(N * (N - 1), dim=[1, 2])
+    aindex = torch.sum(A * (A - 1), dim=1)
+    bindex = torch.sum(Bc * (Bc - 1), dim=1)
+    expected_rindex = aindex * bindex / torch.clamp(num_points * (num_points - 1), min=1)
+    max_rindex = (aindex + bindex) / 2
+    denominator = max_rindex - expected_rindex
+    ari = (rindex - expected_rindex) / denominator
+    return torch.where(denominator != 0, ari, torch.tensor(1.).type_as(ari))
+
+
+def adjusted_rand_index(true_ids, pred_ids, ignore_background=False):
+    """-> float32 [B] (CPU), eval_utils.py:119-176."""
+    N = contingency(true_ids, pred_ids).cpu().float()
+    if ignore_background:
+        N = N[:, 1:]
+    return _ari_from_table(N)
+
+
+def ARI_metric(x, y):
+    return adjusted_rand_index(x, y, ignore_background=False).mean().item()
+
+
+def fARI_metric(x, y):
+    return adjusted_rand_index(x, y, ignore_background=True).mean().item()
+
+
+def _iou_tables(gt_mask, pred_mask):
+    """Per-image (intersect [N_i, M_i] float32) with the per-image one_hot widths of the
+    reference (N_i = max gt id of the image + 1, M_i likewise)."""
+    T = contingency(gt_mask, pred_mask).cpu()
+    out = []
+    for b in range(T.shape[0]):
+        t = T[b]
+        rows = torch.nonzero(t.sum(1)).flatten()
+        cols = torch.nonzero(t.sum(0)).flatten()
+        n = int(rows.max()) + 1 if len(rows) else 1
+        m = int(cols.max()) + 1 if len(cols) else 1
+        out.append(t[:n, :m].float())
+    return out
+
+
+def _iou(inter, ignore_background):
+    true_cnt = inter.sum(1)                      # pixels per gt id (one_hot column sums)
+    pred_cnt = inter.sum(0)
+    if ignore_background:
+        inter, true_cnt = inter[1:], true_cnt[1:]
+    union = true_cnt[:, None] + pred_cnt[None] - inter
+    return (inter / (union + 1e-8)).numpy()
+
+
+def _hungarian_miou(inter, ignore_background):
+    from scipy.optimize import linear_sum_assignment
+    if inter.shape[0] == 1 and ignore_background:          # GT holds only the background id
+        return np.nan
+    iou = _iou(inter, ignore_background)
+    N, M = iou.shape
+    row_ind, col_ind = linear_sum_assignment(iou, maximize=True)
+    if M >= N:
+        return iou[row_ind, col_ind].mean()
+    return iou[row_ind, col_ind].sum() / float(N)
+
+
+def miou_metric(gt_mask, pred_mask, ignore_background=False):
+    ious = [_hungarian_miou(t, ignore_background) for t in _iou_tables(gt_mask, pred_mask)]
+    if all(np.isnan(v) for v in ious):
+        return np.nan
+    return np.nanmean(ious)
+
+
+def fmiou_metric(gt_mask, pred_mask):
+    return miou_metric(gt_mask, pred_mask, ignore_background=True)
+
+
+def mbo_metric(gt_mask, pred_mask):
+    mbos = []
+    for t in _iou_tables(gt_mask, pred_mask):
+        if t.shape[0] == 1:
+            mbos.append(np.nan)
+        else:
+            mbos.append(_iou(t, True).max(1).mean())
+    return np.nanmean(mbos)
+
+
+def _sqerr(x, y):
+    _need_gpu(x)
+    _need_gpu(y)
+    assert x.shape == y.shape
+    B = x.shape[0]
+    xf = x.reshape(B, -1).float().contiguous()
+    yf = y.reshape(B, -1).float().contiguous()
+    n = xf.shape[1]
+    nchunk = max(1, min(64, n // 4096))
+    part = torch.empty((B, nchunk), dtype=torch.float64, device=x.device)
+    _lib.call('sdmi_sqerr_rows', torch.cuda.current_stream().cuda_stream, x=xf.data_ptr(),
+              y=yf.data_ptr(), partial=part.data_ptr(), B=B, n=n, nchunk=nchunk)
+    return part.cpu().sum(1).numpy(), n
+
+
+def mse_metric(x, y):
+    """x/y [B,3,H,W] in [0,1]: squared error summed over an image, mean over the batch."""
+    se, _ = _sqerr(x, y)
+    return float(se.mean())
+
+
+def psnr_metric(x, y):
+    """skimage.metrics.peak_signal_noise_ratio(data_range=1) per image, mean over the batch:
+    10 * log10(1 / mean squared error)."""
+    se, n = _sqerr(x, y)
+    return float(np.mean(10.0 * np.log10(1.0 / (se / n))))

@@ -335,3 +335,39 @@ def test_mask_upsample_argmax_matches_torch():
     up, idx = ops.mask_upsample_argmax(seg.to(DEV), 32, 32, 128, 128)
     assert float((up.cpu() - ref).abs().max()) <= 2e-7
     assert torch.equal(idx.cpu(), ref.argmax(1))
+
+
+def test_eval_metrics_on_device():
+    """slotdiffusion_amd.metrics (sdmi_contingency / sdmi_sqerr_rows + the reference's formulas on
+    the table) against the reference's eval_utils values (tests/golden/metrics_b4.npz) and the
+    oracle on larger random id maps; the contingency table itself is bit-exact."""
+    from oracle import slotdiff_oracle as O
+    from slotdiffusion_amd import metrics as MT
+    from tests import common as C
+    M = C.load_golden('metrics_b4.npz')
+    gt, pred = M['gt'].long(), M['pred'].long()
+    assert torch.equal(MT.adjusted_rand_index(gt.cuda(), pred.cuda(), False), M['ari_per_image'])
+    assert torch.equal(MT.adjusted_rand_index(gt.cuda(), pred.cuda(), True), M['fari_per_image'])
+    assert torch.equal(MT.adjusted_rand_index(gt.view(2, 2, 32, 32).cuda(), pred.view(2, 2, 32, 32).cuda(), True),
+                       M['fari_video'])
+    for name, fn in (('ari', MT.ARI_metric), ('fari', MT.fARI_metric), ('miou', MT.miou_metric),
+                     ('fmiou', MT.fmiou_metric), ('mbo', MT.mbo_metric)):
+        assert abs(float(fn(gt.cuda(), pred.cuda())) - float(M[name])) <= 1e-6, name
+    # larger maps: table against a CPU bincount, scores against the oracle
+    g = torch.Generator().manual_seed(11)
+    B, T, H, W = 3, 6, 128, 128
+    gtv = torch.randint(0, 12, (B, T, H, W), generator=g)
+    pv = torch.where(torch.rand(B, T, H, W, generator=g) < 0.7, (gtv + 3) % 15, torch.randint(0, 15, (B, T, H, W), generator=g))
+    tab = MT.contingency(gtv.cuda(), pv.cuda()).cpu()
+    ref = torch.stack([torch.bincount((gtv[b] * 15 + pv[b]).flatten(), minlength=12 * 15).view(12, 15) for b in range(B)])
+    assert tab.shape == (B, 12, 15) and torch.equal(tab.long(), ref)
+    assert torch.equal(MT.adjusted_rand_index(gtv.cuda(), pv.cuda(), True), O.adjusted_rand_index(gtv, pv, True))
+    r = O.seg_metrics(gtv[:, 0], pv[:, 0])
+    assert abs(MT.fmiou_metric(gtv[:, 0].cuda(), pv[:, 0].cuda()) - r['fmiou']) <= 1e-6
+    assert abs(MT.mbo_metric(gtv[:, 0].cuda(), pv[:, 0].cuda()) - r['mbo']) <= 1e-6
+    x = torch.rand(4, 3, 128, 128, generator=g)
+    y = (x + 0.03 * torch.randn(4, 3, 128, 128, generator=g)).clamp(0, 1)
+    assert abs(MT.psnr_metric(x.cuda(), y.cuda()) - O.psnr_metric(x, y)) <= 1e-6
+    assert abs(MT.mse_metric(x.cuda(), y.cuda()) - O.mse_metric(x, y)) <= 1e-6 * O.mse_metric(x, y)
+    with pytest.raises(RuntimeError):
+        MT.ARI_metric(gt, pred)           # CPU tensors: no fallback

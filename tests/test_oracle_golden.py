@@ -1,6 +1,7 @@
 """Pins the CPU oracle (oracle/slotdiff_oracle.py) against tensors captured from the real
 reference (tests/golden/sadiff_b2.npz, produced by tools/gen_golden.py in the build container).
 CPU only."""
+import numpy as np
 import torch
 
 from oracle import slotdiff_oracle as O
@@ -258,3 +259,20 @@ def test_ancestral_and_x0_oracle_matches_reference():
     assert tr.shape == A['x0_dpm_trace'].shape
     assert float((tr[0] - A['x0_dpm_trace'][0]).abs().max()) <= 2e-4
     assert float((tr - A['x0_dpm_trace']).abs().mean()) <= 1e-2
+
+
+def test_eval_metrics_oracle_matches_reference():
+    """ARI / FG-ARI / Hungarian mIoU / mBO of the oracle against the reference's
+    eval_utils on tests/golden/metrics_b4.npz (incl. the background-only image -> nan handling and
+    the fewer-predictions-than-objects case)."""
+    M = C.load_golden('metrics_b4.npz')
+    gt, pred = M['gt'].long(), M['pred'].long()
+    assert torch.equal(O.adjusted_rand_index(gt, pred, False), M['ari_per_image'])
+    assert torch.equal(O.adjusted_rand_index(gt, pred, True), M['fari_per_image'])
+    assert torch.equal(O.adjusted_rand_index(gt.view(2, 2, 32, 32), pred.view(2, 2, 32, 32), False), M['ari_video'])
+    r = O.seg_metrics(gt, pred)
+    for k in ('ari', 'fari', 'miou', 'fmiou', 'mbo'):
+        assert abs(float(r[k]) - float(M[k])) <= 1e-6, (k, r[k], float(M[k]))
+    x = torch.rand(2, 3, 16, 16, generator=torch.Generator().manual_seed(3))
+    y = (x + 0.05 * torch.randn(2, 3, 16, 16, generator=torch.Generator().manual_seed(4))).clamp(0, 1)
+    assert abs(O.psnr_metric(x, y) - float(np.mean([10 * np.log10(1.0 / float(((x[i] - y[i]).double() ** 2).mean())) for i in range(2)]))) < 1e-9

@@ -253,6 +253,49 @@ def main_anc():
     print('wrote anc_x0_b2.npz', {k: tuple(np.asarray(v).shape) for k, v in arrs.items()})
 
 
+def metric_inputs():
+    """Synthetic id maps for the metric fixtures: B=4 images 32x32; blobs of ids 0..5 (gt) against
+    shifted / merged / split predictions; image 2 holds only background; image 3 has fewer
+    predicted segments than objects."""
+    g = torch.Generator().manual_seed(4321)
+    H = W = 32
+    yy, xx = torch.meshgrid(torch.arange(H), torch.arange(W), indexing='ij')
+    gt = torch.zeros(4, H, W, dtype=torch.long)
+    pred = torch.zeros(4, H, W, dtype=torch.long)
+    for b in (0, 1, 3):
+        for k in range(1, 6):
+            cy, cx = torch.randint(4, 28, (2,), generator=g).tolist()
+            r = int(torch.randint(3, 7, (1,), generator=g))
+            gt[b][((yy - cy) ** 2 + (xx - cx) ** 2) <= r * r] = k
+            sh = int(torch.randint(-2, 3, (1,), generator=g))
+            m = ((yy - cy - sh) ** 2 + (xx - cx + sh) ** 2) <= (r + (k % 2)) ** 2
+            pred[b][m] = (k + 1) % 7 if b != 3 else 1 + (k % 2)
+    pred[2] = torch.randint(0, 3, (H, W), generator=g)
+    return gt, pred
+
+
+def main_metrics():
+    """tests/golden/metrics_b4.npz: the reference's segmentation metrics
+    (video_based/models/eval_utils.py:119-333) on metric_inputs().  PSNR is not generated here
+    (skimage is absent from the image; its definition is restated in the oracle)."""
+    rh.ref_models('video_based')
+    from slotdiffusion.video_based.models import eval_utils as eu
+    gt, pred = metric_inputs()
+    G = dict(gt=gt.to(torch.int16), pred=pred.to(torch.int16),
+             ari_per_image=eu.adjusted_rand_index(gt, pred, False),
+             fari_per_image=eu.adjusted_rand_index(gt, pred, True),
+             ari=torch.tensor(eu.ARI_metric(gt, pred)), fari=torch.tensor(eu.fARI_metric(gt, pred)),
+             miou=torch.tensor(float(eu.miou_metric(gt, pred))),
+             fmiou=torch.tensor(float(eu.fmiou_metric(gt, pred))),
+             mbo=torch.tensor(float(eu.mbo_metric(gt, pred))))
+    # video-shaped ids [B,T,H,W] for the ARI
+    gtv, pv = gt.view(2, 2, 32, 32), pred.view(2, 2, 32, 32)
+    G['ari_video'] = eu.adjusted_rand_index(gtv, pv, False)
+    G['fari_video'] = eu.adjusted_rand_index(gtv, pv, True)
+    np.savez_compressed(os.path.join(OUT, 'metrics_b4.npz'), **{k: v.numpy() for k, v in G.items()})
+    print('wrote metrics_b4.npz', {k: (tuple(v.shape), v.flatten()[:4].tolist()) for k, v in G.items() if k not in ('gt', 'pred')})
+
+
 def main_sa():
     """tests/golden/sa_b2.npz: plain Slot Attention auto-encoder (registry 'SA', BASELINE config 0;
     SURVEY 8(a) row a16): slots, recon, masks, loss and parameter-gradient norms at B=2."""
@@ -347,6 +390,9 @@ if __name__ == '__main__':
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'sa':
         main_sa()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'metrics':
+        main_metrics()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'anc':
         main_anc()
