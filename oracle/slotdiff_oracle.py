@@ -410,6 +410,17 @@ def sa_forward_loss(W, img, plan, dec_plan, dec_resolution, num_iterations, eps=
     return F.mse_loss(recon, img), recon, masks, slots
 
 
+def savi_forward_loss(W, img, plan, dec_plan, dec_resolution, num_iterations, pred_layers, pred_heads,
+                      eps=1e-6):
+    """SAVi._forward + calc_train_loss (video_based/models/savi.py:445-508): img [B,T,3,H,W] ->
+    loss, recon [B,T,3,H,W], masks [B,T,N,1,H,W], slots [B,T,N,D]."""
+    B, T = img.shape[:2]
+    slots, _ = savi_encode(W, img, plan, num_iterations, True, pred_layers, pred_heads, eps)
+    recon, recons, masks = sa_decode(W, slots.flatten(0, 1), dec_plan, dec_resolution)
+    recon, masks = recon.unflatten(0, (B, T)), masks.unflatten(0, (B, T))
+    return F.mse_loss(recon, img), recon, masks, slots
+
+
 # ---------------------------------------------------------------------------
 # a12/a13: DPM-Solver++ (singlestep, order 3, time_uniform) on the discrete schedule
 # ---------------------------------------------------------------------------

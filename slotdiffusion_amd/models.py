@@ -548,6 +548,42 @@ class SADiffusion(SlotModelBase):
         self.dm_decoder._training_step_end()
 
 
+def _encode_clip(self, img, prev_slots=None):
+    """Per-frame Slot Attention recurrence shared by the video models (savi.py:366-397,
+    savi_diffusion.py:169-216): the initial slots of frame t are the transformer predictor's output
+    on frame t-1's slots (the learnt init_latents on the first frame).  -> slots [B,T,N,D],
+    masks [B,T,N,h,w] (train) / [B,T,N,H,W] (eval)."""
+    B, T, _, H, W = img.shape
+    grad = self.training and torch.is_grad_enabled()
+    Kp = self.KG() if grad else self.K()
+    h, w = self.visual_resolution
+    with torch.set_grad_enabled(grad):
+        tok = engine.encoder_out(Kp, self._to_nhwc(img.flatten(0, 1)), self.rplan)
+        tok = tok.view(B, T, tok.shape[1], tok.shape[2])
+        all_s, all_seg = [], []
+        for t in range(T):
+            if prev_slots is None:
+                lat = self.init_latents[0]
+            else:
+                lat = engine.transformer_predictor(Kp, prev_slots.contiguous(),
+                                                   self.pred_dict['pred_num_layers'],
+                                                   self.pred_dict['pred_num_heads'])
+            tk = tok[:, t].contiguous() if T > 1 else tok[:, 0]
+            s, seg = engine.slot_attention(Kp, tk, lat, self.num_iterations, self.eps)
+            all_s.append(s)
+            all_seg.append(seg)
+            prev_slots = s
+        slots = torch.stack(all_s, 1)
+    with torch.no_grad():
+        seg = torch.stack([x.detach() for x in all_seg], 1)            # [B,T,M,N]
+        if not self.training and (h, w) != (H, W):
+            masks, _ = ops.mask_upsample_argmax(seg.flatten(0, 1).contiguous(), h, w, H, W)
+            masks = masks.view(B, T, self.num_slots, H, W)
+        else:
+            masks = seg.permute(0, 1, 3, 2).reshape(B, T, self.num_slots, h, w)
+    return slots, masks
+
+
 class SAViDiffusion(SADiffusion):
     """SlotDiffusion on videos (registry name 'SAViDiffusion', video_based/models/
     savi_diffusion.py:74-302): per-frame Slot Attention whose initial slots are the transformer
@@ -569,35 +605,7 @@ class SAViDiffusion(SADiffusion):
 
     def encode(self, img, prev_slots=None):
         """savi_diffusion.py:169-216: img [B,T,3,H,W] -> slots [B,T,N,D], masks [B,T,N,*,*]."""
-        B, T, _, H, W = img.shape
-        grad = self.training and torch.is_grad_enabled()
-        Kp = self.KG() if grad else self.K()
-        h, w = self.visual_resolution
-        with torch.set_grad_enabled(grad):
-            tok = engine.encoder_out(Kp, self._to_nhwc(img.flatten(0, 1)), self.rplan)
-            tok = tok.view(B, T, tok.shape[1], tok.shape[2])
-            all_s, all_seg = [], []
-            for t in range(T):
-                if prev_slots is None:
-                    lat = self.init_latents[0]
-                else:
-                    lat = engine.transformer_predictor(Kp, prev_slots.contiguous(),
-                                                       self.pred_dict['pred_num_layers'],
-                                                       self.pred_dict['pred_num_heads'])
-                tk = tok[:, t].contiguous() if T > 1 else tok[:, 0]
-                s, seg = engine.slot_attention(Kp, tk, lat, self.num_iterations, self.eps)
-                all_s.append(s)
-                all_seg.append(seg)
-                prev_slots = s
-            slots = torch.stack(all_s, 1)
-        with torch.no_grad():
-            seg = torch.stack([x.detach() for x in all_seg], 1)            # [B,T,M,N]
-            if not self.training and (h, w) != (H, W):
-                masks, _ = ops.mask_upsample_argmax(seg.flatten(0, 1).contiguous(), h, w, H, W)
-                masks = masks.view(B, T, self.num_slots, H, W)
-            else:
-                masks = seg.permute(0, 1, 3, 2).reshape(B, T, self.num_slots, h, w)
-        return slots, masks
+        return _encode_clip(self, img, prev_slots)
 
     def calc_train_loss(self, data_dict, out_dict):
         """savi_diffusion.py:252-264: the LDM sees the B*T frames as independent images."""
@@ -622,7 +630,7 @@ class SA(SlotModelBase):
 
     def __init__(self, resolution, slot_dict, enc_dict, dec_dict, loss_dict=None, eps=1e-6,
                  compute_dtype=None, seed=0):
-        sp = spec.sa_model(resolution, slot_dict, enc_dict, dec_dict)
+        sp = self._make_spec(resolution, slot_dict, enc_dict, dec_dict)
         super().__init__(sp, seed=seed)
         self.resolution = tuple(resolution)
         self.eps = eps
@@ -641,6 +649,9 @@ class SA(SlotModelBase):
         self.compute_dtype = compute_dtype or default_compute_dtype()
         self.step_seed = None
         self._graph_cache = {}
+
+    def _make_spec(self, resolution, slot_dict, enc_dict, dec_dict):
+        return spec.sa_model(resolution, slot_dict, enc_dict, dec_dict)
 
     def encode(self, img, init_slots=None):
         """slot_attention.py:318-334 -> slots [B,N,D] fp32."""
@@ -689,8 +700,67 @@ class SA(SlotModelBase):
 
     @torch.no_grad()
     def calc_eval_loss(self, data_dict, out_dict):
-        return self.calc_train_loss(data_dict, {k: (v.detach() if torch.is_tensor(v) else v)
-                                                for k, v in out_dict.items()})
+        """slot_attention.py:377-420 / savi.py:510-557: the reconstruction loss plus, when GT masks
+        are given, ARI / FG-ARI / mIoU / FG-mIoU / mBO of the argmax of the decoder's alpha masks
+        (a clip's T frames are folded into the spatial dims: temporal consistency counts)."""
+        loss_dict = self.calc_train_loss(data_dict, {k: (v.detach() if torch.is_tensor(v) else v)
+                                                     for k, v in out_dict.items()})
+        if 'masks' in data_dict:
+            from . import metrics
+            pm = out_dict['masks']
+            if pm.dim() in (5, 6) and pm.shape[-3] == 1:
+                pm = pm.squeeze(-3)
+            pred = pm.argmax(dim=-3)
+            gt = data_dict['masks'].to(pred.device)
+            if pred.dim() == 4:
+                pred, gt = pred.flatten(1, 2), gt.flatten(1, 2)
+            for k, fn in (('ari', metrics.ARI_metric), ('fari', metrics.fARI_metric),
+                          ('miou', metrics.miou_metric), ('fmiou', metrics.fmiou_metric),
+                          ('mbo', metrics.mbo_metric)):
+                loss_dict[k] = torch.tensor(fn(gt, pred), dtype=torch.float32, device=pred.device)
+        return loss_dict
+
+
+class SAVi(SA):
+    """Video Slot Attention baseline (registry name 'SAVi', video_based/models/savi.py:117-566):
+    the per-frame recurrence of the video models with the plain-SA transposed-conv decoder applied
+    to every frame, trained with the image reconstruction loss."""
+
+    def __init__(self, resolution, clip_len, slot_dict, enc_dict, dec_dict, pred_dict,
+                 loss_dict=None, eps=1e-6, compute_dtype=None, seed=0):
+        assert pred_dict.get('pred_type', 'transformer') == 'transformer' and \
+            not pred_dict.get('pred_rnn', False), 'hot path covers the transformer predictor'
+        self._pred_dict = dict(pred_dict)
+        super().__init__(resolution, slot_dict, enc_dict, dec_dict, loss_dict, eps, compute_dtype,
+                         seed)
+        self.clip_len = clip_len
+        self.pred_dict = dict(pred_dict)
+        self.pred_dropout = 0.1            # nn.TransformerEncoderLayer default (predictor.py:33-38)
+
+    def _make_spec(self, resolution, slot_dict, enc_dict, dec_dict):
+        return spec.savi_model(resolution, slot_dict, enc_dict, dec_dict, self._pred_dict)
+
+    def encode(self, img, prev_slots=None):
+        """savi.py:366-397: img [B,T,3,H,W] -> slots [B,T,N,D]."""
+        return _encode_clip(self, img, prev_slots)[0]
+
+    def forward(self, data_dict):
+        """savi.py:445-475 (clips longer than clip_len are not split: 288 GB of HBM)."""
+        img = data_dict['img']
+        B, T = img.shape[:2]
+        slots = self.encode(img)
+        if self.testing:
+            return {'slots': slots}
+        recon_img, recons, masks, _ = self.decode(slots.flatten(0, 1))
+        out = {'recon_img': recon_img, 'recons': recons, 'masks': masks}
+        out = {k: v.unflatten(0, (B, T)) for k, v in out.items()}
+        out['slots'] = slots
+        return out
+
+    def calc_train_loss(self, data_dict, out_dict):
+        """savi.py:500-508: mse over all frames."""
+        return super().calc_train_loss({'img': data_dict['img'].flatten(0, 1)},
+                                       {'recon_img': out_dict['recon_img'].flatten(0, 1)})
 
 
 def build_model(params):
@@ -699,6 +769,10 @@ def build_model(params):
     if params.model == 'SA':
         return SA(resolution=params.resolution, slot_dict=params.slot_dict, enc_dict=params.enc_dict,
                   dec_dict=params.dec_dict, loss_dict=params.loss_dict)
+    if params.model == 'SAVi':
+        return SAVi(resolution=params.resolution, clip_len=params.input_frames,
+                    slot_dict=params.slot_dict, enc_dict=params.enc_dict, dec_dict=params.dec_dict,
+                    pred_dict=params.pred_dict, loss_dict=params.loss_dict)
     if params.model == 'SAViDiffusion':
         return SAViDiffusion(resolution=params.resolution, clip_len=params.input_frames,
                              slot_dict=params.slot_dict, enc_dict=params.enc_dict,

@@ -381,6 +381,15 @@ def sa_model(resolution, slot_dict, enc_dict, dec_dict):
     return out
 
 
+def savi_model(resolution, slot_dict, enc_dict, dec_dict, pred_dict):
+    """Video Slot Attention baseline (registry name 'SAVi', video_based/models/savi.py:117-170):
+    the plain-SA tensors followed by the slot transition predictor."""
+    pred = transformer_predictor('predictor', pred_dict['pred_slot_size'] if 'pred_slot_size'
+                                 in pred_dict else slot_dict['slot_size'],
+                                 pred_dict['pred_num_layers'], pred_dict['pred_ffn_dim'])
+    return sa_model(resolution, slot_dict, enc_dict, dec_dict) + pred
+
+
 def sa_diffusion(resolution, slot_dict, enc_dict, dec_dict):
     out, _, _ = sa_encoder_side(resolution, slot_dict, enc_dict)
     return out + ldm('dm_decoder', dec_dict)

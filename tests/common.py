@@ -63,6 +63,31 @@ def oracle_weights_sa(cfg):
     return W
 
 
+def savi_cfg():
+    """Restates video_based/configs/savi/savi_movie_params-res128.py (values only)."""
+    d = 192
+    return dict(resolution=(128, 128), clip_len=3,
+                slot_dict=dict(num_slots=15, slot_size=d, slot_mlp_size=2 * d, num_iterations=2),
+                enc_dict=dict(resnet='resnet18', use_layer4=False, enc_out_channels=d,
+                              replace_stride_with_dilation=[False, False, False]),
+                dec_dict=dict(dec_channels=(d, 64, 64, 64, 64), dec_resolution=(8, 8), dec_ks=5,
+                              dec_norm=''),
+                pred_dict=dict(pred_type='transformer', pred_rnn=False, pred_norm_first=True,
+                               pred_num_layers=2, pred_num_heads=4, pred_ffn_dim=4 * d,
+                               pred_sg_every=None),
+                loss_dict=dict(use_img_recon_loss=True))
+
+
+def oracle_weights_savi(cfg):
+    from slotdiffusion_amd.module import build_grid
+    sp = spec.savi_model(cfg['resolution'], cfg['slot_dict'], cfg['enc_dict'], cfg['dec_dict'],
+                         cfg['pred_dict'])
+    W = {}
+    for i, p in enumerate(sp):
+        W[p.name] = build_grid(p.shape[1:3]) if p.init == 'buf:grid' else det_value(p.name, p.shape, i)
+    return W
+
+
 def load_golden(name='sadiff_b2.npz'):
     z = np.load(os.path.join(GOLD, name))
     return {k: (torch.from_numpy(z[k]) if z[k].dtype.kind in 'fiu' else z[k]) for k in z.files}

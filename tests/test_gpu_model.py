@@ -378,3 +378,51 @@ def test_ancestral_sampler_and_x0_target_fp32():
     assert REPORT['x0_dpm_step0_maxerr'] <= 1e-4 and REPORT['x0_dpm_final_frac_gt_1e-3'] <= 0.02
     assert REPORT['x0_train_loss_err'] <= 1e-5 * max(1.0, float(A['x0_train_loss']))
     assert REPORT['x0_grad_norm_max_rel'] <= 2e-3
+
+
+def test_savi_video_baseline_fp32():
+    """Registry model 'SAVi' (per-frame recurrence + spatial-broadcast decoder on every frame):
+    forward, loss, gradients and calc_eval_loss metrics against the reference
+    (tests/golden/savi_b1t3.npz)."""
+    from slotdiffusion_amd.models import SAVi, build_model
+    cfg = C.savi_cfg()
+    G = C.load_golden('savi_b1t3.npz')
+
+    class P:
+        model = 'SAVi'
+        resolution, input_frames = cfg['resolution'], cfg['clip_len']
+        slot_dict, enc_dict, dec_dict = cfg['slot_dict'], cfg['enc_dict'], cfg['dec_dict']
+        pred_dict, loss_dict = cfg['pred_dict'], cfg['loss_dict']
+    m = build_model(P)
+    assert isinstance(m, SAVi) and list(m.state_dict().keys()) == [str(k) for k in G['state_dict_keys']]
+    m.set_compute_dtype(torch.float32)
+    det_fill_(m.state_dict().items(), skip=is_buffer_name)
+    m = m.cuda().train()
+    m.pred_dropout = 0.0
+    img = C.make_inputs(3, seed=11)[0].view(1, 3, 3, 128, 128).cuda()
+    out = m(dict(img=img))
+    loss = m.calc_train_loss(dict(img=img), out)['img_recon_loss']
+    loss.backward()
+    REPORT['savi_slots_maxerr'] = maxerr(out['slots'].detach(), G['slots'])
+    REPORT['savi_recon_maxerr'] = maxerr(out['recon_img'].detach()[:, :, :, 1::2, ::2], G['recon_img_sub2'])
+    REPORT['savi_masks_maxerr'] = maxerr(out['masks'][:, :, :, 0, ::4, 1::4], G['masks_sub4'])
+    am = out['masks'][:, :, :, 0].argmax(2).cpu()
+    REPORT['savi_argmax_agree'] = float((am == G['masks_argmax'].long()).float().mean())
+    REPORT['savi_loss_err'] = abs(float(loss.detach()) - float(G['img_recon_loss']))
+    named = dict(m.named_parameters())
+    names = [str(n) for n in G['grad_norms_names']]
+    mine = torch.tensor([float(named[n].grad.norm()) for n in names])
+    rel = (mine - G['grad_norms']).abs() / (G['grad_norms'].abs() + 1e-7)
+    REPORT['savi_grad_norm_max_rel'] = float(rel.max())
+    m.eval()
+    with torch.no_grad():
+        oe = m(dict(img=img))
+        ev = m.calc_eval_loss(dict(img=img, masks=G['gt_masks'].long().cuda()), oe)
+    REPORT['savi_eval'] = {k: float(v) for k, v in ev.items()}
+    _dump()
+    assert REPORT['savi_slots_maxerr'] <= 5e-5 and REPORT['savi_recon_maxerr'] <= 5e-5
+    assert REPORT['savi_masks_maxerr'] <= 5e-5 and REPORT['savi_argmax_agree'] >= 0.9999
+    assert REPORT['savi_loss_err'] <= 1e-6 and REPORT['savi_grad_norm_max_rel'] <= 5e-3
+    for k in ('ari', 'fari', 'miou', 'fmiou', 'mbo'):
+        assert abs(float(ev[k]) - float(G['eval_' + k])) <= 2e-4, (k, float(ev[k]), float(G['eval_' + k]))
+    assert abs(float(ev['img_recon_loss']) - float(G['eval_img_recon_loss'])) <= 1e-6

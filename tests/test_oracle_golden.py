@@ -276,3 +276,35 @@ def test_eval_metrics_oracle_matches_reference():
     x = torch.rand(2, 3, 16, 16, generator=torch.Generator().manual_seed(3))
     y = (x + 0.05 * torch.randn(2, 3, 16, 16, generator=torch.Generator().manual_seed(4))).clamp(0, 1)
     assert abs(O.psnr_metric(x, y) - float(np.mean([10 * np.log10(1.0 / float(((x[i] - y[i]).double() ** 2).mean())) for i in range(2)]))) < 1e-9
+
+
+def test_savi_oracle_matches_reference():
+    """video SA baseline (registry 'SAVi'): oracle forward / loss / gradients
+    and the eval metrics against the reference run in tests/golden/savi_b1t3.npz; spec key order =
+    the reference state_dict."""
+    cfg = C.savi_cfg()
+    G = C.load_golden('savi_b1t3.npz')
+    sp = spec.savi_model(cfg['resolution'], cfg['slot_dict'], cfg['enc_dict'], cfg['dec_dict'], cfg['pred_dict'])
+    assert [p.name for p in sp] == [str(k) for k in G['state_dict_keys']]
+    W = C.oracle_weights_savi(cfg)
+    names = [str(n) for n in G['grad_norms_names']]
+    for n in names:
+        W[n].requires_grad_(True)
+    img = C.make_inputs(3, seed=11)[0].view(1, 3, 3, 128, 128)
+    loss, recon, masks, slots = O.savi_forward_loss(
+        W, img, spec.resnet18_plan(False), spec.sa_decoder_plan(cfg['resolution'], cfg['dec_dict']),
+        cfg['dec_dict']['dec_resolution'], cfg['slot_dict']['num_iterations'],
+        cfg['pred_dict']['pred_num_layers'], cfg['pred_dict']['pred_num_heads'])
+    loss.backward()
+    assert float((slots - G['slots']).abs().max()) <= 2e-5
+    assert float((recon[:, :, :, 1::2, ::2] - G['recon_img_sub2']).abs().max()) <= 2e-5
+    assert float((masks[:, :, :, 0, ::4, 1::4] - G['masks_sub4']).abs().max()) <= 2e-5
+    am = masks[:, :, :, 0].argmax(2)
+    assert float((am == G['masks_argmax'].long()).float().mean()) >= 0.9999
+    assert abs(float(loss) - float(G['img_recon_loss'])) <= 1e-6
+    gn = torch.stack([W[n].grad.double().norm() for n in names]).float()
+    rel = (gn - G['grad_norms']).abs() / (G['grad_norms'].abs() + 1e-7)
+    assert float(rel.max()) <= 5e-3, float(rel.max())
+    r = O.seg_metrics(G['gt_masks'].long().flatten(1, 2), G['masks_argmax'].long().flatten(1, 2))
+    for k in ('ari', 'fari', 'miou', 'fmiou', 'mbo'):
+        assert abs(float(r[k]) - float(G['eval_' + k])) <= 1e-6, k

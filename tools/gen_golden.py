@@ -384,12 +384,65 @@ def main_video():
         print(k, v.shape, v.dtype)
 
 
+def main_savi():
+    """tests/golden/savi_b1t3.npz: video_based SAVi baseline (registry 'SAVi', MOVi-E config: 15
+    slots, 2 iterations, transformer predictor, spatial-broadcast transposed-conv decoder), B=1 clip
+    of T=3 frames: slots, reconstruction, masks, loss, gradient norms, and calc_eval_loss metrics
+    against synthetic GT masks."""
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    vm = rh.ref_models('video_based')
+    P = rh.ref_params('video_based', 'savi', 'savi_movie_params-res128')
+    model = vm.build_model(P)
+    keys = list(model.state_dict().keys())
+    det_fill_(model.state_dict().items(), skip=is_buffer_name)
+    B, T = 1, 3
+    img = make_inputs(B * T, seed=11)[0].view(B, T, 3, 128, 128)
+    model.train()
+    model.predictor.eval()                # predictor dropout off
+    out = model(dict(img=img))
+    loss = model.calc_train_loss(dict(img=img), out)['img_recon_loss']
+    loss.backward()
+    G = dict(slots=out['slots'].detach(),
+             recon_img_sub2=out['recon_img'].detach()[:, :, :, 1::2, ::2].contiguous(),
+             recon_checksum=torch.stack([out['recon_img'].detach().double().sum(),
+                                         (out['recon_img'].detach().double() ** 2).sum()]),
+             masks_sub4=out['masks'].detach()[:, :, :, 0, ::4, 1::4].contiguous(),
+             masks_argmax=out['masks'].detach()[:, :, :, 0].argmax(2),
+             img_recon_loss=loss.detach())
+    named = dict(model.named_parameters())
+    names = sorted(n for n, p in named.items() if p.grad is not None)
+    G['grad_norms_names'] = np.array(names)
+    G['grad_norms'] = torch.tensor([float(named[n].grad.norm()) for n in names])
+    # eval loss with GT masks: blobs that follow the predicted segmentation loosely
+    gt = (G['masks_argmax'] % 5).clone()
+    gt[:, :, :40] = 0
+    model.eval()
+    import slotdiffusion.video_based.models.savi as sv
+    with torch.no_grad():
+        oe = model(dict(img=img))
+        ev = model.calc_eval_loss(dict(img=img, masks=gt), oe)
+    G['gt_masks'] = gt
+    for k, v in ev.items():
+        G['eval_' + k] = v.detach().float().cpu()
+    arrs = {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else v) for k, v in G.items()}
+    for k in list(arrs):
+        if arrs[k].dtype == np.int64:
+            arrs[k] = arrs[k].astype(np.int16)
+    np.savez_compressed(os.path.join(OUT, 'savi_b1t3.npz'), **arrs, state_dict_keys=np.array(keys))
+    print('wrote savi_b1t3.npz', {k: tuple(v.shape) for k, v in arrs.items()})
+    print({k: float(v) for k, v in ev.items()})
+
+
 if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'ddim':
         main_ddim()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'sa':
         main_sa()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'savi':
+        main_savi()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'metrics':
         main_metrics()
