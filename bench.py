@@ -161,9 +161,16 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     dist = None
+    if rank != 0:
+        # only rank 0 owns stdout (the result line); native banners of the other ranks (RCCL prints
+        # its version block to stdout) must not trail it
+        os.dup2(os.open(os.devnull, os.O_WRONLY), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    if world > 1:
+    # SDMI_BENCH_FORCE_DIST=1: run the multi-GPU code path (RCCL communicator, split backward with
+    # overlapped all-reduce, barriers, MAX-over-ranks timing) with a single rank -- a self-test of
+    # that path on a 1-GPU box
+    if world > 1 or os.environ.get('SDMI_BENCH_FORCE_DIST'):
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29511')
@@ -318,10 +325,20 @@ def main():
                                           sorted(summ.items(), key=lambda kv: -kv[1]['ms'])}
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(cfg, args.mode)
-    if rank == 0:
-        print(json.dumps(out))
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # the JSON line is the LAST thing on stdout: flush whatever native libraries (the RCCL
+        # version banner) still hold in C stdio buffers first
+        import ctypes
+        sys.stdout.flush()
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(out), flush=True)
+        os._exit(0)              # nothing may print after the result line
 
 
 if __name__ == '__main__':

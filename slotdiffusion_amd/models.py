@@ -358,7 +358,7 @@ class SADiffusion(SlotModelBase):
                 self._dpm_loop(sx, sc, prep, False)
             torch.cuda.current_stream().wait_stream(side)
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            with torch.cuda.graph(graph, capture_error_mode='thread_local'):
                 out, _ = self._dpm_loop(sx, sc, prep, False)
             g = self._graph_cache[key] = (graph, sx, sc, out)
         graph, sx, sc, out = g

@@ -92,6 +92,12 @@ class FusedAdam:
         m.weights_updated(shadow_fresh=True)
 
 
+# Captures use the thread-local error mode: with a process group alive, RCCL's watchdog thread
+# polls events (hipEventQuery) at any time, which a capture in the default global mode treats as an
+# illegal call and is invalidated by.
+CAPTURE_MODE = 'thread_local'
+
+
 class GraphedTrainStep:
     """zero-grad -> forward -> loss -> backward -> clip+Adam captured once into HIP graphs and
     replayed per step (about 2.2k kernel launches per replay instead of 2.2k host launches).
@@ -149,16 +155,16 @@ class GraphedTrainStep:
         self.g_fb = torch.cuda.CUDAGraph()
         self.g_enc = None
         if self.overlap:
-            with torch.cuda.graph(self.g_fb):
+            with torch.cuda.graph(self.g_fb, capture_error_mode=CAPTURE_MODE):
                 self.loss = self._fwd_bwd_denoiser()
             self.g_enc = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.g_enc, pool=self.g_fb.pool()):
+            with torch.cuda.graph(self.g_enc, pool=self.g_fb.pool(), capture_error_mode=CAPTURE_MODE):
                 self._bwd_encoder()
         else:
-            with torch.cuda.graph(self.g_fb):
+            with torch.cuda.graph(self.g_fb, capture_error_mode=CAPTURE_MODE):
                 self.loss = self._fwd_bwd()
         self.g_up = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g_up, pool=self.g_fb.pool()):
+        with torch.cuda.graph(self.g_up, pool=self.g_fb.pool(), capture_error_mode=CAPTURE_MODE):
             self._update()
 
     # -- pieces ---------------------------------------------------------------------------
