@@ -7,11 +7,13 @@ Workload = BASELINE.json configs[1]: img_based SlotDiffusion (Slot Attention + L
 CLEVRTex 128x128, 7 slots, bf16 storage / fp32 accumulate, synthetic data, seeded random weights
 (zero-initialised layers replaced by small random values so no work is optimised away).
 
-A "step" (mode=sample, default this round) is one 20-NFE DPM-Solver++ sampling pass over a batch
-of B images' slots: 20 x (UNet eps evaluation + x0 conversion + VQ quantise) + solver updates,
-inputs resident in HBM.  value = B * 20 * K / seconds  [image-denoise-steps/s], whole job.
-For N > 1 each rank samples its own B images (data parallel, no collective on this path: weak
-scaling); time is max over ranks between barriers.
+A "step" (mode=train, the default) is one optimiser step on a batch of B images: zero-grad, slot
+encoder forward, frozen VQ-VAE encode, q-sample, UNet forward, MSE, full backward, gradient
+all-reduce (N > 1), global-norm clip, Adam.  value = N * B * K / seconds [images/s], whole job.
+mode=sample: one 20-NFE DPM-Solver++ sampling pass over B images' slots (20 x (UNet eps + x0
+conversion + VQ quantise) + solver updates); value = N * B * 20 * K / seconds.  Inputs are resident
+in HBM; for N > 1 every rank works on its own B images (weak scaling), time is the max over ranks
+between barriers.
 Extra JSON objects: roofline (MFMA, dominant kernel sdmi_igemm, measured live with HIP events on
 the launch stream) and cpu_baseline (the CPU oracle on this box's host cores, bounded sample).
 """
@@ -183,6 +185,9 @@ def main():
     B = args.batch
     img = synth_batch(B, rank, dev)
     from slotdiffusion_amd import ops, parallel
+    if dist is not None:                      # every rank starts from rank 0's parameters
+        parallel.broadcast_parameters(model.arena())
+        model.weights_updated()
     from slotdiffusion_amd.optim import FusedAdam
     nfe = 20
 
