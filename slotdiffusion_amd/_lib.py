@@ -84,6 +84,10 @@ def lib():
             raise SdmiError(
                 f'{LIBPATH} not found: the HIP extension is required (no fallback path). '
                 'Build it with `python -m slotdiffusion_amd.csrc.build`.')
+        # torch first: libsdmi.so must bind to the libamdhip64 torch ships and initialises (loaded
+        # the other way round the system runtime under /opt/rocm is picked up and kernel launches
+        # fail with "no ROCm-capable device")
+        import torch  # noqa: F401
         L = ctypes.CDLL(LIBPATH)
         for fname, sname in FUNCS.items():
             fn = getattr(L, fname)          # AttributeError if a declared symbol is missing
