@@ -395,6 +395,7 @@ int sdmi_contingency(const SdmiContingencyArgs* a, void* stream);
  * (the caller adds the nchunk partials of an image in index order). */
 typedef struct {
   const float* x; const float* y; double* partial; int B; long long n; int nchunk;
+  int mode;                      /* 0: (x-y)^2   1: |x-y| (L1 reconstruction loss, vqvae/loss.py:27) */
 } SdmiSqErrArgs;
 int sdmi_sqerr_rows(const SdmiSqErrArgs* a, void* stream);
 

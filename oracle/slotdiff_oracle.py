@@ -275,6 +275,10 @@ def unet_forward(W, plan, x, t, ctx, prefix='dm_decoder.model.diffusion_model', 
 # ---------------------------------------------------------------------------
 # a6/a14/a15: VQ-VAE encode / quantize / decode
 # ---------------------------------------------------------------------------
+def _pj(prefix, name):
+    return f'{prefix}.{name}' if prefix else name
+
+
 def _vae_res(W, name, x):
     """vqvae/modules.py:95-110 (GroupNorm eps 1e-6, swish, dropout 0)."""
     h = _conv(W, f'{name}.conv1', _swish(_gn(W, f'{name}.norm1', x, 1e-6)))
@@ -299,7 +303,7 @@ def _vae_attn(W, name, x):
 
 def vae_encode(W, img, ed, prefix='dm_decoder.vae.vqvae', scale_factor=1.0):
     """VQVAE.py:94-99, 183-184; modules.py:239-261; asymmetric (0,1,0,1) pad before stride-2."""
-    e = f'{prefix}.encoder'
+    e = _pj(prefix, 'encoder')
     mult, nrb = tuple(ed['ch_mult']), ed['num_res_blocks']
     h = _conv(W, f'{e}.conv_in', img)
     for lvl in range(len(mult)):
@@ -312,12 +316,12 @@ def vae_encode(W, img, ed, prefix='dm_decoder.vae.vqvae', scale_factor=1.0):
     h = _vae_attn(W, f'{e}.mid.attn_1', h)
     h = _vae_res(W, f'{e}.mid.block_2', h)
     h = _conv(W, f'{e}.conv_out', _swish(_gn(W, f'{e}.norm_out', h, 1e-6)))
-    return _conv(W, f'{prefix}.quant_conv', h, padding=0) / scale_factor
+    return _conv(W, _pj(prefix, 'quant_conv'), h, padding=0) / scale_factor
 
 
 def vq_nearest(W, z, prefix='dm_decoder.vae.vqvae'):
     """quantize.py:85-94: expanded-square distance, argmin (first minimum) -> int64 [B,h,w]."""
-    emb = W[f'{prefix}.quantize.embedding.weight']
+    emb = W[_pj(prefix, 'quantize.embedding.weight')]
     zf = z.permute(0, 2, 3, 1).contiguous().view(-1, emb.shape[1])
     d = torch.sum(zf ** 2, dim=1, keepdim=True) + torch.sum(emb ** 2, dim=1) - \
         2 * torch.einsum('bd,dn->bn', zf, emb.t())
@@ -329,7 +333,7 @@ def vq_quantize(W, z, prefix='dm_decoder.vae.vqvae', scale_factor=1.0):
     """VQVAE.py:192-194: z*s -> nearest code -> /s.  Returns (z_q [B,C,h,w], idx)."""
     zs = z * scale_factor
     idx = vq_nearest(W, zs, prefix)
-    emb = W[f'{prefix}.quantize.embedding.weight']
+    emb = W[_pj(prefix, 'quantize.embedding.weight')]
     zq = emb[idx].permute(0, 3, 1, 2).contiguous()
     zq = zs + (zq - zs)          # straight-through form (quantize.py:107) -- keeps its rounding
     return zq / scale_factor, idx
@@ -337,9 +341,9 @@ def vq_quantize(W, z, prefix='dm_decoder.vae.vqvae', scale_factor=1.0):
 
 def vae_decode_quant(W, zq, ed, prefix='dm_decoder.vae.vqvae'):
     """VQVAE.py:110-114; modules.py:338-362 (input already quantized)."""
-    d = f'{prefix}.decoder'
+    d = _pj(prefix, 'decoder')
     mult, nrb = tuple(ed['ch_mult']), ed['num_res_blocks']
-    h = _conv(W, f'{prefix}.post_quant_conv', zq, padding=0)
+    h = _conv(W, _pj(prefix, 'post_quant_conv'), zq, padding=0)
     h = _conv(W, f'{d}.conv_in', h)
     h = _vae_res(W, f'{d}.mid.block_1', h)
     h = _vae_attn(W, f'{d}.mid.attn_1', h)
@@ -357,6 +361,21 @@ def vae_decode(W, z, ed, prefix='dm_decoder.vae.vqvae', scale_factor=1.0):
     """VQVAEWrapper.decode(quantize=True) (VQVAE.py:186-190)."""
     zq, _ = vq_quantize(W, z * scale_factor, prefix, 1.0)
     return vae_decode_quant(W, zq, ed, prefix)
+
+
+def vqvae_forward(W, img, ed, prefix='', beta=0.25, percept_loss_w=0.):
+    """Stand-alone VQVAE.forward + calc_eval_loss (VQVAE.py:116-146, quantize.py:80-123,
+    loss.py:19-46 without the LPIPS term): -> dict(recon, token_id, quant_loss, recon_loss,
+    recon_mse)."""
+    z = vae_encode(W, img, ed, prefix)
+    zq, idx = vq_quantize(W, z, prefix)
+    emb = W[_pj(prefix, 'quantize.embedding.weight')]
+    zq_raw = emb[idx].permute(0, 3, 1, 2)
+    quant_loss = torch.mean((zq_raw - z) ** 2) + beta * torch.mean((zq_raw - z) ** 2)
+    recon = vae_decode_quant(W, zq, ed, prefix)
+    recon_loss = torch.abs(img - recon).mean() if percept_loss_w > 0 else F.mse_loss(img, recon)
+    return dict(recon=recon, token_id=idx, quant_loss=quant_loss, recon_loss=recon_loss,
+                recon_mse=F.mse_loss(recon, img))
 
 
 # ---------------------------------------------------------------------------

@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void sqerr_rows_kernel(SdmiSqErrArgs p) {
   double s = 0.0;
   for (long long i = lo + threadIdx.x; i < hi; i += 256) {
     const double d = (double)x[i] - (double)y[i];
-    s += d * d;
+    s += p.mode ? fabs(d) : d * d;
   }
   red[threadIdx.x] = s;
   __syncthreads();

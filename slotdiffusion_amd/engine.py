@@ -232,9 +232,13 @@ def _vae_attn(K, n, x):
     return out.view(B, H, W, C)
 
 
+def _pj(prefix, name):
+    return f'{prefix}.{name}' if prefix else name
+
+
 def vae_encode(K, img_nhwc, ed, prefix='dm_decoder.vae.vqvae', scale_factor=1.0):
     """img [B,H,W,Cpad] -> x0 [B,h,w,4] fp32 (3 latent channels + zero pad)."""
-    e = prefix + '.encoder'
+    e = _pj(prefix, 'encoder')
     mult, nrb = tuple(ed['ch_mult']), ed['num_res_blocks']
     h = K.conv(img_nhwc, e + '.conv_in.weight', e + '.conv_in.bias')
     for lvl in range(len(mult)):
@@ -249,7 +253,7 @@ def vae_encode(K, img_nhwc, ed, prefix='dm_decoder.vae.vqvae', scale_factor=1.0)
     h = K.gn(h, e + '.norm_out', eps=1e-6, act='silu')
     vec = ops.vec_of(h.dtype)
     h = K.conv(h, e + '.conv_out.weight', e + '.conv_out.bias', ldc=vec)
-    z = K.conv(h, prefix + '.quant_conv.weight', prefix + '.quant_conv.bias', kh=1, kw=1,
+    z = K.conv(h, _pj(prefix, 'quant_conv.weight'), _pj(prefix, 'quant_conv.bias'), kh=1, kw=1,
                pad=(0, 0, 0, 0), out_dtype=torch.float32, ldc=4)
     if scale_factor != 1.0:
         z = ops.lincomb(1.0, z, div=scale_factor)
@@ -259,16 +263,16 @@ def vae_encode(K, img_nhwc, ed, prefix='dm_decoder.vae.vqvae', scale_factor=1.0)
 def vae_decode(K, z, ed, prefix='dm_decoder.vae.vqvae', scale_factor=1.0, quantize=True):
     """z [B,h,w,4] fp32 latent -> image [B,H,W,4] fp32 (VQVAEWrapper.decode, VQVAE.py:186-190)."""
     wb = K.wb
-    d = prefix + '.decoder'
+    d = _pj(prefix, 'decoder')
     mult, nrb = tuple(ed['ch_mult']), ed['num_res_blocks']
     if quantize:
-        _, z = ops.vq_nearest(z, wb.f(prefix + '.quantize.embedding.weight'), scale=scale_factor,
+        _, z = ops.vq_nearest(z, wb.f(_pj(prefix, 'quantize.embedding.weight')), scale=scale_factor,
                               want_idx=False)
         if scale_factor != 1.0:      # vq_nearest returns zq / scale; decode wants zq
             z = ops.lincomb(scale_factor, z)
     vec = ops.vec_of(wb.dtype)
     zc = ops.cast2d(z, wb.dtype, cols=3, ldd=vec)
-    h = K.conv(zc, prefix + '.post_quant_conv.weight', prefix + '.post_quant_conv.bias', kh=1, kw=1,
+    h = K.conv(zc, _pj(prefix, 'post_quant_conv.weight'), _pj(prefix, 'post_quant_conv.bias'), kh=1, kw=1,
                pad=(0, 0, 0, 0), ldc=vec)
     h = K.conv(h, d + '.conv_in.weight', d + '.conv_in.bias')
     h = _vae_res(K, d + '.mid.block_1', h)

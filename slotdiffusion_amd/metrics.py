@@ -130,7 +130,7 @@ def mbo_metric(gt_mask, pred_mask):
     return np.nanmean(mbos)
 
 
-def _sqerr(x, y):
+def _sqerr(x, y, mode=0):
     _need_gpu(x)
     _need_gpu(y)
     assert x.shape == y.shape
@@ -141,7 +141,7 @@ def _sqerr(x, y):
     nchunk = max(1, min(64, n // 4096))
     part = torch.empty((B, nchunk), dtype=torch.float64, device=x.device)
     _lib.call('sdmi_sqerr_rows', torch.cuda.current_stream().cuda_stream, x=xf.data_ptr(),
-              y=yf.data_ptr(), partial=part.data_ptr(), B=B, n=n, nchunk=nchunk)
+              y=yf.data_ptr(), partial=part.data_ptr(), B=B, n=n, nchunk=nchunk, mode=mode)
     return part.cpu().sum(1).numpy(), n
 
 

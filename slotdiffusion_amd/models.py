@@ -763,12 +763,118 @@ class SAVi(SA):
                                        {'recon_img': out_dict['recon_img'].flatten(0, 1)})
 
 
+class VQVAE(SlotModelBase):
+    """Stand-alone VQ-VAE (registry name 'VQVAE', video_based/models/vqvae/VQVAE.py:40-172):
+    inference / evaluation of the LDM's first stage -- encode, quantize, decode, the quantizer and
+    reconstruction losses of calc_eval_loss.  Stage-1 TRAINING (its backward pass, SURVEY 8(f) row
+    1) is not built yet: calc_train_loss refuses to run under autograd.  The LPIPS term needs the
+    `lpips` VGG network (absent): percept_loss is reported as 0."""
+
+    def __init__(self, enc_dec_dict, vq_dict, use_loss=True, compute_dtype=None, seed=0):
+        super().__init__(spec.vqvae_model(enc_dec_dict, vq_dict), seed=seed)
+        self.ed, self.vq_dict = dict(enc_dec_dict), dict(vq_dict)
+        self.resolution = enc_dec_dict['resolution']
+        self.embed_dim, self.n_embed = vq_dict['embed_dim'], vq_dict['n_embed']
+        self.percept_loss_w = float(vq_dict.get('percept_loss_w', 0.))
+        self.beta = 0.25
+        self.vq_key = 'quantize.embedding.weight'
+        self.compute_dtype = compute_dtype or default_compute_dtype()
+        self._graph_cache = {}
+
+    @property
+    def device(self):
+        return self.quant_conv.weight.device
+
+    @property
+    def dtype(self):
+        return self.quant_conv.weight.dtype
+
+    def _flat(self, x):
+        return (x.flatten(0, 1), x.shape[:2]) if x.dim() == 5 else (x, None)      # temporal_wrapper
+
+    @torch.no_grad()
+    def encode(self, x):
+        """VQVAE.py:94-99: pre-VQ features [B,embed_dim,h,w] (the x0 of the LDM)."""
+        xf, bt = self._flat(x)
+        z = ops.nhwc_to_nchw(engine.vae_encode(self.K(), self._to_nhwc(xf), self.ed, prefix=''), 3)
+        return z.unflatten(0, tuple(bt)) if bt is not None else z
+
+    def _quantize_nhwc(self, z):
+        idx, zq = ops.vq_nearest(z, self.bank().f(self.vq_key))
+        return zq, idx
+
+    @torch.no_grad()
+    def encode_quantize(self, x):
+        """VQVAE.py:86-92 -> quant [B,3,h,w], quant_loss (scalar), token ids [B,h,w]."""
+        xf, bt = self._flat(x)
+        z = engine.vae_encode(self.K(), self._to_nhwc(xf), self.ed, prefix='')
+        zq, idx = self._quantize_nhwc(z)
+        # legacy loss mean((zq.detach()-z)^2) + beta*mean((zq-z.detach())^2) = (1+beta)*mse(zq, z)
+        # over the embed_dim real channels of the 4-channel NHWC pair
+        ql = (ops.mse(zq, z) * (4.0 / 3.0) * (1.0 + self.beta)).reshape(())
+        q = ops.nhwc_to_nchw(zq, 3)
+        if bt is not None:
+            q, idx = q.unflatten(0, tuple(bt)), idx.unflatten(0, tuple(bt))
+        return q, ql, idx
+
+    @torch.no_grad()
+    def decode(self, quant):
+        """VQVAE.py:110-114: already quantized features -> image."""
+        qf, bt = self._flat(quant)
+        img = engine.vae_decode(self.K(), ops.nchw_to_nhwc(qf.float(), torch.float32, 4), self.ed,
+                                prefix='', quantize=False)
+        out = ops.nhwc_to_nchw(img, 3)
+        return out.unflatten(0, tuple(bt)) if bt is not None else out
+
+    @torch.no_grad()
+    def quantize_decode(self, h):
+        """VQVAE.py:102-107."""
+        hf, bt = self._flat(h)
+        img = engine.vae_decode(self.K(), ops.nchw_to_nhwc(hf.float(), torch.float32, 4), self.ed,
+                                prefix='', quantize=True)
+        out = ops.nhwc_to_nchw(img, 3)
+        return out.unflatten(0, tuple(bt)) if bt is not None else out
+
+    def forward(self, data_dict):
+        if torch.is_grad_enabled() and self.training:
+            raise NotImplementedError('VQ-VAE stage-1 training (backward through the auto-encoder) '
+                                      'is not built yet: run under torch.no_grad() / eval()')
+        quant, quant_loss, token_id = self.encode_quantize(data_dict['img'])
+        return {'recon': self.decode(quant), 'token_id': token_id, 'quant_loss': quant_loss}
+
+    @torch.no_grad()
+    def calc_train_loss(self, data_dict, out_dict):
+        """VQVAE.calc_train_loss + VQLPIPSLoss.forward (VQVAE.py:128-137, loss.py:19-46): L1 when
+        the perceptual term is configured, else MSE."""
+        from . import metrics
+        img, recon = data_dict['img'].float(), out_dict['recon'].float()
+        x = img.reshape(1, -1).to(recon.device)
+        y = recon.reshape(1, -1)
+        se, n = metrics._sqerr(x, y, mode=1 if self.percept_loss_w > 0 else 0)
+        dev = recon.device
+        return {'quant_loss': out_dict['quant_loss'],
+                'recon_loss': torch.tensor(float(se[0]) / n, dtype=torch.float32, device=dev),
+                'percept_loss': torch.zeros((), dtype=torch.float32, device=dev)}
+
+    @torch.no_grad()
+    def calc_eval_loss(self, data_dict, out_dict):
+        """VQVAE.py:139-146."""
+        from . import metrics
+        loss_dict = self.calc_train_loss(data_dict, out_dict)
+        img, recon = data_dict['img'].float(), out_dict['recon'].float()
+        se, n = metrics._sqerr(img.reshape(1, -1).to(recon.device), recon.reshape(1, -1), mode=0)
+        loss_dict['recon_mse'] = torch.tensor(float(se[0]) / n, dtype=torch.float32, device=recon.device)
+        return loss_dict
+
+
 def build_model(params):
     """Registry (img_based/models/__init__.py:12-39, video_based/models/__init__.py:12-33) for the
     hot-path models."""
     if params.model == 'SA':
         return SA(resolution=params.resolution, slot_dict=params.slot_dict, enc_dict=params.enc_dict,
                   dec_dict=params.dec_dict, loss_dict=params.loss_dict)
+    if params.model == 'VQVAE':
+        return VQVAE(enc_dec_dict=params.enc_dec_dict, vq_dict=params.vq_dict)
     if params.model == 'SAVi':
         return SAVi(resolution=params.resolution, clip_len=params.input_frames,
                     slot_dict=params.slot_dict, enc_dict=params.enc_dict, dec_dict=params.dec_dict,

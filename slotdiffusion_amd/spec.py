@@ -305,6 +305,12 @@ def vqvae(prefix, ed, vq):
     return [p._replace(trainable=False) for p in out]
 
 
+def vqvae_model(ed, vq):
+    """Stand-alone VQ-VAE (registry name 'VQVAE', video_based/models/vqvae/VQVAE.py:40-84): the
+    same tensors as the LDM's frozen copy, without a prefix and trainable."""
+    return [p._replace(name=p.name[2:], trainable=True) for p in vqvae('X', ed, vq)]
+
+
 DDPM_BUFFERS = ('betas', 'alphas_bar', 'alphas_bar_prev', 'sqrt_alphas_bar',
                 'sqrt_one_minus_alphas_bar', 'log_one_minus_alphas_bar',
                 'sqrt_recip_alphas_bar', 'sqrt_recipm1_alphas_bar', 'posterior_variance',

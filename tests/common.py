@@ -88,6 +88,12 @@ def oracle_weights_savi(cfg):
     return W
 
 
+def oracle_weights_vqvae(cfg):
+    va = cfg['dec_dict']['vae_dict']
+    sp = spec.vqvae_model(va['enc_dec_dict'], va['vq_dict'])
+    return {p.name: det_value(p.name, p.shape, i) for i, p in enumerate(sp)}
+
+
 def load_golden(name='sadiff_b2.npz'):
     z = np.load(os.path.join(GOLD, name))
     return {k: (torch.from_numpy(z[k]) if z[k].dtype.kind in 'fiu' else z[k]) for k in z.files}

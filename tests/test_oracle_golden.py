@@ -308,3 +308,23 @@ def test_savi_oracle_matches_reference():
     r = O.seg_metrics(G['gt_masks'].long().flatten(1, 2), G['masks_argmax'].long().flatten(1, 2))
     for k in ('ari', 'fari', 'miou', 'fmiou', 'mbo'):
         assert abs(float(r[k]) - float(G['eval_' + k])) <= 1e-6, k
+
+
+def test_vqvae_standalone_oracle_matches_reference():
+    """Registry model 'VQVAE' in eval (VQVAE.forward + calc_eval_loss): the oracle against the
+    reference run in tests/golden/vqvae_b2.npz; spec key order = the reference state_dict."""
+    cfg = C.clevrtex_cfg()
+    va = cfg['dec_dict']['vae_dict']
+    V = C.load_golden('vqvae_b2.npz')
+    sp = spec.vqvae_model(va['enc_dec_dict'], va['vq_dict'])
+    assert [p.name for p in sp] == [str(k) for k in V['state_dict_keys']]
+    W = C.oracle_weights_vqvae(cfg)
+    img = C.make_inputs(2)[0]
+    with torch.no_grad():
+        r = O.vqvae_forward(W, img, va['enc_dec_dict'])
+        r1 = O.vqvae_forward(W, img, va['enc_dec_dict'], percept_loss_w=1.0)
+    assert torch.equal(r['token_id'], V['token_id'].long())
+    assert float((r['recon'][:, :, 1::2, ::2] - V['recon_sub2']).abs().max()) <= 2e-5
+    for k in ('quant_loss', 'recon_loss', 'recon_mse'):
+        assert abs(float(r[k]) - float(V[k])) <= 1e-6 * max(1.0, abs(float(V[k]))), k
+    assert abs(float(r1['recon_loss']) - float(V['recon_l1'])) <= 1e-6

@@ -434,12 +434,44 @@ def main_savi():
     print({k: float(v) for k, v in ev.items()})
 
 
+def main_vqvae():
+    """tests/golden/vqvae_b2.npz: the stand-alone VQ-VAE (registry 'VQVAE', CLEVRTex config) in
+    eval: recon, token ids, quantizer / reconstruction losses of calc_eval_loss at B=2, with the
+    perceptual weight set to 0 (lpips is absent) -- plus the L1 value the configured loss would
+    take (loss.py:27, restated)."""
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    im = rh.ref_models('img_based')
+    P = rh.ref_params('img_based', 'sa_ldm', 'vqvae_clevrtex_params-res128')
+    P.vq_dict['percept_loss_w'] = 0.
+    model = im.build_model(P)
+    keys = [k for k in model.state_dict().keys() if not k.startswith('loss.')]
+    det_fill_([(k, v) for k, v in model.state_dict().items() if not k.startswith('loss.')], skip=is_buffer_name)
+    model.eval()
+    img = make_inputs(2)[0]
+    with torch.no_grad():
+        out = model(dict(img=img))
+        ev = model.calc_eval_loss(dict(img=img), out)
+    G = dict(recon_sub2=out['recon'][:, :, 1::2, ::2].contiguous(),
+             recon_checksum=torch.stack([out['recon'].double().sum(), (out['recon'].double() ** 2).sum()]),
+             token_id=out['token_id'].to(torch.int16), quant_loss=out['quant_loss'],
+             recon_loss=ev['recon_loss'], recon_mse=ev['recon_mse'], percept_loss=ev['percept_loss'],
+             recon_l1=torch.abs(img - out['recon']).mean(),
+             pre_vq=model.encode(img))
+    np.savez_compressed(os.path.join(OUT, 'vqvae_b2.npz'), **{k: v.detach().numpy() for k, v in G.items()},
+                        state_dict_keys=np.array(keys))
+    print('wrote vqvae_b2.npz', {k: (tuple(v.shape), float(v.flatten()[0])) for k, v in G.items()})
+
+
 if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'ddim':
         main_ddim()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'sa':
         main_sa()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'vqvae':
+        main_vqvae()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'savi':
         main_savi()
