@@ -283,6 +283,7 @@ int sdmi_mask_upsample_argmax(const SdmiMaskUpArgs* a, void* stream);
 typedef struct {
   const void* pred; const float* target; float* out; void* dpred; float* partial;
   int dtype; long long n; int nblk; float gscale;
+  int l1;        /* 1: mean |pred - target| (VQ-VAE reconstruction loss, vqvae/loss.py:27), dpred = sign * gscale / n */
 } SdmiMseArgs;
 int sdmi_mse(const SdmiMseArgs* a, void* stream);
 
@@ -398,6 +399,31 @@ typedef struct {
   int mode;                      /* 0: (x-y)^2   1: |x-y| (L1 reconstruction loss, vqvae/loss.py:27) */
 } SdmiSqErrArgs;
 int sdmi_sqerr_rows(const SdmiSqErrArgs* a, void* stream);
+
+
+/* ------------------------------------------------------------------------------------------
+ * VQ-VAE stage-1 training helpers (vqvae/modules.py:113-154, quantize.py:98-107).
+ * The AttnBlock is one head of width C over h*w tokens: its backward runs as batched GEMMs
+ * (sdmi_igemm) around these two kernels.
+ * ------------------------------------------------------------------------------------------ */
+/* batched 2-D transpose dst[z][c][r] = src[z][r][c] (LDS tile transpose, both sides coalesced) */
+typedef struct {
+  const void* src; void* dst; int dtype; int Z, R, C;
+  long long lds, ldd, ss, sd;                 /* row pitches and batch strides, in elements */
+} SdmiTransposeArgs;
+int sdmi_transpose2d(const SdmiTransposeArgs* a, void* stream);
+/* softmax backward in place on dp: ds[r][j] = scale * p[r][j] * (dp[r][j] - sum_k dp[r][k] p[r][k]) */
+typedef struct { const void* p; void* dp; int dtype; int rows, cols, ld; float scale; } SdmiSoftmaxBwdArgs;
+int sdmi_softmax_rows_bwd(const SdmiSoftmaxBwdArgs* a, void* stream);
+/* Straight-through quantizer backward (quantize.py:98-107, legacy loss):
+ *   dz[r][d]          = dzq[r][d] + g * 2/n * (z - zq)            (g = d loss / d quant_loss, device scalar)
+ *   dcode[idx[r]][d] += g * 2*beta/n * (zq - z)                    (fp32 atomics into the codebook gradient)
+ * z / zq / dzq / dz are [R][ldz] fp32 rows using the first `dim` columns; n = R * dim. */
+typedef struct {
+  const float* z; const float* zq; const float* dzq; float* dz; float* dcode;
+  const long long* idx; const float* g; long long R; int dim, ldz; float beta;
+} SdmiVqBwdArgs;
+int sdmi_vq_bwd(const SdmiVqBwdArgs* a, void* stream);
 
 #ifdef __cplusplus
 }

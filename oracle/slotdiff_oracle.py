@@ -335,7 +335,7 @@ def vq_quantize(W, z, prefix='dm_decoder.vae.vqvae', scale_factor=1.0):
     idx = vq_nearest(W, zs, prefix)
     emb = W[_pj(prefix, 'quantize.embedding.weight')]
     zq = emb[idx].permute(0, 3, 1, 2).contiguous()
-    zq = zs + (zq - zs)          # straight-through form (quantize.py:107) -- keeps its rounding
+    zq = zs + (zq - zs).detach()  # straight-through form (quantize.py:107) -- keeps its rounding
     return zq / scale_factor, idx
 
 
@@ -371,7 +371,7 @@ def vqvae_forward(W, img, ed, prefix='', beta=0.25, percept_loss_w=0.):
     zq, idx = vq_quantize(W, z, prefix)
     emb = W[_pj(prefix, 'quantize.embedding.weight')]
     zq_raw = emb[idx].permute(0, 3, 1, 2)
-    quant_loss = torch.mean((zq_raw - z) ** 2) + beta * torch.mean((zq_raw - z) ** 2)
+    quant_loss = torch.mean((zq_raw.detach() - z) ** 2) + beta * torch.mean((zq_raw - z.detach()) ** 2)
     recon = vae_decode_quant(W, zq, ed, prefix)
     recon_loss = torch.abs(img - recon).mean() if percept_loss_w > 0 else F.mse_loss(img, recon)
     return dict(recon=recon, token_id=idx, quant_loss=quant_loss, recon_loss=recon_loss,

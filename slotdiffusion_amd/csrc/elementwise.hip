@@ -277,11 +277,16 @@ template <typename T>
 __global__ __launch_bounds__(256) void mse_kernel(SdmiMseArgs p) {
   __shared__ double red[4];
   double acc = 0.0;
-  const float gs = 2.f * p.gscale / (float)p.n;
+  const float gs = (p.l1 ? 1.f : 2.f) * p.gscale / (float)p.n;
   GRID_STRIDE(i, p.n) {
     const float d = Elem<T>::ld((const T*)p.pred + i) - p.target[i];
-    acc += (double)d * (double)d;
-    if (p.dpred) Elem<T>::st((T*)p.dpred + i, d * gs);
+    if (p.l1) {
+      acc += (double)fabsf(d);
+      if (p.dpred) Elem<T>::st((T*)p.dpred + i, d > 0.f ? gs : (d < 0.f ? -gs : 0.f));
+    } else {
+      acc += (double)d * (double)d;
+      if (p.dpred) Elem<T>::st((T*)p.dpred + i, d * gs);
+    }
   }
   acc = wave_sum_d(acc);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;

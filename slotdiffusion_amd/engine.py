@@ -217,6 +217,13 @@ def _vae_attn(K, n, x):
     wb = K.wb
     B, H, W, C = x.shape
     S = H * W
+    if getattr(K, 'training', False):        # autograd form (VQ-VAE stage-1 training)
+        h = K.gn(x, n + '.norm', eps=1e-6).view(B, S, C)
+        qkv = K.linear(h, (n + '.q.weight', n + '.k.weight', n + '.v.weight'),
+                       (n + '.q.bias', n + '.k.bias', n + '.v.bias'))
+        o = K.vae_attn_core(qkv)
+        out = K.linear(o, n + '.proj_out.weight', n + '.proj_out.bias', residual=x.view(B, S, C))
+        return out.view(B, H, W, C)
     h = K.gn(x, n + '.norm', eps=1e-6).view(B, S, C)
     qk = K.linear(h, (n + '.q.weight', n + '.k.weight'), (n + '.q.bias', n + '.k.bias'))
     # V^T [B,C,S] = Wv [C,Cin] @ h[b]^T : batched GEMM with the weight as the row operand
@@ -271,7 +278,7 @@ def vae_decode(K, z, ed, prefix='dm_decoder.vae.vqvae', scale_factor=1.0, quanti
         if scale_factor != 1.0:      # vq_nearest returns zq / scale; decode wants zq
             z = ops.lincomb(scale_factor, z)
     vec = ops.vec_of(wb.dtype)
-    zc = ops.cast2d(z, wb.dtype, cols=3, ldd=vec)
+    zc = K.cast_pad(z, wb.dtype, 3, vec)
     h = K.conv(zc, _pj(prefix, 'post_quant_conv.weight'), _pj(prefix, 'post_quant_conv.bias'), kh=1, kw=1,
                pad=(0, 0, 0, 0), ldc=vec)
     h = K.conv(h, d + '.conv_in.weight', d + '.conv_in.bias')

@@ -306,6 +306,10 @@ class Kern:
     def cast(self, x, dtype):
         return x if x.dtype == dtype else ops.act(x, None, dtype)
 
+    def cast_pad(self, x, dtype, cols, ldd):
+        """First `cols` channels of x [..., ld] -> dtype [..., ldd] (zero padded)."""
+        return ops.cast2d(x, dtype, cols=cols, ldd=ldd)
+
     def dropout(self, x, site='unet'):
         return x
 
@@ -628,6 +632,17 @@ class CastFn(torch.autograd.Function):
         return ops.act(dy.contiguous(), None, ctx.src), None
 
 
+class CastPadFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, dtype, cols, ldd):
+        ctx.src, ctx.ld, ctx.cols = x.dtype, x.shape[-1], cols
+        return ops.cast2d(x, dtype, cols=cols, ldd=ldd)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.cast2d(dy.contiguous(), ctx.src, cols=ctx.cols, ldd=ctx.ld), None, None, None
+
+
 class AddPosFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, pos):
@@ -737,17 +752,80 @@ class AddFn(torch.autograd.Function):
         return dy, dy
 
 
+class VaeAttnFn(torch.autograd.Function):
+    """Core of the VQ-VAE AttnBlock (vqvae/modules.py:130-150): one head of width C over S tokens,
+    qkv [B,S,3C] -> o [B,S,C], as batched GEMMs (S = q k^T, P = softmax(S / sqrt(C)), o = P v) with
+    batched transposes where a product contracts over a leading dimension."""
+
+    @staticmethod
+    def forward(ctx, qkv):
+        B, S, C3 = qkv.shape
+        C = C3 // 3
+        q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
+        sc = torch.empty((B, S, S), dtype=qkv.dtype, device=qkv.device)
+        ops.bmm_nt(q, k, sc)
+        ops.softmax_rows_(sc, scale=float(C) ** -0.5)
+        o = torch.empty((B, S, C), dtype=qkv.dtype, device=qkv.device)
+        ops.bmm_nt(sc, ops.transpose2d(v), o)
+        ctx.save_for_backward(qkv, sc)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        qkv, p = ctx.saved_tensors
+        B, S, C3 = qkv.shape
+        C = C3 // 3
+        q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
+        do = do.contiguous()
+        dqkv = torch.empty_like(qkv)
+        dp = torch.empty_like(p)
+        ops.bmm_nt(do, v, dp)                                   # dP = dO v^T
+        ops.bmm_nt(ops.transpose2d(p), ops.transpose2d(do), dqkv[..., 2 * C:])     # dv = P^T dO
+        ops.softmax_rows_bwd_(p, dp, scale=float(C) ** -0.5)    # dp <- dS
+        ops.bmm_nt(dp, ops.transpose2d(k), dqkv[..., :C])       # dq = dS k
+        ops.bmm_nt(ops.transpose2d(dp), ops.transpose2d(q), dqkv[..., C:2 * C])    # dk = dS^T q
+        return dqkv
+
+
+class VqFn(torch.autograd.Function):
+    """VectorQuantizer2.forward (quantize.py:80-123): nearest code with the straight-through
+    estimator and the legacy commitment loss.  z [..,4] fp32 NHWC (3 channels used) ->
+    (zq, quant_loss, idx); the codebook gradient is accumulated straight into `dcode`."""
+
+    @staticmethod
+    def forward(ctx, z, anchor, codebook, dcode, beta):
+        idx, zq = ops.vq_nearest(z, codebook)
+        dim = codebook.shape[1]
+        ql = (ops.mse(zq, z) * (z.shape[-1] / float(dim)) * (1.0 + beta)).reshape(())
+        ctx.save_for_backward(z, zq, idx)
+        ctx.dcode, ctx.beta, ctx.dim = dcode, beta, dim
+        ctx.mark_non_differentiable(idx)
+        return zq, ql, idx
+
+    @staticmethod
+    def backward(ctx, dzq, dql, _didx):
+        z, zq, idx = ctx.saved_tensors
+        dz = torch.empty_like(z)
+        g = dql.reshape(1).float().contiguous() if dql is not None else \
+            torch.zeros(1, dtype=torch.float32, device=z.device)
+        dzq = dzq.contiguous() if dzq is not None else None
+        call('sdmi_vq_bwd', _st(), z=_p(z), zq=_p(zq), dzq=_p(dzq), dz=_p(dz), dcode=_p(ctx.dcode),
+             idx=_p(idx), g=_p(g), R=z.numel() // z.shape[-1], dim=ctx.dim, ldz=z.shape[-1],
+             beta=ctx.beta)
+        return dz, None, None, None, None
+
+
 class MseFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, pred, target, scale):
-        val, dpred = ops.mse(pred, target, want_grad=True, gscale=scale)
+    def forward(ctx, pred, target, scale, l1=False):
+        val, dpred = ops.mse(pred, target, want_grad=True, gscale=scale, l1=l1)
         ctx.save_for_backward(dpred)
         return (val * scale).reshape(())
 
     @staticmethod
     def backward(ctx, g):
         (dpred,) = ctx.saved_tensors
-        return dpred * g, None, None
+        return dpred * g, None, None, None
 
 
 class DropoutFn(torch.autograd.Function):
@@ -969,6 +1047,9 @@ class KernGrad(Kern):
     def attn_cross(self, q, kv, heads):
         return AttnFn.apply(q, kv, heads)
 
+    def vae_attn_core(self, qkv):
+        return VaeAttnFn.apply(qkv)
+
     def geglu(self, h):
         return GegluFn.apply(h)
 
@@ -980,6 +1061,9 @@ class KernGrad(Kern):
 
     def cast(self, x, dtype):
         return x if x.dtype == dtype else CastFn.apply(x, dtype)
+
+    def cast_pad(self, x, dtype, cols, ldd):
+        return CastPadFn.apply(x, dtype, cols, ldd)
 
     def slot_attention(self, kv, init, name, iters, eps):
         """Unfused training form of SlotAttentionWMask.forward (sa_diffusion.py:40-68)."""

@@ -34,7 +34,8 @@ class SyntheticDataModule:
 
     def train_loader(self, epoch=0):
         B = self.params.train_batch_size
-        H, W = self.params.resolution
+        res = self.params.resolution
+        H, W = (res, res) if isinstance(res, int) else res
         g = torch.Generator().manual_seed(self.seed + 1000 * epoch + self.rank)
         for _ in range(self.steps_per_epoch):
             shape = (B, 3, H, W) if self.frames is None else (B, self.frames, 3, H, W)
@@ -118,7 +119,9 @@ class Method:
         return self
 
     def _loss_names(self):
-        from .models import SA
+        from .models import SA, VQVAE
+        if isinstance(self.model, VQVAE):        # three weighted terms: eager steps (vqvae/loss.py)
+            return ['quant_loss', 'recon_loss', 'percept_loss']
         return ['img_recon_loss'] if isinstance(self.model, SA) else ['denoise_loss']
 
     def save(self, path):

@@ -765,10 +765,10 @@ class SAVi(SA):
 
 class VQVAE(SlotModelBase):
     """Stand-alone VQ-VAE (registry name 'VQVAE', video_based/models/vqvae/VQVAE.py:40-172):
-    inference / evaluation of the LDM's first stage -- encode, quantize, decode, the quantizer and
-    reconstruction losses of calc_eval_loss.  Stage-1 TRAINING (its backward pass, SURVEY 8(f) row
-    1) is not built yet: calc_train_loss refuses to run under autograd.  The LPIPS term needs the
-    `lpips` VGG network (absent): percept_loss is reported as 0."""
+    the LDM's first stage -- encode, quantize, decode, calc_eval_loss, and stage-1 training
+    (SURVEY 8(f) row 1): backward through the decoder, the straight-through quantizer with its
+    commitment loss, and the encoder, incl. the single-head AttnBlocks.  The LPIPS term needs the
+    `lpips` VGG network (absent): percept_loss is 0 and contributes no gradient."""
 
     def __init__(self, enc_dec_dict, vq_dict, use_loss=True, compute_dtype=None, seed=0):
         super().__init__(spec.vqvae_model(enc_dec_dict, vq_dict), seed=seed)
@@ -836,16 +836,41 @@ class VQVAE(SlotModelBase):
         return out.unflatten(0, tuple(bt)) if bt is not None else out
 
     def forward(self, data_dict):
-        if torch.is_grad_enabled() and self.training:
-            raise NotImplementedError('VQ-VAE stage-1 training (backward through the auto-encoder) '
-                                      'is not built yet: run under torch.no_grad() / eval()')
-        quant, quant_loss, token_id = self.encode_quantize(data_dict['img'])
-        return {'recon': self.decode(quant), 'token_id': token_id, 'quant_loss': quant_loss}
+        """VQVAE.py:116-126.  In training mode with autograd on, the HIP backward is recorded
+        (stage-1 training): encoder -> straight-through quantizer -> decoder."""
+        img = data_dict['img']
+        if not (torch.is_grad_enabled() and self.training):
+            quant, quant_loss, token_id = self.encode_quantize(img)
+            return {'recon': self.decode(quant), 'token_id': token_id, 'quant_loss': quant_loss}
+        xf, bt = self._flat(img)
+        Kp = self.KG()
+        z = engine.vae_encode(Kp, self._to_nhwc(xf), self.ed, prefix='')
+        off, cnt = self._offsets[self.vq_key]
+        dcode = self.grad_arena()[off:off + cnt].view(self.n_embed, self.embed_dim)
+        zq, quant_loss, idx = kern.VqFn.apply(z, self.bank().anchor, self.bank().f(self.vq_key), dcode,
+                                              self.beta)
+        recon = engine.vae_decode(Kp, zq, self.ed, prefix='', quantize=False)
+        self._last_recon_nhwc = recon
+        rec = kern.NhwcToNchwFn.apply(recon, 3)
+        if bt is not None:
+            rec, idx = rec.unflatten(0, tuple(bt)), idx.unflatten(0, tuple(bt))
+        return {'recon': rec, 'token_id': idx, 'quant_loss': quant_loss}
 
-    @torch.no_grad()
     def calc_train_loss(self, data_dict, out_dict):
         """VQVAE.calc_train_loss + VQLPIPSLoss.forward (VQVAE.py:128-137, loss.py:19-46): L1 when
-        the perceptual term is configured, else MSE."""
+        the perceptual term is configured, else MSE; percept_loss = 0 (no LPIPS network here)."""
+        l1 = self.percept_loss_w > 0
+        if out_dict['recon'].requires_grad:
+            img = self._flat(data_dict['img'])[0]
+            tgt = ops.nchw_to_nhwc(img.float(), torch.float32, 4)
+            pred, self._last_recon_nhwc = self._last_recon_nhwc, None
+            rl = kern.MseFn.apply(pred, tgt, 4.0 / 3.0, l1)
+            return {'quant_loss': out_dict['quant_loss'], 'recon_loss': rl,
+                    'percept_loss': torch.zeros((), dtype=torch.float32, device=pred.device)}
+        return self._eval_losses(data_dict, out_dict)
+
+    @torch.no_grad()
+    def _eval_losses(self, data_dict, out_dict):
         from . import metrics
         img, recon = data_dict['img'].float(), out_dict['recon'].float()
         x = img.reshape(1, -1).to(recon.device)

@@ -306,12 +306,33 @@ def mask_upsample_argmax(seg, h, w, H, W, want_up=True):
     return up, idx
 
 
-def mse(pred, target, want_grad=False, gscale=1.0):
+def transpose2d(x, out=None):
+    """[Z,R,C] (row pitch = stride(1), unit column stride) -> contiguous [Z,C,R]."""
+    _need_gpu(x)
+    Z, R, C = x.shape
+    assert x.stride(2) == 1
+    if out is None:
+        out = torch.empty((Z, C, R), dtype=x.dtype, device=x.device)
+    call('sdmi_transpose2d', _stream(), src=_p(x), dst=_p(out), dtype=_dt(x), Z=Z, R=R, C=C,
+         lds=x.stride(1), ldd=out.stride(1), ss=x.stride(0), sd=out.stride(0))
+    return out
+
+
+def softmax_rows_bwd_(p, dp, scale=1.0):
+    """dp <- scale * p * (dp - rowsum(dp * p)) in place (p = softmax output, rows of the last dim)."""
+    _need_gpu(p, dp)
+    cols = p.shape[-1]
+    call('sdmi_softmax_rows_bwd', _stream(), p=_p(p), dp=_p(dp), dtype=_dt(p), rows=p.numel() // cols,
+         cols=cols, ld=cols, scale=scale)
+    return dp
+
+
+def mse(pred, target, want_grad=False, gscale=1.0, l1=False):
     n = pred.numel()
     nblk = max(1, min(1024, (n + 2047) // 2048))
     partial = torch.empty((nblk,), dtype=torch.float32, device=pred.device)
     out = torch.empty((1,), dtype=torch.float32, device=pred.device)
     dpred = torch.empty_like(pred) if want_grad else None
     call('sdmi_mse', _stream(), pred=_p(pred), target=_p(target), out=_p(out), dpred=_p(dpred),
-         partial=_p(partial), dtype=_dt(pred), n=n, nblk=nblk, gscale=gscale)
+         partial=_p(partial), dtype=_dt(pred), n=n, nblk=nblk, gscale=gscale, l1=int(l1))
     return (out, dpred) if want_grad else out

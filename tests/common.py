@@ -163,6 +163,12 @@ class Params:
 
 
 def make_params(model='SADiffusion', batch=2):
+    if model == 'VQVAE':           # img_based/configs/sa_ldm/vqvae_clevrtex_params-res128.py (values)
+        va = clevrtex_cfg()['dec_dict']['vae_dict']
+        return Params(model=model, optimizer='Adam', weight_decay=0.0, max_epochs=1, lr=1e-3,
+                      clip_grad=-1, warmup_steps_pct=0.05, train_batch_size=batch, dataset='clevrtex',
+                      san_check_val_step=0, resolution=(128, 128), enc_dec_dict=va['enc_dec_dict'],
+                      vq_dict=va['vq_dict'], recon_loss_w=1., quant_loss_w=1., percept_loss_w=1.)
     cfg = sa_plain_cfg() if model == 'SA' else clevrtex_cfg()
     extra = dict(lr=4e-4, clip_grad=-1, warmup_steps_pct=0.025, img_recon_loss_w=1.) if model == 'SA' \
         else dict(lr=1e-4, dec_lr=2e-4, clip_grad=1.0, warmup_steps_pct=0.05, denoise_loss_w=1.)

@@ -461,6 +461,56 @@ def test_vqvae_standalone_eval_fp32():
     assert maxerr(m.quantize_decode(m.encode(img)), out['recon'].cpu()) <= 1e-6
     clip = img.view(1, 2, 3, 128, 128)             # temporal wrapper
     assert m.encode(clip).shape == (1, 2, 3, 32, 32)
-    m.train()
-    with pytest.raises(NotImplementedError):
-        m(dict(img=img))
+
+
+def test_vqvae_stage1_training_gradients():
+    """VQ-VAE stage-1 training step on the GPU (decoder, straight-through
+    quantizer + commitment loss, encoder, single-head AttnBlocks): parameter gradients against the
+    reference's (tests/golden/vqvae_b2.npz) in fp32 (MSE and L1 reconstruction loss); bf16 close;
+    one fused Adam step runs."""
+    from slotdiffusion_amd.models import VQVAE
+    from slotdiffusion_amd.optim import FusedAdam
+    cfg = C.clevrtex_cfg()
+    va = cfg['dec_dict']['vae_dict']
+    V = C.load_golden('vqvae_b2.npz')
+    names = [str(n) for n in V['grad_norms_names']]
+    img = C.make_inputs(2)[0].cuda()
+
+    def grads(dtype, w):
+        m = VQVAE(va['enc_dec_dict'], dict(va['vq_dict'], percept_loss_w=w), compute_dtype=dtype)
+        det_fill_(m.state_dict().items(), skip=is_buffer_name)
+        m = m.cuda().train()
+        m.grad_arena().zero_()
+        out = m(dict(img=img))
+        ld = m.calc_train_loss(dict(img=img), out)
+        (ld['recon_loss'] + ld['quant_loss']).backward()
+        named = dict(m.named_parameters())
+        return m, ld, named, torch.tensor([float(named[n].grad.double().norm()) for n in names])
+
+    m, ld, named, gn = grads(torch.float32, 0.)
+    # (attn_1.k.bias has a mathematically zero gradient -- softmax is shift invariant per query --
+    #  so the comparison carries an absolute floor of 1e-6 of the largest norm)
+    floor = 1e-6 * float(V['grad_norms'].max())
+    rel = (gn - V['grad_norms']).abs() / (V['grad_norms'].abs() + floor / 5e-3)
+    REPORT['vqvae_train_grad_norm_max_rel'] = float(rel.max())
+    REPORT['vqvae_train_loss_err'] = abs(float(ld['recon_loss'].detach()) - float(V['train_recon_loss']))
+    worst = 0.0
+    for n in ('quantize.embedding.weight', 'encoder.conv_in.weight', 'decoder.mid.attn_1.k.weight',
+              'encoder.mid.attn_1.proj_out.bias', 'decoder.conv_out.bias'):
+        ref = V['grad/' + n]
+        worst = max(worst, float((named[n].grad.cpu() - ref).abs().max()) / (float(ref.abs().max()) + 1e-12))
+    REPORT['vqvae_train_grad_max_rel_elem'] = worst
+    opt = FusedAdam(m, lr=1e-4, dec_lr=1e-4, clip_grad=1.0)
+    before = m.arena().clone()
+    opt.step()
+    assert float((m.arena() - before).abs().max()) > 0 and bool(torch.isfinite(m.arena()).all())
+    _, _, _, gn1 = grads(torch.float32, 1.)
+    rel1 = (gn1 - V['grad_norms_l1']).abs() / (V['grad_norms_l1'].abs() + floor / 5e-3)
+    REPORT['vqvae_train_l1_grad_norm_max_rel'] = float(rel1.max())
+    _, _, _, gnb = grads(torch.bfloat16, 0.)
+    relb = (gnb - V['grad_norms']).abs() / (V['grad_norms'].abs() + floor / 5e-3)
+    REPORT['vqvae_train_bf16_grad_norm_median_rel'] = float(relb.median())
+    _dump()
+    assert REPORT['vqvae_train_loss_err'] <= 1e-6 and REPORT['vqvae_train_grad_norm_max_rel'] <= 5e-3
+    assert worst <= 5e-3 and REPORT['vqvae_train_l1_grad_norm_max_rel'] <= 5e-3
+    assert REPORT['vqvae_train_bf16_grad_norm_median_rel'] <= 0.1

@@ -490,7 +490,7 @@ def test_ema_hook_matches_reference_formula():
     assert torch.equal(m.arena(), before)
 
 
-@pytest.mark.parametrize('name', ['SADiffusion', 'SA'])
+@pytest.mark.parametrize('name', ['SADiffusion', 'SA', 'VQVAE'])
 def test_method_fit_through_the_registry(name):
     """build_model -> build_dataset -> build_method -> fit(): the plugin path of scripts/train.py,
     3 optimiser steps on synthetic data (graph replay on), losses finite, weights move."""
@@ -507,6 +507,69 @@ def test_method_fit_through_the_registry(name):
                                use_ddp=False, use_fp16=False)
     method.fit(resume_from='', san_check_val_step=0, max_steps=5)
     losses = [float(l) for l in method.history]
-    assert len(losses) == 3 and all(math.isfinite(l) for l in losses), losses   # 2 warm-up + 3 replays
+    n_logged = 5 if name == 'VQVAE' else 3        # (graphed models: 2 warm-up steps + 3 replays)
+    assert len(losses) == n_logged and all(math.isfinite(l) for l in losses), losses
+    if name == 'VQVAE':
+        assert losses[-1] < losses[0]             # stage-1 training reduces recon + commitment loss
     assert method.optimizer.step_count == 5
     assert float((model.arena() - before).abs().max()) > 0
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_vae_train_kernels(dtype):
+    """VQ-VAE stage-1 backward helpers: batched transpose, softmax backward, the single-head
+    AttnBlock core (VaeAttnFn) against torch autograd, the straight-through quantizer backward and
+    the L1 loss."""
+    from slotdiffusion_amd import ops
+    from slotdiffusion_amd.kern import MseFn, VaeAttnFn, VqFn
+    g = torch.Generator().manual_seed(5)
+    q = lambda t: t.to(dtype).float()
+    # transpose (ragged sizes, strided source)
+    x = q(torch.randn(3, 70, 200, generator=g))
+    xd = x.to(dtype).cuda()
+    assert torch.equal(ops.transpose2d(xd[..., 8:136]).cpu().float(), x[..., 8:136].transpose(1, 2))
+    # attention core
+    B, S, C = 2, 192, 64
+    qkv = q(torch.randn(B, S, 3 * C, generator=g)).requires_grad_(True)
+    do = q(torch.randn(B, S, C, generator=g))
+    qq, kk, vv = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
+    p = torch.softmax(qq @ kk.transpose(1, 2) * C ** -0.5, -1)
+    (p @ vv).backward(do)
+    qd = qkv.detach().to(dtype).cuda().requires_grad_(True)
+    o = VaeAttnFn.apply(qd)
+    o.backward(do.to(dtype).cuda())
+    tol = 2e-5 if dtype == torch.float32 else 3e-2
+    rel = lambda a, b: float((a.float().cpu() - b).norm() / b.norm())
+    assert rel(o.detach(), (p @ vv).detach()) <= tol
+    assert rel(qd.grad, qkv.grad) <= tol, rel(qd.grad, qkv.grad)
+    if dtype == torch.bfloat16:
+        return
+    # straight-through quantizer: gradients of  w1 * sum(zq * a) + w2 * quant_loss
+    R, n_codes, beta = 300, 64, 0.25
+    code = torch.randn(n_codes, 3, generator=g).requires_grad_(True)
+    z = F.pad(torch.randn(R, 3, generator=g), (0, 1)).requires_grad_(True)
+    a = torch.randn(R, 4, generator=g)
+    d = (z[:, :3] ** 2).sum(1, keepdim=True) + (code ** 2).sum(1) - 2 * z[:, :3] @ code.t()
+    idx = d.argmin(1)
+    zq = code[idx]
+    ql = ((zq.detach() - z[:, :3]) ** 2).mean() + beta * ((zq - z[:, :3].detach()) ** 2).mean()
+    st = z[:, :3] + (zq - z[:, :3]).detach()
+    ((st * a[:, :3]).sum() * 0.7 + 1.3 * ql).backward()
+    zd = z.detach().cuda().requires_grad_(True)
+    dcode = torch.zeros(n_codes, 3, device='cuda')
+    anchor = torch.zeros(1, device='cuda', requires_grad=True)
+    zq_d, ql_d, idx_d = VqFn.apply(zd, anchor, code.detach().cuda(), dcode, beta)
+    assert torch.equal(idx_d.cpu(), idx) and abs(float(ql_d) - float(ql)) <= 1e-6
+    ((zq_d * a.cuda()).sum() * 0.7 + 1.3 * ql_d).backward()
+    assert float((zd.grad.cpu() - z.grad).abs().max()) <= 1e-6
+    assert float((dcode.cpu() - code.grad).abs().max()) <= 1e-6
+    # L1 loss
+    pr = torch.randn(2, 8, 8, 4, generator=g)
+    tg = torch.randn(2, 8, 8, 4, generator=g)
+    pd = pr.cuda().requires_grad_(True)
+    l = MseFn.apply(pd, tg.cuda(), 1.0, True)
+    l.backward()
+    pr.requires_grad_(True)
+    lr = (pr - tg).abs().mean()
+    lr.backward()
+    assert abs(float(l) - float(lr)) <= 1e-6 and float((pd.grad.cpu() - pr.grad).abs().max()) <= 1e-7

@@ -328,3 +328,28 @@ def test_vqvae_standalone_oracle_matches_reference():
     for k in ('quant_loss', 'recon_loss', 'recon_mse'):
         assert abs(float(r[k]) - float(V[k])) <= 1e-6 * max(1.0, abs(float(V[k]))), k
     assert abs(float(r1['recon_loss']) - float(V['recon_l1'])) <= 1e-6
+
+
+def test_vqvae_training_gradients_oracle_matches_reference():
+    """gradients of recon_loss + quant_loss through decoder, straight-through
+    quantizer and encoder of the oracle against the reference's (tests/golden/vqvae_b2.npz), for
+    the MSE and the L1 reconstruction loss."""
+    cfg = C.clevrtex_cfg()
+    va = cfg['dec_dict']['vae_dict']
+    V = C.load_golden('vqvae_b2.npz')
+    names = [str(n) for n in V['grad_norms_names']]
+    img = C.make_inputs(2)[0]
+    for key, w in (('grad_norms', 0.), ('grad_norms_l1', 1.)):
+        W = C.oracle_weights_vqvae(cfg)
+        for n in names:
+            W[n].requires_grad_(True)
+        r = O.vqvae_forward(W, img, va['enc_dec_dict'], percept_loss_w=w)
+        (r['recon_loss'] + r['quant_loss']).backward()
+        gn = torch.stack([W[n].grad.double().norm() for n in names]).float()
+        rel = (gn - V[key]).abs() / (V[key].abs() + 1e-9)
+        assert float(rel.max()) <= 5e-3, (key, float(rel.max()))
+        if w == 0.:
+            assert abs(float(r['recon_loss']) - float(V['train_recon_loss'])) <= 1e-6
+            for n in ('quantize.embedding.weight', 'decoder.mid.attn_1.k.weight'):
+                ref = V['grad/' + n]
+                assert float((W[n].grad - ref).abs().max()) <= 2e-3 * float(ref.abs().max()) + 1e-9, n

@@ -458,7 +458,28 @@ def main_vqvae():
              recon_loss=ev['recon_loss'], recon_mse=ev['recon_mse'], percept_loss=ev['percept_loss'],
              recon_l1=torch.abs(img - out['recon']).mean(),
              pre_vq=model.encode(img))
+    # stage-1 training step: recon (MSE) + quantizer loss, parameter gradients
+    model.train()
+    for p in model.parameters():
+        p.grad = None
+    out = model(dict(img=img))
+    ld = model.calc_train_loss(dict(img=img), out)
+    (ld['recon_loss'] + ld['quant_loss']).backward()
+    named = {n: p for n, p in model.named_parameters() if not n.startswith('loss.')}
+    names = sorted(n for n, p in named.items() if p.grad is not None)
+    G['train_recon_loss'], G['train_quant_loss'] = ld['recon_loss'].detach(), ld['quant_loss'].detach()
+    G['grad_norms'] = torch.tensor([float(named[n].grad.double().norm()) for n in names])
+    for n in ('quantize.embedding.weight', 'encoder.conv_in.weight', 'decoder.mid.attn_1.k.weight',
+              'encoder.mid.attn_1.proj_out.bias', 'decoder.conv_out.bias'):
+        G['grad/' + n] = named[n].grad.detach().clone()
+    # the L1 form (percept weight > 0 in the shipped config) at the same point: gradient norms only
+    for p in model.parameters():
+        p.grad = None
+    out = model(dict(img=img))
+    (torch.abs(img - out['recon']).mean() + out['quant_loss']).backward()
+    G['grad_norms_l1'] = torch.tensor([float(named[n].grad.double().norm()) for n in names])
     np.savez_compressed(os.path.join(OUT, 'vqvae_b2.npz'), **{k: v.detach().numpy() for k, v in G.items()},
+                        grad_norms_names=np.array(names),
                         state_dict_keys=np.array(keys))
     print('wrote vqvae_b2.npz', {k: (tuple(v.shape), float(v.flatten()[0])) for k, v in G.items()})
 
