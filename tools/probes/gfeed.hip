@@ -2,6 +2,11 @@
 // WG, 2 WGs per CU, two register sets of loads in flight (like igemm's loaders), ds_write_b128.
 //   PAT 0: 1 KB contiguous per wave-instr
 //   PAT 1: 8 rows x 128 B per wave-instr, row pitch `pitch` bytes, K-tile kt reads 128-B chunk (kt % (pitch/128)) of the rows
+// Measured on MI355X (round 1), 512 workgroups x 400 K tiles of 32 KB, 2 workgroups per CU:
+//   L2-resident footprint (16 MB): 24-27 TB/s = 94-106 GB/s/CU for contiguous 1 KB pieces and for
+//   128-byte rows at pitch 256 ... 8192 B alike (no channel camping);
+//   HBM streaming (1 GB footprint, contiguous): 6.5 TB/s = 25.5 GB/s/CU;
+//   many workgroups on the SAME rows (weights-like sharing, pitch 4608-9344): 12-18 TB/s.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;

@@ -1,6 +1,17 @@
 // Probe: cost of filling LDS with global_load_lds_dwordx4 (LDS-DMA) vs global_load + ds_write_b128
 // while 4 other waves of the workgroup read fragments with ds_read_b128 and issue MFMAs.
 // build: hipcc --offload-arch=gfx950 -O3 tools/probes/ldsdma.hip -o /tmp/ldsdma
+// Measured on MI355X (round 1), ns per K-tile iteration of a CU, 2 workgroups per CU (1 per CU):
+//   readers only (16 ds_read_b128 + 16 MFMA per wave) 530 (340)    MFMA only 433 (227)    LDS reads only 301
+//   fill only: LDS-DMA 426 (387), load + ds_write_b128 560 (460)
+//   fill + readers, VALU address arithmetic in the loaders: DMA 880-920 (590), ds_write 880-905 (515)
+//   LDS-DMA + MFMA only: 800 (526) -- the two ADD UP; LDS-DMA + LDS reads only: 440-527 (overlap)
+//   sleep-loader + MFMA 380, DMA + sleep-reader 396 (1 per CU): the barrier structure overlaps fine
+//   LDS-DMA with SCALAR-only loaders (buffer_load ... lds, fixed voffset, soffset walk):
+//       + MFMA only 547 (394), + full readers 545-555 (396)  -> MFMA bound
+//   register-staged buffer loads (scalar addressing) + ds_write_b128 + readers: 749
+//   s_setprio(3) in the loaders: no change.  Shader clock 2.2-2.4 GHz in every mode.
+// => VALU instructions of a loader wave serialise with the MFMAs of the wave next to it on the SIMD.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>

@@ -1,5 +1,11 @@
 // Probe: LDS write throughput per CU by instruction width / address pattern (all waves of a CU
 // hammer the LDS; shader cycles per wave-instruction from s_memtime).
+// build: hipcc --offload-arch=gfx950 -O3 tools/probes/ldswrite.hip -o ldswrite.bin
+// Measured on MI355X (round 1), ticks per wave-instruction as seen by ONE wave / aggregate B/tick/CU:
+//   4 waves: b128 52.0 / 78.8   b64 24-26.5 / 77-85   b32 16.0 / 63.9      (any address pattern)
+//   8 waves: b128 52.0 / 157.5  b64 27.0 / 151.6      b32 20.0 / 102.3
+// -> a wave's ds_write_b128 issues every 52 cycles regardless of contention: the per-CU rate
+//    scales with the number of writing waves (no LDS write-bandwidth wall at 8 waves).
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
