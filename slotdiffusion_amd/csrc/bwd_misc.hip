@@ -188,10 +188,17 @@ __global__ __launch_bounds__(256) void sqsum_kernel(SdmiSqSumArgs p) {
   const long long i0 = (long long)blockIdx.x * per;
   long long i1 = i0 + per;
   if (i1 > p.n) i1 = p.n;
-  for (long long i = i0 + threadIdx.x; i < i1; i += 256) {
-    const float g = p.g[i];
-    acc += (double)g * (double)g;
+  // 16-byte loads over the aligned middle of the slice, scalar head / tail
+  long long a0 = (i0 + 3) & ~3ll, a1 = i1 & ~3ll;
+  if (a0 > a1) a0 = a1 = i0;
+  for (long long i = i0 + threadIdx.x; i < a0; i += 256) acc += (double)p.g[i] * (double)p.g[i];
+  const f32x4* __restrict__ g4 = reinterpret_cast<const f32x4*>(p.g);
+  for (long long i = (a0 >> 2) + threadIdx.x; i < (a1 >> 2); i += 256) {
+    const f32x4 g = g4[i];
+    acc += ((double)g[0] * (double)g[0] + (double)g[1] * (double)g[1]) +
+           ((double)g[2] * (double)g[2] + (double)g[3] * (double)g[3]);
   }
+  for (long long i = a1 + threadIdx.x; i < i1; i += 256) acc += (double)p.g[i] * (double)p.g[i];
   acc = wave_sum_d(acc);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
   __syncthreads();
