@@ -68,6 +68,12 @@ typedef struct {
   int zins;             /* >1: input is read through virtual zero-insertion upsampling by zins
                            (data-gradient of a stride-`zins` conv: flipped weights, stride=1) */
   long long sa, sw, sc, sr;
+  /* Sub-sampled output placement (osy > 0): output row m = (b, oy, ox) is stored at pixel
+   * (oy*osy + ooy, ox*osx + oox) of a [B][oH][oW][ldc] tensor instead of row m.  The data gradient
+   * of a stride-s convolution is computed as s*s plain stride-1 convolutions over dy -- one per
+   * input-pixel parity, each with the filter taps of that parity -- written interleaved this
+   * way (no multiply-adds on inserted zeros, unlike `zins`).  No residual / split-K in this mode. */
+  int oH, oW, osy, osx, ooy, oox;
 } SdmiGemmArgs;
 int sdmi_igemm(const SdmiGemmArgs* a, void* stream);
 

@@ -61,6 +61,33 @@ __device__ __forceinline__ void wave_epilogue(const SdmiGemmArgs& p, f32x16 (&ac
       }
     return;
   }
+  if (p.osy > 0) {
+    // sub-sampled output placement (data gradient of a strided conv, one parity per launch):
+    // plain alpha * acc (+ bias), row m = (b, oy, ox) -> pixel (oy*osy + ooy, ox*osx + oox)
+    const int HoWo_ = p.Ho * p.Wo;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int n = nw0 + j * 32 + col_l;
+        const float bn = (p.bias && n < p.N) ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = mw0 + i * 32 + (r & 3) + 8 * (r >> 2) + row_l;
+          if (m < p.M && n < p.N) {
+            const int b = hw_shift >= 0 ? (m >> hw_shift) : (m / HoWo_);
+            const int rem = m - b * HoWo_;
+            const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+            const long long o = (((long long)b * p.oH + oy * p.osy + p.ooy) * p.oW + ox * p.osx + p.oox) *
+                                    p.ldc + n;
+            const float v = acc[i][j][r] * p.alpha + bn;
+            if (p.out_dtype == SDMI_BF16) ((bf16_t*)p.out)[o] = f32_to_bf16(v);
+            else ((float*)p.out)[o] = v;
+          }
+        }
+      }
+    return;
+  }
   char* outp = (char*)p.out;
   const char* resp = (const char*)p.residual;
   const long long zc = (long long)zb * p.sc, zr = (long long)zb * p.sr;
@@ -821,7 +848,7 @@ int dispatch(const SdmiGemmArgs& p, hipStream_t st) {
   const bool wide = kbytes >= 512;
   int split_k = 1;
   if (p.split_k > 0) split_k = p.split_k;       // caller override
-  else if (!big && batch == 1 && p.workspace) {
+  else if (!big && batch == 1 && p.workspace && p.osy == 0) {
     const long long t64 = (long long)((p.M + 63) / 64) * ((p.N + 63) / 64);
     const int nk = (kbytes + (wide ? 127 : 63)) / (wide ? 128 : 64);
     while (t64 * split_k < 384 && split_k * 2 <= nk / 4 && split_k < 16) split_k *= 2;
@@ -883,6 +910,10 @@ extern "C" int sdmi_igemm(const SdmiGemmArgs* a, void* stream) {
   SDMI_REQUIRE(!(a->batch > 1) || (a->KH == 1 && a->KW == 1), "batched mode is 1x1 only");
   SDMI_REQUIRE(!(a->batch > 1 && a->split_k > 1), "batched split-K unsupported");
   SDMI_REQUIRE(a->sa % vec == 0 && a->sw % vec == 0, "batch strides must keep 16-byte alignment");
+  SDMI_REQUIRE(a->osy == 0 || (a->osy > 0 && a->osx > 0 && a->oH > 0 && a->oW > 0 && !a->residual &&
+                               a->split_k <= 1 && !(a->batch > 1)),
+               "sub-sampled output: needs osy/osx/oH/oW > 0, no residual / split-K / batch");
+  SDMI_REQUIRE(a->osy == 0 || (!a->rowvec && !a->act && !a->bias_m), "sub-sampled output: plain epilogue only");
   hipStream_t st = (hipStream_t)stream;
   return a->dtype == SDMI_BF16 ? dispatch<bf16_t>(*a, st) : dispatch<float>(*a, st);
 }

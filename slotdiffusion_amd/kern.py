@@ -418,7 +418,9 @@ class GemmFn(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             wd = wb.wd(wnames, dt, kh, kw, Cin)
-            if is_conv:
+            if is_conv and stride > 1 and not ups:
+                dx = GemmFn._dgrad_strided(dy, wd, B, H, W_, Ho, Wo, Cin, ldy, kh, kw, stride, pad, dt)
+            elif is_conv:
                 Hs, Ws = (2 * H, 2 * W_) if ups else (H, W_)
                 out = torch.empty((B, Hs, Ws, Cin), dtype=dt, device=x.device)
                 call('sdmi_igemm', _st(), a=_p(dy), w=_p(wd), out=_p(out), dtype=_DT[dt],
@@ -445,6 +447,37 @@ class GemmFn(torch.autograd.Function):
             assert dres is not None
         _dbg(f'gemm {wnames if isinstance(wnames, str) else wnames[0]}', dy=dy, dx=dx, drv=drv)
         return dx, drv, dres, None, None, None, None, None, None, None
+
+    @staticmethod
+    def _dgrad_strided(dy, wd, B, H, W_, Ho, Wo, Cin, ldy, kh, kw, s, pad, dt):
+        """Data gradient of a stride-s convolution as s*s plain stride-1 convolutions over dy, one
+        per input-pixel parity (py, px): only the filter taps kh = (py + pad_t) mod s (+ s, ...)
+        reach that parity, so each launch uses its sub-filter (a strided slice of the flipped
+        operand) and writes its pixels interleaved into dx (igemm's sub-sampled output placement).
+        No multiply-adds on inserted zeros: 1/s^2 of the work of the zero-insertion form."""
+        w4 = wd.view(Cin, kh, kw, ldy)
+        full = all(len(range((p + pd) % s, k, s)) > 0
+                   for k, pd in ((kh, pad[0]), (kw, pad[2])) for p in range(s))
+        dx = (torch.empty if full else torch.zeros)((B, H, W_, Cin), dtype=dt, device=dy.device)
+        for py in range(s):
+            ay = (py + pad[0]) % s
+            nky = len(range(ay, kh, s))
+            hs = len(range(py, H, s))
+            for px in range(s):
+                ax = (px + pad[2]) % s
+                nkx = len(range(ax, kw, s))
+                ws_ = len(range(px, W_, s))
+                if nky == 0 or nkx == 0 or hs == 0 or ws_ == 0:
+                    continue
+                sub = w4[:, (kh - 1 - ay) % s::s, (kw - 1 - ax) % s::s, :].contiguous()
+                K = nky * nkx * ldy
+                call('sdmi_igemm', _st(), a=_p(dy), w=_p(sub), out=_p(dx), dtype=_DT[dt],
+                     out_dtype=_DT[dt], M=B * hs * ws_, N=Cin, K=K, lda=ldy, ldw=K, ldc=Cin, B=B,
+                     H=Ho, W=Wo, Cin=ldy, Ho=hs, Wo=ws_, KH=nky, KW=nkx, stride=1,
+                     pad_t=(nky - 1) - (py + pad[0] - ay) // s, pad_l=(nkx - 1) - (px + pad[2] - ax) // s,
+                     ups=0, act=0, alpha=1.0, split_k=1, batch=1, oH=H, oW=W_, osy=s, osx=s, ooy=py,
+                     oox=px)
+        return dx
 
     @staticmethod
     def _wgrad(wb, x, dy, dt, names, bnames, dst, direct, splits, M, N, K, Cin, ldy, B, H, W_, Ho,

@@ -573,3 +573,38 @@ def test_vae_train_kernels(dtype):
     lr = (pr - tg).abs().mean()
     lr.backward()
     assert abs(float(l) - float(lr)) <= 1e-6 and float((pd.grad.cpu() - pr.grad).abs().max()) <= 1e-7
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('case', [(2, 32, 48, 16, 3, 2, (1, 1, 1, 1)),      # UNet / ResNet downsample
+                                  (2, 32, 40, 16, 3, 2, (0, 1, 0, 1)),      # VQ-VAE asymmetric pad
+                                  (2, 64, 128, 16, 1, 2, (0, 0, 0, 0)),     # 1x1 stride 2: empty parities
+                                  (1, 16, 32, 15, 3, 2, (1, 1, 1, 1)),      # odd image
+                                  (2, 16, 24, 18, 5, 3, (2, 2, 2, 2))])     # 5x5 stride 3
+def test_strided_dgrad_by_parity(case, dtype):
+    """Data gradient of stride-s convolutions as s*s stride-1 convolutions written interleaved
+    (igemm's sub-sampled output placement) against torch autograd."""
+    from slotdiffusion_amd import _lib, ops
+    from slotdiffusion_amd.kern import _DT, GemmFn
+    B, Cin, Cout, H, k, stride, pad = case
+    g = torch.Generator().manual_seed(sum(case[:6]))
+    q = lambda t: t.to(dtype).float()
+    x = q(torch.randn(B, Cin, H, H, generator=g)).requires_grad_(True)
+    w = q(torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k))
+    y = F.conv2d(F.pad(x, (pad[2], pad[3], pad[0], pad[1])), w, None, stride=stride)
+    dy = q(torch.randn(y.shape, generator=g))
+    y.backward(dy)
+    vec = ops.vec_of(dtype)
+    npad = (Cout + vec - 1) // vec * vec
+    Ho = y.shape[2]
+    K = k * k * Cin
+    dyd = F.pad(dy.permute(0, 2, 3, 1), (0, npad - Cout)).contiguous().to(dtype).cuda()
+    wp = w.permute(0, 2, 3, 1).reshape(Cout, K).contiguous().to(dtype).cuda()
+    wd = torch.zeros(Cin * k * k, npad, dtype=dtype, device='cuda')
+    _lib.call('sdmi_pack_dgrad', torch.cuda.current_stream().cuda_stream, src=wp.data_ptr(),
+              dst=wd.data_ptr(), dtype=_DT[dtype], Cout=Cout, KH=k, KW=k, Cin=Cin, CoutPad=npad)
+    dx = GemmFn._dgrad_strided(dyd, wd.view(Cin, k * k * npad), B, H, H, Ho, Ho, Cin, npad, k, k,
+                               stride, pad, dtype)
+    ref = x.grad.permute(0, 2, 3, 1)
+    e = float((dx.float().cpu() - ref).norm() / ref.norm())
+    assert e <= (2e-5 if dtype == torch.float32 else 2e-2), e
