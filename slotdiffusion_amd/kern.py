@@ -62,8 +62,8 @@ class WeightBank:
         # the join (HBM is plentiful), so no allocator stream bookkeeping is needed.
         self.overlap_wgrad = os.environ.get('SDMI_WGRAD_STREAM', '1') != '0'
         self.n_side = max(1, int(os.environ.get('SDMI_WGRAD_STREAMS', '4')))
-        self._sides, self._side_i = [], 0
-        self._pending = []
+        self._sides = []
+        self._pending, self._side_of = [], {}
         self._join_queued = False
         # dgrad operands: key -> [buffer, epoch, (stable source view | None, geometry)]
         self._wd, self._wd_epoch, self._wd_stale, self._wd_table = {}, 0, False, None
@@ -72,21 +72,32 @@ class WeightBank:
         n = names if isinstance(names, str) else names[0]
         return self.anchor_dec if n.startswith('dm_decoder') else self.anchor
 
-    def side_stream(self):
+    def side_index(self, key):
+        """Side stream of a parameter (by name): a parameter used several times per step (Slot
+        Attention iterations, the per-frame predictor) accumulates its gradient in stream order on
+        ONE stream; different parameters are spread round-robin."""
+        i = self._side_of.get(key)
+        if i is None:
+            i = self._side_of[key] = len(self._side_of) % self.n_side
+        return i
+
+    def side_stream(self, key=None):
         if not self.overlap_wgrad:
             return None
-        # round-robin over a few streams: most weight-gradient launches are small (<= 128
-        # workgroups + their reduction) and two of them fit the chip next to the dgrad chain
+        # a few streams: most weight-gradient launches are small (<= 128 workgroups + their
+        # reduction) and several of them fit the chip next to the dgrad chain
         if not self._sides:
             self._sides = [torch.cuda.Stream() for _ in range(self.n_side)]
-        self._side_i = (self._side_i + 1) % len(self._sides)
-        return self._sides[self._side_i]
+        return self._sides[self.side_index(key)]
 
-    def defer(self, *tensors):
-        self._pending.append(tensors)
+    def ensure_join(self):
         if not self._join_queued:
             self._join_queued = True
             torch.autograd.Variable._execution_engine.queue_callback(self.join)
+
+    def defer(self, *tensors):
+        self._pending.append(tensors)
+        self.ensure_join()
 
     def join(self):
         for side in self._sides:
@@ -404,7 +415,7 @@ class GemmFn(torch.autograd.Function):
         splits = max(1, min((512 + tiles - 1) // tiles, M // (8 * mt), 512))
         if M <= 16 * mt:
             splits = 1
-        side = wb.side_stream()
+        side = wb.side_stream(names[0])
         if side is not None:
             ev = torch.cuda.Event()
             ev.record()
@@ -572,9 +583,9 @@ class LayerNormFn(torch.autograd.Function):
         nblk = max(1, min(512, rows // 16))
         partial = torch.empty((nblk * C * 2,), dtype=torch.float32, device=x.device)
         dx = torch.empty_like(x)
+        dg, db = _grads_of(wb, name + '.weight'), _grads_of(wb, name + '.bias')
         call('sdmi_layernorm_bwd', _st(), x=_p(x), dy=_p(dy), dx=_p(dx),
-             gamma=_p(wb.f(name + '.weight')), stats=_p(stats),
-             dgamma=_p(_grads_of(wb, name + '.weight')), dbeta=_p(_grads_of(wb, name + '.bias')),
+             gamma=_p(wb.f(name + '.weight')), stats=_p(stats), dgamma=_p(dg), dbeta=_p(db),
              partial=_p(partial), dtype=_DT[x.dtype], rows=rows, C=C, nblk=nblk, accumulate=1)
         _dbg(f'ln {name}', dy=dy, dx=dx)
         return dx, None, None, None
