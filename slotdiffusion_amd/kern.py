@@ -408,11 +408,13 @@ class GemmFn(torch.autograd.Function):
         k_true = wb.t[names[0]].numel() // wb.t[names[0]].shape[0]
         direct = dst is not None and k_true == K
         tiles = ((N + 127) // 128) * ((K + 127) // 128)
-        # M is split so that >= ~2 workgroups per CU exist while each still walks >= 8 m-steps
+        # M is split so that ~0.75 workgroups per CU exist (the launches share the chip with the
+        # dgrad chain and three more weight-gradient streams; sweep 128 ... 768 on one box: 192-256
+        # best, 512 is +0.7 ... +1.8 ms per step) while each still walks >= 8 m-steps
         # (64 rows per step in the bf16 kernel, 32 in the fp32 one); short contractions take one
         # launch straight into the gradient arena
         mt = 64 if dt == torch.bfloat16 else 32
-        splits = max(1, min((512 + tiles - 1) // tiles, M // (8 * mt), 512))
+        splits = max(1, min((192 + tiles - 1) // tiles, M // (8 * mt), 512))
         if M <= 16 * mt:
             splits = 1
         side = wb.side_stream(names[0])
@@ -949,7 +951,7 @@ class DeconvFn(torch.autograd.Function):
         M, N, K = B * H * W_, Cin, k * k * Cout
         mt = 64 if dt == torch.bfloat16 else 32
         tiles = ((N + 127) // 128) * ((K + 127) // 128)
-        splits = max(1, min((512 + tiles - 1) // tiles, M // (8 * mt), 512))
+        splits = max(1, min((192 + tiles - 1) // tiles, M // (8 * mt), 512))
         ws = torch.empty((splits * (N * K + N),), dtype=torch.float32, device=x.device)
         call('sdmi_wgrad', _st(), a=_p(dz), dy=_p(x), dw=_p(_grads_of(wb, wname)), dbias=0,
              workspace=_p(ws), dtype=_DT[dt], M=M, N=N, K=K, lda=Cout, ldy=Cin, B=B, H=Ho, W=Wo,
