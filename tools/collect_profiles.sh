@@ -13,8 +13,10 @@ timeout 600 rocprofv3 --kernel-trace --stats -d $O/sample -o sample --output-for
 for mode in train sample; do
   if [ $mode = train ]; then ARGS="--only-train --no-graph --no-cpu-baseline --no-roofline --steps 2 --warmup 1"; else ARGS="--mode sample --big-batch 0 --no-graph --no-cpu-baseline --no-roofline --steps 1 --warmup 1"; fi
   timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_BF16 -d $O/pmc_${mode}_1 -o p --output-format csv -- python $R/bench.py $ARGS > $O/pmc_${mode}_1.log 2>&1
-  timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_${mode}_2 -o p --output-format csv -- python $R/bench.py $ARGS > $O/pmc_${mode}_2.log 2>&1
-  timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_${mode}_3 -o p --output-format csv -- python $R/bench.py $ARGS > $O/pmc_${mode}_3.log 2>&1
+  if [ $mode = train ]; then     # TCC passes: train only (see the note above)
+    timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_${mode}_2 -o p --output-format csv -- python $R/bench.py $ARGS > $O/pmc_${mode}_2.log 2>&1
+    timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_${mode}_3 -o p --output-format csv -- python $R/bench.py $ARGS > $O/pmc_${mode}_3.log 2>&1
+  fi
 done
 cd $R
 cp $O/train/train_kernel_stats.csv $O/${TAG}_train_b64_bf16_kernel_stats.csv 2>/dev/null
