@@ -124,8 +124,10 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(SdmiGroupNormArgs p, int 
 }
 
 
-// Small images: one workgroup per image keeps its whole [HW][C] slab in registers (<= 16 vectors
-// per thread): statistics and normalisation in ONE launch, x read once.
+// Single-pass GroupNorm: grid (B, S); a workgroup owns 1/S of an image's channels (whole groups)
+// and keeps its [HW][C/S] slab in registers (<= 16 vectors per thread): statistics and
+// normalisation in ONE launch, x read once.  S = 1 is the small-image case; the channel split lets
+// the 16x16 / 32x32 levels take this path too and fills the chip at B = 64.
 template <typename T>
 __global__ __launch_bounds__(256) void gn_fused_kernel(SdmiGroupNormArgs p) {
   constexpr int VEC = Elem<T>::VEC;
@@ -133,11 +135,13 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(SdmiGroupNormArgs p) {
   __shared__ float part[256][VEC][2];
   __shared__ float s_stats[128][2];
   const int b = blockIdx.x;
-  const int CV = p.C / VEC, CVp = next_pow2(CV);
+  const int S = gridDim.y, sidx = blockIdx.y;
+  const int CV = p.C / VEC / S, CVp = next_pow2(CV);     // this workgroup's channel vectors
+  const int c_lo = sidx * CV * VEC;                       // first channel of the chunk
   const int R = 256 / CVp;
   const int cv = threadIdx.x % CVp, r0 = threadIdx.x / CVp;
   const bool act_c = cv < CV;
-  const long long base = (long long)b * p.HW * p.C + (act_c ? cv : 0) * VEC;
+  const long long base = (long long)b * p.HW * p.C + c_lo + (act_c ? cv : 0) * VEC;
   const T* xb = (const T*)p.x + base;
   uint4 xr[NV];
   float s[VEC], ss[VEC];
@@ -162,10 +166,11 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(SdmiGroupNormArgs p) {
   for (int j = 0; j < VEC; ++j) { part[threadIdx.x][j][0] = s[j]; part[threadIdx.x][j][1] = ss[j]; }
   __syncthreads();
   const int cpg = p.C / p.groups;
-  if ((int)threadIdx.x < 2 * p.groups) {     // 2 threads per group: (sum | sumsq), fp64 combine
+  const int gs = p.groups / S;               // groups of this chunk
+  if ((int)threadIdx.x < 2 * gs) {           // 2 threads per group: (sum | sumsq), fp64 combine
     const int g = threadIdx.x >> 1, which = threadIdx.x & 1;
     double acc = 0.0;
-    for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+    for (int c = g * cpg; c < (g + 1) * cpg; ++c) {      // c: channel inside the chunk
       const int ccv = c / VEC, j = c % VEC;
       for (int r = 0; r < R; ++r) acc += (double)part[r * CVp + ccv][j][which];
     }
@@ -179,8 +184,8 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(SdmiGroupNormArgs p) {
       const float mf = (float)mean, rf = (float)(1.0 / sqrt(var + (double)p.eps));
       s_stats[g][0] = mf;
       s_stats[g][1] = rf;
-      p.stats[(b * p.groups + g) * 2 + 0] = mf;
-      p.stats[(b * p.groups + g) * 2 + 1] = rf;
+      p.stats[(b * p.groups + sidx * gs + g) * 2 + 0] = mf;
+      p.stats[(b * p.groups + sidx * gs + g) * 2 + 1] = rf;
     }
   }
   __syncthreads();
@@ -188,9 +193,9 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(SdmiGroupNormArgs p) {
   float sc[VEC], sh[VEC];
 #pragma unroll
   for (int j = 0; j < VEC; ++j) {
-    const int c = cv * VEC + j, g = c / cpg;
-    sc[j] = s_stats[g][1] * p.gamma[c];
-    sh[j] = p.beta[c] - s_stats[g][0] * sc[j];
+    const int cl = cv * VEC + j, g = cl / cpg;            // chunk-local channel / group
+    sc[j] = s_stats[g][1] * p.gamma[c_lo + cl];
+    sh[j] = p.beta[c_lo + cl] - s_stats[g][0] * sc[j];
   }
   T* yb = (T*)p.y + base;
   const T* rb = p.residual ? (const T*)p.residual + base : nullptr;
@@ -312,14 +317,29 @@ extern "C" int sdmi_groupnorm(const SdmiGroupNormArgs* a, void* stream) {
   if (rc) return rc;
   SDMI_REQUIRE(a->y, "null output");
   const int vec = a->dtype == SDMI_BF16 ? 8 : 4;
-  int cvp = 1;
-  while (cvp < a->C / vec) cvp <<= 1;
-  const int R = 256 / cvp;
-  if ((a->HW + R - 1) / R <= 16) {          // the image fits in one workgroup's registers
-    hipStream_t st = (hipStream_t)stream;
-    if (a->dtype == SDMI_BF16) hipLaunchKernelGGL(gn_fused_kernel<bf16_t>, dim3(a->B), dim3(256), 0, st, *a);
-    else hipLaunchKernelGGL(gn_fused_kernel<float>, dim3(a->B), dim3(256), 0, st, *a);
-    return sdmi_check_launch("groupnorm (fused)");
+  // single-pass kernel: the smallest channel split S (whole groups, >= SDMI_GN_MIN_SEG bytes of a
+  // row per workgroup) whose [HW][C/S] slab fits 16 vectors per thread, preferring >= 256 workgroups
+  {
+    const int cvt = a->C / vec;
+    int pick = 0;
+    for (int S = 1; S <= a->groups && S <= 32; S <<= 1) {
+      if (a->groups % S || cvt % S) break;
+      const int cv = cvt / S;
+      if (cv * 16 < 64 && S > 1) break;            // segments shorter than 64 B: not worth it
+      int cvp = 1;
+      while (cvp < cv) cvp <<= 1;
+      const int R = 256 / cvp;
+      if ((a->HW + R - 1) / R > 16) continue;       // does not fit yet: split further
+      pick = S;
+      if ((long long)a->B * S >= 256) break;
+    }
+    if (pick) {
+      hipStream_t st = (hipStream_t)stream;
+      dim3 grid(a->B, pick);
+      if (a->dtype == SDMI_BF16) hipLaunchKernelGGL(gn_fused_kernel<bf16_t>, grid, dim3(256), 0, st, *a);
+      else hipLaunchKernelGGL(gn_fused_kernel<float>, grid, dim3(256), 0, st, *a);
+      return sdmi_check_launch("groupnorm (fused)");
+    }
   }
   rc = sdmi_groupnorm_stats(a, stream);
   return rc ? rc : sdmi_groupnorm_apply(a, stream);
