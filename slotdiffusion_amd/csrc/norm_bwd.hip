@@ -90,21 +90,24 @@ __global__ __launch_bounds__(256) void gn_bwd_fused_kernel(SdmiGroupNormBwdArgs 
   __shared__ float part[256][VEC][2];
   __shared__ float gsum[256][2];
   const int b = blockIdx.x;
-  const int CV = p.C / VEC, CVp = next_pow2(CV);
+  const int S = gridDim.y, sidx = blockIdx.y;            // channel chunk (whole groups) of this workgroup
+  const int CV = p.C / VEC / S, CVp = next_pow2(CV);
+  const int c_lo = sidx * CV * VEC;
   const int R = 256 / CVp;
   const int cv = threadIdx.x % CVp, r0 = threadIdx.x / CVp;
   const bool act_c = cv < CV;
   const int cpg = p.C / p.groups;
+  const int gs = p.groups / S;
   float mu[VEC], rs[VEC], ga[VEC], be[VEC];
 #pragma unroll
   for (int j = 0; j < VEC; ++j) {
-    const int c = (act_c ? cv : 0) * VEC + j, g = c / cpg;
+    const int c = c_lo + (act_c ? cv : 0) * VEC + j, g = c / cpg;
     mu[j] = p.stats[(b * p.groups + g) * 2];
     rs[j] = p.stats[(b * p.groups + g) * 2 + 1];
     ga[j] = p.gamma[c];
     be[j] = p.beta[c];
   }
-  const long long base = (long long)b * p.HW * p.C + (act_c ? cv : 0) * VEC;
+  const long long base = (long long)b * p.HW * p.C + c_lo + (act_c ? cv : 0) * VEC;
   const T* xb = (const T*)p.x + base;
   const T* db = (const T*)p.dy + base;
   const T* rb = p.residual ? (const T*)p.residual + base : nullptr;
@@ -150,17 +153,17 @@ __global__ __launch_bounds__(256) void gn_bwd_fused_kernel(SdmiGroupNormBwdArgs 
       for (int r = 0; r < R; ++r) { sa += part[r * CVp + cv][j][0]; sb += part[r * CVp + cv][j][1]; }
       part[cv][j][0] = (float)sa;          // row 0 of the column: no other thread reads rows r>0 of it now
       part[cv][j][1] = (float)sb;
-      float* q = p.partial + (((long long)b * p.C) + cv * VEC + j) * 2;
+      float* q = p.partial + (((long long)b * p.C) + c_lo + cv * VEC + j) * 2;
       q[0] = (float)sa;
       q[1] = (float)sb;
     }
   }
   __syncthreads();
-  for (int g = threadIdx.x; g < p.groups; g += 256) {
+  for (int g = threadIdx.x; g < gs; g += 256) {          // groups / channels local to the chunk
     double s1 = 0.0, s2 = 0.0;
     for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
-      s1 += (double)p.gamma[c] * part[c / VEC][c % VEC][0];
-      s2 += (double)p.gamma[c] * part[c / VEC][c % VEC][1];
+      s1 += (double)p.gamma[c_lo + c] * part[c / VEC][c % VEC][0];
+      s2 += (double)p.gamma[c_lo + c] * part[c / VEC][c % VEC][1];
     }
     gsum[g][0] = (float)s1;
     gsum[g][1] = (float)s2;
@@ -423,14 +426,26 @@ extern "C" int sdmi_groupnorm_bwd(const SdmiGroupNormBwdArgs* a, void* stream) {
   if (rows_per > a->HW) rows_per = a->HW;
   dim3 g3((a->HW + rows_per - 1) / rows_per, a->B);
   {
-    int cvp = 1;
-    while (cvp < a->C / vec) cvp <<= 1;
-    const int R = 256 / cvp;
-    if (a->nsplit == 1 && (a->HW + R - 1) / R <= 16) {      // small image: one fused launch
+    // single-pass kernel (x and dy slabs in registers), same channel split as the forward pass
+    const int cvt = a->C / vec;
+    int pick = 0;
+    for (int S = 1; S <= a->groups && S <= 32; S <<= 1) {
+      if (a->groups % S || cvt % S) break;
+      const int cv = cvt / S;
+      if (cv * 16 < 64 && S > 1) break;
+      int cvp = 1;
+      while (cvp < cv) cvp <<= 1;
+      const int R = 256 / cvp;
+      if ((a->HW + R - 1) / R > 16) continue;
+      pick = S;
+      if ((long long)a->B * S >= 256) break;
+    }
+    if (pick) {
+      dim3 gf(a->B, pick);
       if (a->dtype == SDMI_BF16)
-        hipLaunchKernelGGL(gn_bwd_fused_kernel<bf16_t>, dim3(a->B), dim3(256), 0, st, *a);
+        hipLaunchKernelGGL(gn_bwd_fused_kernel<bf16_t>, gf, dim3(256), 0, st, *a);
       else
-        hipLaunchKernelGGL(gn_bwd_fused_kernel<float>, dim3(a->B), dim3(256), 0, st, *a);
+        hipLaunchKernelGGL(gn_bwd_fused_kernel<float>, gf, dim3(256), 0, st, *a);
       hipLaunchKernelGGL(pair_colsum_kernel, dim3((a->C + 15) / 16), dim3(256), 0, st, a->partial,
                          a->B, a->C, a->dbeta, a->dgamma, a->accumulate);
       return sdmi_check_launch("groupnorm_bwd (fused)");
