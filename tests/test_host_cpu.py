@@ -28,6 +28,28 @@ def test_invalid_arguments_are_rejected_without_launch():
     with pytest.raises(_lib.SdmiError):
         _lib.call('sdmi_igemm', None, a=16, w=16, out=16, dtype=7, M=1, N=1, K=1)
     assert b'dtype' in _lib.lib().sdmi_last_error()
+    # null operands, empty problems, misaligned / inconsistent geometry: every entry point returns an
+    # error code (negative) with a message instead of launching
+    bad = [
+        ('sdmi_igemm', dict(a=0, w=16, out=16, dtype=_lib.BF16, M=1, N=1, K=8)),                 # null A
+        ('sdmi_igemm', dict(a=16, w=16, out=16, dtype=_lib.BF16, out_dtype=_lib.BF16, M=0, N=8, K=8)),   # empty
+        ('sdmi_igemm', dict(a=16, w=16, out=16, dtype=_lib.BF16, out_dtype=_lib.BF16, M=4, N=8, K=16,
+                            KH=1, KW=1, Cin=8, B=4, Ho=1, Wo=1, lda=8, ldw=16)),                 # K != KH*KW*Cin
+        ('sdmi_igemm', dict(a=18, w=16, out=16, dtype=_lib.BF16, out_dtype=_lib.BF16, M=4, N=8, K=8,
+                            KH=1, KW=1, Cin=8, B=4, Ho=1, Wo=1, lda=8, ldw=8)),                  # unaligned A
+        ('sdmi_igemm', dict(a=16, w=16, out=16, dtype=_lib.BF16, out_dtype=_lib.BF16, M=4, N=8, K=8,
+                            KH=1, KW=1, Cin=8, B=4, Ho=1, Wo=1, lda=8, ldw=8, osy=2)),           # osy without oH/oW
+        ('sdmi_wgrad', dict(a=0, dy=16, dw=16, dtype=_lib.BF16, M=8, N=8, K=8)),
+        ('sdmi_groupnorm', dict(x=16, y=16, gamma=16, beta=16, stats=16, partial=16, dtype=_lib.BF16,
+                                B=1, HW=4, C=12, groups=32, nsplit=1)),                          # C not a vector multiple
+        ('sdmi_contingency', dict(gt=16, pred=16, counts=16, B=1, P=4, Kg=100, Kp=100)),         # table too large
+        ('sdmi_transpose2d', dict(src=16, dst=16, dtype=9, Z=1, R=4, C=4, lds=4, ldd=4)),
+        ('sdmi_vq_bwd', dict(z=16, zq=16, dz=16, dcode=16, idx=16, R=0, dim=3, ldz=4)),
+    ]
+    for fname, kw in bad:
+        with pytest.raises(_lib.SdmiError):
+            _lib.call(fname, None, **kw)
+        assert len(_lib.lib().sdmi_last_error()) > 0, fname
 
 
 def test_dpm_plan_matches_oracle_exactly():
