@@ -89,3 +89,24 @@ def test_two_rank_graphed_step_equals_full_batch():
     assert rel <= 2e-5, rel
     moved = float((a0 - m.arena().detach().cpu()).abs().max())
     assert 0 < moved < 1e-2
+
+
+def test_bench_rccl_path_single_rank():
+    """bench.py's multi-GPU code path over the real RCCL backend with ONE rank
+    (SDMI_BENCH_FORCE_DIST=1): process group init, parameter broadcast, HIP-graph capture while the
+    RCCL watchdog thread is alive, split backward with the overlapped all-reduce, barriers,
+    MAX-over-ranks timing -- and the result line must be the LAST line of stdout (RCCL prints its
+    version banner to stdout)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SDMI_BENCH_FORCE_DIST='1', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()))
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--only-train', '--no-cpu-baseline',
+                        '--no-roofline', '--steps', '2', '--warmup', '1', '--batch', '8'],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    out = json.loads(lines[-1])
+    assert out['n_gpus'] == 1 and out['unit'] == 'images/s' and out['value'] > 0
+    assert out['config']['parallelism'] == 'dp1' and out['steps'] == 2
