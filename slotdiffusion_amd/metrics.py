@@ -42,19 +42,20 @@ def contingency(true_ids, pred_ids, num_true=None, num_pred=None):
     return counts
 
 
-def _ari_from_table(N):
-    """eval_utils.py:157-176 on the [B, C, K] float32 table."""
-    A = torch.sum(N, dim=-1)
-    Bc = torch.sum(N, dim=-2)
-    num_points = torch.sum(A, dim=1)
-    rindex = torch.sum(N * (N - 1), dim=[1, 2])
-    aindex = torch.sum(A * (A - 1), dim=1)
-    bindex = torch.sum(Bc * (Bc - 1), dim=1)
-    expected_rindex = aindex * bindex / torch.clamp(num_points * (num_points - 1), min=1)
-    max_rindex = (aindex + bindex) / 2
-    denominator = max_rindex - expected_rindex
-    ari = (rindex - expected_rindex) / denominator
-    return torch.where(denominator != 0, ari, torch.tensor(1.).type_as(ari))
+def _ari_from_table(tab):
+    """Adjusted Rand index per image from the float32 contingency table [B, C, K], with the float32
+    operation order of the reference (eval_utils.py:157-176) so that the scores are identical:
+    pairs(v) = sum v*(v-1) over cells / row sums / column sums; expected = rows*cols / total pairs;
+    score = (cells - expected) / ((rows + cols)/2 - expected), 1 where that denominator is 0."""
+    pairs = lambda v, dims: torch.sum(v * (v - 1), dim=dims)
+    row_tot, col_tot = tab.sum(-1), tab.sum(-2)
+    n_pix = row_tot.sum(1)
+    same_cell = pairs(tab, [1, 2])
+    same_row, same_col = pairs(row_tot, 1), pairs(col_tot, 1)
+    chance = same_row * same_col / torch.clamp(n_pix * (n_pix - 1), min=1)
+    gap = (same_row + same_col) / 2 - chance
+    score = (same_cell - chance) / gap
+    return torch.where(gap != 0, score, torch.ones_like(score))
 
 
 def adjusted_rand_index(true_ids, pred_ids, ignore_background=False):
