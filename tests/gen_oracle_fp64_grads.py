@@ -3,7 +3,11 @@
 The reference's own fp32 CPU gradients of the slot-encoder side deviate from the exact (fp64)
 gradients by 0.1-0.5 % (ill-conditioned eps-renormalised attention); this fixture lets the GPU
 tests also check the HIP backward against the exact values.  Produced by OUR oracle (already pinned
-against the reference in tests/test_oracle_golden.py), not by the reference."""
+against the reference in tests/test_oracle_golden.py), not by the reference.  Lives under tests/
+because it executes the oracle (test infrastructure: only tests/ may).
+
+    python tests/gen_oracle_fp64_grads.py
+"""
 import os
 import sys
 

@@ -79,7 +79,7 @@ def test_train_step_gradients_fp32():
     _dump()
     assert abs(REPORT['train_loss'] - REPORT['train_loss_ref']) <= 1e-4
     # the reference's own fp32 gradients are 0.1-0.5 % off the exact ones on the slot-encoder
-    # side (see tools/gen_oracle_fp64_grads.py); the HIP backward must match the exact gradients
+    # side (see tests/gen_oracle_fp64_grads.py); the HIP backward must match the exact gradients
     # tightly and the reference within that conditioning band
     assert REPORT['grad_norm_max_rel_vs_exact_fp64'] <= 2e-4
     assert max(errs_exact.values()) <= 5e-4, errs_exact
