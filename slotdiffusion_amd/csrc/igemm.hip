@@ -690,6 +690,166 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64 + 256) void igemm_dma_ke
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Direct 3x3 convolution for the 64 -> 64 channel layers at full resolution (slot encoder / VQ-VAE
+// at 128^2: M = 1M pixels, N = 64 -- as a GEMM this shape is bound by re-fetching the activation
+// tile for each of the 9 taps, 0.4 PF).  bf16, stride 1, pad 1, W % 64 == 0, H % 4 == 0.
+//   * persistent workgroup (256 threads = 4 MFMA waves), one per CU; the WHOLE filter
+//     ([64 cout][9 taps x 64 cin], 74 KB) is loaded into LDS once;
+//   * output tile = 4 image rows x 64 pixels; its 6 x 66 pixel input halo (57 KB, zeros outside
+//     the image) is staged once and serves all 9 taps: the tap only shifts the fragment address;
+//   * the NEXT tile's halo is prefetched into registers while the current one is multiplied.
+// Wave w owns image row oy0 + w: 64 consecutive output pixels x 64 channels (2x2 MFMA tiles), so
+// the generic wave epilogue applies unchanged.  Pixel pitch 144 B / filter row pitch 1168 B (odd
+// multiples of 16 B): conflict-free ds_read_b128.
+constexpr int D33_PIX = 144, D33_WROW = 9 * 64 * 2 + 16;
+constexpr int D33_HALO = 6 * 66, D33_HALO_V = (D33_HALO * 8 + 255) / 256;     // uint4 per thread
+constexpr int D33_STAGE = 32 * D33_PIX;                       // per-wave epilogue staging (32 px x 32 ch fp32)
+constexpr int D33_SMEM = 64 * D33_WROW + D33_HALO * D33_PIX + 4 * D33_STAGE;
+
+__global__ __launch_bounds__(256) void conv3x3_c64_kernel(SdmiGemmArgs p, int hw_shift) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const Ws = smem;
+  char* const Xs = smem + 64 * D33_WROW;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bf16_t* __restrict__ Ag = (const bf16_t*)p.a;
+  const bf16_t* __restrict__ Wg = (const bf16_t*)p.w;
+  const int tiles_x = p.W / 64, tiles_y = p.H / 4;
+  const int n_tiles = p.B * tiles_y * tiles_x;
+  // ---- the filter: [n][576] rows -> LDS rows of pitch D33_WROW
+  for (int v = tid; v < 64 * 72; v += 256) {
+    const int n = v / 72, c = v - n * 72;
+    const u32x4 w4 = n < p.N ? *reinterpret_cast<const u32x4*>(Wg + (long long)n * p.ldw + c * 8)
+                             : u32x4{0u, 0u, 0u, 0u};
+    *reinterpret_cast<u32x4*>(Ws + n * D33_WROW + c * 16) = w4;
+  }
+  // ---- halo fetch of tile t into registers (zeros outside the image)
+  u32x4 pre[D33_HALO_V];
+  auto fetch = [&](int t) __attribute__((always_inline)) {
+    const int b = t / (tiles_y * tiles_x), r = t - b * tiles_y * tiles_x;
+    const int ty = r / tiles_x, tx = r - ty * tiles_x;
+    const int iy0 = ty * 4 - 1, ix0 = tx * 64 - 1;
+#pragma unroll
+    for (int i = 0; i < D33_HALO_V; ++i) {
+      const int v = tid + i * 256, px = v >> 3, ch = v & 7;
+      const int hy = px / 66, hx = px - hy * 66;
+      const int iy = iy0 + hy, ix = ix0 + hx;
+      const bool ok = px < D33_HALO && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+      pre[i] = ok ? *reinterpret_cast<const u32x4*>(Ag + ((long long)(b * p.H + iy) * p.W + ix) * p.lda + ch * 8)
+                  : u32x4{0u, 0u, 0u, 0u};
+    }
+  };
+  auto stash = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < D33_HALO_V; ++i) {
+      const int v = tid + i * 256, px = v >> 3, ch = v & 7;
+      if (px < D33_HALO) *reinterpret_cast<u32x4*>(Xs + px * D33_PIX + ch * 16) = pre[i];
+    }
+  };
+  int t = blockIdx.x;
+  if (t < n_tiles) fetch(t);
+  const int R = lane & 31, kb = (lane >> 5) * 16;
+  for (; t < n_tiles; t += gridDim.x) {
+    __syncthreads();                       // previous tile's fragment reads are done
+    stash();
+    __syncthreads();
+    if (t + (int)gridDim.x < n_tiles) fetch(t + gridDim.x);     // in flight under the MFMAs below
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    // wave's output row = halo row wave + kh; pixel ox = i*32 + R -> halo column ox + kw
+    const char* xrow = Xs + (wave * 66 + R) * D33_PIX + kb;
+    const char* wrow = Ws + R * D33_WROW + kb;
+    u32x4 fa[2][2], fb[2][2];
+    auto frags = [&](int step, u32x4 (&a)[2], u32x4 (&b)[2]) __attribute__((always_inline)) {
+      const int tap = step >> 2, c = step & 3;
+      const int kh = tap / 3, kw = tap - kh * 3;
+      const char* xa = xrow + (kh * 66 + kw) * D33_PIX + c * 32;
+      const char* wb = wrow + (tap * 64 + c * 16) * 2;
+      a[0] = *reinterpret_cast<const u32x4*>(xa);
+      a[1] = *reinterpret_cast<const u32x4*>(xa + 32 * D33_PIX);
+      b[0] = *reinterpret_cast<const u32x4*>(wb);
+      b[1] = *reinterpret_cast<const u32x4*>(wb + 32 * D33_WROW);
+    };
+    frags(0, fa[0], fb[0]);
+#pragma unroll
+    for (int step = 0; step < 36; ++step) {
+      if (step + 1 < 36) frags(step + 1, fa[(step + 1) & 1], fb[(step + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+              __builtin_bit_cast(bf16x8, fa[step & 1][i]), __builtin_bit_cast(bf16x8, fb[step & 1][j]),
+              acc[i][j], 0, 0, 0);
+    }
+    const int b = t / (tiles_y * tiles_x), r = t - b * tiles_y * tiles_x;
+    const int ty = r / tiles_x, tx = r - ty * tiles_x;
+    const int m0 = (b * p.H + ty * 4 + wave) * p.W + tx * 64;
+    // ---- epilogue: the generic per-element store (64 two-byte stores per lane) is store-issue
+    // bound and nothing hides it here, so the wave transposes its tile through LDS (32 pixels at a
+    // time) and writes whole 128-byte pixel rows: bias / per-image row vector in registers,
+    // residual + activation on the way out.
+    char* stg = smem + 64 * D33_WROW + D33_HALO * D33_PIX + wave * D33_STAGE;
+    const float* rv = p.rowvec ? p.rowvec + (long long)b * p.ldrv : nullptr;
+    const bf16_t* resp = (const bf16_t*)p.residual;
+    bf16_t* outp = (bf16_t*)p.out;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      // fp32 values are needed until residual + activation are applied: the staging holds fp32,
+      // one 32-pixel x 32-channel quarter (4 KB) at a time
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int n = j * 32 + R;
+        const int nc = n < p.N ? n : p.N - 1;
+        const float add = (p.bias ? p.bias[nc] : 0.f) + (rv ? rv[nc] : 0.f);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the quarter before was read out (LDS only:
+                                                               // global stores / prefetch stay in flight)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          *reinterpret_cast<float*>(stg + row * D33_PIX + R * 4) = acc[i][j][r] * p.alpha + add;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // 32 rows x 32 channels fp32: lane -> (row = lane >> 1 [+0], 16-channel half = lane & 1)
+        const int row = lane >> 1, hf = lane & 1;
+        const int m = m0 + i * 32 + row;
+        const int c0 = j * 32 + hf * 16;
+        if (c0 < p.N) {
+          float v[16];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const f32x4 t4 = *reinterpret_cast<const f32x4*>(stg + row * D33_PIX + (hf * 16 + q * 4) * 4);
+            v[q * 4 + 0] = t4[0]; v[q * 4 + 1] = t4[1]; v[q * 4 + 2] = t4[2]; v[q * 4 + 3] = t4[3];
+          }
+          if (resp) {
+            float rr[8];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              unpack16<bf16_t>(*reinterpret_cast<const uint4*>(resp + (long long)m * p.ldr + c0 + h * 8), rr);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[h * 8 + e] += rr[e];
+            }
+          }
+          if (p.act) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) v[e] = act_apply(v[e], p.act);
+          }
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+            if (c0 + h * 8 < p.N)
+              *reinterpret_cast<uint4*>(outp + (long long)m * p.ldc + c0 + h * 8) = pack16<bf16_t>(v + h * 8);
+        }
+      }
+    }
+  }
+}
+
 // Two entry points over the same body: <= 128 VGPRs (two workgroups per CU) for the tiles whose
 // double-buffered LDS image allows it, unconstrained for the 256-row tile (92 KB of LDS).
 template <typename T, int BM, int BN, int BKB, int MODE>
@@ -856,6 +1016,30 @@ int dispatch(const SdmiGemmArgs& p, hipStream_t st) {
   if (split_k > 1 && !p.workspace) split_k = 1;
   (void)VEC;
   const bool plain = !is1x1 && !p.ups && p.zins <= 1;
+  // direct 3x3 kernel for the 64 -> 64 channel convolutions at full resolution
+  if (sizeof(T) == 2 && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad_t == 1 && p.pad_l == 1 &&
+      !p.ups && p.zins <= 1 && p.osy == 0 && p.Cin == 64 && p.N <= 64 && p.N > 32 && batch == 1 &&
+      p.split_k <= 1 && p.H == p.Ho && p.W == p.Wo && p.W % 64 == 0 && p.H % 4 == 0 &&
+      p.out_dtype == SDMI_BF16 && p.ldc % 8 == 0 && p.N % 8 == 0 && !p.bias_m &&
+      (!p.residual || p.ldr % 8 == 0) &&
+      (long long)p.B * (p.H / 4) * (p.W / 64) >= 2 * device_cus()) {
+    static bool attr_done = false;
+    if (!attr_done) {
+      if (hipFuncSetAttribute((const void*)conv3x3_c64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              D33_SMEM) != hipSuccess) {
+        sdmi_set_error("igemm: hipFuncSetAttribute failed");
+        return SDMI_ELAUNCH;
+      }
+      attr_done = true;
+    }
+    SdmiGemmArgs q = p;
+    q.split_k = 1;
+    int grid = device_cus();
+    const long long n_tiles = (long long)p.B * (p.H / 4) * (p.W / 64);
+    if (grid > n_tiles) grid = (int)n_tiles;
+    hipLaunchKernelGGL(conv3x3_c64_kernel, dim3(grid), dim3(256), D33_SMEM, st, q, hw_shift);
+    return sdmi_check_launch("igemm (direct 3x3 c64)");
+  }
   // the scalar-offset loaders (MODE 1 / 2) address operands with 31-bit byte offsets
   const long long a_bytes =
       ((long long)p.B * p.H * p.W + (long long)(p.KH + 1) * p.W) * p.lda * (long long)sizeof(T);

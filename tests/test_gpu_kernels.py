@@ -75,6 +75,10 @@ CONV_CASES = [
     (48, 64, 128, 32, 5, 1, (2, 2, 2, 2), False, 'bias'),            # 5x5 taps
     (48, 64, 136, 64, 3, 2, (1, 1, 1, 1), False, 'bias,res'),        # stride 2, ragged N
     (48, 328, 128, 32, 1, 1, (0, 0, 0, 0), False, 'bias,res'),       # 1x1 with a K tail
+    # direct 3x3 kernel (64 -> 64 channels at full resolution, >= 512 tiles of 4 x 64 pixels)
+    (8, 64, 64, 128, 3, 1, (1, 1, 1, 1), False, 'bias,res'),
+    (8, 64, 48, 128, 3, 1, (1, 1, 1, 1), False, 'bias,rowvec,silu'),     # ragged N
+    (16, 64, 64, 64, 3, 1, (1, 1, 1, 1), False, ''),
 ]
 
 
