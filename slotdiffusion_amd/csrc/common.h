@@ -25,11 +25,15 @@ int sdmi_check_launch(const char* what);
 __device__ __forceinline__ float bf16_to_f32(bf16_t h) {
   return __uint_as_float(((uint32_t)h) << 16);
 }
-__device__ __forceinline__ bf16_t f32_to_bf16(float f) {  // round-to-nearest-even
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // NaN
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
+typedef float sdmi_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 sdmi_bf16x2 __attribute__((ext_vector_type(2)));
+// round-to-nearest-even through gfx950's v_cvt_pk_bf16_f32 (one instruction per PAIR instead of the
+// ~6 integer ops per value of the bit-twiddling form; same results for every finite input)
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+  return __builtin_bit_cast(bf16_t, (__bf16)f);
+}
+__device__ __forceinline__ uint32_t f32x2_to_bf16x2(float lo, float hi) {
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(sdmi_f32x2{lo, hi}, sdmi_bf16x2));
 }
 
 template <typename T> struct Elem;
@@ -63,10 +67,10 @@ template <> __device__ __forceinline__ uint4 pack16<float>(const float* f) {
 }
 template <> __device__ __forceinline__ uint4 pack16<bf16_t>(const float* f) {
   uint4 v;
-  v.x = (uint32_t)f32_to_bf16(f[0]) | ((uint32_t)f32_to_bf16(f[1]) << 16);
-  v.y = (uint32_t)f32_to_bf16(f[2]) | ((uint32_t)f32_to_bf16(f[3]) << 16);
-  v.z = (uint32_t)f32_to_bf16(f[4]) | ((uint32_t)f32_to_bf16(f[5]) << 16);
-  v.w = (uint32_t)f32_to_bf16(f[6]) | ((uint32_t)f32_to_bf16(f[7]) << 16);
+  v.x = f32x2_to_bf16x2(f[0], f[1]);
+  v.y = f32x2_to_bf16x2(f[2], f[3]);
+  v.z = f32x2_to_bf16x2(f[4], f[5]);
+  v.w = f32x2_to_bf16x2(f[6], f[7]);
   return v;
 }
 
