@@ -159,9 +159,22 @@ def main():
                     help='profiling aid: skip the sampling leg of --mode train')
     args = ap.parse_args()
 
+    # --gpus N is the number of ranks (one per GPU).  Started without a launcher it re-executes
+    # itself under `python -m torch.distributed.run --nproc-per-node N` (the reference's launch:
+    # torch.distributed.launch --nproc_per_node=$GPUS, scripts/sbatch_run.sh:36-39); a mismatch
+    # between --gpus and the world the launcher set up, or fewer visible devices than ranks, is an
+    # error -- never a silent single-GPU measurement.
+    n_vis = torch.cuda.device_count()
+    if args.gpus > n_vis:
+        sys.exit(f'bench.py: --gpus {args.gpus} requested but only {n_vis} GPU(s) are visible on this box')
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        from slotdiffusion_amd import parallel as _par
+        _par.respawn_under_launcher(args.gpus, os.path.abspath(__file__), sys.argv[1:])
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
+    if world != args.gpus:
+        sys.exit(f'bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks')
     dist = None
     if rank != 0:
         # only rank 0 owns stdout (the result line); native banners of the other ranks (RCCL prints
@@ -257,6 +270,7 @@ def main():
 
     train_rate = None
     dt_t = None
+    comm = None
     if args.mode == 'train':
         run_step = train_step
         if not args.no_graph:
@@ -268,6 +282,22 @@ def main():
             run_step = lambda: graphed(dict(img=img))
         dt_t = timed(run_step, args.steps, args.warmup)
         train_rate = world * B * args.steps / dt_t
+        if dist is not None:
+            # the exchange by itself (all ranks idle otherwise) and what of it the step exposes:
+            # the same graphed step without the collective, timed the same way
+            def only_reduce():
+                parallel.allreduce_gradients(garena, world, n_buckets=4)
+            dt_ar = timed(only_reduce, 3, 1)
+            dt_nored = None
+            if not args.no_graph:
+                nored = GraphedTrainStep(model, opt, dict(img=img), allreduce=None, world=world)
+                dt_nored = timed(lambda: nored(dict(img=img)), args.steps, 1)
+            comm = {'rccl_ranks': dist.get_world_size(), 'backend': dist.get_backend(),
+                    'devices': [f'cuda:{i}' for i in range(world)],
+                    'grad_dtype_on_wire': 'bf16' if parallel.grad_bf16_enabled() else 'fp32',
+                    'grad_bytes_per_step': garena.numel() * (2 if parallel.grad_bf16_enabled() else 4),
+                    'all_reduce_ms': 1e3 * dt_ar / 3,
+                    'exposed_comm_ms': (1e3 * (dt_t - dt_nored) / args.steps) if dt_nored else None}
 
     if True:
         if args.mode == 'train':
@@ -291,6 +321,7 @@ def main():
                                    'batch': args.big_batch} if big_rate else None),
             'denoise': {'value': denoise_rate, 'unit': 'image-denoise-steps/s',
                         'ms_per_20nfe_pass': 1e3 * dt_s / n_s, 'nfe': nfe},
+            'comm': comm,
         }
         # rank-0-only instrumentation pass: no collective inside
         step = (lambda: train_step(reduce=False)) if args.mode == 'train' else sample_step

@@ -389,12 +389,21 @@ def q_sample(W, x0, t, noise, prefix='dm_decoder'):
 
 
 def ldm_loss(W, plan, ed, img, slots, t, noise, mc=128, pred_target='eps'):
-    """ldm.py:59-83 with t / noise supplied by the caller; target = noise ('eps') or x0 ('x0')."""
+    """ldm.py:59-83 with t / noise supplied by the caller; target = noise ('eps'), x0 ('x0') or
+    v = alpha_t * noise - sigma_t * x0 ('v', video_based/models/ddpm/ldm.py:74-78)."""
     with torch.no_grad():
         x0 = vae_encode(W, img, ed)
     xt = q_sample(W, x0, t, noise)
     pred = unet_forward(W, plan, xt, t, slots, mc=mc)
-    return F.mse_loss(pred, noise if pred_target == 'eps' else x0), pred, x0
+    if pred_target == 'eps':
+        gt = noise
+    elif pred_target == 'v':
+        a = W['dm_decoder.sqrt_alphas_bar'][t].view(-1, 1, 1, 1)
+        sg = W['dm_decoder.sqrt_one_minus_alphas_bar'][t].view(-1, 1, 1, 1)
+        gt = a * noise - sg * x0
+    else:
+        gt = x0
+    return F.mse_loss(pred, gt), pred, x0
 
 
 # ---------------------------------------------------------------------------
@@ -540,6 +549,8 @@ def dpm_solver_sample(eps_fn, quantize_fn, betas, x, steps=20, order=3, trace=No
         eps = eps_fn(xc, t_in)
         if model_type == 'x_start':          # model_wrapper.noise_pred_fn (dpm_solver.py:358-361)
             eps = (xc - ns.alpha(tc) * eps) / ns.std(tc)
+        elif model_type == 'v':              # dpm_solver.py:362-365
+            eps = ns.alpha(tc) * eps + ns.std(tc) * xc
         x0 = (xc - ns.std(tc) * eps) / ns.alpha(tc)
         return quantize_fn(x0)
 
@@ -586,6 +597,8 @@ def p_mean(W, model_out, x, t, quantize_fn, pred_target='eps', clip_denoised=Fal
     g = lambda k: W[f'{prefix}.{k}'][t].view(-1, 1, 1, 1)
     if pred_target == 'eps':
         x0 = g('sqrt_recip_alphas_bar') * x - g('sqrt_recipm1_alphas_bar') * model_out
+    elif pred_target == 'v':                 # video_based/models/ddpm/cond_ddpm.py:63-67
+        x0 = g('sqrt_alphas_bar') * x - g('sqrt_one_minus_alphas_bar') * model_out
     else:
         x0 = model_out
     if clip_denoised:

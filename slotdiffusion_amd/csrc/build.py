@@ -21,7 +21,7 @@ def _obj(src):
 def _stale(src, obj):
     if not os.path.exists(obj):
         return True
-    deps = [os.path.join(HERE, src), os.path.join(HERE, 'common.h'),
+    deps = [os.path.join(HERE, src), os.path.join(HERE, 'common.h'), os.path.join(HERE, 'gn_geom.h'),
             os.path.join(HERE, '..', '..', 'include', 'sdmi.h')]
     return any(os.path.getmtime(d) > os.path.getmtime(obj) for d in deps)
 

@@ -6,6 +6,7 @@
 // every wave reads whole 128-byte lines.  Statistics are accumulated per thread in fp32 over short
 // strided runs, combined across threads and splits in fp64, deterministically (no atomics).
 #include "common.h"
+#include "gn_geom.h"
 
 namespace {
 
@@ -124,21 +125,24 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(SdmiGroupNormArgs p, int 
 }
 
 
-// Single-pass GroupNorm: grid (B, S); a workgroup owns 1/S of an image's channels (whole groups)
-// and keeps its [HW][C/S] slab in registers (<= 16 vectors per thread): statistics and
-// normalisation in ONE launch, x read once.  S = 1 is the small-image case; the channel split lets
-// the 16x16 / 32x32 levels take this path too and fills the chip at B = 64.
-template <typename T>
-__global__ __launch_bounds__(256) void gn_fused_kernel(SdmiGroupNormArgs p) {
+// Single-pass GroupNorm: grid (B, S); a workgroup of THREADS (256 / 512 / 1024) threads owns 1/S of
+// an image's channels (whole groups) and keeps its [HW][C/S] slab in registers (<= NV vectors per
+// thread): statistics and normalisation in ONE launch, x read once.  Per-thread fp32 sums are folded
+// across the lanes that share a vector column with xor-butterflies, so the LDS combine (fp64) only
+// walks one entry per wave.  Wide workgroups keep whole 128-byte lines per row segment even when the
+// image needs many row passes (THREADS / CVp rows per pass).
+template <typename T, int THREADS, int NV>
+__global__ __launch_bounds__(THREADS) void gn_fused_kernel(SdmiGroupNormArgs p) {
   constexpr int VEC = Elem<T>::VEC;
-  constexpr int NV = 16;
-  __shared__ float part[256][VEC][2];
-  __shared__ float s_stats[128][2];
+  extern __shared__ __attribute__((aligned(16))) float gn_smem[];
   const int b = blockIdx.x;
   const int S = gridDim.y, sidx = blockIdx.y;
   const int CV = p.C / VEC / S, CVp = next_pow2(CV);     // this workgroup's channel vectors
   const int c_lo = sidx * CV * VEC;                       // first channel of the chunk
-  const int R = 256 / CVp;
+  const int R = THREADS / CVp;
+  const int RR = CVp < 64 ? THREADS / 64 : R;             // LDS entries per vector column
+  float (*part)[VEC][2] = reinterpret_cast<float (*)[VEC][2]>(gn_smem);
+  float (*s_stats)[2] = reinterpret_cast<float (*)[2]>(gn_smem + RR * CVp * VEC * 2);
   const int cv = threadIdx.x % CVp, r0 = threadIdx.x / CVp;
   const bool act_c = cv < CV;
   const long long base = (long long)b * p.HW * p.C + c_lo + (act_c ? cv : 0) * VEC;
@@ -162,8 +166,18 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(SdmiGroupNormArgs p) {
       for (int j = 0; j < VEC; ++j) { s[j] += f[j]; ss[j] += f[j] * f[j]; }
     }
   }
+  for (int off = CVp; off < 64; off <<= 1) {
 #pragma unroll
-  for (int j = 0; j < VEC; ++j) { part[threadIdx.x][j][0] = s[j]; part[threadIdx.x][j][1] = ss[j]; }
+    for (int j = 0; j < VEC; ++j) {
+      s[j] += __shfl_xor(s[j], off, 64);
+      ss[j] += __shfl_xor(ss[j], off, 64);
+    }
+  }
+  if (CVp >= 64 || (int)(threadIdx.x & 63) < CVp) {
+    const int slot = CVp < 64 ? (threadIdx.x >> 6) * CVp + cv : threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { part[slot][j][0] = s[j]; part[slot][j][1] = ss[j]; }
+  }
   __syncthreads();
   const int cpg = p.C / p.groups;
   const int gs = p.groups / S;               // groups of this chunk
@@ -172,7 +186,7 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(SdmiGroupNormArgs p) {
     double acc = 0.0;
     for (int c = g * cpg; c < (g + 1) * cpg; ++c) {      // c: channel inside the chunk
       const int ccv = c / VEC, j = c % VEC;
-      for (int r = 0; r < R; ++r) acc += (double)part[r * CVp + ccv][j][which];
+      for (int r = 0; r < RR; ++r) acc += (double)part[r * CVp + ccv][j][which];
     }
     const double other = __shfl_xor(acc, 1, 64);
     const double sum = which ? other : acc, sq = which ? acc : other;
@@ -317,27 +331,40 @@ extern "C" int sdmi_groupnorm(const SdmiGroupNormArgs* a, void* stream) {
   if (rc) return rc;
   SDMI_REQUIRE(a->y, "null output");
   const int vec = a->dtype == SDMI_BF16 ? 8 : 4;
-  // single-pass kernel: the smallest channel split S (whole groups, >= SDMI_GN_MIN_SEG bytes of a
-  // row per workgroup) whose [HW][C/S] slab fits 16 vectors per thread, preferring >= 256 workgroups
+  // single-pass kernel when the image (or a whole-group channel chunk of it) fits a workgroup's registers
   {
-    const int cvt = a->C / vec;
-    int pick = 0;
-    for (int S = 1; S <= a->groups && S <= 32; S <<= 1) {
-      if (a->groups % S || cvt % S) break;
-      const int cv = cvt / S;
-      if (cv * 16 < 64 && S > 1) break;            // segments shorter than 64 B: not worth it
+    int nv_of_T[3] = {16, 16, 16};
+    const GnGeom gg = gn_pick(a->B, a->HW, a->C, a->groups, vec, nv_of_T);
+    if (gg.T) {
+      hipStream_t st = (hipStream_t)stream;
+      dim3 grid(a->B, gg.S);
+      const int cv = a->C / vec / gg.S;
       int cvp = 1;
       while (cvp < cv) cvp <<= 1;
-      const int R = 256 / cvp;
-      if ((a->HW + R - 1) / R > 16) continue;       // does not fit yet: split further
-      pick = S;
-      if ((long long)a->B * S >= 256) break;
-    }
-    if (pick) {
-      hipStream_t st = (hipStream_t)stream;
-      dim3 grid(a->B, pick);
-      if (a->dtype == SDMI_BF16) hipLaunchKernelGGL(gn_fused_kernel<bf16_t>, grid, dim3(256), 0, st, *a);
-      else hipLaunchKernelGGL(gn_fused_kernel<float>, grid, dim3(256), 0, st, *a);
+      const int RR = cvp < 64 ? gg.T / 64 : gg.T / cvp;
+      const size_t smem = ((size_t)RR * cvp * vec * 2 + 2 * 128) * sizeof(float);
+#define GN_GO2(T_, TH, NV_)                                                                        \
+  do {                                                                                             \
+    static bool attr = false;                                                                      \
+    if (!attr) {                                                                                   \
+      (void)hipFuncSetAttribute((const void*)gn_fused_kernel<T_, TH, NV_>,                         \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);            \
+      attr = true;                                                                                 \
+    }                                                                                              \
+    hipLaunchKernelGGL((gn_fused_kernel<T_, TH, NV_>), grid, dim3(TH), smem, st, *a);              \
+  } while (0)
+      // fewest registers that hold the slab: more workgroups per CU
+#define GN_GO(T_, TH)                                                                              \
+  do {                                                                                             \
+    if (gg.need <= 4) GN_GO2(T_, TH, 4); else if (gg.need <= 8) GN_GO2(T_, TH, 8); else GN_GO2(T_, TH, 16); \
+  } while (0)
+      if (a->dtype == SDMI_BF16) {
+        if (gg.T == 1024) GN_GO(bf16_t, 1024); else if (gg.T == 512) GN_GO(bf16_t, 512); else GN_GO(bf16_t, 256);
+      } else {
+        if (gg.T == 1024) GN_GO(float, 1024); else if (gg.T == 512) GN_GO(float, 512); else GN_GO(float, 256);
+      }
+#undef GN_GO2
+#undef GN_GO
       return sdmi_check_launch("groupnorm (fused)");
     }
   }

@@ -10,6 +10,7 @@
 // folds them into dgamma / dbeta.  Same fixed-channel thread organisation as the forward; fp64
 // combines, no atomics.
 #include "common.h"
+#include "gn_geom.h"
 
 namespace {
 
@@ -81,19 +82,22 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(SdmiGroupNormBwdArgs 
   }
 }
 
-// Small images (the whole [HW][C] slab of x and dy fits one workgroup's registers, nsplit == 1):
-// both streaming passes in one launch.
-template <typename T>
-__global__ __launch_bounds__(256) void gn_bwd_fused_kernel(SdmiGroupNormBwdArgs p) {
+// Small images (the [HW][C/S] slab of x and dy fits one workgroup's registers, nsplit == 1): both
+// streaming passes in one launch.  Same geometry as the forward single-pass kernel (gn_geom.h):
+// THREADS-wide workgroups, per-thread sums folded with xor-butterflies across the lanes that share a
+// vector column, one LDS entry per wave.
+template <typename T, int THREADS, int NV>
+__global__ __launch_bounds__(THREADS) void gn_bwd_fused_kernel(SdmiGroupNormBwdArgs p) {
   constexpr int VEC = Elem<T>::VEC;
-  constexpr int NV = 16;
-  __shared__ float part[256][VEC][2];
-  __shared__ float gsum[256][2];
+  extern __shared__ __attribute__((aligned(16))) float gnb_smem[];
   const int b = blockIdx.x;
   const int S = gridDim.y, sidx = blockIdx.y;            // channel chunk (whole groups) of this workgroup
   const int CV = p.C / VEC / S, CVp = next_pow2(CV);
   const int c_lo = sidx * CV * VEC;
-  const int R = 256 / CVp;
+  const int R = THREADS / CVp;
+  const int RR = CVp < 64 ? THREADS / 64 : R;
+  float (*part)[VEC][2] = reinterpret_cast<float (*)[VEC][2]>(gnb_smem);
+  float (*gsum)[2] = reinterpret_cast<float (*)[2]>(gnb_smem + RR * CVp * VEC * 2);
   const int cv = threadIdx.x % CVp, r0 = threadIdx.x / CVp;
   const bool act_c = cv < CV;
   const int cpg = p.C / p.groups;
@@ -143,14 +147,24 @@ __global__ __launch_bounds__(256) void gn_bwd_fused_kernel(SdmiGroupNormBwdArgs 
       dr[i] = pack16<T>(dy);               // (bf16: dz rounded once more, as dresidual stores it)
     }
   }
+  for (int off = CVp; off < 64; off <<= 1) {
 #pragma unroll
-  for (int j = 0; j < VEC; ++j) { part[threadIdx.x][j][0] = A[j]; part[threadIdx.x][j][1] = Bv[j]; }
+    for (int j = 0; j < VEC; ++j) {
+      A[j] += __shfl_xor(A[j], off, 64);
+      Bv[j] += __shfl_xor(Bv[j], off, 64);
+    }
+  }
+  if (CVp >= 64 || (int)(threadIdx.x & 63) < CVp) {
+    const int slot = CVp < 64 ? (threadIdx.x >> 6) * CVp + cv : threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { part[slot][j][0] = A[j]; part[slot][j][1] = Bv[j]; }
+  }
   __syncthreads();
   if (r0 == 0 && act_c) {                  // channel totals -> partial[b][0][c] (for dgamma/dbeta)
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
       double sa = 0.0, sb = 0.0;
-      for (int r = 0; r < R; ++r) { sa += part[r * CVp + cv][j][0]; sb += part[r * CVp + cv][j][1]; }
+      for (int r = 0; r < RR; ++r) { sa += part[r * CVp + cv][j][0]; sb += part[r * CVp + cv][j][1]; }
       part[cv][j][0] = (float)sa;          // row 0 of the column: no other thread reads rows r>0 of it now
       part[cv][j][1] = (float)sb;
       float* q = p.partial + (((long long)b * p.C) + c_lo + cv * VEC + j) * 2;
@@ -159,7 +173,7 @@ __global__ __launch_bounds__(256) void gn_bwd_fused_kernel(SdmiGroupNormBwdArgs 
     }
   }
   __syncthreads();
-  for (int g = threadIdx.x; g < gs; g += 256) {          // groups / channels local to the chunk
+  for (int g = threadIdx.x; g < gs; g += THREADS) {      // groups / channels local to the chunk
     double s1 = 0.0, s2 = 0.0;
     for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
       s1 += (double)p.gamma[c_lo + c] * part[c / VEC][c % VEC][0];
@@ -426,26 +440,38 @@ extern "C" int sdmi_groupnorm_bwd(const SdmiGroupNormBwdArgs* a, void* stream) {
   if (rows_per > a->HW) rows_per = a->HW;
   dim3 g3((a->HW + rows_per - 1) / rows_per, a->B);
   {
-    // single-pass kernel (x and dy slabs in registers), same channel split as the forward pass
-    const int cvt = a->C / vec;
-    int pick = 0;
-    for (int S = 1; S <= a->groups && S <= 32; S <<= 1) {
-      if (a->groups % S || cvt % S) break;
-      const int cv = cvt / S;
-      if (cv * 16 < 64 && S > 1) break;
+    // single-pass kernel (x and dy slabs in registers), geometry shared with the forward pass
+    int nv_of_T[3] = {16, 16, a->dtype == SDMI_BF16 ? 4 : 8};   // 1024 threads: 128 VGPRs each
+    const GnGeom gg = gn_pick(a->B, a->HW, a->C, a->groups, vec, nv_of_T);
+    if (gg.T) {
+      dim3 gf(a->B, gg.S);
+      const int cv = a->C / vec / gg.S;
       int cvp = 1;
       while (cvp < cv) cvp <<= 1;
-      const int R = 256 / cvp;
-      if ((a->HW + R - 1) / R > 16) continue;
-      pick = S;
-      if ((long long)a->B * S >= 256) break;
-    }
-    if (pick) {
-      dim3 gf(a->B, pick);
-      if (a->dtype == SDMI_BF16)
-        hipLaunchKernelGGL(gn_bwd_fused_kernel<bf16_t>, gf, dim3(256), 0, st, *a);
-      else
-        hipLaunchKernelGGL(gn_bwd_fused_kernel<float>, gf, dim3(256), 0, st, *a);
+      const int RR = cvp < 64 ? gg.T / 64 : gg.T / cvp;
+      const size_t smem = ((size_t)RR * cvp * vec * 2 + 2 * 256) * sizeof(float);
+#define GNB_GO(T_, TH, NV_)                                                                        \
+  do {                                                                                             \
+    static bool attr = false;                                                                      \
+    if (!attr) {                                                                                   \
+      (void)hipFuncSetAttribute((const void*)gn_bwd_fused_kernel<T_, TH, NV_>,                     \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);            \
+      attr = true;                                                                                 \
+    }                                                                                              \
+    hipLaunchKernelGGL((gn_bwd_fused_kernel<T_, TH, NV_>), gf, dim3(TH), smem, st, *a);            \
+  } while (0)
+#define GNB_PICK(T_, TH)                                                                           \
+  do {                                                                                             \
+    if (gg.need <= 4) GNB_GO(T_, TH, 4); else if (gg.need <= 8) GNB_GO(T_, TH, 8); else GNB_GO(T_, TH, 16); \
+  } while (0)
+      if (a->dtype == SDMI_BF16) {
+        if (gg.T == 1024) GNB_GO(bf16_t, 1024, 4); else if (gg.T == 512) GNB_PICK(bf16_t, 512); else GNB_PICK(bf16_t, 256);
+      } else {
+        if (gg.T == 1024) { if (gg.need <= 4) GNB_GO(float, 1024, 4); else GNB_GO(float, 1024, 8); }
+        else if (gg.T == 512) GNB_PICK(float, 512); else GNB_PICK(float, 256);
+      }
+#undef GNB_PICK
+#undef GNB_GO
       hipLaunchKernelGGL(pair_colsum_kernel, dim3((a->C + 15) / 16), dim3(256), 0, st, a->partial,
                          a->B, a->C, a->dbeta, a->dgamma, a->accumulate);
       return sdmi_check_launch("groupnorm_bwd (fused)");

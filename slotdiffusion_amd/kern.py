@@ -509,6 +509,9 @@ class GemmFn(torch.autograd.Function):
              lda=(Cin if is_conv else x.stride(-2)), ldy=ldy, B=B, H=H, W=W_,
              Cin=Cin, Ho=Ho, Wo=Wo, KH=kh, KW=kw, stride=stride, pad_t=pad[0], pad_l=pad[2],
              ups=int(ups), splits=splits, accumulate=1)
+        # non-direct destinations (channel-padded Cin, non-adjacent fused parameters) ACCUMULATE like
+        # the direct path does: a parameter used several times per step (per-frame modules,
+        # gradient accumulation over micro-batches) keeps every contribution
         if not direct:
             g = wb.model.grad_arena()
             o = 0
@@ -518,17 +521,17 @@ class GemmFn(torch.autograd.Function):
                 taps = kh * kw
                 ci_true = cnt // (rows * taps)
                 # [rows*taps, Cin(pad)] -> [rows*taps, ci_true]
-                ops.cast2d(dwbuf[o:o + rows].reshape(rows * taps, Cin), torch.float32,
-                           cols=ci_true, out=g[off:off + cnt].view(rows * taps, ci_true),
-                           ldd=ci_true)
+                tmp = ops.cast2d(dwbuf[o:o + rows].reshape(rows * taps, Cin), torch.float32,
+                                 cols=ci_true, ldd=ci_true)
+                call('sdmi_add', _st(), x=_p(g[off:]), z=_p(tmp), y=_p(g[off:]), dtype=_lib.F32, n=cnt)
                 o += rows
         if bnames is not None and bdst is None:
             g = wb.model.grad_arena()
             o = 0
             for nme in (bnames if not isinstance(bnames, str) else (bnames,)):
                 off, cnt = wb.model._offsets[nme]
-                ops.cast2d(btmp[o:o + cnt].view(-1, 1), torch.float32,
-                           out=g[off:off + cnt].view(-1, 1))
+                call('sdmi_add', _st(), x=_p(g[off:]), z=_p(btmp[o:]), y=_p(g[off:]), dtype=_lib.F32,
+                     n=cnt)
                 o += cnt
 
 
@@ -1037,8 +1040,13 @@ class KernGrad(Kern):
     """Training provider (autograd)."""
     training = True
     dropout_p = 0.0
-    seed = 0
     _drop_ctr = 0
+
+    def __init__(self, wb):
+        super().__init__(wb)
+        # run seed and data-parallel rank: ranks must not share dropout masks
+        rank = int(os.environ.get('RANK', 0))
+        self.seed = ((int(getattr(wb.model, 'seed', 0)) * 1000003 + rank * 7919 + 1) & 0xffffffff)
 
     def _p_drop(self, site):
         attr = 'train_dropout' if site == 'unet' else 'pred_dropout'
@@ -1060,6 +1068,13 @@ class KernGrad(Kern):
                                getattr(self.wb.model, 'step_seed', None))
 
     def begin_step(self):
+        """Start of a training step (eager or under graph capture): advance the device-side seed word
+        (a captured add, so replays draw new masks too) and restart the per-step site counter."""
+        m = self.wb.model
+        dev = m.arena().device
+        if getattr(m, 'step_seed', None) is None or m.step_seed.device != dev:
+            m.step_seed = torch.zeros(1, dtype=torch.int64, device=dev)
+        m.step_seed.add_(1)
         self._drop_ctr = 0
 
     def conv(self, x, wname, bname=None, *, kh=3, kw=3, stride=1, pad=(1, 1, 1, 1), ups=False,

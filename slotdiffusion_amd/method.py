@@ -67,7 +67,8 @@ class Method:
         assert p.optimizer.lower() in ('adam', 'adamw') and p.weight_decay == 0., \
             'the path covers Adam without weight decay (every shipped config)'
         total = p.max_epochs * len(self.datamodule)
-        clip = p.clip_grad if getattr(p, 'clip_grad', -1) and p.clip_grad > 0 else 0.0
+        clip = self._get('clip_grad', 0) or 0
+        clip = clip if clip > 0 else 0.0
         return FusedAdam(self.model, lr=p.lr, dec_lr=self._get('dec_lr', p.lr), clip_grad=clip,
                          total_steps=total, warmup_pct=p.warmup_steps_pct)
 
@@ -82,8 +83,6 @@ class Method:
 
     def _eager_step(self, batch):
         self.optimizer.zero_grad()
-        if hasattr(self.model, 'KG'):
-            self.model.KG().begin_step()
         total, losses = self._loss(batch)
         total.backward()
         if self.world > 1:
@@ -92,27 +91,32 @@ class Method:
         return total.detach()
 
     def fit(self, resume_from='', san_check_val_step=0, max_steps=None):
+        ckp = None
         if resume_from:
-            self.model.load_weight(resume_from)
+            ckp = torch.load(resume_from, map_location='cpu')
+            self.model.load_state_dict(ckp.get('state_dict', ckp))
         self.model.train()
         if self.use_ddp:
             parallel.broadcast_parameters(self.model.arena())
         self.optimizer = self._configure_optimizers()
+        if ckp is not None:
+            self._restore_training_state(ckp)
         graphed = None
-        for epoch in range(self.params.max_epochs):
+        steps_per_epoch = len(self.datamodule)
+        for epoch in range(self.it // max(1, steps_per_epoch), self.params.max_epochs):
             for batch in self.datamodule.train_loader(epoch):
+                if max_steps is not None and self.it >= max_steps:
+                    return self
                 if self.use_graph and graphed is None and len(self._loss_names()) == 1:
                     ar = True if self.world > 1 else None      # overlapped gradient all-reduce
                     key = self._loss_names()[0]
-                    # capturing the step runs two (real) warm-up steps on this first batch
+                    # (the capture's warm-up passes are rolled back: optim.GraphedTrainStep)
                     graphed = GraphedTrainStep(self.model, self.optimizer, batch, allreduce=ar,
                                                loss_key=key, loss_weight=self._get(f'{key}_w', 1.0),
                                                world=self.world)
-                    self.it += 2
-                else:
-                    loss = graphed(batch) if graphed is not None else self._eager_step(batch)
-                    self.it += 1
-                    self.history.append(loss)
+                loss = graphed(batch) if graphed is not None else self._eager_step(batch)
+                self.it += 1
+                self.history.append(loss)
                 self.model._training_step_end(self)
                 if max_steps is not None and self.it >= max_steps:
                     return self
@@ -125,7 +129,37 @@ class Method:
         return ['img_recon_loss'] if isinstance(self.model, SA) else ['denoise_loss']
 
     def save(self, path):
-        torch.save({'state_dict': self.model.state_dict(), 'it': self.it}, path)
+        """Checkpoint = weights + everything a resumed run needs to continue the same trajectory:
+        Adam moments, step (bias correction and schedule position), iteration, EMA shadow."""
+        ckp = {'state_dict': self.model.state_dict(), 'it': self.it}
+        if self.optimizer is not None:
+            ckp['optimizer'] = self.optimizer.state_dict()
+        dm = getattr(self.model, 'dm_decoder', None)
+        if dm is not None and getattr(dm, 'use_ema', False):
+            ckp['ema'] = {'shadow': dm._ema_shadow.detach().cpu(), 'num_updates': dm.ema_num_updates,
+                          'decay': dm.ema_decay}
+        seed = getattr(self.model, 'step_seed', None)
+        if seed is not None:
+            ckp['step_seed'] = int(seed)
+        if self.model.arena().is_cuda:           # t / noise draws continue the same stream
+            ckp['cuda_rng_state'] = torch.cuda.get_rng_state(self.model.arena().device)
+        torch.save(ckp, path)
+
+    def _restore_training_state(self, ckp):
+        self.it = int(ckp.get('it', 0))
+        if 'optimizer' in ckp:
+            self.optimizer.load_state_dict(ckp['optimizer'])
+        dm = getattr(self.model, 'dm_decoder', None)
+        if dm is not None and 'ema' in ckp:
+            e = ckp['ema']
+            dm.enable_ema(e['decay'], use_num_updates=e['num_updates'] >= 0)
+            dm._ema_shadow.copy_(e['shadow'])
+            dm.ema_num_updates = e['num_updates']
+        if 'cuda_rng_state' in ckp and self.model.arena().is_cuda:
+            torch.cuda.set_rng_state(ckp['cuda_rng_state'], self.model.arena().device)
+        if 'step_seed' in ckp:
+            dev = self.model.arena().device
+            self.model.step_seed = torch.full((1,), ckp['step_seed'], dtype=torch.int64, device=dev)
 
 
 def build_method(**kwargs):

@@ -152,7 +152,12 @@ class LDM(_Owned):
         with torch.set_grad_enabled(grad):
             pred = r._unet_eps(xt, t.float(), slots, Kp)
             # the 4th (zero pad) channel adds no error but is counted in n: rescale 4/3
-            gt = nz if self.pred_target == 'eps' else x0       # ldm.py:76-79
+            if self.pred_target == 'eps':                      # ldm.py:71-79
+                gt = nz
+            elif self.pred_target == 'v':                      # v = alpha_t * noise - sigma_t * x0
+                gt = ops.row_lincomb(nz, x0, ca, (-cb).contiguous())
+            else:
+                gt = x0
             if grad:
                 loss = kern.MseFn.apply(pred, gt, 4.0 / 3.0)
             else:
@@ -265,6 +270,13 @@ class SlotModelBase(FlatModule):
     def _to_nhwc(self, img):
         return ops.nchw_to_nhwc(img.float(), self.compute_dtype, ops.vec_of(self.compute_dtype))
 
+    def _begin_train_forward(self):
+        """Every training forward (eager, captured or replayed) starts a new dropout step: the
+        device seed word advances, so consecutive steps -- and data-parallel ranks -- draw
+        different masks."""
+        if self.training and torch.is_grad_enabled():
+            self.KG().begin_step()
+
     def _training_step_end(self, method=None):
         pass
 
@@ -281,7 +293,7 @@ class SADiffusion(SlotModelBase):
                  if k in dd}
         super().__init__(sp, schedule_kwargs=sched, seed=seed,
                          node_classes={'dm_decoder': LDM, 'dm_decoder.vae': VQVAEWrapper})
-        assert dd.get('pred_target', 'eps') in ('eps', 'x0')          # ddpm.py:79
+        assert dd.get('pred_target', 'eps') in ('eps', 'x0', 'v')     # video_based ddpm.py:79
         self.dm_decoder.pred_target = dd.get('pred_target', 'eps')
         self.resolution = tuple(resolution)
         self.eps = eps
@@ -396,7 +408,8 @@ class SADiffusion(SlotModelBase):
         Kp = self.K()
         tab = {k: getattr(dm, k).detach().double().cpu() for k in
                ('sqrt_recip_alphas_bar', 'sqrt_recipm1_alphas_bar', 'posterior_mean_coef1',
-                'posterior_mean_coef2', 'posterior_log_variance_clipped')}
+                'posterior_mean_coef2', 'posterior_log_variance_clipped', 'sqrt_alphas_bar',
+                'sqrt_one_minus_alphas_bar')}
         ctx_kv = u.context_kv(Kp, self._ctx(cond))
         B = x.shape[0]
         code = self.bank().f(self.vq_key)
@@ -410,6 +423,9 @@ class SADiffusion(SlotModelBase):
                 if dm.pred_target == 'eps':
                     x0 = ops.lincomb(float(tab['sqrt_recip_alphas_bar'][t]), x,
                                      -float(tab['sqrt_recipm1_alphas_bar'][t]), out)
+                elif dm.pred_target == 'v':          # cond_ddpm.py:63-67: x0 = alpha_t x - sigma_t v
+                    x0 = ops.lincomb(float(tab['sqrt_alphas_bar'][t]), x,
+                                     -float(tab['sqrt_one_minus_alphas_bar'][t]), out)
                 else:
                     x0 = out
                 x0 = ops.vq_nearest(x0, code, scale=self.z_scale, want_idx=False)[1]
@@ -464,6 +480,7 @@ class SADiffusion(SlotModelBase):
         code = self.bank().f(self.vq_key)
         nfe = [0]
         x_start = self.dm_decoder.pred_target == 'x0'
+        v_pred = self.dm_decoder.pred_target == 'v'
 
         def data_pred(xc, e):
             rv = rv_all[nfe[0]:nfe[0] + 1].expand(B, -1)      # pitch-0 view: same row for all b
@@ -471,6 +488,8 @@ class SADiffusion(SlotModelBase):
             eps = u.forward(Kp, self._unet_in(xc), rv, ctx_kv)
             if x_start:        # model_wrapper 'x_start' (dpm_solver.py:358-361): output -> noise
                 eps = ops.lincomb(1.0, xc, -e['alpha'], eps, div=e['sigma'])
+            elif v_pred:       # model_wrapper 'v' (dpm_solver.py:362-365): alpha_t * v + sigma_t * x
+                eps = ops.lincomb(e['alpha'], eps, e['sigma'], xc)
             x0 = ops.lincomb(1.0, xc, -e['sigma'], eps, div=e['alpha'])
             return ops.vq_nearest(x0, code, scale=self.z_scale, want_idx=False)[1]
 
@@ -519,6 +538,7 @@ class SADiffusion(SlotModelBase):
         if kwargs.pop('log_images', False):
             return self.log_images(data_dict, **kwargs)
         assert kwargs == {}
+        self._begin_train_forward()
         slots, masks = self.encode(data_dict['img'])
         return {'masks': masks, 'slots': slots}
 
@@ -680,6 +700,7 @@ class SA(SlotModelBase):
         return recon_img, recons, masks.detach().view(B, N, 1, H, W), slots
 
     def forward(self, data_dict):
+        self._begin_train_forward()
         slots = self.encode(data_dict['img'])
         if self.testing:
             return {'slots': slots}
@@ -748,6 +769,7 @@ class SAVi(SA):
         """savi.py:445-475 (clips longer than clip_len are not split: 288 GB of HBM)."""
         img = data_dict['img']
         B, T = img.shape[:2]
+        self._begin_train_forward()
         slots = self.encode(img)
         if self.testing:
             return {'slots': slots}
@@ -843,6 +865,7 @@ class VQVAE(SlotModelBase):
             quant, quant_loss, token_id = self.encode_quantize(img)
             return {'recon': self.decode(quant), 'token_id': token_id, 'quant_loss': quant_loss}
         xf, bt = self._flat(img)
+        self._begin_train_forward()
         Kp = self.KG()
         z = engine.vae_encode(Kp, self._to_nhwc(xf), self.ed, prefix='')
         off, cnt = self._offsets[self.vq_key]

@@ -123,6 +123,7 @@ class FlatModule(nn.Module):
         super().__init__()
         node_classes = node_classes or {}
         self._spec = list(spec_list)
+        self.seed = int(seed)               # run seed (also keys the dropout generator)
         gen = torch.Generator().manual_seed(seed)
         sched = ddpm_schedule(**schedule_kwargs) if schedule_kwargs is not None else None
         # ---- arena layout: trainable params in spec order, then frozen ones

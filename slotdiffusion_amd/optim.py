@@ -36,22 +36,40 @@ class FusedAdam:
         self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
         self.lr_dev = torch.tensor([self.lr, self.dec_lr], dtype=torch.float32, device=dev)
         self._lr_ring = torch.empty(64, 2, dtype=torch.float32)
+        self._lr_ev = [None] * 64             # copy-done event per ring slot
         if dev.type == 'cuda':
             self._lr_ring = self._lr_ring.pin_memory()
-        self.total_steps, self.warmup = total_steps, (int(warmup_pct * total_steps)
-                                                       if total_steps else 0)
+        # warm-up length stays a float, as the reference passes `warmup_steps_pct * total_steps`
+        self.total_steps, self.warmup = total_steps, (float(warmup_pct * total_steps)
+                                                       if total_steps else 0.0)
 
-    def lr_scale(self, it):
-        """CosineAnnealingWarmupRestarts(min_lr=0) factor at iteration `it` (single cycle)."""
+    def lr_scale(self, done):
+        """CosineAnnealingWarmupRestarts(first_cycle_steps=total, min_lr=0, single cycle) factor for
+        the optimiser step that follows `done` completed steps -- the scheduler is stepped after the
+        optimiser, so the first update runs at min_lr = 0 and update k at (k-1)/warmup (nerv's
+        scheduler, recalled: not under /root/reference)."""
         if not self.total_steps:
             return 1.0
-        if it < self.warmup:
-            return it / max(1, self.warmup)
-        prog = (it - self.warmup) / max(1, self.total_steps - self.warmup)
+        if done < self.warmup:
+            return done / self.warmup
+        span = self.total_steps - self.warmup
+        prog = (done - self.warmup) / span if span > 0 else 1.0
         return 0.5 * (1. + math.cos(math.pi * min(1.0, prog)))
 
     def zero_grad(self):
         self.model.grad_arena().zero_()
+
+    def state_dict(self):
+        """Everything a resumed run needs: moments, step (bias correction + schedule position)."""
+        return {'m': self.m.detach().cpu(), 'v': self.v.detach().cpu(), 'step_count': self.step_count,
+                'total_steps': self.total_steps, 'warmup': self.warmup}
+
+    def load_state_dict(self, sd):
+        self.m.copy_(sd['m'])
+        self.v.copy_(sd['v'])
+        self.step_count = int(sd['step_count'])
+        self.step_dev.fill_(self.step_count)
+        self.set_lr_for_next_step()
 
     def grad_norm(self):
         """Global L2 norm of the last step's gradients (syncs; diagnostics only)."""
@@ -59,10 +77,16 @@ class FusedAdam:
 
     def set_lr_for_next_step(self):
         """Host side of the schedule: refresh the device lr scalars (outside any graph)."""
-        scale = self.lr_scale(self.step_count + 1)
-        slot = self._lr_ring[self.step_count % 64]      # ring: the async copy may still be pending
+        scale = self.lr_scale(self.step_count)
+        i = self.step_count % 64
+        if self._lr_ev[i] is not None:                  # the slot's previous async copy has landed
+            self._lr_ev[i].synchronize()
+        slot = self._lr_ring[i]
         slot[0], slot[1] = self.lr * scale, self.dec_lr * scale
         self.lr_dev.copy_(slot, non_blocking=True)
+        if self.lr_dev.is_cuda:
+            self._lr_ev[i] = torch.cuda.Event()
+            self._lr_ev[i].record()
 
     @torch.no_grad()
     def step(self, capturable=False):
@@ -118,7 +142,7 @@ class GraphedTrainStep:
         self.static = {k: v.clone() for k, v in example_batch.items()}
         dev = model.arena().device
         if getattr(model, 'step_seed', None) is None or model.step_seed.device != dev:
-            model.step_seed = torch.zeros(1, dtype=torch.int64, device=dev)
+            model.step_seed = torch.zeros(1, dtype=torch.int64, device=dev)   # dropout seed word
         self.world = world
         if allreduce is not None and world is None:
             import torch.distributed as dist
@@ -133,6 +157,11 @@ class GraphedTrainStep:
             self.allreduce = allreduce = lambda g: parallel.allreduce_gradients(g, self.world)
         self.loss = None
         self._slots = self._dslots = None
+        # The warm-up passes below (lazy operands, func attributes, allocator pool) are real steps on
+        # the example batch: weights, moments, step counters and the dropout seed word are
+        # snapshotted and rolled back, so a captured run walks the same trajectory as an eager one.
+        snap = (model.arena().detach().clone(), opt.m.clone(), opt.v.clone(), opt.step_count,
+                opt.step_dev.clone(), model.step_seed.clone())
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -152,6 +181,16 @@ class GraphedTrainStep:
                 self._update()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        with torch.no_grad():
+            model.arena().copy_(snap[0])
+            opt.m.copy_(snap[1])
+            opt.v.copy_(snap[2])
+            opt.step_count = snap[3]
+            opt.step_dev.copy_(snap[4])
+            model.step_seed.copy_(snap[5])
+        model.weights_updated()
+        del snap
+        torch.cuda.synchronize()
         self.g_fb = torch.cuda.CUDAGraph()
         self.g_enc = None
         if self.overlap:
@@ -170,9 +209,7 @@ class GraphedTrainStep:
     # -- pieces ---------------------------------------------------------------------------
     def _forward_loss(self):
         m = self.model
-        m.grad_arena().zero_()
-        m.step_seed.add_(1)
-        m.KG().begin_step()
+        m.grad_arena().zero_()           # (the model's forward starts a new dropout step itself)
         out = m(self.static)
         loss = m.calc_train_loss(self.static, out)[self.loss_key]
         if self.loss_weight != 1.0:

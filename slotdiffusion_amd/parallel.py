@@ -9,8 +9,49 @@ keeps every link busy.  Buckets are launched asynchronously on the collective st
 arena order (the order backward finishes them) and the 1/world scaling is folded into the fused
 clip+Adam kernel's inputs by scaling the arena once.
 """
+import os
+import sys
+
 import torch
 import torch.distributed as dist
+
+
+def respawn_under_launcher(n_ranks, script, argv, port=None):
+    """Replace this process by `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    script argv...` (one rank per GPU over RCCL; the reference's launch is
+    `torch.distributed.launch --nproc_per_node=$GPUS`, scripts/sbatch_run.sh:36-39).  Used by
+    `bench.py --gpus N` when it was started without a launcher.  Does not return."""
+    port = port or os.environ.get('MASTER_PORT', '29517')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n_ranks}',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), script] + list(argv)
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC (RCCL across processes)
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os.execve(sys.executable, cmd, env)
+
+
+def grad_bf16_enabled():
+    """SDMI_GRAD_BF16=1: gradients cross xGMI as bf16 (277 MB instead of 554 MB per step for
+    SADiffusion); accumulation inside the collective is RCCL's, the average is applied in fp32."""
+    return os.environ.get('SDMI_GRAD_BF16', '0') == '1'
+
+
+def _to_bf16(x):
+    if x.is_cuda:
+        from . import ops
+        return ops.act(x, None, torch.bfloat16)
+    return x.to(torch.bfloat16)
+
+
+def _from_bf16_(dst, src):
+    if dst.is_cuda:
+        from . import _lib
+        _lib.call('sdmi_act', torch.cuda.current_stream().cuda_stream, x=src.data_ptr(),
+                  y=dst.data_ptr(), src_dtype=_lib.BF16, dst_dtype=_lib.F32, act=0, n=dst.numel())
+    else:
+        dst.copy_(src)
+    return dst
 
 
 def shard_range(n_items, rank, world):
@@ -32,13 +73,22 @@ def allreduce_gradients(arena, world=None, n_buckets=4, group=None):
         world = dist.get_world_size(group)
     if world == 1:
         return arena
-    works = []
-    for lo, hi in reversed(bucket_bounds(arena.numel(), n_buckets)):
-        works.append(dist.all_reduce(arena[lo:hi], op=dist.ReduceOp.SUM, group=group, async_op=True))
-    for w in works:
+    for w in allreduce_range_async(arena, 0, arena.numel(), n_buckets, group):
         w.wait()
     arena.mul_(1.0 / world)
     return arena
+
+
+class _Bf16Work:
+    """Work handle of a bf16 bucket: wait() finishes the collective and widens the sum back into
+    the fp32 gradient range."""
+
+    def __init__(self, work, dst, buf):
+        self.work, self.dst, self.buf = work, dst, buf
+
+    def wait(self):
+        self.work.wait()
+        _from_bf16_(self.dst, self.buf)
 
 
 def allreduce_range_async(arena, lo, hi, n_buckets=2, group=None):
@@ -48,8 +98,14 @@ def allreduce_range_async(arena, lo, hi, n_buckets=2, group=None):
     if hi <= lo:
         return works
     view = arena[lo:hi]
+    bf16 = grad_bf16_enabled()
     for a, b in reversed(bucket_bounds(hi - lo, n_buckets)):
-        works.append(dist.all_reduce(view[a:b], op=dist.ReduceOp.SUM, group=group, async_op=True))
+        if bf16:
+            buf = _to_bf16(view[a:b])
+            works.append(_Bf16Work(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group, async_op=True),
+                                   view[a:b], buf))
+        else:
+            works.append(dist.all_reduce(view[a:b], op=dist.ReduceOp.SUM, group=group, async_op=True))
     return works
 
 

@@ -134,6 +134,17 @@ def movie_cfg():
     return cfg
 
 
+def movid_cfg(num_slots=11, clip_len=6):
+    """video_based/configs/savi_ldm/savi_ldm_movid_params-res128.py with the two values BASELINE.json
+    config 2 overrides (11 slots, 6-frame clips; the file ships 15 / 3).  Everything else equals
+    the MOVi-E config (only dataset level and checkpoint path differ)."""
+    cfg = movie_cfg()
+    cfg['slot_dict']['num_slots'] = num_slots
+    cfg['clip_len'] = clip_len
+    cfg['dec_dict']['vae_dict']['vqvae_ckp_path'] = './pretrained/vqvae_movid_params-res128.pth'
+    return cfg
+
+
 def oracle_weights_video(cfg, seed=1234):
     from slotdiffusion_amd.module import build_grid, ddpm_schedule
     sp = spec.savi_diffusion(cfg['resolution'], cfg['slot_dict'], cfg['enc_dict'], cfg['dec_dict'],

@@ -147,54 +147,65 @@ def test_bf16_path_deviation():
     x0 = m.dm_decoder.vae.encode(img)
     REPORT['bf16_x0_rel_l2'] = float((x0.cpu() - G['x0']).norm() / G['x0'].norm())
     _dump()
-    assert REPORT['bf16_eps_rel_l2'] < 0.05 and REPORT['bf16_x0_rel_l2'] < 0.05
-    assert REPORT['bf16_masks_eval_argmax_agree'] > 0.97
+    # measured on MI355X: eps rel-L2 1.3 %, mask agreement 99.5 % -- bounds leave ~1.5x head-room
+    assert REPORT['bf16_eps_rel_l2'] < 0.02 and REPORT['bf16_x0_rel_l2'] < 0.02
+    assert REPORT['bf16_masks_eval_argmax_agree'] > 0.99
 
 
-def test_video_model_fp32():
-    """SAViDiffusion (MOVi-E config, 15 slots): predictor, per-frame Slot Attention, masks, and the
-    train-step gradients of every tensor against the reference's (tests/golden/savidiff_b1t3.npz)."""
+def _video_parity(cfg, fixture, T, seed, tag):
     from slotdiffusion_amd.models import SAViDiffusion
-    cfg = C.movie_cfg()
-    G = C.load_golden('savidiff_b1t3.npz')
-    m = SAViDiffusion(cfg['resolution'], 3, cfg['slot_dict'], cfg['enc_dict'], cfg['dec_dict'],
+    G = C.load_golden(fixture)
+    m = SAViDiffusion(cfg['resolution'], T, cfg['slot_dict'], cfg['enc_dict'], cfg['dec_dict'],
                       cfg['pred_dict'], cfg['loss_dict'], compute_dtype=torch.float32)
     det_fill_(m.state_dict().items(), skip=is_buffer_name)
     m.train_dropout = m.pred_dropout = 0.0
     m = m.cuda()
-    img = C.make_inputs(3, seed=11)[0].view(1, 3, 3, 128, 128).cuda()
+    img = C.make_inputs(T, seed=seed)[0].view(1, T, 3, 128, 128).cuda()
     m.train()
     m.grad_arena().zero_()
     out = m(dict(img=img))
     R = {}
-    R['video_slots_maxerr'] = maxerr(out['slots'].detach(), G['slots'])
-    R['video_masks_argmax_agree'] = float(
+    R[tag + '_slots_maxerr'] = maxerr(out['slots'].detach(), G['slots'])
+    R[tag + '_masks_argmax_agree'] = float(
         (out['masks'].cpu().argmax(2) == G['masks_train_argmax'].long()).float().mean())
     loss = m.calc_train_loss(dict(img=img, t=G['t'].cuda(), noise=G['noise'].cuda()), out)[
         'denoise_loss']
     loss.backward()
-    R['video_loss'] = float(loss.detach())
-    R['video_loss_ref'] = float(G['train_loss'])
+    R[tag + '_loss'] = float(loss.detach())
+    R[tag + '_loss_ref'] = float(G['train_loss'])
     named = dict(m.named_parameters())
     names = [str(n) for n in G['grad_norms_names']]
     mine = torch.tensor([float(named[n].grad.norm()) for n in names])
     ref = G['grad_norms']
     big = ref > 1e-6
     rel = ((mine - ref).abs() / (ref.abs() + 1e-12))[big]
-    R['video_grad_norm_max_rel_vs_reference'] = float(rel.max())
+    R[tag + '_grad_norm_max_rel_vs_reference'] = float(rel.max())
     errs = {k[5:]: float((named[k[5:]].grad.float().cpu() - G[k]).abs().max() / G[k].abs().max())
             for k in G if k.startswith('grad:')}
-    R['video_grad_tensor_rel_err'] = errs
+    R[tag + '_grad_tensor_rel_err'] = errs
     m.eval()
     oe = m(dict(img=img))
-    R['video_masks_eval_argmax_agree'] = float(
+    R[tag + '_masks_eval_argmax_agree'] = float(
         (oe['masks'].cpu().argmax(2) == G['masks_eval_argmax'].long()).float().mean())
     REPORT.update(R)
     _dump()
-    assert R['video_slots_maxerr'] <= 1e-4 and R['video_masks_argmax_agree'] == 1.0
-    assert R['video_masks_eval_argmax_agree'] == 1.0
-    assert abs(R['video_loss'] - R['video_loss_ref']) <= 1e-4
-    assert R['video_grad_norm_max_rel_vs_reference'] <= 2e-2 and max(errs.values()) <= 2e-2
+    assert R[tag + '_slots_maxerr'] <= 1e-4 and R[tag + '_masks_argmax_agree'] == 1.0
+    assert R[tag + '_masks_eval_argmax_agree'] == 1.0
+    assert abs(R[tag + '_loss'] - R[tag + '_loss_ref']) <= 1e-4
+    assert R[tag + '_grad_norm_max_rel_vs_reference'] <= 2e-2 and max(errs.values()) <= 2e-2
+
+
+def test_video_model_fp32():
+    """SAViDiffusion (MOVi-E config, 15 slots, T=3): predictor, per-frame Slot Attention, masks, and
+    the train-step gradients of every tensor against the reference's (tests/golden/savidiff_b1t3.npz)."""
+    _video_parity(C.movie_cfg(), 'savidiff_b1t3.npz', 3, 11, 'video')
+
+
+def test_video_model_cfg2_11slots_6frames_fp32():
+    """BASELINE config 2: video SAVi+LDM on the MOVi-D config with 11 slots and 6-frame clips
+    (tests/golden/savidiff_b1t6_n11.npz, generated from the reference by tools/gen_golden.py
+    video11x6): slots, train / eval mask argmax, loss and all parameter-gradient norms."""
+    _video_parity(C.movid_cfg(), 'savidiff_b1t6_n11.npz', 6, 13, 'video_cfg2')
 
 
 def _plain_sa(dtype):
@@ -378,6 +389,56 @@ def test_ancestral_sampler_and_x0_target_fp32():
     assert REPORT['x0_dpm_step0_maxerr'] <= 1e-4 and REPORT['x0_dpm_final_frac_gt_1e-3'] <= 0.02
     assert REPORT['x0_train_loss_err'] <= 1e-5 * max(1.0, float(A['x0_train_loss']))
     assert REPORT['x0_grad_norm_max_rel'] <= 2e-3
+
+
+def test_v_prediction_target_fp32():
+    """SURVEY 8(f) row 2, pred_target='v': v loss target (+ gradient norms), ancestral step through
+    the v branch, DPM-Solver++ with the 'v' wrapper -- SAViDiffusion against the video reference run
+    in tests/golden/vpred_b1t2.npz (only video_based accepts 'v')."""
+    from slotdiffusion_amd import ops
+    from slotdiffusion_amd.models import SAViDiffusion
+    cfg = C.movie_cfg()
+    cfg['dec_dict']['diffusion_dict']['pred_target'] = 'v'
+    A = C.load_golden('vpred_b1t2.npz')
+    m = SAViDiffusion(cfg['resolution'], 2, cfg['slot_dict'], cfg['enc_dict'], cfg['dec_dict'],
+                      cfg['pred_dict'], cfg['loss_dict'], compute_dtype=torch.float32)
+    det_fill_(m.state_dict().items(), skip=is_buffer_name)
+    m.train_dropout = m.pred_dropout = 0.0
+    m = m.cuda().eval()
+    m.use_graph = False
+    assert m.dm_decoder.pred_target == 'v'
+    slots = A['slots'].cuda()
+    nz = A['anc_noise'].cuda()
+    agree, x_in = 1.0, A['x_T']
+    for j, tv in enumerate(int(v) for v in A['anc_t'].tolist()):
+        x = ops.nchw_to_nhwc(x_in.cuda(), torch.float32, 4)
+        x_dev = next(m._ancestral_steps(x, slots, [tv], noises=[nz]))[0]
+        ok = ((ops.nhwc_to_nchw(x_dev, 3).cpu() - A['v_anc_x'][j]).abs() <= 1e-4).float().mean()
+        agree = min(agree, float(ok))
+        x_in = A['v_anc_x'][j]
+    REPORT['v_ancestral_step_agree'] = agree
+    x, tr = m.dm_decoder.generate_imgs(cond=slots, batch_size=2, x_T=A['x_T'].cuda(), ret_intermed=True)
+    REPORT['v_dpm_step0_maxerr'] = maxerr(tr[0], A['v_dpm_trace'][0])
+    REPORT['v_dpm_final_frac_gt_1e-3'] = float(((x.cpu() - A['v_dpm_final']).abs() > 1e-3).float().mean())
+    m.train()
+    for p in m.parameters():
+        p.grad = None
+    img = C.make_inputs(2, seed=17)[0].view(1, 2, 3, 128, 128).cuda()
+    data = dict(img=img, t=A['t'].long().cuda(), noise=A['noise'].cuda())
+    loss = m.calc_train_loss(data, m(data))['denoise_loss']
+    loss.backward()
+    named = dict(m.named_parameters())
+    names = [str(n) for n in A['v_grad_norms_names']]
+    mine = torch.tensor([float(named[n].grad.norm()) for n in names])
+    big = A['v_grad_norms'] > 1e-6
+    rel = ((mine - A['v_grad_norms']).abs() / (A['v_grad_norms'].abs() + 1e-12))[big]
+    REPORT['v_train_loss_err'] = abs(float(loss.detach()) - float(A['v_train_loss']))
+    REPORT['v_grad_norm_max_rel'] = float(rel.max())
+    _dump()
+    assert REPORT['v_ancestral_step_agree'] >= 0.995
+    assert REPORT['v_dpm_step0_maxerr'] <= 1e-4 and REPORT['v_dpm_final_frac_gt_1e-3'] <= 0.02
+    assert REPORT['v_train_loss_err'] <= 1e-5 * max(1.0, float(A['v_train_loss']))
+    assert REPORT['v_grad_norm_max_rel'] <= 2e-2
 
 
 def test_savi_video_baseline_fp32():

@@ -132,3 +132,42 @@ def test_registry_modules_expose_the_plugin_api():
     from slotdiffusion_amd.img_based import build_model
     m = build_model(C.make_params('SA'))
     assert type(m).__name__ == 'SA' and len(list(m.parameters())) == 83
+
+
+def test_lr_schedule_closed_form():
+    """FusedAdam.lr_scale = nerv's CosineAnnealingWarmupRestarts(first_cycle_steps=total, min_lr=0,
+    warmup_steps=pct*total as a float) stepped after the optimiser: update k runs at the factor of
+    k-1 completed steps (0 for the first update).  Closed form at it = 0, warmup-1, warmup, mid,
+    total (img_based/method.py:275-285)."""
+    import math
+    from slotdiffusion_amd.optim import FusedAdam
+
+    class Fake:
+        def arena_ranges(self):
+            return 8, 16, 16
+
+        def arena(self):
+            return torch.zeros(16)
+
+    total, pct = 1000, 0.05
+    opt = FusedAdam(Fake(), lr=1e-4, dec_lr=2e-4, total_steps=total, warmup_pct=pct)
+    w = pct * total
+    assert opt.warmup == w and isinstance(opt.warmup, float)
+    assert opt.lr_scale(0) == 0.0
+    assert abs(opt.lr_scale(int(w) - 1) - (w - 1) / w) < 1e-12
+    assert abs(opt.lr_scale(int(w)) - 1.0) < 1e-12
+    mid = int(w) + (total - int(w)) // 2
+    ref = 0.5 * (1 + math.cos(math.pi * (mid - w) / (total - w)))
+    assert abs(opt.lr_scale(mid) - ref) < 1e-12 and abs(ref - 0.5) < 2e-3
+    assert abs(opt.lr_scale(total)) < 1e-12
+    # fractional warm-up length (pct * total not an integer) stays a float
+    opt2 = FusedAdam(Fake(), lr=1.0, total_steps=30, warmup_pct=0.05)
+    assert opt2.warmup == 1.5 and abs(opt2.lr_scale(1) - 1 / 1.5) < 1e-12 and opt2.lr_scale(2) < 1.0
+    # the device lr pair follows the schedule: before update 1 it is (0, 0)
+    opt.set_lr_for_next_step()
+    assert opt.lr_dev.tolist() == [0.0, 0.0]
+    opt.step_count = int(w)
+    opt.set_lr_for_next_step()
+    assert abs(opt.lr_dev[0].item() - 1e-4) < 1e-10 and abs(opt.lr_dev[1].item() - 2e-4) < 1e-10
+    # no schedule configured: constant factor
+    assert FusedAdam(Fake(), lr=1.0).lr_scale(123) == 1.0

@@ -163,6 +163,26 @@ def test_video_model_oracle():
         assert torch.equal(me.argmax(2), G['masks_eval_argmax'].long())
 
 
+def test_video_model_oracle_cfg2_11slots_6frames():
+    """BASELINE config 2 (MOVi-D, 11 slots x 6 frames): the oracle against the reference fixture
+    tests/golden/savidiff_b1t6_n11.npz (tools/gen_golden.py video11x6)."""
+    cfg = C.movid_cfg()
+    G = C.load_golden('savidiff_b1t6_n11.npz')
+    W = C.oracle_weights_video(cfg)
+    img = C.make_inputs(6, seed=13)[0].view(1, 6, 3, 128, 128)
+    assert torch.equal(torch.stack([img.double().sum(), (img.double() ** 2).sum()]), G['img_checksum'])
+    rplan = spec.resnet18_plan(False)
+    with torch.no_grad():
+        close(O.transformer_predictor(W, W['init_latents'], 2, 4), G['pred_of_init'], 1e-5)
+        slots, masks = O.savi_encode(W, img, rplan, 2, True, 2, 4)
+        assert slots.shape == (1, 6, 11, 192)
+        close(slots, G['slots'], 5e-5)
+        close(masks[:, :, :, ::2, 1::2], G['masks_train_sub'], 1e-5)
+        assert torch.equal(masks.argmax(2), G['masks_train_argmax'].long())
+        _, me = O.savi_encode(W, img, rplan, 2, False, 2, 4)
+        assert torch.equal(me.argmax(2), G['masks_eval_argmax'].long())
+
+
 def test_plain_sa_oracle_matches_reference():
     """Row a16 (SA.decode, config 0): the oracle's spatial-broadcast decoder + reconstruction loss
     and their gradients against the reference run captured in tests/golden/sa_b2.npz; the spec's
@@ -259,6 +279,42 @@ def test_ancestral_and_x0_oracle_matches_reference():
     assert tr.shape == A['x0_dpm_trace'].shape
     assert float((tr[0] - A['x0_dpm_trace'][0]).abs().max()) <= 2e-4
     assert float((tr - A['x0_dpm_trace']).abs().mean()) <= 1e-2
+
+
+def test_v_prediction_oracle_matches_reference():
+    """SURVEY 8(f) row 2, pred_target='v' (video_based only): loss target, _p_mean_variance's v branch
+    and DPM-Solver's model_type 'v' of the oracle against the reference (tests/golden/vpred_b1t2.npz)."""
+    cfg = C.movie_cfg()
+    A = C.load_golden('vpred_b1t2.npz')
+    W = C.oracle_weights_video(cfg)
+    plan = spec.unet_plan(cfg['dec_dict']['unet_dict'])
+    ed = cfg['dec_dict']['vae_dict']['enc_dec_dict']
+    slots = A['slots']
+    fn = lambda xc, t: O.unet_forward(W, plan, xc, t, slots)
+    q_fn = lambda x0: O.vq_quantize(W, x0)[0]
+    x = A['x_T']
+    with torch.no_grad():
+        for j, tv in enumerate(A['anc_t'].tolist()):
+            t = torch.full((2,), int(tv), dtype=torch.long)
+            mean, _ = O.p_mean(W, fn(x, t), x, t, q_fn, 'v')
+            assert float((mean - A['v_anc_mean'][j]).abs().max()) <= 2e-4, tv
+            x = O.p_sample(W, fn, x, t, A['anc_noise'], q_fn, 'v')
+            assert float((x - A['v_anc_x'][j]).abs().max()) <= 2e-4, tv
+            x = A['v_anc_x'][j]
+        img = C.make_inputs(2, seed=17)[0]
+        loss, pred, _ = O.ldm_loss(W, plan, ed, img, slots, A['t'].long(), A['noise'], pred_target='v')
+    # (slots here are the eval-mode ones of the fixture; the fixture's loss used the train-mode
+    # forward of the same weights -- identical without dropout)
+    assert float((pred - A['v_pred']).abs().max()) <= 2e-4
+    assert abs(float(loss) - float(A['v_train_loss'])) <= 1e-5 * max(1.0, float(A['v_train_loss']))
+    tr = []
+    with torch.no_grad():
+        O.dpm_solver_sample(fn, q_fn, W['dm_decoder.betas'], A['x_T'], steps=20, order=3, trace=tr,
+                            model_type='v')
+    tr = torch.stack(tr, 0)
+    assert tr.shape == A['v_dpm_trace'].shape
+    assert float((tr[0] - A['v_dpm_trace'][0]).abs().max()) <= 2e-4
+    assert float((tr - A['v_dpm_trace']).abs().mean()) <= 1e-2
 
 
 def test_eval_metrics_oracle_matches_reference():

@@ -253,6 +253,97 @@ def main_anc():
     print('wrote anc_x0_b2.npz', {k: tuple(np.asarray(v).shape) for k, v in arrs.items()})
 
 
+def main_vpred():
+    """tests/golden/vpred_b1t2.npz (pred_target='v'): the video reference model
+    (only video_based accepts 'v': ddpm.py:79) with the MOVi-E config, a B=1 clip of T=2 frames --
+    the v loss target (ldm.py:74-78) with a few gradient norms, single ancestral steps through
+    _p_mean_variance's v branch (cond_ddpm.py:63-67) and DPM-Solver++ with model_type 'v'
+    (cond_ddpm.py:163-164, dpm_solver.py:362-365)."""
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    vm = rh.ref_models('video_based')
+    import slotdiffusion.video_based.models.ddpm.cond_ddpm as cd
+    P = rh.ref_params('video_based', 'savi_ldm', 'savi_ldm_movie_params-res128')
+    P.dec_dict['diffusion_dict']['pred_target'] = 'v'
+    P.n_sample_frames = P.input_frames = 2
+    model = vm.build_model(P)
+    det_fill_(model.state_dict().items(), skip=is_buffer_name)
+    T = 2
+    img, t, noise, x_T = make_inputs(T, seed=17)
+    clip = img.view(1, T, 3, 128, 128)
+    dm = model.dm_decoder
+    assert dm.pred_target == 'v' and dm.vq_denoised and not dm.clip_denoised
+    G = dict(t=t, noise=noise, x_T=x_T)
+    model.eval()
+    with torch.no_grad():
+        slots = model(dict(img=clip))['slots'].flatten(0, 1)
+    G['slots'] = slots
+    nz = torch.randn(x_T.shape, generator=torch.Generator().manual_seed(78))
+    G['anc_noise'] = nz
+    cd.noise_like = lambda shape, device, repeat=False: nz.clone()
+    ts = [999, 500, 1, 0]
+    G['anc_t'] = torch.tensor(ts)
+    outs, means = [], []
+    x = x_T.clone()
+    with torch.no_grad():
+        for tv in ts:
+            tt = torch.full((T,), tv, dtype=torch.long)
+            mean, _, _ = dm._p_mean_variance(x.clone(), tt, slots, clip_denoised=False, vq_denoised=True)
+            means.append(mean)
+            x = dm._p_sample(x, tt, slots, clip_denoised=False, vq_denoised=True)
+            outs.append(x)
+    G['v_anc_mean'], G['v_anc_x'] = torch.stack(means, 0), torch.stack(outs, 0)
+    # loss with the v target at explicit t / noise
+    model.train()
+    dm.model.eval()
+    model.predictor.eval()
+    for p in model.parameters():
+        p.grad = None
+    out = model(dict(img=clip))
+    with torch.no_grad():
+        x0 = dm.vae.encode(img)
+    xt = dm._sample_xt_from_x0(x0=x0, t=t, noise=noise)
+    pred = dm.forward(xt, t, context=out['slots'].flatten(0, 1))
+    a = dm.sqrt_alphas_bar[t].view(-1, 1, 1, 1)
+    sg = dm.sqrt_one_minus_alphas_bar[t].view(-1, 1, 1, 1)
+    loss = torch.nn.functional.mse_loss(pred, (a * noise - sg * x0).detach())
+    # (the library path must give the same number: LDM.loss_function draws its own t / noise, so the
+    # formula is restated here and cross-checked once with patched RNG below)
+    loss.backward()
+    G['v_train_loss'], G['v_pred'] = loss.detach(), pred.detach()
+    named = dict(model.named_parameters())
+    names = sorted(n for n, p in named.items() if p.grad is not None)[::16]
+    G['v_grad_norms_names'] = np.array(names)
+    G['v_grad_norms'] = torch.tensor([float(named[n].grad.norm()) for n in names])
+    # cross-check against the reference's own loss_function with its RNG pinned to (t, noise)
+    ri, rl = torch.randint, torch.randn_like
+    try:
+        torch.randint = lambda *a_, **k_: t.clone()
+        torch.randn_like = lambda *_a, **_k: noise.clone()
+        with torch.no_grad():
+            ref_loss = dm.loss_function(dict(img=img, slots=out['slots'].flatten(0, 1).detach()))['denoise_loss']
+    finally:
+        torch.randint, torch.randn_like = ri, rl
+    assert abs(float(ref_loss) - float(loss)) <= 1e-6 * max(1.0, float(loss)), (float(ref_loss), float(loss))
+    # DPM-Solver++ with model_type 'v'
+    model.eval()
+    from slotdiffusion.video_based.models.ddpm import dpm_solver as ds
+    nsch = ds.NoiseScheduleVP(betas=dm.betas)
+    with torch.no_grad():
+        dm.model.vae = dm.vae
+        model_fn = ds.model_wrapper(model=dm.model, noise_schedule=nsch, model_type='v',
+                                    guidance_type='classifier-free', condition=slots)
+        sampler = ds.DPM_Solver(model_fn, nsch, algorithm_type='dpmsolver++', correcting_x0_fn=False,
+                                vq_denoised=True)
+        xx, inter = sampler.sample(x_T.clone(), steps=20, order=3, method='singlestep',
+                                   return_intermediate=True)
+        dm.model.vae = None
+    G['v_dpm_trace'], G['v_dpm_final'] = torch.stack(inter, 0), xx
+    arrs = {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else v) for k, v in G.items()}
+    np.savez_compressed(os.path.join(OUT, 'vpred_b1t2.npz'), **arrs)
+    print('wrote vpred_b1t2.npz', {k: tuple(np.asarray(v).shape) for k, v in arrs.items()})
+
+
 def metric_inputs():
     """Synthetic id maps for the metric fixtures: B=4 images 32x32; blobs of ids 0..5 (gt) against
     shifted / merged / split predictions; image 2 holds only background; image 3 has fewer
@@ -331,16 +422,22 @@ def main_sa():
     print('wrote sa_b2.npz', {k: tuple(v.shape) for k, v in G.items()})
 
 
-def main_video():
-    """video_based SAViDiffusion (MOVi-E config, 15 slots, 2 iterations), B=1 clip of T=3 frames."""
+def main_video(cfg_name='savi_ldm_movie_params-res128', num_slots=None, T=3, out_name='savidiff_b1t3.npz',
+               seed=11):
+    """video_based SAViDiffusion (MOVi-E config, 15 slots, 2 iterations), B=1 clip of T=3 frames.
+    `video11x6`: BASELINE config 2 -- the MOVi-D config with num_slots=11 and 6-frame clips
+    (n_sample_frames / input_frames = 6, the values BASELINE.json asks for)."""
     torch.manual_seed(0)
     torch.set_num_threads(8)
     vm = rh.ref_models('video_based')
-    P = rh.ref_params('video_based', 'savi_ldm', 'savi_ldm_movie_params-res128')
+    P = rh.ref_params('video_based', 'savi_ldm', cfg_name)
+    if num_slots is not None:
+        P.slot_dict['num_slots'] = num_slots
+    P.n_sample_frames = P.input_frames = T
     model = vm.build_model(P)
     det_fill_(model.state_dict().items(), skip=is_buffer_name)
-    B, T = 1, 3
-    img, t, noise, x_T = make_inputs(B * T, seed=11)
+    B = 1
+    img, t, noise, x_T = make_inputs(B * T, seed=seed)
     img = img.view(B, T, 3, 128, 128)
     G = dict(t=t, noise=noise, img_checksum=torch.stack([img.double().sum(), (img.double() ** 2).sum()]))
     model.train()
@@ -377,7 +474,7 @@ def main_video():
     for k in list(arrs):
         if arrs[k].dtype == np.int64 and k != 't':
             arrs[k] = arrs[k].astype(np.int16)
-    np.savez_compressed(os.path.join(OUT, 'savidiff_b1t3.npz'), **arrs)
+    np.savez_compressed(os.path.join(OUT, out_name), **arrs)
     keys = {'params': [[k, list(v.shape)] for k, v in model.named_parameters()],
             'frozen': [k for k, v in model.named_parameters() if not v.requires_grad]}
     for k, v in arrs.items():
@@ -503,7 +600,13 @@ if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'anc':
         main_anc()
         sys.exit(0)
-    if len(sys.argv) > 1 and sys.argv[1] == 'video':
+    if len(sys.argv) > 1 and sys.argv[1] == 'vpred':
+        main_vpred()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'video11x6':
+        main_video('savi_ldm_movid_params-res128', num_slots=11, T=6, out_name='savidiff_b1t6_n11.npz',
+                   seed=13)
+    elif len(sys.argv) > 1 and sys.argv[1] == 'video':
         main_video()
     else:
         main()
