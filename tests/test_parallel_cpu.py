@@ -81,7 +81,7 @@ def test_respawn_under_launcher_starts_n_ranks(tmp_path):
         'dist.init_process_group("gloo")\n'
         't = torch.ones(1) * (dist.get_rank() + 1)\n'
         'dist.all_reduce(t)\n'
-        'os.write(1, ("RANK %d WORLD %d SUM %d %s\\n" % (dist.get_rank(), dist.get_world_size(), int(t), sys.argv[1])).encode())\n'
+        'os.write(1, ("RANK %%d WORLD %%d SUM %%d %%s\\n" %% (dist.get_rank(), dist.get_world_size(), int(t), sys.argv[1])).encode())\n'
         'dist.destroy_process_group()\n'
         % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), _free_port()))
     r = subprocess.run([sys.executable, str(script), 'tag7'], capture_output=True, text=True, timeout=300)
