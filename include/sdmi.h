@@ -137,6 +137,8 @@ typedef struct {
   const void* residual; /* forward residual (for act derivative) or NULL */
   void* dresidual;      /* optional: receives the gradient flowing to the residual branch */
   int accumulate;       /* != 0: dgamma/dbeta += (parameter used more than once per step) */
+  const void* dextra0;  /* optional [B][HW][C]: gradients reaching x through OTHER consumers (the */
+  const void* dextra1;  /* residual / skip / concat branches); dx = gn_bwd(dy) + dextra0 + dextra1 */
 } SdmiGroupNormBwdArgs;
 int sdmi_groupnorm_bwd(const SdmiGroupNormBwdArgs* a, void* stream);
 
@@ -153,6 +155,7 @@ typedef struct {
   float* dgamma; float* dbeta;   /* [C] fp32, accumulated via per-block partials */
   float* partial;                /* workspace [nblk][C][2] */
   int dtype; int rows, C; int nblk; int accumulate;
+  const void* dextra;            /* optional [rows][C]: dx = ln_bwd(dy) + dextra (residual branch of x) */
 } SdmiLayerNormBwdArgs;
 int sdmi_layernorm_bwd(const SdmiLayerNormBwdArgs* a, void* stream);
 

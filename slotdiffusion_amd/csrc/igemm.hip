@@ -80,7 +80,10 @@ __device__ __forceinline__ void wave_epilogue(const SdmiGemmArgs& p, f32x16 (&ac
             const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
             const long long o = (((long long)b * p.oH + oy * p.osy + p.ooy) * p.oW + ox * p.osx + p.oox) *
                                     p.ldc + n;
-            const float v = acc[i][j][r] * p.alpha + bn;
+            float v = acc[i][j][r] * p.alpha + bn;
+            if (p.residual)             // same layout as the output (gradient of another consumer)
+              v += p.out_dtype == SDMI_BF16 ? bf16_to_f32(((const bf16_t*)p.residual)[o])
+                                            : ((const float*)p.residual)[o];
             if (p.out_dtype == SDMI_BF16) ((bf16_t*)p.out)[o] = f32_to_bf16(v);
             else ((float*)p.out)[o] = v;
           }
@@ -1094,9 +1097,11 @@ extern "C" int sdmi_igemm(const SdmiGemmArgs* a, void* stream) {
   SDMI_REQUIRE(!(a->batch > 1) || (a->KH == 1 && a->KW == 1), "batched mode is 1x1 only");
   SDMI_REQUIRE(!(a->batch > 1 && a->split_k > 1), "batched split-K unsupported");
   SDMI_REQUIRE(a->sa % vec == 0 && a->sw % vec == 0, "batch strides must keep 16-byte alignment");
-  SDMI_REQUIRE(a->osy == 0 || (a->osy > 0 && a->osx > 0 && a->oH > 0 && a->oW > 0 && !a->residual &&
+  SDMI_REQUIRE(a->osy == 0 || (a->osy > 0 && a->osx > 0 && a->oH > 0 && a->oW > 0 &&
                                a->split_k <= 1 && !(a->batch > 1)),
-               "sub-sampled output: needs osy/osx/oH/oW > 0, no residual / split-K / batch");
+               "sub-sampled output: needs osy/osx/oH/oW > 0, no split-K / batch");
+  SDMI_REQUIRE(a->osy == 0 || !a->residual || a->ldr == a->ldc,
+               "sub-sampled output: the residual shares the output's layout");
   SDMI_REQUIRE(a->osy == 0 || (!a->rowvec && !a->act && !a->bias_m), "sub-sampled output: plain epilogue only");
   hipStream_t st = (hipStream_t)stream;
   return a->dtype == SDMI_BF16 ? dispatch<bf16_t>(*a, st) : dispatch<float>(*a, st);

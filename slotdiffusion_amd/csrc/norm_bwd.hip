@@ -194,6 +194,8 @@ __global__ __launch_bounds__(THREADS) void gn_bwd_fused_kernel(SdmiGroupNormBwdA
   }
   T* dxb = (T*)p.dx + base;
   T* drb = p.dresidual ? (T*)p.dresidual + base : nullptr;
+  const T* e0 = p.dextra0 ? (const T*)p.dextra0 + base : nullptr;
+  const T* e1 = p.dextra1 ? (const T*)p.dextra1 + base : nullptr;
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int row = r0 + i * R;
@@ -206,6 +208,18 @@ __global__ __launch_bounds__(THREADS) void gn_bwd_fused_kernel(SdmiGroupNormBwdA
       for (int j = 0; j < VEC; ++j) {
         const float xh = (x[j] - mu[j]) * rs[j];
         dx[j] = rs[j] * (ga[j] * dz[j] - (s1[j] + xh * s2[j]));
+      }
+      if (e0) {                           // gradients of x's other consumers, summed here
+        float ex[VEC];
+        unpack16<T>(*reinterpret_cast<const uint4*>(e0 + o), ex);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) dx[j] += ex[j];
+      }
+      if (e1) {
+        float ex[VEC];
+        unpack16<T>(*reinterpret_cast<const uint4*>(e1 + o), ex);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) dx[j] += ex[j];
       }
       *reinterpret_cast<uint4*>(dxb + o) = pack16<T>(dx);
       if (drb) *reinterpret_cast<uint4*>(drb + o) = dr[i];
@@ -303,6 +317,8 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(SdmiGroupNormBwdArgs 
   const T* rb = p.residual ? (const T*)p.residual + base : nullptr;
   T* dxb = (T*)p.dx + base;
   T* drb = p.dresidual ? (T*)p.dresidual + base : nullptr;
+  const T* e0 = p.dextra0 ? (const T*)p.dextra0 + base : nullptr;
+  const T* e1 = p.dextra1 ? (const T*)p.dextra1 + base : nullptr;
   for (int row = row_begin + r0; row < row_end; row += R) {
     const long long o = (long long)row * p.C;
     float x[VEC], dy[VEC], rr[VEC], dx[VEC], dz[VEC];
@@ -315,6 +331,18 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(SdmiGroupNormBwdArgs 
       const float z = xh * ga[j] + be[j] + (rb ? rr[j] : 0.f);
       dz[j] = dy[j] * act_grad(z, p.act);
       dx[j] = rs[j] * (ga[j] * dz[j] - (s1[j] + xh * s2[j]));
+    }
+    if (e0) {
+      float ex[VEC];
+      unpack16<T>(*reinterpret_cast<const uint4*>(e0 + o), ex);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) dx[j] += ex[j];
+    }
+    if (e1) {
+      float ex[VEC];
+      unpack16<T>(*reinterpret_cast<const uint4*>(e1 + o), ex);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) dx[j] += ex[j];
     }
     *reinterpret_cast<uint4*>(dxb + o) = pack16<T>(dx);
     if (drb) *reinterpret_cast<uint4*>(drb + o) = pack16<T>(dz);
@@ -385,12 +413,19 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(SdmiLayerNormBwdArgs p, int
     s2 *= invC;
     if (rok) {
       T* dx = (T*)p.dx + ro;
+      const T* ex = p.dextra ? (const T*)p.dextra + ro : nullptr;
 #pragma unroll
       for (int i = 0; i < VPL; ++i) {
         if (!act[i]) continue;
         float o[VEC];
 #pragma unroll
         for (int j = 0; j < VEC; ++j) o[j] = rstd * (dxh[i][j] - s1 - xh[i][j] * s2);
+        if (ex) {                         // gradient of the row's residual branch, summed here
+          float ev[VEC];
+          unpack16<T>(*reinterpret_cast<const uint4*>(ex + (sub + i * LPR) * VEC), ev);
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) o[j] += ev[j];
+        }
         *reinterpret_cast<uint4*>(dx + (sub + i * LPR) * VEC) = pack16<T>(o);
       }
     }
