@@ -113,6 +113,12 @@ typedef struct {
   int act;
   int nsplit;
   const void* residual; /* optional [B][HW][C] added AFTER the affine, before act (ResNet block) */
+  /* optional inverted dropout applied to the activated output (ResBlock: Dropout(SiLU(GN(h))),
+   * unet.py:243-250): y = keep ? y / (1 - p) : 0 with the counter-based keep mask of
+   * sdmi_dropout's family, keyed on (drop_seed + *drop_seed_dev, 16-byte vector index). */
+  float drop_p;
+  long long drop_seed;
+  const long long* drop_seed_dev;
 } SdmiGroupNormArgs;
 int sdmi_groupnorm_stats(const SdmiGroupNormArgs* a, void* stream);
 int sdmi_groupnorm_apply(const SdmiGroupNormArgs* a, void* stream);
@@ -139,6 +145,9 @@ typedef struct {
   int accumulate;       /* != 0: dgamma/dbeta += (parameter used more than once per step) */
   const void* dextra0;  /* optional [B][HW][C]: gradients reaching x through OTHER consumers (the */
   const void* dextra1;  /* residual / skip / concat branches); dx = gn_bwd(dy) + dextra0 + dextra1 */
+  float drop_p;         /* the forward's fused dropout (mask regenerated from the seed) */
+  long long drop_seed;
+  const long long* drop_seed_dev;
 } SdmiGroupNormBwdArgs;
 int sdmi_groupnorm_bwd(const SdmiGroupNormBwdArgs* a, void* stream);
 

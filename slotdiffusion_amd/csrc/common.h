@@ -114,4 +114,29 @@ __device__ __forceinline__ double wave_sum_d(double v) {
   return v;
 }
 
+// ---- counter-based dropout shared by the fused GroupNorm kernels: one splitmix64 finaliser yields
+// four 16-bit lots, element j of 16-byte vector `vi` is kept when its lot >= thr16 = p * 65536.
+__device__ __forceinline__ unsigned long long sdmi_mix64(unsigned long long z) {
+  z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
+  z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
+  return z ^ (z >> 31);
+}
+__device__ __forceinline__ unsigned long long sdmi_drop_seed(long long seed, const long long* seed_dev) {
+  return (unsigned long long)seed + (seed_dev ? (unsigned long long)(*seed_dev) * 0x100000001b3ULL : 0ULL);
+}
+template <int VEC>
+__device__ __forceinline__ void sdmi_drop_apply(float* f, unsigned long long seed, long long vi,
+                                                unsigned thr16, float inv) {
+#pragma unroll
+  for (int h = 0; h < VEC / 4; ++h) {
+    const unsigned long long r =
+        sdmi_mix64(seed + 0x9e3779b97f4a7c15ULL * (unsigned long long)(vi * (VEC / 4) + h + 1));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const unsigned lot = (unsigned)(r >> (16 * j)) & 0xffffu;
+      f[h * 4 + j] = lot >= thr16 ? f[h * 4 + j] * inv : 0.f;
+    }
+  }
+}
+
 static inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }

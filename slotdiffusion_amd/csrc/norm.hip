@@ -106,6 +106,10 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(SdmiGroupNormArgs p, int 
   const T* xb = (const T*)p.x + base;
   T* yb = (T*)p.y + base;
   const T* rb = p.residual ? (const T*)p.residual + base : nullptr;
+  const bool drop = p.drop_p > 0.f;
+  const unsigned long long dseed = drop ? sdmi_drop_seed(p.drop_seed, p.drop_seed_dev) : 0ULL;
+  const unsigned thr16 = (unsigned)(p.drop_p * 65536.f);
+  const float dinv = 1.f / (1.f - p.drop_p);
   for (int row = row_begin + r0; row < row_end; row += R) {
     const long long o = (long long)row * p.C;
     const uint4 v = *reinterpret_cast<const uint4*>(xb + o);
@@ -120,6 +124,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(SdmiGroupNormArgs p, int 
 #pragma unroll
       for (int j = 0; j < VEC; ++j) f[j] = act_apply(f[j] * sc[j] + sh[j], p.act);
     }
+    if (drop) sdmi_drop_apply<VEC>(f, dseed, (base + o) / VEC, thr16, dinv);
     *reinterpret_cast<uint4*>(yb + o) = pack16<T>(f);
   }
 }
@@ -213,6 +218,10 @@ __global__ __launch_bounds__(THREADS) void gn_fused_kernel(SdmiGroupNormArgs p) 
   }
   T* yb = (T*)p.y + base;
   const T* rb = p.residual ? (const T*)p.residual + base : nullptr;
+  const bool drop = p.drop_p > 0.f;
+  const unsigned long long dseed = drop ? sdmi_drop_seed(p.drop_seed, p.drop_seed_dev) : 0ULL;
+  const unsigned thr16 = (unsigned)(p.drop_p * 65536.f);
+  const float dinv = 1.f / (1.f - p.drop_p);
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int row = r0 + i * R;
@@ -229,6 +238,7 @@ __global__ __launch_bounds__(THREADS) void gn_fused_kernel(SdmiGroupNormArgs p) 
 #pragma unroll
         for (int j = 0; j < VEC; ++j) f[j] = act_apply(f[j] * sc[j] + sh[j], p.act);
       }
+      if (drop) sdmi_drop_apply<VEC>(f, dseed, (base + o) / VEC, thr16, dinv);
       *reinterpret_cast<uint4*>(yb + o) = pack16<T>(f);
     }
   }

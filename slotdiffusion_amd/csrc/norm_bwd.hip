@@ -51,11 +51,16 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(SdmiGroupNormBwdArgs 
     const T* xb = (const T*)p.x + base;
     const T* db = (const T*)p.dy + base;
     const T* rb = p.residual ? (const T*)p.residual + base : nullptr;
+    const bool drop = p.drop_p > 0.f;
+    const unsigned long long dseed = drop ? sdmi_drop_seed(p.drop_seed, p.drop_seed_dev) : 0ULL;
+    const unsigned thr16 = (unsigned)(p.drop_p * 65536.f);
+    const float dinv = 1.f / (1.f - p.drop_p);
     for (int row = row_begin + r0; row < row_end; row += R) {
       const long long o = (long long)row * p.C;
       float x[VEC], dy[VEC], rr[VEC];
       unpack16<T>(*reinterpret_cast<const uint4*>(xb + o), x);
       unpack16<T>(*reinterpret_cast<const uint4*>(db + o), dy);
+      if (drop) sdmi_drop_apply<VEC>(dy, dseed, (base + o) / VEC, thr16, dinv);
       if (rb) unpack16<T>(*reinterpret_cast<const uint4*>(rb + o), rr);
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
@@ -127,6 +132,10 @@ __global__ __launch_bounds__(THREADS) void gn_bwd_fused_kernel(SdmiGroupNormBwdA
   float A[VEC], Bv[VEC];
 #pragma unroll
   for (int j = 0; j < VEC; ++j) A[j] = Bv[j] = 0.f;
+  const bool drop = p.drop_p > 0.f;
+  const unsigned long long dseed = drop ? sdmi_drop_seed(p.drop_seed, p.drop_seed_dev) : 0ULL;
+  const unsigned thr16 = (unsigned)(p.drop_p * 65536.f);
+  const float dinv = 1.f / (1.f - p.drop_p);
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int row = r0 + i * R;
@@ -134,6 +143,7 @@ __global__ __launch_bounds__(THREADS) void gn_bwd_fused_kernel(SdmiGroupNormBwdA
       float x[VEC], dy[VEC], rr[VEC];
       unpack16<T>(xr[i], x);
       unpack16<T>(dr[i], dy);
+      if (drop) sdmi_drop_apply<VEC>(dy, dseed, (base + (long long)row * p.C) / VEC, thr16, dinv);
       if (rb) unpack16<T>(*reinterpret_cast<const uint4*>(rb + (long long)row * p.C), rr);
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
@@ -319,11 +329,16 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(SdmiGroupNormBwdArgs 
   T* drb = p.dresidual ? (T*)p.dresidual + base : nullptr;
   const T* e0 = p.dextra0 ? (const T*)p.dextra0 + base : nullptr;
   const T* e1 = p.dextra1 ? (const T*)p.dextra1 + base : nullptr;
+  const bool drop = p.drop_p > 0.f;
+  const unsigned long long dseed = drop ? sdmi_drop_seed(p.drop_seed, p.drop_seed_dev) : 0ULL;
+  const unsigned thr16 = (unsigned)(p.drop_p * 65536.f);
+  const float dinv = 1.f / (1.f - p.drop_p);
   for (int row = row_begin + r0; row < row_end; row += R) {
     const long long o = (long long)row * p.C;
     float x[VEC], dy[VEC], rr[VEC], dx[VEC], dz[VEC];
     unpack16<T>(*reinterpret_cast<const uint4*>(xb + o), x);
     unpack16<T>(*reinterpret_cast<const uint4*>(db + o), dy);
+    if (drop) sdmi_drop_apply<VEC>(dy, dseed, (base + o) / VEC, thr16, dinv);
     if (rb) unpack16<T>(*reinterpret_cast<const uint4*>(rb + o), rr);
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {

@@ -21,12 +21,12 @@ def resnet_encoder(K, x, plan, prefix='encoder'):
     h = K.gn(h, f'{prefix}.bn1', eps=1e-5, act='relu')
     for blk, cin, cout, stride, has_ds in plan:
         b = f'{prefix}.{blk}'
-        o = K.conv(h, f'{b}.conv1.weight', stride=stride)
+        # h feeds conv1 and the identity branch: the branch's gradient is summed in conv1's dgrad
+        o, idt = K.conv_fan(h, f'{b}.conv1.weight', stride=stride)
         o = K.gn(o, f'{b}.bn1', eps=1e-5, act='relu')
         o = K.conv(o, f'{b}.conv2.weight')
-        idt = h
         if has_ds:
-            idt = K.conv(h, f'{b}.downsample.0.weight', kh=1, kw=1, stride=stride, pad=(0, 0, 0, 0))
+            idt = K.conv(idt, f'{b}.downsample.0.weight', kh=1, kw=1, stride=stride, pad=(0, 0, 0, 0))
             idt = K.gn(idt, f'{b}.downsample.1', eps=1e-5)
         # relu(gn(conv2) + identity) fused in the GN apply kernel
         h = K.gn(o, f'{b}.bn2', eps=1e-5, act='relu', residual=idt)
@@ -75,13 +75,13 @@ def transformer_predictor(K, x, num_layers, num_heads, name='predictor'):
     hd = D // num_heads
     for i in range(num_layers):
         l = f'{name}.transformer_encoder.layers.{i}'
-        qkv = K.linear(K.ln(x, f'{l}.norm1'), f'{l}.self_attn.in_proj_weight',
-                       f'{l}.self_attn.in_proj_bias')
+        n1, xr = K.ln_fan(x, f'{l}.norm1')
+        qkv = K.linear(n1, f'{l}.self_attn.in_proj_weight', f'{l}.self_attn.in_proj_bias')
         a = K.attn_self(qkv, num_heads, hd)
-        x = K.linear_drop_res(a, f'{l}.self_attn.out_proj.weight', f'{l}.self_attn.out_proj.bias', x)
-        h = K.dropout(K.linear(K.ln(x, f'{l}.norm2'), f'{l}.linear1.weight', f'{l}.linear1.bias',
-                               act='relu'), site='pred')
-        x = K.linear_drop_res(h, f'{l}.linear2.weight', f'{l}.linear2.bias', x)
+        x = K.linear_drop_res(a, f'{l}.self_attn.out_proj.weight', f'{l}.self_attn.out_proj.bias', xr)
+        n2, xr = K.ln_fan(x, f'{l}.norm2')
+        h = K.dropout(K.linear(n2, f'{l}.linear1.weight', f'{l}.linear1.bias', act='relu'), site='pred')
+        x = K.linear_drop_res(h, f'{l}.linear2.weight', f'{l}.linear2.bias', xr)
     return x
 
 
@@ -128,70 +128,89 @@ class UNetRunner:
         return out
 
     # -- blocks ---------------------------------------------------------------------------
-    def _res(self, K, name, x, rowvecs):
+    def _res(self, K, name, x, rowvecs, want_cat=False):
+        """-> (block output, alias of x for the UNet skip-concat or None).  x has up to three
+        consumers (GroupNorm, skip branch, skip-concat): the aliases route their gradients into
+        the GroupNorm backward kernel."""
         n = self.P + name
         off, cout = self.emb_off[name]
         rv = rowvecs[:, off:off + cout]            # strided view; the kernel takes its row pitch
-        h = K.gn(x, n + '.in_layers.0', eps=1e-5, act='silu')
+        outs = K.gn_fan(x, n + '.in_layers.0', eps=1e-5, act='silu', n_alias=2 if want_cat else 1)
+        h, skip = outs[0], outs[1]
         h = K.conv(h, n + '.in_layers.2.weight', n + '.in_layers.2.bias', rowvec=rv)
-        h = K.dropout(K.gn(h, n + '.out_layers.0', eps=1e-5, act='silu'))   # p=0 outside training
-        skip = x
+        h = K.gn(h, n + '.out_layers.0', eps=1e-5, act='silu', dropout='unet')   # training only
         if (n + '.skip_connection.weight') in K.wb.t:
-            skip = K.conv(x, n + '.skip_connection.weight', n + '.skip_connection.bias', kh=1, kw=1,
+            skip = K.conv(skip, n + '.skip_connection.weight', n + '.skip_connection.bias', kh=1, kw=1,
                           pad=(0, 0, 0, 0))
-        return K.conv(h, n + '.out_layers.3.weight', n + '.out_layers.3.bias', residual=skip)
+        out = K.conv(h, n + '.out_layers.3.weight', n + '.out_layers.3.bias', residual=skip)
+        return out, (outs[2] if want_cat else None)
 
     def _st(self, K, name, x, heads, kv):
         n = self.P + name
         B, H, W, C = x.shape
-        h = K.gn(x, n + '.norm', eps=1e-6)
+        # (every residual branch takes an alias of the normalised tensor: its gradient is summed
+        # inside the norm's backward kernel)
+        h, xres = K.gn_fan(x, n + '.norm', eps=1e-6)
         tok = K.linear(h.view(B, H * W, C), n + '.proj_in.weight', n + '.proj_in.bias')
         t = n + '.transformer_blocks.0'
         # self attention
-        n1 = K.ln(tok, t + '.norm1')
+        n1, tres = K.ln_fan(tok, t + '.norm1')
         qkv = K.linear(n1, (t + '.attn1.to_q.weight', t + '.attn1.to_k.weight',
                             t + '.attn1.to_v.weight'))
         a = K.attn_self(qkv, heads)
-        tok = K.linear(a, t + '.attn1.to_out.0.weight', t + '.attn1.to_out.0.bias', residual=tok)
+        tok = K.linear(a, t + '.attn1.to_out.0.weight', t + '.attn1.to_out.0.bias', residual=tres)
         # slot cross attention (K/V precomputed per sample call)
-        n2 = K.ln(tok, t + '.norm2')
+        n2, tres = K.ln_fan(tok, t + '.norm2')
         q = K.linear(n2, t + '.attn2.to_q.weight')
         a = K.attn_cross(q, kv, heads)
-        tok = K.linear(a, t + '.attn2.to_out.0.weight', t + '.attn2.to_out.0.bias', residual=tok)
+        tok = K.linear(a, t + '.attn2.to_out.0.weight', t + '.attn2.to_out.0.bias', residual=tres)
         # GEGLU feed-forward
-        n3 = K.ln(tok, t + '.norm3')
+        n3, tres = K.ln_fan(tok, t + '.norm3')
         g = K.geglu(K.linear(n3, t + '.ff.net.0.proj.weight', t + '.ff.net.0.proj.bias'))
-        tok = K.linear(g, t + '.ff.net.2.weight', t + '.ff.net.2.bias', residual=tok)
+        tok = K.linear(g, t + '.ff.net.2.weight', t + '.ff.net.2.bias', residual=tres)
         out = K.linear(tok, n + '.proj_out.weight', n + '.proj_out.bias',
-                       residual=x.view(B, H * W, C))
+                       residual=xres.view(B, H * W, C))
         return out.view(B, H, W, C)
 
-    def _run(self, K, layers, h, rowvecs, ctx_kv):
-        for l in layers:
+    def _run(self, K, layers, h, rowvecs, ctx_kv, want_cat=False):
+        """-> (output, alias of the block INPUT for the skip-concat when want_cat, else None)."""
+        cat = None
+        for i, l in enumerate(layers):
             kind, name = l[0], l[1]
             n = self.P + name
+            fan = want_cat and i == 0
             if kind == 'conv':
                 h = K.conv(h, n + '.weight', n + '.bias')
             elif kind == 'res':
-                h = self._res(K, name, h, rowvecs)
+                h, c = self._res(K, name, h, rowvecs, want_cat=fan)
+                cat = c if fan else cat
             elif kind == 'st':
                 h = self._st(K, name, h, l[3], ctx_kv[name])
             elif kind == 'down':
-                h = K.conv(h, n + '.op.weight', n + '.op.bias', stride=2)
+                if fan:
+                    h, cat = K.conv_fan(h, n + '.op.weight', n + '.op.bias', stride=2)
+                else:
+                    h = K.conv(h, n + '.op.weight', n + '.op.bias', stride=2)
             elif kind == 'up':      # nearest x2 folded into the conv's gather
                 h = K.conv(h, n + '.conv.weight', n + '.conv.bias', ups=True)
-        return h
+        return h, cat
 
     def forward(self, K, x, rowvecs, ctx_kv):
         """x [B,h,w,Cpad] compute dtype -> eps [B,h,w,4] fp32 (3 channels + zero pad)."""
         hs = []
         h = x
-        for blk in self.plan['input']:
-            h = self._run(K, blk, h, rowvecs, ctx_kv)
+        # every input-block output has two consumers, the next block and a skip-concat: the next
+        # block's first layer hands back an alias of it for the concat (gradients meet in-kernel)
+        for i, blk in enumerate(self.plan['input']):
+            h, cat = self._run(K, blk, h, rowvecs, ctx_kv, want_cat=i > 0)
+            if cat is not None:
+                hs[-1] = cat
             hs.append(h)
-        h = self._run(K, self.plan['middle'], h, rowvecs, ctx_kv)
+        h, cat = self._run(K, self.plan['middle'], h, rowvecs, ctx_kv, want_cat=True)
+        if cat is not None:
+            hs[-1] = cat
         for blk in self.plan['output']:
-            h = self._run(K, blk, K.concat(h, hs.pop()), rowvecs, ctx_kv)
+            h, _ = self._run(K, blk, K.concat(h, hs.pop()), rowvecs, ctx_kv)
         P = self.P
         h = K.gn(h, P + 'out.0', eps=1e-5, act='silu')
         return K.conv(h, P + 'out.2.weight', P + 'out.2.bias', out_dtype=torch.float32, ldc=4)
@@ -201,12 +220,11 @@ class UNetRunner:
 # a6/a14/a15: VQ-VAE (VQVAE.py:94-114, 183-194; modules.py:239-261, 338-362) -- frozen, no grad
 # ------------------------------------------------------------------------------------------
 def _vae_res(K, n, x):
-    h = K.gn(x, n + '.norm1', eps=1e-6, act='silu')
+    h, skip = K.gn_fan(x, n + '.norm1', eps=1e-6, act='silu')
     h = K.conv(h, n + '.conv1.weight', n + '.conv1.bias')
     h = K.gn(h, n + '.norm2', eps=1e-6, act='silu')
-    skip = x
     if (n + '.nin_shortcut.weight') in K.wb.t:
-        skip = K.conv(x, n + '.nin_shortcut.weight', n + '.nin_shortcut.bias', kh=1, kw=1,
+        skip = K.conv(skip, n + '.nin_shortcut.weight', n + '.nin_shortcut.bias', kh=1, kw=1,
                       pad=(0, 0, 0, 0))
     return K.conv(h, n + '.conv2.weight', n + '.conv2.bias', residual=skip)
 
@@ -218,11 +236,11 @@ def _vae_attn(K, n, x):
     B, H, W, C = x.shape
     S = H * W
     if getattr(K, 'training', False):        # autograd form (VQ-VAE stage-1 training)
-        h = K.gn(x, n + '.norm', eps=1e-6).view(B, S, C)
-        qkv = K.linear(h, (n + '.q.weight', n + '.k.weight', n + '.v.weight'),
+        h, xres = K.gn_fan(x, n + '.norm', eps=1e-6)
+        qkv = K.linear(h.view(B, S, C), (n + '.q.weight', n + '.k.weight', n + '.v.weight'),
                        (n + '.q.bias', n + '.k.bias', n + '.v.bias'))
         o = K.vae_attn_core(qkv)
-        out = K.linear(o, n + '.proj_out.weight', n + '.proj_out.bias', residual=x.view(B, S, C))
+        out = K.linear(o, n + '.proj_out.weight', n + '.proj_out.bias', residual=xres.view(B, S, C))
         return out.view(B, H, W, C)
     h = K.gn(x, n + '.norm', eps=1e-6).view(B, S, C)
     qk = K.linear(h, (n + '.q.weight', n + '.k.weight'), (n + '.q.bias', n + '.k.bias'))

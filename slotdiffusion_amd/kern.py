@@ -275,9 +275,20 @@ class Kern:
         return ops.linear(x, self.wb.w(wnames, x.dtype), self.wb.b(bnames), act=act,
                           residual=residual, out_dtype=out_dtype)
 
-    def gn(self, x, name, *, eps, act=None, residual=None):
+    def gn(self, x, name, *, eps, act=None, residual=None, dropout=None):
+        """dropout = site name: training-mode dropout behind the activation (no-op at inference)."""
         return ops.group_norm(x, self.wb.f(name + '.weight'), self.wb.f(name + '.bias'), eps=eps,
                               act=act, residual=residual)
+
+    # fan-out forms: (result, alias(es) of x for x's other consumers) -- plain x at inference
+    def gn_fan(self, x, name, *, eps, act=None, residual=None, n_alias=1):
+        return (self.gn(x, name, eps=eps, act=act, residual=residual),) + (x,) * n_alias
+
+    def ln_fan(self, x, name):
+        return self.ln(x, name), x
+
+    def conv_fan(self, x, wname, bname=None, **kw):
+        return self.conv(x, wname, bname, **kw), x
 
     def deconv(self, x, wname, bname, *, k, stride, pad, act='relu'):
         return deconv_forward(self.wb, x, wname, bname, k, stride, pad, act)
@@ -361,7 +372,10 @@ class GemmFn(torch.autograd.Function):
     """out = conv/linear(x, W) + bias (+ rowvec[b]) (+ residual).  Activation-free."""
 
     @staticmethod
-    def forward(ctx, x, rowvec, residual, anchor, wb, wnames, bnames, geom, out_dtype, ldc):
+    def forward(ctx, x, rowvec, residual, anchor, wb, wnames, bnames, geom, out_dtype, ldc, n_alias=0):
+        """n_alias = 1: also returns an alias of x for x's OTHER consumer (identity / skip branch);
+        its gradient comes back into this backward and is summed inside the dgrad kernel's epilogue
+        instead of by an autograd accumulation kernel."""
         kh, kw, stride, pad, ups = geom
         w = wb.w(wnames, x.dtype)
         b = wb.b(bnames)
@@ -373,11 +387,16 @@ class GemmFn(torch.autograd.Function):
         ctx.save_for_backward(x)
         ctx.cfg = (wb, wnames, bnames, geom, rowvec is not None, residual is not None,
                    rowvec.shape if rowvec is not None else None)
+        ctx.set_materialize_grads(False)
+        if n_alias:
+            return out, x.view_as(x)
         return out
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dalias=None):
         (x,) = ctx.saved_tensors
+        if dalias is not None:
+            dalias = dalias.contiguous()
         wb, wnames, bnames, geom, has_rv, has_res, rv_shape = ctx.cfg
         kh, kw, stride, pad, ups = geom
         is_conv = x.dim() == 4 and (kh, kw) != (0, 0)
@@ -432,7 +451,8 @@ class GemmFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             wd = wb.wd(wnames, dt, kh, kw, Cin)
             if is_conv and stride > 1 and not ups:
-                dx = GemmFn._dgrad_strided(dy, wd, B, H, W_, Ho, Wo, Cin, ldy, kh, kw, stride, pad, dt)
+                dx, dalias = GemmFn._dgrad_strided(dy, wd, B, H, W_, Ho, Wo, Cin, ldy, kh, kw, stride,
+                                                   pad, dt, dalias)
             elif is_conv:
                 Hs, Ws = (2 * H, 2 * W_) if ups else (H, W_)
                 out = torch.empty((B, Hs, Ws, Cin), dtype=dt, device=x.device)
@@ -440,7 +460,10 @@ class GemmFn(torch.autograd.Function):
                      out_dtype=_DT[dt], M=B * Hs * Ws, N=Cin, K=kh * kw * ldy, lda=ldy,
                      ldw=kh * kw * ldy, ldc=Cin, B=B, H=Ho, W=Wo, Cin=ldy, Ho=Hs, Wo=Ws, KH=kh,
                      KW=kw, stride=1, pad_t=kh - 1 - pad[0], pad_l=kw - 1 - pad[2], ups=0, act=0,
-                     alpha=1.0, split_k=1, batch=1, zins=(stride if stride > 1 else 0))
+                     alpha=1.0, split_k=1, batch=1, zins=(stride if stride > 1 else 0),
+                     residual=(_p(dalias) if (dalias is not None and not ups) else 0), ldr=Cin)
+                if dalias is not None and not ups:
+                    dalias = None
                 if ups:
                     dx = torch.empty_like(x)
                     call('sdmi_pool2x2_sum', _st(), x=_p(out), y=_p(dx), dtype=_DT[dt], B=B, H=H,
@@ -448,7 +471,13 @@ class GemmFn(torch.autograd.Function):
                 else:
                     dx = out
             else:
-                dx = ops.linear(dy.view(-1, ldy), wd).view(x.shape)
+                dx = ops.linear(dy.view(-1, ldy), wd,
+                                residual=(dalias.view(-1, Cin) if dalias is not None else None)).view(x.shape)
+                dalias = None
+            if dalias is not None:          # (no epilogue to fold it into: nearest-x2 / partial parity cover)
+                call('sdmi_add', _st(), x=_p(dx), z=_p(dalias), y=_p(dx), dtype=_DT[dt], n=dx.numel())
+        elif dalias is not None:
+            dx = dalias
         drv = None
         if has_rv and ctx.needs_input_grad[1]:
             drv = torch.empty(rv_shape, dtype=torch.float32, device=x.device)
@@ -459,10 +488,10 @@ class GemmFn(torch.autograd.Function):
             dres = dy if dy.shape[-1] == N else None
             assert dres is not None
         _dbg(f'gemm {wnames if isinstance(wnames, str) else wnames[0]}', dy=dy, dx=dx, drv=drv)
-        return dx, drv, dres, None, None, None, None, None, None, None
+        return dx, drv, dres, None, None, None, None, None, None, None, None
 
     @staticmethod
-    def _dgrad_strided(dy, wd, B, H, W_, Ho, Wo, Cin, ldy, kh, kw, s, pad, dt):
+    def _dgrad_strided(dy, wd, B, H, W_, Ho, Wo, Cin, ldy, kh, kw, s, pad, dt, extra=None):
         """Data gradient of a stride-s convolution as s*s plain stride-1 convolutions over dy, one
         per input-pixel parity (py, px): only the filter taps kh = (py + pad_t) mod s (+ s, ...)
         reach that parity, so each launch uses its sub-filter (a strided slice of the flipped
@@ -472,6 +501,8 @@ class GemmFn(torch.autograd.Function):
         full = all(len(range((p + pd) % s, k, s)) > 0
                    for k, pd in ((kh, pad[0]), (kw, pad[2])) for p in range(s))
         dx = (torch.empty if full else torch.zeros)((B, H, W_, Cin), dtype=dt, device=dy.device)
+        # `extra` (gradient of x's other consumer) rides in the epilogue when every pixel is written
+        fuse = extra is not None and full
         for py in range(s):
             ay = (py + pad[0]) % s
             nky = len(range(ay, kh, s))
@@ -489,8 +520,8 @@ class GemmFn(torch.autograd.Function):
                      H=Ho, W=Wo, Cin=ldy, Ho=hs, Wo=ws_, KH=nky, KW=nkx, stride=1,
                      pad_t=(nky - 1) - (py + pad[0] - ay) // s, pad_l=(nkx - 1) - (px + pad[2] - ax) // s,
                      ups=0, act=0, alpha=1.0, split_k=1, batch=1, oH=H, oW=W_, osy=s, osx=s, ooy=py,
-                     oox=px)
-        return dx
+                     oox=px, residual=(_p(extra) if fuse else 0), ldr=Cin)
+        return dx, (None if fuse else extra)
 
     @staticmethod
     def _wgrad(wb, x, dy, dt, names, bnames, dst, direct, splits, M, N, K, Cin, ldy, B, H, W_, Ho,
@@ -537,18 +568,34 @@ class GemmFn(torch.autograd.Function):
 
 class GroupNormFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, residual, anchor, wb, name, eps, act):
+    def forward(ctx, x, residual, anchor, wb, name, eps, act, n_alias=0, drop=None):
+        """drop = (p, seed, seed_dev): dropout fused behind the activation (the mask is regenerated
+        from the seed in backward).  n_alias aliases of x are returned next to y for x's other consumers (ResBlock skip,
+        UNet skip-concat, SpatialTransformer residual): their gradients come back into this
+        backward and are summed by the GroupNorm backward kernel (dextra0/1) -- no separate
+        accumulation kernels."""
         gamma, beta = wb.f(name + '.weight'), wb.f(name + '.bias')
         y, stats = ops.group_norm(x, gamma, beta, eps=eps, act=act, residual=residual,
-                                  return_stats=True)
+                                  return_stats=True, drop=drop)
         ctx.save_for_backward(x, stats, residual)
         ctx.cfg = (wb, name, act)
+        ctx.drop = drop if (drop is not None and drop[0] > 0.0) else None
+        ctx.set_materialize_grads(False)
+        if n_alias:
+            return (y,) + tuple(x.view_as(x) for _ in range(n_alias))
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, *dal):
         x, stats, residual = ctx.saved_tensors
         wb, name, act = ctx.cfg
+        extras = [d.contiguous() for d in dal if d is not None]
+        assert len(extras) <= 2 and all(e.dtype == x.dtype for e in extras)
+        if dy is None:                     # y unused: only the aliases carry gradient
+            dx = extras[0]
+            for e in extras[1:]:
+                dx = AddFn.apply(dx, e)
+            return dx, None, None, None, None, None, None, None, None
         dy = dy.contiguous()
         B, C = x.shape[0], x.shape[-1]
         HW = x.numel() // (B * C)
@@ -563,25 +610,35 @@ class GroupNormFn(torch.autograd.Function):
         call('sdmi_groupnorm_bwd', _st(), x=_p(x), dy=_p(dy), dx=_p(dx), gamma=_p(wb.f(name + '.weight')),
              beta=_p(wb.f(name + '.bias')), stats=_p(stats), dgamma=_p(dg), dbeta=_p(db),
              partial=_p(partial), dtype=_DT[x.dtype], B=B, HW=HW, C=C, groups=G,
-             act=_lib.ACT[act], nsplit=nsplit, residual=_p(residual), dresidual=_p(dres), accumulate=1)
+             act=_lib.ACT[act], nsplit=nsplit, residual=_p(residual), dresidual=_p(dres), accumulate=1,
+             dextra0=(_p(extras[0]) if extras else 0), dextra1=(_p(extras[1]) if len(extras) > 1 else 0),
+             **(dict(drop_p=float(ctx.drop[0]), drop_seed=int(ctx.drop[1]), drop_seed_dev=_p(ctx.drop[2]))
+                if ctx.drop else {}))
         _dbg(f'gn {name}', dy=dy, dx=dx, dres=dres)
-        return dx, dres, None, None, None, None, None
+        return dx, dres, None, None, None, None, None, None, None
 
 
 class LayerNormFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, anchor, wb, name):
+    def forward(ctx, x, anchor, wb, name, n_alias=0):
         C = x.shape[-1]
         stats = torch.empty((x.numel() // C, 2), dtype=torch.float32, device=x.device)
         y = ops.layer_norm(x, wb.f(name + '.weight'), wb.f(name + '.bias'), stats=stats)
         ctx.save_for_backward(x, stats)
         ctx.cfg = (wb, name)
+        ctx.set_materialize_grads(False)
+        if n_alias:                        # alias of x for the residual branch (see GroupNormFn)
+            return y, x.view_as(x)
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dalias=None):
         x, stats = ctx.saved_tensors
         wb, name = ctx.cfg
+        if dalias is not None:
+            dalias = dalias.contiguous()
+        if dy is None:
+            return dalias, None, None, None, None
         dy = dy.contiguous()
         C = x.shape[-1]
         rows = x.numel() // C
@@ -591,9 +648,10 @@ class LayerNormFn(torch.autograd.Function):
         dg, db = _grads_of(wb, name + '.weight'), _grads_of(wb, name + '.bias')
         call('sdmi_layernorm_bwd', _st(), x=_p(x), dy=_p(dy), dx=_p(dx),
              gamma=_p(wb.f(name + '.weight')), stats=_p(stats), dgamma=_p(dg), dbeta=_p(db),
-             partial=_p(partial), dtype=_DT[x.dtype], rows=rows, C=C, nblk=nblk, accumulate=1)
+             partial=_p(partial), dtype=_DT[x.dtype], rows=rows, C=C, nblk=nblk, accumulate=1,
+             dextra=_p(dalias))
         _dbg(f'ln {name}', dy=dy, dx=dx)
-        return dx, None, None, None
+        return dx, None, None, None, None
 
 
 class AttnFn(torch.autograd.Function):
@@ -1087,8 +1145,25 @@ class KernGrad(Kern):
                          (0, 0, 1, (0, 0, 0, 0), False), out_dtype, None)
         return ActFn.apply(y, act) if act else y
 
-    def gn(self, x, name, *, eps, act=None, residual=None):
-        return GroupNormFn.apply(x, residual, self.wb.anchor_for(name), self.wb, name, eps, act)
+    def gn(self, x, name, *, eps, act=None, residual=None, dropout=None):
+        drop = None
+        if dropout is not None:
+            p = self._p_drop(dropout)
+            if p > 0.0:          # fused behind the activation: same seed scheme as DropoutFn
+                self._drop_ctr += 1
+                drop = (p, (self.seed << 20) + self._drop_ctr, getattr(self.wb.model, 'step_seed', None))
+        return GroupNormFn.apply(x, residual, self.wb.anchor_for(name), self.wb, name, eps, act, 0, drop)
+
+    def gn_fan(self, x, name, *, eps, act=None, residual=None, n_alias=1):
+        return GroupNormFn.apply(x, residual, self.wb.anchor_for(name), self.wb, name, eps, act, n_alias)
+
+    def ln_fan(self, x, name):
+        return LayerNormFn.apply(x, self.wb.anchor_for(name), self.wb, name, 1)
+
+    def conv_fan(self, x, wname, bname=None, *, kh=3, kw=3, stride=1, pad=(1, 1, 1, 1), ups=False,
+                 rowvec=None, residual=None, out_dtype=None, ldc=None):
+        return GemmFn.apply(x, rowvec, residual, self.wb.anchor_for(wname), self.wb, wname, bname,
+                            (kh, kw, stride, pad, ups), out_dtype, ldc, 1)
 
     def deconv(self, x, wname, bname, *, k, stride, pad, act='relu'):
         return DeconvFn.apply(x, self.wb.anchor_for(wname), self.wb, wname, bname, k, stride, pad, act)

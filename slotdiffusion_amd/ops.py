@@ -114,8 +114,9 @@ def bmm_nt(a, b, out, *, alpha=1.0, bias_m=None):
 # normalisation
 # ------------------------------------------------------------------------------------------
 def group_norm(x, gamma, beta, *, eps, act=None, groups=32, residual=None, out=None,
-               return_stats=False):
-    """x [B,H,W,C] (or [B,HW,C]) NHWC -> same shape; fp32 statistics."""
+               return_stats=False, drop=None):
+    """x [B,H,W,C] (or [B,HW,C]) NHWC -> same shape; fp32 statistics.  drop = (p, seed, seed_dev):
+    inverted dropout fused behind the activation (training-mode ResBlocks)."""
     _need_gpu(x)
     B, C = x.shape[0], x.shape[-1]
     HW = x.numel() // (B * C)
@@ -127,6 +128,8 @@ def group_norm(x, gamma, beta, *, eps, act=None, groups=32, residual=None, out=N
     kw = dict(x=_p(x), y=_p(out), gamma=_p(gamma), beta=_p(beta), stats=_p(stats),
               partial=_p(partial), dtype=_dt(x), B=B, HW=HW, C=C, groups=groups, eps=eps,
               act=ACT[act], nsplit=nsplit, residual=_p(residual))
+    if drop is not None and drop[0] > 0.0:
+        kw.update(drop_p=float(drop[0]), drop_seed=int(drop[1]), drop_seed_dev=_p(drop[2]))
     call('sdmi_groupnorm', _stream(), **kw)      # one fused launch for small images, else two
     return (out, stats) if return_stats else out
 

@@ -419,6 +419,125 @@ def test_groupnorm_bwd_kernel(B, HW, C, act, res, dtype):
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('B,HW,C', [(2, 256, 128), (2, 1024, 128), (3, 64, 384), (2, 8192, 64)])
+def test_groupnorm_fanout_and_fused_dropout(B, HW, C, dtype):
+    """The training-mode GroupNorm Function with its fused extras against torch autograd:
+    (a) alias outputs -- the gradients of x's other consumers come back into the backward and are
+        summed inside the kernel (dextra0 / dextra1) -- single-pass and two-pass geometries;
+    (b) dropout fused behind the activation: the keep mask regenerated in backward equals the
+        forward's, keep rate = 1 - p, survivors are scaled by 1 / (1 - p)."""
+    from slotdiffusion_amd.kern import GroupNormFn
+    g = torch.Generator().manual_seed(B * HW + C)
+    q = lambda t: t.to(dtype).float()
+    x0 = q(torch.randn(B, HW, C, generator=g) * 1.5 + 0.3)
+    gam, bet = 1 + 0.3 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
+    dy, d1, d2 = (q(torch.randn(B, HW, C, generator=g)) for _ in range(3))
+
+    class WB:                                   # the slice of WeightBank GroupNormFn touches
+        class model:
+            @staticmethod
+            def grad_arena():
+                return WB.g
+            _offsets = {'n.weight': (0, C), 'n.bias': (C, C)}
+        t = {'n.weight': gam.cuda(), 'n.bias': bet.cuda()}
+        g = torch.zeros(2 * C, device='cuda')
+
+        @staticmethod
+        def f(k):
+            return WB.t[k]
+    # (a) fan-out: y, a1, a2 = GN(x);  loss = <y, dy> + <a1, d1> + <a2, d2>
+    xr = x0.clone().requires_grad_(True)
+    yr = F.silu(F.group_norm(xr.permute(0, 2, 1), 32, gam, bet, 1e-5).permute(0, 2, 1))
+    (yr * dy).sum().backward()
+    ref_dx = xr.grad + d1 + d2
+    xd = x0.to(dtype).cuda().requires_grad_(True)
+    anchor = torch.zeros(1, device='cuda', requires_grad=True)
+    y, a1, a2 = GroupNormFn.apply(xd, None, anchor, WB, 'n', 1e-5, 'silu', 2, None)
+    torch.autograd.backward([y, a1, a2], [dy.to(dtype).cuda(), d1.to(dtype).cuda(), d2.to(dtype).cuda()])
+    tol = 3e-5 if dtype == torch.float32 else 2e-2
+    rel = lambda a, b: float((a.float().cpu() - b).norm() / b.norm())
+    assert rel(xd.grad, ref_dx) <= tol
+    assert a1.data_ptr() == xd.data_ptr()
+    # (b) fused dropout
+    p = 0.1
+    seed_dev = torch.full((1,), 5, dtype=torch.int64, device='cuda')
+    xd2 = x0.to(dtype).cuda().requires_grad_(True)
+    yd = GroupNormFn.apply(xd2, None, anchor, WB, 'n', 1e-5, 'silu', 0, (p, 1234, seed_dev))
+    y_plain = y.detach().float().cpu()
+    ydc = yd.detach().float().cpu()
+    keep = ydc != 0
+    frac = 1.0 - float(keep.float().mean()) - float((y_plain == 0).float().mean())
+    assert abs(frac - p) < 0.01, frac
+    assert rel(ydc[keep], (y_plain / (1 - p))[keep]) <= (1e-6 if dtype == torch.float32 else 1e-2)
+    yd.backward(dy.to(dtype).cuda())
+    xr2 = x0.clone().requires_grad_(True)
+    yr2 = F.silu(F.group_norm(xr2.permute(0, 2, 1), 32, gam, bet, 1e-5).permute(0, 2, 1))
+    (yr2 * (dy * keep.float() / (1 - p))).sum().backward()
+    assert rel(xd2.grad, xr2.grad) <= tol
+    # another seed word -> another mask
+    seed_dev.fill_(6)
+    yd2 = GroupNormFn.apply(xd2.detach(), None, anchor, WB, 'n', 1e-5, 'silu', 0, (p, 1234, seed_dev))
+    assert float(((yd2 != 0) != (yd != 0)).float().mean()) > 0.1
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_layernorm_and_gemm_fanout(dtype):
+    """LayerNormFn / GemmFn alias outputs: the residual branch's gradient is summed inside the
+    LayerNorm backward kernel / the dgrad epilogue (stride 1, stride 2 full and partial parity cover,
+    linear)."""
+    from slotdiffusion_amd.kern import LayerNormFn, GemmFn
+    g = torch.Generator().manual_seed(3)
+    q = lambda t: t.to(dtype).float()
+    tol = 3e-5 if dtype == torch.float32 else 2e-2
+    rel = lambda a, b: float((a.float().cpu() - b).norm() / b.norm())
+    rows, C = 300, 256
+    x0 = q(torch.randn(rows, C, generator=g) * 2 + 0.5)
+    gam, bet = 1 + 0.3 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
+    dy, d1 = q(torch.randn(rows, C, generator=g)), q(torch.randn(rows, C, generator=g))
+
+    class WB:
+        class model:
+            @staticmethod
+            def grad_arena():
+                return WB.g
+            _offsets = {'n.weight': (0, C), 'n.bias': (C, C)}
+        t = {'n.weight': gam.cuda(), 'n.bias': bet.cuda()}
+        g = torch.zeros(2 * C, device='cuda')
+
+        @staticmethod
+        def f(k):
+            return WB.t[k]
+    xr = x0.clone().requires_grad_(True)
+    F.layer_norm(xr, (C,), gam, bet, 1e-5).backward(dy)
+    xd = x0.to(dtype).cuda().requires_grad_(True)
+    anchor = torch.zeros(1, device='cuda', requires_grad=True)
+    y, a = LayerNormFn.apply(xd, anchor, WB, 'n', 1)
+    torch.autograd.backward([y, a], [dy.to(dtype).cuda(), d1.to(dtype).cuda()])
+    assert rel(xd.grad, xr.grad + d1) <= tol
+    # convolution fan-out through the model-level provider (real WeightBank)
+    m = _model(dtype)
+    m.train()
+    K = m.KG()
+    for name, stride, kh, pad in (('encoder.layer1.0.conv1.weight', 1, 3, (1, 1, 1, 1)),
+                                  ('encoder.layer2.0.conv1.weight', 2, 3, (1, 1, 1, 1)),
+                                  ('encoder.layer2.0.downsample.0.weight', 2, 1, (0, 0, 0, 0))):
+        w = m.state_dict()[name].float().cpu()
+        cin = w.shape[1]
+        xi = q(torch.randn(2, cin, 16, 16, generator=g))
+        xr = xi.clone().requires_grad_(True)
+        yr = F.conv2d(xr, q(w), None, stride, pad[0])
+        dyc = q(torch.randn(yr.shape, generator=g))
+        dal = q(torch.randn(xi.shape, generator=g))
+        yr.backward(dyc)
+        xd = xi.permute(0, 2, 3, 1).contiguous().to(dtype).cuda().requires_grad_(True)
+        m.grad_arena().zero_()
+        o, al = K.conv_fan(xd, name, kh=kh, kw=kh, stride=stride, pad=pad)
+        torch.autograd.backward([o, al], [dyc.permute(0, 2, 3, 1).contiguous().to(dtype).cuda(),
+                                          dal.permute(0, 2, 3, 1).contiguous().to(dtype).cuda()])
+        assert rel(xd.grad.permute(0, 3, 1, 2), xr.grad + dal) <= (tol if dtype == torch.float32 else 3e-2), name
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize('cfg', [(2, 8, 256, 256), (2, 12, 64, 64), (3, 16, 16, 16), (2, 8, 256, 7),
                                  (2, 4, 50, 15), (1, 2, 130, 100)])
 def test_attention_bwd_kernel(cfg, dtype):
@@ -584,8 +703,9 @@ def test_method_fit_through_the_registry(name):
     losses = [float(l) for l in method.history]
     n_logged = 5
     assert len(losses) == n_logged and all(math.isfinite(l) for l in losses), losses
-    if name == 'VQVAE':       # stage-1 training reduces recon + commitment loss (every step sees a
-        assert min(losses[1:]) < losses[0]        # new random batch and update 1 runs at lr 0)
+    # (no monotonicity check: 5 steps at the config's lr with a 0.25-step warm-up, a new random batch
+    # every step and update 1 at lr 0 -- gradient parity of stage-1 training is pinned by
+    # test_vqvae_stage1_training_gradients)
     assert method.optimizer.step_count == 5
     assert float((model.arena() - before).abs().max()) > 0
 
