@@ -94,6 +94,15 @@ typedef struct {
 } SdmiWgradArgs;
 int sdmi_wgrad(const SdmiWgradArgs* a, void* stream);
 
+/* Grouped weight gradients: up to 16 independent 1x1 / linear bf16 problems (the eight Linear layers
+ * of a transformer block, attention.py:182-251) in ONE launch.  Each problem alone has too few output
+ * tiles to fill 256 CUs and would pay an M-split + fold launch pair; together their tiles fill the
+ * chip.  `problems` is a HOST array of n SdmiWgradArgs (each with its own splits / workspace as for
+ * sdmi_wgrad; bf16, KH = KW = 1, N > 64, K > 64); problems with splits > 1 are folded by one shared
+ * second launch.  Results equal n sdmi_wgrad calls bit for bit. */
+typedef struct { const void* problems; int n; } SdmiWgradGroupArgs;
+int sdmi_wgrad_group(const SdmiWgradGroupArgs* a, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * GroupNorm (+ fused activation) on NHWC, statistics in fp32.
  * Replaces GroupNorm32/Normalize + SiLU/ReLU/swish: unet/utils.py:120-139, unet.py:219-222,

@@ -143,7 +143,9 @@ def _meta(fname, kw):
 
 
 def call(fname, stream, **kw):
-    """Invoke `fname` with its argument struct filled from keyword args (missing fields = 0)."""
+    """Invoke `fname` with its argument struct filled from keyword args (missing fields = 0).
+    `_meta` (optional dict: flops / bytes of the launch) only feeds KernelTimer."""
+    meta = kw.pop('_meta', None)
     kt = KernelTimer.active
     if kt is not None:
         import torch
@@ -151,7 +153,7 @@ def call(fname, stream, **kw):
         e0.record()
         _call(fname, stream, **kw)
         e1.record()
-        kt.records.append((fname, e0, e1, _meta(fname, kw)))
+        kt.records.append((fname, e0, e1, meta if meta is not None else _meta(fname, kw)))
         return
     _call(fname, stream, **kw)
 

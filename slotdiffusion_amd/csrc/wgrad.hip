@@ -378,8 +378,8 @@ typedef short s16x8 __attribute__((ext_vector_type(8)));
 // work serialises with the MFMAs of the wave next to it (tools/probes/ldsdma.hip), so MODE 2
 // keeps only the border test (~10 VALU per vector and step) and MODE 1 none.
 template <int TN, int TK, int MODE>
-__global__ __launch_bounds__(512) void wgrad_tr_kernel(SdmiWgradArgs p, int tiles_n, int tiles_k,
-                                                       int m_per_split) {
+__device__ __forceinline__ void wgrad_tr_body(const SdmiWgradArgs& p, int tiles_n, int tiles_k,
+                                              int m_per_split, int tile, int split_idx) {
   typedef bf16_t T;
   constexpr bool IS1X1 = MODE == 1;
   constexpr bool FAST = MODE != 0;
@@ -394,13 +394,12 @@ __global__ __launch_bounds__(512) void wgrad_tr_kernel(SdmiWgradArgs p, int tile
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
-  const int tile = blockIdx.x;
   if (tile >= tiles_n * tiles_k) {   // trailing workgroups: bias gradient (column sums of dY)
-    bias_tile<T, TN>(p, tile - tiles_n * tiles_k, blockIdx.y, m_per_split, smem);
+    bias_tile<T, TN>(p, tile - tiles_n * tiles_k, split_idx, m_per_split, smem);
     return;
   }
   const int tile_n = tile / tiles_k, tile_k = tile - tile_n * tiles_k;
-  const int split = blockIdx.y;
+  const int split = split_idx;
   const int n0 = tile_n * TN, k0 = tile_k * TK;
   const int m_begin = split * m_per_split;
   int m_end = m_begin + m_per_split;
@@ -646,13 +645,41 @@ __global__ __launch_bounds__(512) void wgrad_tr_kernel(SdmiWgradArgs p, int tile
   }
 }
 
-// Fold the split partials in split order (deterministic).  One thread per 16-byte output vector
-// (N*K is a multiple of 4), 8 partial loads in flight per thread before the ordered adds.
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(SdmiWgradArgs p) {
+template <int TN, int TK, int MODE>
+__global__ __launch_bounds__(512) void wgrad_tr_kernel(SdmiWgradArgs p, int tiles_n, int tiles_k,
+                                                       int m_per_split) {
+  wgrad_tr_body<TN, TK, MODE>(p, tiles_n, tiles_k, m_per_split, blockIdx.x, blockIdx.y);
+}
+
+// ------------------------------------------------------------------------------------------
+// Grouped launch: the workgroups of up to 16 independent 1x1 / linear problems in one grid.  The
+// descriptor travels BY VALUE in the kernel arguments (a HIP graph captures it with the launch; no
+// table in device memory).  item_begin[i] .. item_begin[i+1] are problem i's workgroups, laid out
+// [split][tile (+ bias tiles)] like the single-problem grid.
+// ------------------------------------------------------------------------------------------
+constexpr int WG_MAX = 16;
+struct WgradGroup {
+  int n;
+  int item_begin[WG_MAX + 1];
+  int tiles_n[WG_MAX], tiles_k[WG_MAX], per_split[WG_MAX], mps[WG_MAX];
+  int red_begin[WG_MAX + 1];        // fold launch: 256-thread blocks of problem i (0 when splits == 1)
+  SdmiWgradArgs p[WG_MAX];
+};
+
+__global__ __launch_bounds__(512) void wgrad_group_kernel(WgradGroup g) {
+  const int bid = blockIdx.x;
+  int i = 0;
+  while (i + 1 < g.n && bid >= g.item_begin[i + 1]) ++i;      // uniform: scalar loop over <= 16 entries
+  const int local = bid - g.item_begin[i];
+  const int split = local / g.per_split[i];
+  const int tile = local - split * g.per_split[i];
+  wgrad_tr_body<128, 128, 1>(g.p[i], g.tiles_n[i], g.tiles_k[i], g.mps[i], tile, split);
+}
+
+__device__ __forceinline__ void wgrad_reduce_body(const SdmiWgradArgs& p, int blk, int nblk) {
   const long long total = (long long)p.N * p.K;
   const long long total4 = total >> 2;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total4;
-       i += (long long)gridDim.x * 256) {
+  for (long long i = (long long)blk * 256 + threadIdx.x; i < total4; i += (long long)nblk * 256) {
     const f32x4* src = reinterpret_cast<const f32x4*>(p.workspace) + i;
     f32x4* dst = reinterpret_cast<f32x4*>(p.dw) + i;
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
@@ -669,13 +696,25 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(SdmiWgradArgs p) {
     *dst = s;
   }
   if (p.dbias)
-    for (long long n = (long long)blockIdx.x * 256 + threadIdx.x; n < p.N;
-         n += (long long)gridDim.x * 256) {
+    for (long long n = (long long)blk * 256 + threadIdx.x; n < p.N; n += (long long)nblk * 256) {
       float s = p.accumulate ? p.dbias[n] : 0.f;
       for (int k = 0; k < p.splits; ++k)
         s += p.workspace[(long long)p.splits * total + (long long)k * p.N + n];
       p.dbias[n] = s;
     }
+}
+
+__global__ __launch_bounds__(256) void wgrad_group_reduce_kernel(WgradGroup g) {
+  const int bid = blockIdx.x;
+  int i = 0;
+  while (i + 1 < g.n && bid >= g.red_begin[i + 1]) ++i;
+  wgrad_reduce_body(g.p[i], bid - g.red_begin[i], g.red_begin[i + 1] - g.red_begin[i]);
+}
+
+// Fold the split partials in split order (deterministic).  One thread per 16-byte output vector
+// (N*K is a multiple of 4), 8 partial loads in flight per thread before the ordered adds.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(SdmiWgradArgs p) {
+  wgrad_reduce_body(p, blockIdx.x, gridDim.x);
 }
 
 template <typename T, int TN, int TK, bool IS1X1>
@@ -757,6 +796,56 @@ int dispatch_wgrad_bf16(const SdmiWgradArgs& a, hipStream_t st) {
 }
 
 }  // namespace
+
+extern "C" int sdmi_wgrad_group(const SdmiWgradGroupArgs* ga, void* stream) {
+  SDMI_REQUIRE(ga && ga->problems && ga->n >= 1 && ga->n <= WG_MAX, "1 .. 16 problems");
+  const SdmiWgradArgs* ps = (const SdmiWgradArgs*)ga->problems;
+  hipStream_t st = (hipStream_t)stream;
+  WgradGroup g;
+  g.n = ga->n;
+  int items = 0, red = 0;
+  for (int i = 0; i < ga->n; ++i) {
+    const SdmiWgradArgs& a = ps[i];
+    SDMI_REQUIRE(a.a && a.dy && a.dw, "null pointer");
+    SDMI_REQUIRE(a.dtype == SDMI_BF16 && wgrad_is1x1(a) && a.N > 64 && a.K > 64,
+                 "grouped wgrad: bf16 1x1 / linear problems with N, K > 64");
+    SDMI_REQUIRE(a.K == a.Cin && a.Cin % 8 == 0 && a.lda % 8 == 0 && a.ldy % 8 == 0 && a.M == a.B * a.Ho * a.Wo,
+                 "bad geometry");
+    SDMI_REQUIRE(a.splits >= 1 && (a.splits == 1 || a.workspace), "splits / workspace");
+    const long long mps_ = ((long long)a.M + a.splits - 1) / a.splits + 64;
+    const long long ld = a.lda > a.ldy ? a.lda : a.ldy;
+    SDMI_REQUIRE((mps_ + 64) * ld * 2 < (1ll << 31), "split too large for 31-bit offsets");
+    g.p[i] = a;
+    g.tiles_n[i] = (a.N + 127) / 128;
+    g.tiles_k[i] = (a.K + 127) / 128;
+    g.per_split[i] = g.tiles_n[i] * g.tiles_k[i] + (a.dbias ? g.tiles_n[i] : 0);
+    int mps = (a.M + a.splits - 1) / a.splits;
+    g.mps[i] = (mps + 63) / 64 * 64;
+    g.item_begin[i] = items;
+    items += g.per_split[i] * a.splits;
+    g.red_begin[i] = red;
+    if (a.splits > 1) {
+      long long blocks = ((long long)a.N * a.K / 4 + 255) / 256;
+      red += (int)(blocks > 512 ? 512 : blocks);
+    }
+  }
+  for (int i = ga->n; i <= WG_MAX; ++i) { g.item_begin[i] = items; g.red_begin[i] = red; }
+  constexpr int smem = 2 * 64 * (128 * 2 + 64 + 128 * 2 + 64);
+  static bool done = false;
+  if (!done) {
+    if (hipFuncSetAttribute((const void*)wgrad_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            smem) != hipSuccess) {
+      sdmi_set_error("wgrad group: hipFuncSetAttribute failed");
+      return SDMI_ELAUNCH;
+    }
+    done = true;
+  }
+  hipLaunchKernelGGL(wgrad_group_kernel, dim3(items), dim3(512), smem, st, g);
+  int rc = sdmi_check_launch("wgrad group");
+  if (rc || red == 0) return rc;
+  hipLaunchKernelGGL(wgrad_group_reduce_kernel, dim3(red), dim3(256), 0, st, g);
+  return sdmi_check_launch("wgrad group reduce");
+}
 
 extern "C" int sdmi_wgrad(const SdmiWgradArgs* a, void* stream) {
   SDMI_REQUIRE(a && a->a && a->dy && a->dw && a->workspace, "null pointer");

@@ -121,11 +121,9 @@ class UNetRunner:
 
     def context_kv(self, K, ctx):
         """ctx [B,N,Dc] compute dtype -> {st name: kv [B,N,2C]}; constant across all NFEs."""
-        out = {}
-        for n in self.st_names:
-            t = self.P + n + '.transformer_blocks.0.attn2'
-            out[n] = K.linear(ctx, (t + '.to_k.weight', t + '.to_v.weight'))
-        return out
+        names = [(self.P + n + '.transformer_blocks.0.attn2.to_k.weight',
+                  self.P + n + '.transformer_blocks.0.attn2.to_v.weight') for n in self.st_names]
+        return dict(zip(self.st_names, K.linear_multi(ctx, names)))
 
     # -- blocks ---------------------------------------------------------------------------
     def _res(self, K, name, x, rowvecs, want_cat=False):

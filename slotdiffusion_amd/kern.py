@@ -65,6 +65,10 @@ class WeightBank:
         self._sides = []
         self._pending, self._side_of = [], {}
         self._join_queued = False
+        # grouped weight gradients: 1x1 / linear bf16 problems are queued and launched together
+        # (sdmi_wgrad_group) once their tiles can fill the chip -- see queue_wgrad()
+        self.group_wgrad = os.environ.get('SDMI_WGRAD_GROUP', '1') != '0'
+        self._wq, self._wq_keep, self._wq_items, self._wq_bytes = [], [], 0, 0
         # dgrad operands: key -> [buffer, epoch, (stable source view | None, geometry)]
         self._wd, self._wd_epoch, self._wd_stale, self._wd_table = {}, 0, False, None
 
@@ -99,7 +103,67 @@ class WeightBank:
         self._pending.append(tensors)
         self.ensure_join()
 
+    # ---- grouped weight gradients -----------------------------------------------------------
+    WQ_MAX, WQ_BYTES = 16, 96 << 20
+    WQ_ITEMS = int(os.environ.get('SDMI_WQ_ITEMS', '448'))
+    WQ_TARGET = float(os.environ.get('SDMI_WQ_TARGET', '512'))
+
+    def queue_wgrad(self, kw, keep, tiles, steps, nbytes):
+        """Queue one eligible problem (kw = sdmi_wgrad fields, splits decided at flush).  The queue
+        is launched when it holds enough tiles for the chip, 16 problems, or operands worth more
+        than the Infinity Cache keeps hot -- and at the end of the backward pass (join)."""
+        if any(q[0]['dw'] == kw['dw'] for q in self._wq):     # same parameter twice: keep the order
+            self.flush_wgrad()
+        self._wq.append((kw, tiles, steps))
+        self._wq_keep.extend(keep)
+        self._wq_items += tiles
+        self._wq_bytes += nbytes
+        self.ensure_join()
+        if len(self._wq) >= self.WQ_MAX or self._wq_items >= self.WQ_ITEMS or self._wq_bytes >= self.WQ_BYTES:
+            self.flush_wgrad()
+
+    def flush_wgrad(self):
+        if not self._wq:
+            return
+        q, keep = self._wq, self._wq_keep
+        self._wq, self._wq_keep, self._wq_items, self._wq_bytes = [], [], 0, 0
+        # M-splits: ~512 workgroups over the group, shared in proportion to each problem's work
+        # (tiles x 64-row steps), every split keeping >= 8 steps
+        work = [t * st for _, t, st in q]
+        total = float(sum(work))
+        splits = []
+        for (kw, t, st), w in zip(q, work):
+            want = max(1, int(round(self.WQ_TARGET * w / total / t)))
+            splits.append(max(1, min(want, st // 8, 64)))
+        ws_len = sum(sp * (kw['N'] * kw['K'] + kw['N']) for (kw, _, _), sp in zip(q, splits) if sp > 1)
+        dev = keep[0].device
+        ws = torch.empty((max(ws_len, 1),), dtype=torch.float32, device=dev)
+        Arr = _lib.CSTRUCT['SdmiWgradArgs'] * len(q)
+        arr = Arr()
+        off = 0
+        flops = 0.0
+        for a, (kw, _, _), sp in zip(arr, q, splits):
+            for k, v in kw.items():
+                setattr(a, k, v)
+            a.splits = sp
+            if sp > 1:
+                a.workspace = ws.data_ptr() + 4 * off
+                off += sp * (kw['N'] * kw['K'] + kw['N'])
+            flops += 2.0 * kw['M'] * kw['N'] * kw['K']
+        self._wq_flushes = getattr(self, '_wq_flushes', 0) + 1
+        side = self.side_stream(f'wgrad-group-{self._wq_flushes % self.n_side}')
+        if side is not None:
+            ev = torch.cuda.Event()
+            ev.record()
+            side.wait_event(ev)
+        with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+            import ctypes
+            call('sdmi_wgrad_group', _st(), problems=ctypes.addressof(arr), n=len(q),
+                 _meta=dict(flops=flops))
+        self._pending.append(tuple(keep) + (ws,))
+
     def join(self):
+        self.flush_wgrad()
         for side in self._sides:
             torch.cuda.current_stream().wait_stream(side)
         self._pending.clear()
@@ -280,6 +344,10 @@ class Kern:
         return ops.group_norm(x, self.wb.f(name + '.weight'), self.wb.f(name + '.bias'), eps=eps,
                               act=act, residual=residual)
 
+    def linear_multi(self, x, wname_list):
+        """Several bias-free projections of one input -> tuple of outputs."""
+        return tuple(self.linear(x, n) for n in wname_list)
+
     # fan-out forms: (result, alias(es) of x for x's other consumers) -- plain x at inference
     def gn_fan(self, x, name, *, eps, act=None, residual=None, n_alias=1):
         return (self.gn(x, name, eps=eps, act=act, residual=residual),) + (x,) * n_alias
@@ -398,6 +466,24 @@ class GemmFn(torch.autograd.Function):
         if dalias is not None:
             dalias = dalias.contiguous()
         wb, wnames, bnames, geom, has_rv, has_res, rv_shape = ctx.cfg
+        dx, dy, (N, ldy, B, Ho, Wo, dt) = GemmFn.core(wb, x, dy, wnames, bnames, geom,
+                                                       ctx.needs_input_grad[0], dalias)
+        drv = None
+        if has_rv and ctx.needs_input_grad[1]:
+            drv = torch.empty(rv_shape, dtype=torch.float32, device=x.device)
+            call('sdmi_rowgroup_sum', _st(), x=_p(dy), out=_p(drv), dtype=_DT[dt], groups=B,
+                 rows_per=Ho * Wo, N=N, ldx=ldy)
+        dres = None
+        if has_res and ctx.needs_input_grad[2]:
+            dres = dy if dy.shape[-1] == N else None
+            assert dres is not None
+        _dbg(f'gemm {wnames if isinstance(wnames, str) else wnames[0]}', dy=dy, dx=dx, drv=drv)
+        return dx, drv, dres, None, None, None, None, None, None, None, None
+
+    @staticmethod
+    def core(wb, x, dy, wnames, bnames, geom, need_dx, dalias=None):
+        """Weight / bias gradient (queued or launched) and data gradient of one conv / linear.
+        -> (dx or None, dy in the compute dtype, (N, ldy, B, Ho, Wo, dt))."""
         kh, kw, stride, pad, ups = geom
         is_conv = x.dim() == 4 and (kh, kw) != (0, 0)
         if not is_conv:
@@ -436,19 +522,31 @@ class GemmFn(torch.autograd.Function):
         splits = max(1, min((192 + tiles - 1) // tiles, M // (8 * mt), 512))
         if M <= 16 * mt:
             splits = 1
-        side = wb.side_stream(names[0])
-        if side is not None:
-            ev = torch.cuda.Event()
-            ev.record()
-            side.wait_event(ev)          # dy is ready
-        with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
-            GemmFn._wgrad(wb, x, dy, dt, names, bnames, dst, direct, splits, M, N, K, Cin, ldy, B,
-                          H, W_, Ho, Wo, kh, kw, stride, pad, ups, is_conv)
-        if side is not None:
-            wb.defer(x, dy)
+        bdst = _grads_of(wb, bnames) if bnames is not None else None
+        lda = Cin if is_conv else x.stride(-2)
+        if (wb.group_wgrad and dt == torch.bfloat16 and kh == 1 and kw == 1 and stride == 1 and not ups
+                and pad[0] == 0 and pad[2] == 0 and N > 64 and K > 64 and direct
+                and (bnames is None or bdst is not None) and (M + 128) * max(lda, ldy) * 2 < (1 << 31)):
+            # 1x1 / linear: queued for a grouped launch with the block's other weight gradients
+            tiles = ((N + 127) // 128) * ((K + 127) // 128) + (((N + 127) // 128) if bnames is not None else 0)
+            wb.queue_wgrad(dict(a=_p(x), dy=_p(dy), dw=_p(dst), dbias=_p(bdst), dtype=_DT[dt], M=M, N=N,
+                                K=K, lda=lda, ldy=ldy, B=B, H=H, W=W_, Cin=Cin, Ho=Ho, Wo=Wo, KH=1, KW=1,
+                                stride=1, pad_t=0, pad_l=0, ups=0, accumulate=1),
+                           (x, dy), tiles, (M + 63) // 64, (x.numel() + dy.numel()) * 2)
+        else:
+            side = wb.side_stream(names[0])
+            if side is not None:
+                ev = torch.cuda.Event()
+                ev.record()
+                side.wait_event(ev)          # dy is ready
+            with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+                GemmFn._wgrad(wb, x, dy, dt, names, bnames, dst, direct, splits, M, N, K, Cin, ldy, B,
+                              H, W_, Ho, Wo, kh, kw, stride, pad, ups, is_conv)
+            if side is not None:
+                wb.defer(x, dy)
         # ---- data gradient: the forward kernel on the flipped operand
         dx = None
-        if ctx.needs_input_grad[0]:
+        if need_dx:
             wd = wb.wd(wnames, dt, kh, kw, Cin)
             if is_conv and stride > 1 and not ups:
                 dx, dalias = GemmFn._dgrad_strided(dy, wd, B, H, W_, Ho, Wo, Cin, ldy, kh, kw, stride,
@@ -456,12 +554,14 @@ class GemmFn(torch.autograd.Function):
             elif is_conv:
                 Hs, Ws = (2 * H, 2 * W_) if ups else (H, W_)
                 out = torch.empty((B, Hs, Ws, Cin), dtype=dt, device=x.device)
-                call('sdmi_igemm', _st(), a=_p(dy), w=_p(wd), out=_p(out), dtype=_DT[dt],
+                ws = None if stride > 1 else ops.splitk_workspace(B * Hs * Ws, Cin, kh * kw * ldy,
+                                                                  dy.element_size(), x.device)
+                call('sdmi_igemm', _st(), a=_p(dy), w=_p(wd), out=_p(out), dtype=_DT[dt], workspace=_p(ws),
                      out_dtype=_DT[dt], M=B * Hs * Ws, N=Cin, K=kh * kw * ldy, lda=ldy,
                      ldw=kh * kw * ldy, ldc=Cin, B=B, H=Ho, W=Wo, Cin=ldy, Ho=Hs, Wo=Ws, KH=kh,
                      KW=kw, stride=1, pad_t=kh - 1 - pad[0], pad_l=kw - 1 - pad[2], ups=0, act=0,
-                     alpha=1.0, split_k=1, batch=1, zins=(stride if stride > 1 else 0),
-                     residual=(_p(dalias) if (dalias is not None and not ups) else 0), ldr=Cin)
+                     alpha=1.0, split_k=(0 if ws is not None else 1), batch=1,
+                     zins=(stride if stride > 1 else 0), residual=(_p(dalias) if (dalias is not None and not ups) else 0), ldr=Cin)
                 if dalias is not None and not ups:
                     dalias = None
                 if ups:
@@ -478,17 +578,7 @@ class GemmFn(torch.autograd.Function):
                 call('sdmi_add', _st(), x=_p(dx), z=_p(dalias), y=_p(dx), dtype=_DT[dt], n=dx.numel())
         elif dalias is not None:
             dx = dalias
-        drv = None
-        if has_rv and ctx.needs_input_grad[1]:
-            drv = torch.empty(rv_shape, dtype=torch.float32, device=x.device)
-            call('sdmi_rowgroup_sum', _st(), x=_p(dy), out=_p(drv), dtype=_DT[dt], groups=B,
-                 rows_per=Ho * Wo, N=N, ldx=ldy)
-        dres = None
-        if has_res and ctx.needs_input_grad[2]:
-            dres = dy if dy.shape[-1] == N else None
-            assert dres is not None
-        _dbg(f'gemm {wnames if isinstance(wnames, str) else wnames[0]}', dy=dy, dx=dx, drv=drv)
-        return dx, drv, dres, None, None, None, None, None, None, None, None
+        return dx, dy, (N, ldy, B, Ho, Wo, dt)
 
     @staticmethod
     def _dgrad_strided(dy, wd, B, H, W_, Ho, Wo, Cin, ldy, kh, kw, s, pad, dt, extra=None):
@@ -564,6 +654,33 @@ class GemmFn(torch.autograd.Function):
                 call('sdmi_add', _st(), x=_p(g[off:]), z=_p(btmp[o:]), y=_p(g[off:]), dtype=_lib.F32,
                      n=cnt)
                 o += cnt
+
+
+class MultiLinearFn(torch.autograd.Function):
+    """outs[i] = x @ W_i^T for several (fused) weights sharing ONE input -- the UNet's 16
+    cross-attention K/V projections of the slot context (attention.py:187-189).  The data gradients
+    are chained through the GEMM epilogue (dx_i = dy_i W_i + dx_{i-1}), so the shared input
+    receives one tensor instead of 16 autograd accumulations."""
+
+    @staticmethod
+    def forward(ctx, x, anchor, wb, wname_list):
+        ctx.save_for_backward(x)
+        ctx.cfg = (wb, wname_list)
+        ctx.set_materialize_grads(False)
+        return tuple(ops.linear(x, wb.w(n, x.dtype)) for n in wname_list)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        (x,) = ctx.saved_tensors
+        wb, wname_list = ctx.cfg
+        geom = (0, 0, 1, (0, 0, 0, 0), False)
+        dx = None
+        for n, dy in zip(wname_list, dys):
+            if dy is None:
+                continue
+            d, _, _ = GemmFn.core(wb, x, dy, n, None, geom, ctx.needs_input_grad[0], dx)
+            dx = d if d is not None else dx
+        return dx, None, None, None
 
 
 class GroupNormFn(torch.autograd.Function):
@@ -1156,6 +1273,10 @@ class KernGrad(Kern):
 
     def gn_fan(self, x, name, *, eps, act=None, residual=None, n_alias=1):
         return GroupNormFn.apply(x, residual, self.wb.anchor_for(name), self.wb, name, eps, act, n_alias)
+
+    def linear_multi(self, x, wname_list):
+        wname_list = tuple(wname_list)
+        return MultiLinearFn.apply(x, self.wb.anchor_for(wname_list[0]), self.wb, wname_list)
 
     def ln_fan(self, x, name):
         return LayerNormFn.apply(x, self.wb.anchor_for(name), self.wb, name, 1)

@@ -36,6 +36,16 @@ def _need_gpu(*ts):
 # ------------------------------------------------------------------------------------------
 # implicit GEMM
 # ------------------------------------------------------------------------------------------
+def splitk_workspace(M, N, K, elt, device):
+    """fp32 partial-sum workspace for skinny problems (few output tiles, deep K) or None: the
+    launcher then picks the K split itself (igemm.hip: dispatch)."""
+    t64 = ((M + 63) // 64) * ((N + 63) // 64)
+    t128 = ((M + 127) // 128) * ((N + 127) // 128)
+    if not (N > 64 and t128 >= 192) and t64 < 384 and K * elt >= 2048:
+        return torch.empty((16 * M * N,), dtype=torch.float32, device=device)
+    return None
+
+
 def conv2d(x, w, bias=None, *, kh=3, kw=3, stride=1, pad=(1, 1, 1, 1), ups=False, cout=None,
            rowvec=None, residual=None, act=None, out=None, out_dtype=None, ldc=None,
            split_k=0):
@@ -55,13 +65,7 @@ def conv2d(x, w, bias=None, *, kh=3, kw=3, stride=1, pad=(1, 1, 1, 1), ups=False
     if out is None:
         out = (torch.zeros if ldc != N else torch.empty)((B, Ho, Wo, ldc), dtype=odt, device=x.device)
     M = B * Ho * Wo
-    ws = None
-    # split-K workspace for skinny problems (few tiles, deep K)
-    if split_k != 1:
-        t64 = ((M + 63) // 64) * ((N + 63) // 64)
-        t128 = ((M + 127) // 128) * ((N + 127) // 128)
-        if not (N > 64 and t128 >= 192) and t64 < 384 and K * x.element_size() >= 2048:
-            ws = torch.empty((16 * M * N,), dtype=torch.float32, device=x.device)
+    ws = splitk_workspace(M, N, K, x.element_size(), x.device) if split_k != 1 else None
     call('sdmi_igemm', _stream(), a=_p(x), w=_p(w), out=_p(out), bias=_p(bias), rowvec=_p(rowvec),
          residual=_p(residual), workspace=_p(ws), dtype=_dt(x), out_dtype=_DT[odt], M=M, N=N, K=K,
          lda=Cin, ldw=K, ldc=ldc, ldr=(residual.shape[-1] if residual is not None else 0),

@@ -480,6 +480,55 @@ def test_groupnorm_fanout_and_fused_dropout(B, HW, C, dtype):
     assert float(((yd2 != 0) != (yd != 0)).float().mean()) > 0.1
 
 
+def test_wgrad_group_matches_single_launches():
+    """sdmi_wgrad_group: several 1x1 / linear bf16 problems (different shapes, ragged M, with and
+    without bias, with and without M-splits) in one launch equal the single-problem launches bit for
+    bit and torch's fp32 result within bf16 tolerance; accumulate adds to the existing gradient."""
+    import ctypes
+    from slotdiffusion_amd import _lib
+    g = torch.Generator().manual_seed(11)
+    shapes = [(1024, 512, 512, True, 1), (1000, 1536, 512, False, 1), (4096, 384, 1536, True, 4),
+              (448, 256, 192, True, 1), (16384, 256, 256, True, 8), (777, 128, 136, False, 2)]
+    st = torch.cuda.current_stream().cuda_stream
+    probs, refs, keep = [], [], []
+    for M, N, K, bias, splits in shapes:
+        x = (torch.randn(M, K, generator=g)).bfloat16().cuda()
+        dy = (torch.randn(M, N, generator=g) / 8).bfloat16().cuda()
+        init = torch.randn(N, K, generator=g).cuda()
+        binit = torch.randn(N, generator=g).cuda()
+        ws = torch.empty(splits * (N * K + N), device='cuda')
+        kw = dict(a=x.data_ptr(), dy=dy.data_ptr(), dtype=_lib.BF16, M=M, N=N, K=K, lda=K, ldy=N, B=M, H=1,
+                  W=1, Cin=K, Ho=1, Wo=1, KH=1, KW=1, stride=1, pad_t=0, pad_l=0, ups=0, splits=splits,
+                  accumulate=1, workspace=ws.data_ptr())
+        outs = []
+        for _ in range(2):                                 # [0]: single launches, [1]: grouped
+            dw, db = init.clone(), binit.clone()
+            outs.append((dw, db))
+        _lib.call('sdmi_wgrad', st, dw=outs[0][0].data_ptr(), dbias=(outs[0][1].data_ptr() if bias else 0), **kw)
+        probs.append(dict(kw, dw=outs[1][0].data_ptr(), dbias=(outs[1][1].data_ptr() if bias else 0)))
+        refs.append((init.cpu() + dy.float().cpu().t() @ x.float().cpu(),
+                     binit.cpu() + dy.float().cpu().sum(0), outs, bias))
+        keep += [x, dy, ws]
+    arr = (_lib.CSTRUCT['SdmiWgradArgs'] * len(probs))()
+    for a, kw in zip(arr, probs):
+        for k, v in kw.items():
+            setattr(a, k, v)
+    _lib.call('sdmi_wgrad_group', st, problems=ctypes.addressof(arr), n=len(probs))
+    torch.cuda.synchronize()
+    for (rw, rb, outs, bias), sh in zip(refs, shapes):
+        assert torch.equal(outs[0][0], outs[1][0]), sh
+        assert float((outs[1][0].cpu() - rw).norm() / rw.norm()) < 2e-3, sh
+        if bias:
+            assert torch.equal(outs[0][1], outs[1][1]), sh
+            assert float((outs[1][1].cpu() - rb).norm() / rb.norm()) < 2e-3, sh
+    # argument validation: fp32 / 3x3 / narrow problems are refused without a launch
+    bad = (_lib.CSTRUCT['SdmiWgradArgs'] * 1)()
+    for k, v in dict(probs[0], N=32).items():
+        setattr(bad[0], k, v)
+    with pytest.raises(_lib.SdmiError):
+        _lib.call('sdmi_wgrad_group', st, problems=ctypes.addressof(bad), n=1)
+
+
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 def test_layernorm_and_gemm_fanout(dtype):
     """LayerNormFn / GemmFn alias outputs: the residual branch's gradient is summed inside the
@@ -798,8 +847,17 @@ def test_strided_dgrad_by_parity(case, dtype):
     wd = torch.zeros(Cin * k * k, npad, dtype=dtype, device='cuda')
     _lib.call('sdmi_pack_dgrad', torch.cuda.current_stream().cuda_stream, src=wp.data_ptr(),
               dst=wd.data_ptr(), dtype=_DT[dtype], Cout=Cout, KH=k, KW=k, Cin=Cin, CoutPad=npad)
-    dx = GemmFn._dgrad_strided(dyd, wd.view(Cin, k * k * npad), B, H, H, Ho, Ho, Cin, npad, k, k,
-                               stride, pad, dtype)
+    dx, _ = GemmFn._dgrad_strided(dyd, wd.view(Cin, k * k * npad), B, H, H, Ho, Ho, Cin, npad, k, k,
+                                  stride, pad, dtype)
     ref = x.grad.permute(0, 2, 3, 1)
     e = float((dx.float().cpu() - ref).norm() / ref.norm())
     assert e <= (2e-5 if dtype == torch.float32 else 2e-2), e
+    # with the gradient of x's other consumer riding in the epilogue (full parity cover) or handed
+    # back to the caller (partial cover)
+    extra = q(torch.randn(B, H, H, Cin, generator=g)).to(dtype).cuda()
+    dx2, left = GemmFn._dgrad_strided(dyd, wd.view(Cin, k * k * npad), B, H, H, Ho, Ho, Cin, npad, k, k,
+                                      stride, pad, dtype, extra)
+    if left is not None:
+        dx2 = dx2.float() + left.float()
+    e2 = float((dx2.float().cpu() - (ref + extra.float().cpu())).norm() / ref.norm())
+    assert e2 <= (2e-5 if dtype == torch.float32 else 3e-2), e2
