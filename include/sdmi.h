@@ -157,8 +157,13 @@ typedef struct {
   float drop_p;         /* the forward's fused dropout (mask regenerated from the seed) */
   long long drop_seed;
   const long long* drop_seed_dev;
+  int defer_colsum;     /* != 0: leave the per-image channel sums in `partial` ([B*nsplit][C][2]); the
+                           caller folds them into dbeta / dgamma later with sdmi_colsum_group */
 } SdmiGroupNormBwdArgs;
 int sdmi_groupnorm_bwd(const SdmiGroupNormBwdArgs* a, void* stream);
+/* number of [C][2] entries sdmi_groupnorm_bwd leaves in `partial` for this geometry (B for the
+ * single-pass kernels, B * nsplit for the two-pass ones); no launch.  Returns the count (> 0). */
+int sdmi_groupnorm_bwd_entries(const SdmiGroupNormBwdArgs* a, void* stream);
 
 /* LayerNorm over the last dim (eps 1e-5 default): attention.py:238-240, savi.py:38-54. */
 typedef struct {
@@ -174,8 +179,18 @@ typedef struct {
   float* partial;                /* workspace [nblk][C][2] */
   int dtype; int rows, C; int nblk; int accumulate;
   const void* dextra;            /* optional [rows][C]: dx = ln_bwd(dy) + dextra (residual branch of x) */
+  int defer_colsum;              /* != 0: partials stay in `partial` ([nblk][C][2]) for sdmi_colsum_group */
 } SdmiLayerNormBwdArgs;
 int sdmi_layernorm_bwd(const SdmiLayerNormBwdArgs* a, void* stream);
+
+/* Deferred folds of the normalisation backward passes: up to 64 independent column sums
+ *   out0[c] += sum_e partial[e][c][0],  out1[c] += sum_e partial[e][c][1]   (e < nblk)
+ * in ONE launch (a train step has ~190 of them, each a few microseconds of work behind a launch).
+ * `items` is a HOST array of n SdmiColsumItem. */
+typedef struct { const float* partial; float* out0; float* out1; int nblk, C; } SdmiColsumItem;
+typedef struct { const void* items; int n; } SdmiColsumGroupArgs;
+int sdmi_colsum_group(const SdmiColsumGroupArgs* a, void* stream);
+
 
 /* ------------------------------------------------------------------------------------------
  * Multi-head attention, head_dim 32 (UNet self- and slot cross-attention).
@@ -262,8 +277,33 @@ int sdmi_nhwc_to_nchw(const SdmiNhwcToNchwArgs* a, void* stream);
 /* generic cast/copy of a strided 2-D view: dst[r][c] = (dst_dtype) src[r][c] */
 typedef struct {
   const void* src; void* dst; int src_dtype, dst_dtype; long long rows; int cols, lds, ldd;
+  int zpad;      /* != 0: columns [cols, ldd) of dst are written with zeros (channel padding) */
 } SdmiCast2dArgs;
 int sdmi_cast2d(const SdmiCast2dArgs* a, void* stream);
+
+/* Small stream-ordered helpers that keep the training step free of framework kernels:
+ *   sdmi_memset0 ...... zero `bytes` bytes (gradient arena, padded buffers) -- a memset node in a graph
+ *   sdmi_scale_dev .... y = x * s[0], s a DEVICE scalar (upstream gradient of the loss)
+ *   sdmi_counters_inc . ++step[0] (int) and ++seed[0] (long long), either may be NULL (Adam step,
+ *                       dropout seed word: advanced inside the captured step)
+ *   sdmi_draw_tn ...... the training draws of LDM.loss_function (ldm.py:65-69) in one launch:
+ *                       t[b] ~ U{0..T-1} (int64) with tf[b] = (float) t[b], ca[b] = tab_a[t[b]],
+ *                       cb[b] = tab_b[t[b]] (sqrt_alphas_bar / sqrt_one_minus_alphas_bar) and
+ *                       noise ~ N(0,1) as NHWC fp32 [B][hw][4] (channel 3 = 0); counter-based
+ *                       generator keyed on seed + *seed_dev (a graph replay draws new values). */
+typedef struct { void* ptr; long long bytes; } SdmiMemsetArgs;
+int sdmi_memset0(const SdmiMemsetArgs* a, void* stream);
+typedef struct { const void* x; void* y; const float* s; int dtype; long long n; } SdmiScaleDevArgs;
+int sdmi_scale_dev(const SdmiScaleDevArgs* a, void* stream);
+typedef struct { int* step; long long* seed; } SdmiCountersArgs;
+int sdmi_counters_inc(const SdmiCountersArgs* a, void* stream);
+typedef struct {
+  long long* t; float* tf; float* ca; float* cb; float* noise;
+  const float* tab_a; const float* tab_b;
+  int B, T; long long per;     /* per = h*w*4 floats of noise per image */
+  long long seed; const long long* seed_dev;
+} SdmiDrawTnArgs;
+int sdmi_draw_tn(const SdmiDrawTnArgs* a, void* stream);
 
 /* sinusoidal timestep embedding [cos | sin], fractional t (unet/utils.py:70-92) -> fp32 [B][dim],
  * optionally followed by nothing (MLP runs on the GEMM). */
@@ -311,6 +351,7 @@ typedef struct {
   const void* pred; const float* target; float* out; void* dpred; float* partial;
   int dtype; long long n; int nblk; float gscale;
   int l1;        /* 1: mean |pred - target| (VQ-VAE reconstruction loss, vqvae/loss.py:27), dpred = sign * gscale / n */
+  float oscale;  /* != 0: out[0] = mean * oscale (the 4/3 channel-pad correction of the NHWC pair) */
 } SdmiMseArgs;
 int sdmi_mse(const SdmiMseArgs* a, void* stream);
 
@@ -377,6 +418,8 @@ typedef struct {
   const float* den; const float* dupd; float* dq; void* dk; void* dv;
   int dtype; int B, M, N, D, ldkv; float eps, scale;
   float* workspace;   /* optional, B*ceil(M/64)*N*D floats (see SdmiSaAttendArgs) */
+  int accumulate;     /* != 0: dk / dv += (k, v feed every iteration: the iterations' gradients are
+                         summed in place instead of by separate accumulation kernels) */
 } SdmiSaAttendBwdArgs;
 int sdmi_sa_attend_bwd(const SdmiSaAttendBwdArgs* a, void* stream);
 /* GRUCell gate arithmetic on gi = W_ih x + b_ih, gh = W_hh h + b_hh ([R][3D], gates r,z,n). */
@@ -426,6 +469,16 @@ typedef struct {
   int mode;                      /* 0: (x-y)^2   1: |x-y| (L1 reconstruction loss, vqvae/loss.py:27) */
 } SdmiSqErrArgs;
 int sdmi_sqerr_rows(const SdmiSqErrArgs* a, void* stream);
+/* Structural similarity (eval_utils.py:91-106 -> skimage.metrics.structural_similarity with
+ * gaussian_weights=True, sigma=1.5, use_sample_covariance=False, data_range=L, channel_axis=0;
+ * skimage is a third-party dependency absent here: the published algorithm, Wang et al. 2004, is
+ * restated -- parity with skimage itself is unpinned).  Per plane p of x, y [P][H][W] fp32:
+ *   out[p] = mean over the interior (5-pixel border cropped) of
+ *            ((2 ux uy + C1)(2 vxy + C2)) / ((ux^2 + uy^2 + C1)(vx + vy + C2)),
+ * ux, uy, vx, vy, vxy = 11x11 Gaussian-window moments (sigma 1.5, truncate 3.5), C1 = (0.01 L)^2,
+ * C2 = (0.03 L)^2.  fp64 arithmetic; out [P] fp64. */
+typedef struct { const float* x; const float* y; double* out; int P, H, W; float data_range; } SdmiSsimArgs;
+int sdmi_ssim(const SdmiSsimArgs* a, void* stream);
 
 
 /* ------------------------------------------------------------------------------------------

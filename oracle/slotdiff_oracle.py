@@ -785,3 +785,43 @@ def psnr_metric(x, y):
     peak_signal_noise_ratio(a, b, data_range=1) = 10 log10(1 / mean((a-b)^2)), float64."""
     d = ((x.double() - y.double()) ** 2).flatten(1).mean(1)
     return float((10.0 * torch.log10(1.0 / d)).mean())
+
+
+def ssim_metric(x, y):
+    """eval_utils.ssim_metric (video_based/models/eval_utils.py:91-106): mean over images of
+    skimage.metrics.structural_similarity(x*255, y*255, channel_axis=0, gaussian_weights=True,
+    sigma=1.5, use_sample_covariance=False, data_range=255).  skimage v0.19 (environment.yml) is absent
+    offline -> PARITY UNPINNED for this function; its documented algorithm (Wang et al. 2004 as
+    skimage implements it) is restated on scipy.ndimage.gaussian_filter, the very filter skimage
+    calls: float64, truncate=3.5 (radius 5 -> 11 taps), K1 = 0.01, K2 = 0.03, cov_norm = 1, SSIM map
+    averaged over the interior left by cropping (win_size - 1) // 2 = 5 pixels, channels averaged."""
+    import numpy as np
+    from scipy.ndimage import gaussian_filter
+    x = np.asarray(x, dtype=np.float64) * 255.
+    y = np.asarray(y, dtype=np.float64) * 255.
+    L = 255.
+    C1, C2 = (0.01 * L) ** 2, (0.03 * L) ** 2
+    flt = lambda a: gaussian_filter(a, sigma=1.5, truncate=3.5, mode='reflect')
+    vals = []
+    for i in range(x.shape[0]):
+        ch = []
+        for c in range(x.shape[1]):
+            a, b = x[i, c], y[i, c]
+            ux, uy = flt(a), flt(b)
+            vx, vy, vxy = flt(a * a) - ux * ux, flt(b * b) - uy * uy, flt(a * b) - ux * uy
+            S = ((2 * ux * uy + C1) * (2 * vxy + C2)) / ((ux ** 2 + uy ** 2 + C1) * (vx + vy + C2))
+            ch.append(S[5:-5, 5:-5].mean())
+        vals.append(np.mean(ch))
+    return float(np.mean(vals))
+
+
+def shuffle_slots(slots):
+    """video_based/test_comp_gen.py:25-31, out of place: slot i of item b comes from item (b + i) % B."""
+    out = slots.clone()
+    N = slots.shape[-2]
+    for i in range(N):
+        if slots.dim() == 4:
+            out[:, :, i] = torch.cat([slots[i:, :, i], slots[:i, :, i]])
+        else:
+            out[:, i] = torch.cat([slots[i:, i], slots[:i, i]])
+    return out

@@ -1,0 +1,2 @@
+"""`slotdiffusion.img_based` registry surface (build_dataset / build_model / build_method)."""
+from slotdiffusion_amd.img_based import build_dataset, build_method, build_model  # noqa: F401

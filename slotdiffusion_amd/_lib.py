@@ -158,6 +158,16 @@ def call(fname, stream, **kw):
     _call(fname, stream, **kw)
 
 
+def query(fname, **kw):
+    """Call a no-launch query entry point and return its integer result."""
+    L = lib()
+    sname = FUNCS[fname]
+    args = CSTRUCT[sname]()
+    for k, v in kw.items():
+        setattr(args, k, v)
+    return int(getattr(L, fname)(ctypes.byref(args), None))
+
+
 def _call(fname, stream, **kw):
     L = lib()
     sname = FUNCS[fname]

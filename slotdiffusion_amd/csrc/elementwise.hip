@@ -68,11 +68,51 @@ __global__ void nhwc_to_nchw_kernel(SdmiNhwcToNchwArgs p) {
 
 template <typename S, typename D>
 __global__ void cast2d_kernel(SdmiCast2dArgs p) {
-  const long long n = p.rows * p.cols;
+  const int wc = p.zpad ? p.ldd : p.cols;          // columns written per row
+  const long long n = p.rows * wc;
   GRID_STRIDE(i, n) {
-    const long long r = i / p.cols;
-    const int c = (int)(i - r * p.cols);
-    Elem<D>::st((D*)p.dst + r * p.ldd + c, Elem<S>::ld((const S*)p.src + r * p.lds + c));
+    const long long r = i / wc;
+    const int c = (int)(i - r * wc);
+    Elem<D>::st((D*)p.dst + r * p.ldd + c, c < p.cols ? Elem<S>::ld((const S*)p.src + r * p.lds + c) : 0.f);
+  }
+}
+
+template <typename T>
+__global__ void scale_dev_kernel(SdmiScaleDevArgs p) {
+  const float s = p.s[0];
+  GRID_STRIDE(i, p.n) Elem<T>::st((T*)p.y + i, Elem<T>::ld((const T*)p.x + i) * s);
+}
+
+__global__ void counters_inc_kernel(SdmiCountersArgs p) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    if (p.step) p.step[0] += 1;
+    if (p.seed) p.seed[0] += 1;
+  }
+}
+
+// training draws: uniform timesteps + Box-Muller normals from a splitmix64 counter generator
+__global__ void draw_tn_kernel(SdmiDrawTnArgs p) {
+  const unsigned long long seed = sdmi_drop_seed(p.seed, p.seed_dev);
+  const long long n = (long long)p.B * p.per;
+  GRID_STRIDE(i, n + p.B) {
+    if (i >= n) {                                   // the B timestep draws ride in the tail threads
+      const int b = (int)(i - n);
+      const unsigned long long r = sdmi_mix64((seed ^ 0x7f4a7c159e3779b9ULL) + 0x9e3779b97f4a7c15ULL * (unsigned long long)(b + 1));
+      const long long t = (long long)(r % (unsigned long long)p.T);
+      p.t[b] = t;
+      if (p.tf) p.tf[b] = (float)t;
+      if (p.ca) p.ca[b] = p.tab_a[t];
+      if (p.cb) p.cb[b] = p.tab_b[t];
+      continue;
+    }
+    float z = 0.f;
+    if ((i & 3) != 3) {
+      const unsigned long long r = sdmi_mix64(seed + 0x9e3779b97f4a7c15ULL * (unsigned long long)(i + 1));
+      const float u1 = ((float)(unsigned)(r >> 40) + 0.5f) * (1.f / 16777216.f);        // (0, 1)
+      const float u2 = ((float)(unsigned)((r >> 8) & 0xffffffu)) * (1.f / 16777216.f);  // [0, 1)
+      z = sqrtf(-2.f * logf(u1)) * cosf(6.28318530717958647692f * u2);
+    }
+    p.noise[i] = z;
   }
 }
 
@@ -297,7 +337,8 @@ __global__ void mse_final_kernel(SdmiMseArgs p) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     double s = 0.0;
     for (int i = 0; i < p.nblk; ++i) s += (double)p.partial[i];
-    p.out[0] = (float)(s / (double)p.n);
+    const float m = (float)(s / (double)p.n);
+    p.out[0] = p.oscale != 0.f ? m * p.oscale : m;
   }
 }
 
@@ -344,6 +385,35 @@ extern "C" int sdmi_cast2d(const SdmiCast2dArgs* a, void* stream) {
   else if (db) hipLaunchKernelGGL((cast2d_kernel<float, bf16_t>), dim3(g), dim3(EW_THREADS), 0, ST, *a);
   else hipLaunchKernelGGL((cast2d_kernel<float, float>), dim3(g), dim3(EW_THREADS), 0, ST, *a);
   return sdmi_check_launch("cast2d");
+}
+extern "C" int sdmi_memset0(const SdmiMemsetArgs* a, void* stream) {
+  SDMI_REQUIRE(a && a->ptr && a->bytes >= 0, "bad args");
+  if (a->bytes == 0) return SDMI_OK;
+  if (hipMemsetAsync(a->ptr, 0, (size_t)a->bytes, ST) != hipSuccess) {
+    sdmi_set_error("memset0: hipMemsetAsync failed");
+    return SDMI_ELAUNCH;
+  }
+  return SDMI_OK;
+}
+extern "C" int sdmi_scale_dev(const SdmiScaleDevArgs* a, void* stream) {
+  SDMI_REQUIRE(a && a->x && a->y && a->s, "null pointer");
+  if (a->dtype == SDMI_BF16)
+    hipLaunchKernelGGL(scale_dev_kernel<bf16_t>, dim3(ew_blocks(a->n)), dim3(EW_THREADS), 0, ST, *a);
+  else
+    hipLaunchKernelGGL(scale_dev_kernel<float>, dim3(ew_blocks(a->n)), dim3(EW_THREADS), 0, ST, *a);
+  return sdmi_check_launch("scale_dev");
+}
+extern "C" int sdmi_counters_inc(const SdmiCountersArgs* a, void* stream) {
+  SDMI_REQUIRE(a && (a->step || a->seed), "null pointer");
+  hipLaunchKernelGGL(counters_inc_kernel, dim3(1), dim3(64), 0, ST, *a);
+  return sdmi_check_launch("counters_inc");
+}
+extern "C" int sdmi_draw_tn(const SdmiDrawTnArgs* a, void* stream) {
+  SDMI_REQUIRE(a && a->t && a->noise && a->B > 0 && a->T > 0 && a->per > 0 && a->per % 4 == 0, "bad args");
+  SDMI_REQUIRE((!a->ca && !a->cb) || (a->tab_a && a->tab_b), "coefficient tables missing");
+  hipLaunchKernelGGL(draw_tn_kernel, dim3(ew_blocks((long long)a->B * a->per + a->B)), dim3(EW_THREADS),
+                     0, ST, *a);
+  return sdmi_check_launch("draw_tn");
 }
 extern "C" int sdmi_timestep_embedding(const SdmiTimeEmbArgs* a, void* stream) {
   SDMI_REQUIRE(a && a->t && a->out && a->dim % 2 == 0, "bad args");

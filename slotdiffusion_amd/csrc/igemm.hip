@@ -22,6 +22,7 @@
 // contiguous range of tile ids, with the n-tiles of one m-tile adjacent, so an activation tile is
 // fetched into one L2 and re-used by its n-tiles there.
 #include "common.h"
+#include <stdlib.h>
 
 #ifndef SDMI_IGEMM_DMA
 #define SDMI_IGEMM_DMA 0
@@ -488,13 +489,18 @@ __device__ __forceinline__ void igemm_body(const SdmiGemmArgs& p, int tiles_m, i
 // Prefetch depth comes from NSTAGE LDS stages (NSTAGE-1 K tiles in flight), one s_barrier per K
 // tile: before barrier g the loaders have waited for K tile g to land; after it they refill the
 // stage that K tile g-1 just vacated.
+// MFMA waves: always FOUR (2 x 2 over the tile, one per SIMD), each owning (BM/2) x (BN/2): at
+// 256 x 128 a wave computes 128 x 64 = 4 x 2 MFMA tiles and reads 6 fragments per 8 MFMAs -- 96 B/clk
+// of LDS reads per CU at full matrix rate, where 64 x 64 wave tiles (4 fragments per 4 MFMAs) need
+// the LDS's whole 256 B/clk (the limit the 128 x 128 kernels run into).
 template <typename T, int BM, int BN, int NSTAGE, int MODE>
-__global__ __launch_bounds__((BM / 64) * (BN / 64) * 64 + 256) void igemm_dma_kernel(
+__global__ __launch_bounds__(512) void igemm_dma_kernel(
     SdmiGemmArgs p, int tiles_m, int tiles_n, int kt_per_split, int hw_shift) {
   constexpr int VEC = 16 / sizeof(T);
   constexpr int BK = 128 / sizeof(T);
-  constexpr int WGN = BN / 64;
-  constexpr int NMFMA = (BM / 64) * WGN * 64;        // MFMA threads; 256 loader threads follow
+  constexpr int WM = BM / 2, WN = BN / 2;            // wave tile
+  constexpr int TMf = WM / 32, TNf = WN / 32;
+  constexpr int NMFMA = 256;                         // MFMA threads; 256 loader threads follow
   constexpr int STAGE = (BM + BN) * 128;
   constexpr int A_PC = BM / 32, B_PC = BN / 32;      // 1 KB pieces per loader wave per K tile
   constexpr int NLOAD = A_PC + B_PC;
@@ -634,31 +640,31 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64 + 256) void igemm_dma_ke
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int wm = wave / WGN, wn = wave - wm * WGN;
+  const int wm = wave >> 1, wn = wave & 1;
   const int R = lane & 31;
   int swz[4];
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) swz[ks] = ((2 * ks + (lane >> 5)) ^ ((R >> 1) & 7)) * 16;
-  const int a_off = (wm * 64 + R) * 128;
-  const int b_off = BM * 128 + (wn * 64 + R) * 128;
-  auto read_frags = [&](const char* base, int ks, u32x4 (&fa)[2], u32x4 (&fb)[2])
+  const int a_off = (wm * WM + R) * 128;
+  const int b_off = BM * 128 + (wn * WN + R) * 128;
+  auto read_frags = [&](const char* base, int ks, u32x4 (&fa)[TMf], u32x4 (&fb)[TNf])
                         __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TMf; ++i)
       fa[i] = *reinterpret_cast<const u32x4*>(base + a_off + i * 4096 + swz[ks]);
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < TNf; ++j)
       fb[j] = *reinterpret_cast<const u32x4*>(base + b_off + j * 4096 + swz[ks]);
   };
   int stage = 0;
   for (int ti = 0; ti < my_tiles; ++ti) {
     int m0, n0;
     tile_of((int)blockIdx.x + ti * (int)gridDim.x, m0, n0);
-    f32x16 acc[2][2];
+    f32x16 acc[TMf][TNf];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TMf; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < TNf; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     for (int t = 0; t < n_kt; ++t) {
@@ -666,16 +672,16 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64 + 256) void igemm_dma_ke
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
       const char* base = smem + stage * STAGE;
       if (++stage == NSTAGE) stage = 0;
-      u32x4 fa[2][2], fb[2][2];
+      u32x4 fa[2][TMf], fb[2][TNf];
       read_frags(base, 0, fa[0], fb[0]);
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         if (ks + 1 < 4) read_frags(base, ks + 1, fa[(ks + 1) & 1], fb[(ks + 1) & 1]);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < TMf; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j) {
+          for (int j = 0; j < TNf; ++j) {
             const u32x4 a4 = fa[ks & 1][i], b4 = fb[ks & 1][j];
             if constexpr (sizeof(T) == 2) {
               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
@@ -689,7 +695,7 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64 + 256) void igemm_dma_ke
           }
       }
     }
-    wave_epilogue<2, 2>(p, acc, m0 + wm * 64, n0 + wn * 64, zb, hw_shift, lane);
+    wave_epilogue<TMf, TNf>(p, acc, m0 + wm * WM, n0 + wn * WN, zb, hw_shift, lane);
   }
 }
 
@@ -955,7 +961,7 @@ template <typename T, int BM, int BN, int NSTAGE, int MODE>
 int launch_dma(const SdmiGemmArgs& p, int hw_shift, hipStream_t st) {
   constexpr int BK = 128 / sizeof(T);
   constexpr int smem = NSTAGE * (BM + BN) * 128;
-  constexpr int threads = (BM / 64) * (BN / 64) * 64 + 256;
+  constexpr int threads = 512;
   static bool attr_done = false;
   auto kern = igemm_dma_kernel<T, BM, BN, NSTAGE, MODE>;
   if (!attr_done) {
@@ -1051,7 +1057,12 @@ int dispatch(const SdmiGemmArgs& p, hipStream_t st) {
   // LDS-DMA kernels (one workgroup per CU, 3-4 LDS stages): deep-K 1x1 / plain convolutions with
   // wide outputs, no split-K
   {
-    const bool dma_ok = SDMI_IGEMM_DMA && wide && kbytes >= 8 * 128 && split_k == 1 && p.N > 64 && fits31 &&
+    static int dma_env = -1;
+    if (dma_env < 0) {
+      const char* e = getenv("SDMI_IGEMM_DMA");
+      dma_env = e ? atoi(e) : SDMI_IGEMM_DMA;
+    }
+    const bool dma_ok = dma_env && wide && kbytes >= 8 * 128 && split_k == 1 && p.N > 64 && fits31 &&
                         (is1x1 || (plain && p.Cin % (128 / (int)sizeof(T)) == 0)) && p.KH * p.KW <= 32;
     if (dma_ok) {
       const long long t256 = ((p.M + 255) / 256) * ((p.N + 127) / 128) * batch;
@@ -1059,7 +1070,7 @@ int dispatch(const SdmiGemmArgs& p, hipStream_t st) {
         if (is1x1) return launch_dma<T, 256, 128, 3, 1>(p, hw_shift, st);
         return launch_dma<T, 256, 128, 3, 2>(p, hw_shift, st);
       }
-      if (t128 >= 192) {
+      if (t128 >= 192 && dma_env >= 2) {
         if (is1x1) return launch_dma<T, 128, 128, 4, 1>(p, hw_shift, st);
         return launch_dma<T, 128, 128, 4, 2>(p, hw_shift, st);
       }

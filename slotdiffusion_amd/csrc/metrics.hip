@@ -50,7 +50,56 @@ __global__ __launch_bounds__(256) void sqerr_rows_kernel(SdmiSqErrArgs p) {
   if (threadIdx.x == 0) p.partial[(long long)b * p.nchunk + j] = red[0];
 }
 
+// grid (P): one workgroup per image plane; every thread walks interior pixels, 121 window taps each
+__global__ __launch_bounds__(256) void ssim_kernel(SdmiSsimArgs p) {
+  __shared__ double red[256];
+  __shared__ double w1[11];
+  if (threadIdx.x == 0) {
+    double s = 0.0;
+    for (int i = 0; i < 11; ++i) { w1[i] = exp(-0.5 * (double)((i - 5) * (i - 5)) / (1.5 * 1.5)); s += w1[i]; }
+    for (int i = 0; i < 11; ++i) w1[i] /= s;
+  }
+  __syncthreads();
+  const float* __restrict__ x = p.x + (long long)blockIdx.x * p.H * p.W;
+  const float* __restrict__ y = p.y + (long long)blockIdx.x * p.H * p.W;
+  const int h = p.H - 10, w = p.W - 10;
+  const double L = (double)p.data_range;
+  const double C1 = (0.01 * L) * (0.01 * L), C2 = (0.03 * L) * (0.03 * L);
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < h * w; i += 256) {
+    const int cy = i / w + 5, cx = i % w + 5;
+    double ux = 0, uy = 0, uxx = 0, uyy = 0, uxy = 0;
+    for (int dy = -5; dy <= 5; ++dy) {
+      double rx = 0, ry = 0, rxx = 0, ryy = 0, rxy = 0;        // separable: rows first, like the filter
+      const float* xr = x + (long long)(cy + dy) * p.W + cx;
+      const float* yr = y + (long long)(cy + dy) * p.W + cx;
+      for (int dx = -5; dx <= 5; ++dx) {
+        const double a = (double)xr[dx], b = (double)yr[dx], g = w1[dx + 5];
+        rx += g * a; ry += g * b; rxx += g * a * a; ryy += g * b * b; rxy += g * a * b;
+      }
+      const double g = w1[dy + 5];
+      ux += g * rx; uy += g * ry; uxx += g * rxx; uyy += g * ryy; uxy += g * rxy;
+    }
+    const double vx = uxx - ux * ux, vy = uyy - uy * uy, vxy = uxy - ux * uy;
+    acc += ((2.0 * ux * uy + C1) * (2.0 * vxy + C2)) / ((ux * ux + uy * uy + C1) * (vx + vy + C2));
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) p.out[blockIdx.x] = red[0] / (double)(h * w);
+}
+
 }  // namespace
+
+extern "C" int sdmi_ssim(const SdmiSsimArgs* a, void* stream) {
+  SDMI_REQUIRE(a && a->x && a->y && a->out, "null pointer");
+  SDMI_REQUIRE(a->P >= 1 && a->H >= 11 && a->W >= 11 && a->data_range > 0.f, "images of at least 11 x 11");
+  hipLaunchKernelGGL(ssim_kernel, dim3(a->P), dim3(256), 0, (hipStream_t)stream, *a);
+  return sdmi_check_launch("ssim");
+}
 
 extern "C" int sdmi_contingency(const SdmiContingencyArgs* a, void* stream) {
   SDMI_REQUIRE(a && a->gt && a->pred && a->counts, "null pointer");

@@ -245,7 +245,56 @@ __global__ __launch_bounds__(THREADS) void gn_fused_kernel(SdmiGroupNormArgs p) 
 }
 
 // ------------------------------------------------------------------------------------------
-// LayerNorm: one wave per row, two-pass in registers (C <= 1024).
+// LayerNorm: a row is covered by LPR = pow2 >= C/VEC lanes holding one 16-byte vector each (two
+// when C/VEC > 64), so a wave handles 64/LPR rows per pass and every access is a whole 16-byte
+// vector; mean and variance (two-pass, in registers) are xor-butterflies inside the LPR lanes.
+template <typename T, int VPL>
+__global__ __launch_bounds__(256) void layernorm_vec_kernel(SdmiLayerNormArgs p, int LPR) {
+  constexpr int VEC = Elem<T>::VEC;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane & (LPR - 1), slot = lane / LPR, RW = 64 / LPR;
+  const int CV = p.C / VEC;
+  const long long row = ((long long)blockIdx.x * 4 + wave) * RW + slot;
+  const bool rok = row < p.rows;
+  const T* x = (const T*)p.x + (rok ? row : 0) * p.ldx;
+  float v[VPL][VEC];
+  bool act[VPL];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const int cv = sub + i * LPR;
+    act[i] = cv < CV;
+    unpack16<T>(*reinterpret_cast<const uint4*>(x + (act[i] ? cv : 0) * VEC), v[i]);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) s += act[i] ? v[i][j] : 0.f;
+  }
+  for (int off = 1; off < LPR; off <<= 1) s += __shfl_xor(s, off, 64);
+  const float mean = s / (float)p.C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i)
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      const float d = act[i] ? v[i][j] - mean : 0.f;
+      q += d * d;
+    }
+  for (int off = 1; off < LPR; off <<= 1) q += __shfl_xor(q, off, 64);
+  const float rstd = rsqrtf(q / (float)p.C + p.eps);
+  if (!rok) return;
+  if (p.stats && sub == 0) { p.stats[row * 2] = mean; p.stats[row * 2 + 1] = rstd; }
+  T* y = (T*)p.y + row * p.ldy;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    if (!act[i]) continue;
+    const int c0 = (sub + i * LPR) * VEC;
+    float o[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) o[j] = (v[i][j] - mean) * rstd * p.gamma[c0 + j] + p.beta[c0 + j];
+    *reinterpret_cast<uint4*>(y + c0) = pack16<T>(o);
+  }
+}
+
+// scalar form (rows whose pitch or width is not a multiple of the 16-byte vector)
 template <typename T>
 __global__ __launch_bounds__(256) void layernorm_kernel(SdmiLayerNormArgs p) {
   const int lane = threadIdx.x & 63;
@@ -386,6 +435,24 @@ extern "C" int sdmi_layernorm(const SdmiLayerNormArgs* a, void* stream) {
   SDMI_REQUIRE(a && a->x && a->y && a->gamma && a->beta, "null pointer");
   SDMI_REQUIRE(a->C > 0 && a->C <= 1024, "C must be <= 1024");
   hipStream_t st = (hipStream_t)stream;
+  const int vec = a->dtype == SDMI_BF16 ? 8 : 4;
+  if (a->C % vec == 0 && a->ldx % vec == 0 && a->ldy % vec == 0 && ((uintptr_t)a->x & 15) == 0 &&
+      ((uintptr_t)a->y & 15) == 0) {
+    const int cv = a->C / vec;
+    int lpr = 1;
+    while (lpr < cv && lpr < 64) lpr <<= 1;
+    const int vpl = (cv + 63) / 64;
+    const int rows_per_wg = 4 * (64 / lpr);
+    dim3 gridv((unsigned)((a->rows + rows_per_wg - 1) / rows_per_wg));
+#define LNF_GO(T, V) hipLaunchKernelGGL((layernorm_vec_kernel<T, V>), gridv, dim3(256), 0, st, *a, lpr)
+    if (a->dtype == SDMI_BF16) {
+      if (vpl <= 1) LNF_GO(bf16_t, 1); else LNF_GO(bf16_t, 2);
+    } else {
+      if (vpl <= 1) LNF_GO(float, 1); else if (vpl == 2) LNF_GO(float, 2); else LNF_GO(float, 4);
+    }
+#undef LNF_GO
+    return sdmi_check_launch("layernorm");
+  }
   dim3 grid((a->rows + 3) / 4);
   if (a->dtype == SDMI_BF16) hipLaunchKernelGGL(layernorm_kernel<bf16_t>, grid, dim3(256), 0, st, *a);
   else hipLaunchKernelGGL(layernorm_kernel<float>, grid, dim3(256), 0, st, *a);

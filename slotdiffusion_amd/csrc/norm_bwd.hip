@@ -275,6 +275,44 @@ __global__ __launch_bounds__(256) void pair_colsum_kernel(const float* partial, 
   }
 }
 
+// Grouped form: blockIdx.y = item, the descriptors travel by value in the kernel arguments.
+constexpr int CS_MAX = 64;
+struct ColsumGroup { int n; SdmiColsumItem it[CS_MAX]; };
+__global__ __launch_bounds__(256) void colsum_group_kernel(ColsumGroup g) {
+  const SdmiColsumItem& q_ = g.it[blockIdx.y];
+  const int C = q_.C, nblk = q_.nblk;
+  if ((int)blockIdx.x * 16 >= C) return;
+  __shared__ float red[16][16][2];
+  const int cl = threadIdx.x & 15, kg = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
+  float s0 = 0.f, s1 = 0.f;
+  if (c < C) {
+    const float2* q = reinterpret_cast<const float2*>(q_.partial) + c;
+    int k = kg;
+    for (; k + 48 < nblk; k += 64) {
+      const float2 v0 = q[(long long)k * C], v1 = q[(long long)(k + 16) * C];
+      const float2 v2 = q[(long long)(k + 32) * C], v3 = q[(long long)(k + 48) * C];
+      s0 += (v0.x + v1.x) + (v2.x + v3.x);
+      s1 += (v0.y + v1.y) + (v2.y + v3.y);
+    }
+    for (; k < nblk; k += 16) {
+      const float2 v = q[(long long)k * C];
+      s0 += v.x;
+      s1 += v.y;
+    }
+  }
+  red[kg][cl][0] = s0;
+  red[kg][cl][1] = s1;
+  __syncthreads();
+  if (kg == 0 && c < C) {
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { a += red[k][cl][0]; b += red[k][cl][1]; }
+    q_.out0[c] += a;
+    q_.out1[c] += b;
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(SdmiGroupNormBwdArgs p, int rows_per) {
   constexpr int VEC = Elem<T>::VEC;
@@ -476,6 +514,14 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(SdmiLayerNormBwdArgs p, int
 }
 }  // namespace
 
+extern "C" int sdmi_groupnorm_bwd_entries(const SdmiGroupNormBwdArgs* a, void*) {
+  if (!a || a->C <= 0 || a->groups <= 0) return 0;
+  const int vec = a->dtype == SDMI_BF16 ? 8 : 4;
+  int nv_of_T[3] = {16, 16, a->dtype == SDMI_BF16 ? 4 : 8};
+  const GnGeom gg = gn_pick(a->B, a->HW, a->C, a->groups, vec, nv_of_T);
+  return gg.T ? a->B : a->B * a->nsplit;
+}
+
 extern "C" int sdmi_groupnorm_bwd(const SdmiGroupNormBwdArgs* a, void* stream) {
   SDMI_REQUIRE(a && a->x && a->dy && a->dx && a->gamma && a->beta && a->stats && a->dgamma &&
                    a->dbeta && a->partial, "null pointer");
@@ -522,8 +568,9 @@ extern "C" int sdmi_groupnorm_bwd(const SdmiGroupNormBwdArgs* a, void* stream) {
       }
 #undef GNB_PICK
 #undef GNB_GO
-      hipLaunchKernelGGL(pair_colsum_kernel, dim3((a->C + 15) / 16), dim3(256), 0, st, a->partial,
-                         a->B, a->C, a->dbeta, a->dgamma, a->accumulate);
+      if (!a->defer_colsum)
+        hipLaunchKernelGGL(pair_colsum_kernel, dim3((a->C + 15) / 16), dim3(256), 0, st, a->partial,
+                           a->B, a->C, a->dbeta, a->dgamma, a->accumulate);
       return sdmi_check_launch("groupnorm_bwd (fused)");
     }
   }
@@ -533,8 +580,9 @@ extern "C" int sdmi_groupnorm_bwd(const SdmiGroupNormBwdArgs* a, void* stream) {
     hipLaunchKernelGGL(gn_bwd_stats_kernel<float>, g1, dim3(256), 0, st, *a);
   SDMI_REQUIRE(a->groups <= 256, "at most 256 groups");
   // dbeta = sum dz, dgamma = sum dz*xhat over all (image, split) partial entries
-  hipLaunchKernelGGL(pair_colsum_kernel, dim3((a->C + 15) / 16), dim3(256), 0, st, a->partial,
-                     a->B * a->nsplit, a->C, a->dbeta, a->dgamma, a->accumulate);
+  if (!a->defer_colsum)
+    hipLaunchKernelGGL(pair_colsum_kernel, dim3((a->C + 15) / 16), dim3(256), 0, st, a->partial,
+                       a->B * a->nsplit, a->C, a->dbeta, a->dgamma, a->accumulate);
   if (a->dtype == SDMI_BF16)
     hipLaunchKernelGGL(gn_bwd_apply_kernel<bf16_t>, g3, dim3(256), 0, st, *a, rows_per);
   else
@@ -562,7 +610,23 @@ extern "C" int sdmi_layernorm_bwd(const SdmiLayerNormBwdArgs* a, void* stream) {
     if (vpl <= 1) LN_GO(float, 1); else if (vpl == 2) LN_GO(float, 2); else LN_GO(float, 4);
   }
 #undef LN_GO
-  hipLaunchKernelGGL(pair_colsum_kernel, dim3((a->C + 15) / 16), dim3(256), 0, st, a->partial,
-                     a->nblk, a->C, a->dgamma, a->dbeta, a->accumulate);
+  if (!a->defer_colsum)
+    hipLaunchKernelGGL(pair_colsum_kernel, dim3((a->C + 15) / 16), dim3(256), 0, st, a->partial,
+                       a->nblk, a->C, a->dgamma, a->dbeta, a->accumulate);
   return sdmi_check_launch("layernorm_bwd");
+}
+
+extern "C" int sdmi_colsum_group(const SdmiColsumGroupArgs* ga, void* stream) {
+  SDMI_REQUIRE(ga && ga->items && ga->n >= 1 && ga->n <= CS_MAX, "1 .. 64 items");
+  const SdmiColsumItem* it = (const SdmiColsumItem*)ga->items;
+  ColsumGroup g;
+  g.n = ga->n;
+  int cmax = 0;
+  for (int i = 0; i < ga->n; ++i) {
+    SDMI_REQUIRE(it[i].partial && it[i].out0 && it[i].out1 && it[i].nblk >= 1 && it[i].C >= 1, "bad item");
+    g.it[i] = it[i];
+    if (it[i].C > cmax) cmax = it[i].C;
+  }
+  hipLaunchKernelGGL(colsum_group_kernel, dim3((cmax + 15) / 16, ga->n), dim3(256), 0, (hipStream_t)stream, g);
+  return sdmi_check_launch("colsum_group");
 }

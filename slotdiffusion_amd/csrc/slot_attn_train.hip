@@ -186,8 +186,10 @@ __global__ __launch_bounds__(SA_THREADS) void sa_attend_bwd_kernel(SdmiSaAttendB
     for (int i = 0; i < DPL; ++i) {
       const int c = lane + 64 * i;
       if (c < D) {
-        Elem<T>::st(dkb + (long long)m * p.ldkv + c, dkx[i]);
-        Elem<T>::st(dvb + (long long)m * p.ldkv + c, dvx[i]);
+        T* dko = dkb + (long long)m * p.ldkv + c;
+        T* dvo = dvb + (long long)m * p.ldkv + c;
+        Elem<T>::st(dko, dkx[i] + (p.accumulate ? Elem<T>::ld(dko) : 0.f));
+        Elem<T>::st(dvo, dvx[i] + (p.accumulate ? Elem<T>::ld(dvo) : 0.f));
       }
     }
   }
@@ -470,8 +472,8 @@ __global__ __launch_bounds__(256) void sat_bwd_kernel(SdmiSaAttendBwdArgs p, int
       T* dvp = dvb + (long long)(m0 + m) * p.ldkv + ch * CW;
 #pragma unroll
       for (int j = 0; j < CW; ++j) {
-        Elem<T>::st(dkp + j, dkx[j]);
-        Elem<T>::st(dvp + j, dvx[j]);
+        Elem<T>::st(dkp + j, dkx[j] + (p.accumulate ? Elem<T>::ld(dkp + j) : 0.f));
+        Elem<T>::st(dvp + j, dvx[j] + (p.accumulate ? Elem<T>::ld(dvp + j) : 0.f));
       }
     }
   }

@@ -69,6 +69,7 @@ class WeightBank:
         # (sdmi_wgrad_group) once their tiles can fill the chip -- see queue_wgrad()
         self.group_wgrad = os.environ.get('SDMI_WGRAD_GROUP', '1') != '0'
         self._wq, self._wq_keep, self._wq_items, self._wq_bytes = [], [], 0, 0
+        self.defer_colsum = os.environ.get('SDMI_DEFER_COLSUM', '1') != '0'
         # dgrad operands: key -> [buffer, epoch, (stable source view | None, geometry)]
         self._wd, self._wd_epoch, self._wd_stale, self._wd_table = {}, 0, False, None
 
@@ -162,8 +163,42 @@ class WeightBank:
                  _meta=dict(flops=flops))
         self._pending.append(tuple(keep) + (ws,))
 
+    # ---- deferred dgamma / dbeta folds of the normalisation backward passes ---------------------
+    def queue_colsum(self, partial, nblk, C, out0, out1):
+        self._cq = getattr(self, '_cq', [])
+        self._cq.append((partial, nblk, C, out0, out1))
+        self.ensure_join()
+
+    def flush_colsum(self):
+        q = getattr(self, '_cq', [])
+        if not q:
+            return
+        self._cq = []
+        import ctypes
+        Item = _lib.CSTRUCT['SdmiColsumItem']
+        # a parameter used several times per step (Slot Attention iterations, per-frame modules)
+        # has several items with the same destination: they go to successive launches (the
+        # workgroups of one launch read-modify-write their destinations concurrently)
+        chunks = []
+        for it in q:
+            for ch in chunks:
+                if len(ch[0]) < 64 and _p(it[3]) not in ch[1]:
+                    break
+            else:
+                ch = ([], set())
+                chunks.append(ch)
+            ch[0].append(it)
+            ch[1].add(_p(it[3]))
+        for chunk, _ in chunks:
+            arr = (Item * len(chunk))()
+            for a, (partial, nblk, C, o0, o1) in zip(arr, chunk):
+                a.partial, a.out0, a.out1, a.nblk, a.C = _p(partial), _p(o0), _p(o1), nblk, C
+            call('sdmi_colsum_group', _st(), items=ctypes.addressof(arr), n=len(chunk))
+        # (the partial buffers die with q: the launches above are ordered before their reuse)
+
     def join(self):
         self.flush_wgrad()
+        self.flush_colsum()
         for side in self._sides:
             torch.cuda.current_stream().wait_stream(side)
         self._pending.clear()
@@ -357,6 +392,9 @@ class Kern:
 
     def conv_fan(self, x, wname, bname=None, **kw):
         return self.conv(x, wname, bname, **kw), x
+
+    def linear_fan(self, x, wnames, bnames=None):
+        return self.linear(x, wnames, bnames), x
 
     def deconv(self, x, wname, bname, *, k, stride, pad, act='relu'):
         return deconv_forward(self.wb, x, wname, bname, k, stride, pad, act)
@@ -590,7 +628,9 @@ class GemmFn(torch.autograd.Function):
         w4 = wd.view(Cin, kh, kw, ldy)
         full = all(len(range((p + pd) % s, k, s)) > 0
                    for k, pd in ((kh, pad[0]), (kw, pad[2])) for p in range(s))
-        dx = (torch.empty if full else torch.zeros)((B, H, W_, Cin), dtype=dt, device=dy.device)
+        dx = torch.empty((B, H, W_, Cin), dtype=dt, device=dy.device)
+        if not full:
+            ops.zero_(dx)
         # `extra` (gradient of x's other consumer) rides in the epilogue when every pixel is written
         fuse = extra is not None and full
         for py in range(s):
@@ -618,18 +658,24 @@ class GemmFn(torch.autograd.Function):
                Wo, kh, kw, stride, pad, ups, is_conv):
         """Weight / bias gradient launches (on whatever stream is current)."""
         ws = torch.empty((splits * (N * K + N),), dtype=torch.float32, device=x.device)
-        dwbuf = dst if direct else torch.zeros((N, K), dtype=torch.float32, device=x.device)
-        bdst = None
-        btmp = None
+        # (temporaries of non-direct destinations are overwritten by the kernel, then added to the arena)
+        acc = 1 if direct else 0
+        dwbuf = dst if direct else torch.empty((N, K), dtype=torch.float32, device=x.device)
+        btmp, stage_bias = None, False
         if bnames is not None:
             bdst = _grads_of(wb, bnames)
-            btmp = bdst if bdst is not None else torch.zeros((N,), dtype=torch.float32,
-                                                             device=x.device)
+            if direct and bdst is not None:
+                btmp = bdst
+            else:
+                stage_bias = True
+                btmp = torch.empty((N,), dtype=torch.float32, device=x.device)
+                if acc:
+                    ops.zero_(btmp)
         call('sdmi_wgrad', _st(), a=_p(x), dy=_p(dy), dw=_p(dwbuf), dbias=_p(btmp),
              workspace=_p(ws), dtype=_DT[dt], M=M, N=N, K=K,
              lda=(Cin if is_conv else x.stride(-2)), ldy=ldy, B=B, H=H, W=W_,
              Cin=Cin, Ho=Ho, Wo=Wo, KH=kh, KW=kw, stride=stride, pad_t=pad[0], pad_l=pad[2],
-             ups=int(ups), splits=splits, accumulate=1)
+             ups=int(ups), splits=splits, accumulate=acc)
         # non-direct destinations (channel-padded Cin, non-adjacent fused parameters) ACCUMULATE like
         # the direct path does: a parameter used several times per step (per-frame modules,
         # gradient accumulation over micro-batches) keeps every contribution
@@ -646,7 +692,7 @@ class GemmFn(torch.autograd.Function):
                                  cols=ci_true, ldd=ci_true)
                 call('sdmi_add', _st(), x=_p(g[off:]), z=_p(tmp), y=_p(g[off:]), dtype=_lib.F32, n=cnt)
                 o += rows
-        if bnames is not None and bdst is None:
+        if stage_bias:
             g = wb.model.grad_arena()
             o = 0
             for nme in (bnames if not isinstance(bnames, str) else (bnames,)):
@@ -724,10 +770,14 @@ class GroupNormFn(torch.autograd.Function):
         dres = torch.empty_like(x) if residual is not None else None
         dg = _grads_of(wb, name + '.weight')
         db = _grads_of(wb, name + '.bias')
+        geo = dict(dtype=_DT[x.dtype], B=B, HW=HW, C=C, groups=G, nsplit=nsplit)
+        defer = wb.defer_colsum
+        if defer:          # the dbeta / dgamma folds of the whole step run in a few grouped launches
+            wb.queue_colsum(partial, _lib.query('sdmi_groupnorm_bwd_entries', **geo), C, db, dg)
         call('sdmi_groupnorm_bwd', _st(), x=_p(x), dy=_p(dy), dx=_p(dx), gamma=_p(wb.f(name + '.weight')),
              beta=_p(wb.f(name + '.bias')), stats=_p(stats), dgamma=_p(dg), dbeta=_p(db),
-             partial=_p(partial), dtype=_DT[x.dtype], B=B, HW=HW, C=C, groups=G,
-             act=_lib.ACT[act], nsplit=nsplit, residual=_p(residual), dresidual=_p(dres), accumulate=1,
+             partial=_p(partial), defer_colsum=int(defer), **geo,
+             act=_lib.ACT[act], residual=_p(residual), dresidual=_p(dres), accumulate=1,
              dextra0=(_p(extras[0]) if extras else 0), dextra1=(_p(extras[1]) if len(extras) > 1 else 0),
              **(dict(drop_p=float(ctx.drop[0]), drop_seed=int(ctx.drop[1]), drop_seed_dev=_p(ctx.drop[2]))
                 if ctx.drop else {}))
@@ -763,10 +813,13 @@ class LayerNormFn(torch.autograd.Function):
         partial = torch.empty((nblk * C * 2,), dtype=torch.float32, device=x.device)
         dx = torch.empty_like(x)
         dg, db = _grads_of(wb, name + '.weight'), _grads_of(wb, name + '.bias')
+        defer = wb.defer_colsum
+        if defer:
+            wb.queue_colsum(partial, nblk, C, dg, db)
         call('sdmi_layernorm_bwd', _st(), x=_p(x), dy=_p(dy), dx=_p(dx),
              gamma=_p(wb.f(name + '.weight')), stats=_p(stats), dgamma=_p(dg), dbeta=_p(db),
              partial=_p(partial), dtype=_DT[x.dtype], rows=rows, C=C, nblk=nblk, accumulate=1,
-             dextra=_p(dalias))
+             dextra=_p(dalias), defer_colsum=int(defer))
         _dbg(f'ln {name}', dy=dy, dx=dx)
         return dx, None, None, None, None
 
@@ -906,7 +959,9 @@ class SaAttendFn(torch.autograd.Function):
     """One Slot Attention iteration's streaming pass: (kv, q) -> (updates, attn)."""
 
     @staticmethod
-    def forward(ctx, kv, q, eps):
+    def forward(ctx, kv, q, eps, chain=False):
+        """chain=True: also returns an alias of kv for the NEXT iteration; the gradient that comes
+        back through it is the buffer this iteration's dk / dv are accumulated into."""
         B, M, D2 = kv.shape
         D = D2 // 2
         N = q.shape[1]
@@ -922,24 +977,30 @@ class SaAttendFn(torch.autograd.Function):
         ctx.save_for_backward(kv, q, attn, upd, den)
         ctx.eps = eps
         ctx.mark_non_differentiable(attn)
+        ctx.set_materialize_grads(False)
+        if chain:
+            return upd, attn, kv.view_as(kv)
         return upd, attn
 
     @staticmethod
-    def backward(ctx, dupd, _dattn):
+    def backward(ctx, dupd, _dattn, dkv_next=None):
         kv, q, attn, upd, den = ctx.saved_tensors
         B, M, D2 = kv.shape
         D = D2 // 2
         N = q.shape[1]
         dupd = dupd.contiguous()
         dq = torch.empty_like(q)
-        dkv = torch.empty_like(kv)
+        acc = dkv_next is not None and dkv_next.is_contiguous()
+        dkv = dkv_next if acc else torch.empty_like(kv)
         ws = torch.empty((B * ((M + 63) // 64) * N * D,), dtype=torch.float32, device=kv.device)
         call('sdmi_sa_attend_bwd', _st(), k=_p(kv), v=_p(kv[..., D:]), q=_p(q), attn=_p(attn),
              upd=_p(upd), den=_p(den), dupd=_p(dupd), dq=_p(dq), dk=_p(dkv), dv=_p(dkv[..., D:]),
              dtype=_DT[kv.dtype], B=B, M=M, N=N, D=D, ldkv=D2, eps=ctx.eps, scale=D ** -0.5,
-             workspace=_p(ws))
+             workspace=_p(ws), accumulate=int(acc))
+        if dkv_next is not None and not acc:
+            dkv = AddFn.apply(dkv, dkv_next)
         _dbg('sa_attend', dupd=dupd, dkv=dkv, dq=dq)
-        return dkv, dq, None
+        return dkv, dq, None, None
 
 
 class GruGatesFn(torch.autograd.Function):
@@ -1042,14 +1103,17 @@ class VqFn(torch.autograd.Function):
 class MseFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pred, target, scale, l1=False):
-        val, dpred = ops.mse(pred, target, want_grad=True, gscale=scale, l1=l1)
+        val, dpred = ops.mse(pred, target, want_grad=True, gscale=scale, l1=l1, oscale=scale)
         ctx.save_for_backward(dpred)
-        return (val * scale).reshape(())
+        return val.reshape(())
 
     @staticmethod
     def backward(ctx, g):
         (dpred,) = ctx.saved_tensors
-        return dpred * g, None, None, None
+        out = torch.empty_like(dpred)                  # dpred * g, g a device scalar
+        call('sdmi_scale_dev', _st(), x=_p(dpred), y=_p(out), s=_p(g.reshape(1).float().contiguous()),
+             dtype=_DT[dpred.dtype], n=dpred.numel())
+        return out, None, None, None
 
 
 class DropoutFn(torch.autograd.Function):
@@ -1186,6 +1250,7 @@ class SaCombineFn(torch.autograd.Function):
              B=B, N=N, HW=H * W_, ldo=ld)
         ctx.save_for_backward(o, masks)
         ctx.mark_non_differentiable(masks)
+        ctx.set_materialize_grads(False)
         return recon, masks
 
     @staticmethod
@@ -1249,7 +1314,7 @@ class KernGrad(Kern):
         dev = m.arena().device
         if getattr(m, 'step_seed', None) is None or m.step_seed.device != dev:
             m.step_seed = torch.zeros(1, dtype=torch.int64, device=dev)
-        m.step_seed.add_(1)
+        call('sdmi_counters_inc', _st(), seed=_p(m.step_seed))
         self._drop_ctr = 0
 
     def conv(self, x, wname, bname=None, *, kh=3, kw=3, stride=1, pad=(1, 1, 1, 1), ups=False,
@@ -1273,6 +1338,10 @@ class KernGrad(Kern):
 
     def gn_fan(self, x, name, *, eps, act=None, residual=None, n_alias=1):
         return GroupNormFn.apply(x, residual, self.wb.anchor_for(name), self.wb, name, eps, act, n_alias)
+
+    def linear_fan(self, x, wnames, bnames=None):
+        return GemmFn.apply(x, None, None, self.wb.anchor_for(wnames), self.wb, wnames, bnames,
+                            (0, 0, 1, (0, 0, 0, 0), False), None, None, 1)
 
     def linear_multi(self, x, wname_list):
         wname_list = tuple(wname_list)
@@ -1331,16 +1400,22 @@ class KernGrad(Kern):
         slots = init.contiguous()
         N = slots.shape[1]
         seg = None
-        for _ in range(iters):
-            prev = slots.reshape(B * N, D)
-            q = self.linear(self.ln(slots, f'{name}.project_q.0'), f'{name}.project_q.1.weight')
-            upd, attn = SaAttendFn.apply(kv, q, eps)
+        # every tensor with several consumers hands out aliases (ln_fan / linear_fan / the kv chain):
+        # the consumers' gradients meet inside a backward kernel, not in accumulation kernels
+        for it in range(iters):
+            nq, s_alias = self.ln_fan(slots, f'{name}.project_q.0')
+            q = self.linear(nq, f'{name}.project_q.1.weight')
+            if it + 1 < iters:
+                upd, attn, kv = SaAttendFn.apply(kv, q, eps, True)
+            else:
+                upd, attn = SaAttendFn.apply(kv, q, eps)
             seg = attn
             gi = self.linear(upd.reshape(B * N, D), f'{name}.gru.weight_ih', f'{name}.gru.bias_ih')
-            gh = self.linear(prev, f'{name}.gru.weight_hh', f'{name}.gru.bias_hh')
+            gh, prev = self.linear_fan(s_alias.reshape(B * N, D), f'{name}.gru.weight_hh',
+                                       f'{name}.gru.bias_hh')
             h = GruGatesFn.apply(gi, gh, prev)
-            hid = self.linear(self.ln(h, f'{name}.mlp.0'), f'{name}.mlp.1.weight',
-                              f'{name}.mlp.1.bias', act='relu')
+            nh, h_alias = self.ln_fan(h, f'{name}.mlp.0')
+            hid = self.linear(nh, f'{name}.mlp.1.weight', f'{name}.mlp.1.bias', act='relu')
             slots = self.linear(hid, f'{name}.mlp.3.weight', f'{name}.mlp.3.bias',
-                                residual=h).view(B, N, D)
+                                residual=h_alias).view(B, N, D)
         return slots, seg

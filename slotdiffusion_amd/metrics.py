@@ -157,3 +157,35 @@ def psnr_metric(x, y):
     10 * log10(1 / mean squared error)."""
     se, n = _sqerr(x, y)
     return float(np.mean(10.0 * np.log10(1.0 / (se / n))))
+
+
+def ssim_metric(x, y):
+    """eval_utils.ssim_metric (eval_utils.py:91-106): x / y [B,3,H,W] in [0,1] -> mean over images of
+    skimage's structural_similarity(x*255, y*255, channel_axis=0, gaussian_weights=True, sigma=1.5,
+    use_sample_covariance=False, data_range=255).  skimage is absent offline: the published algorithm
+    is restated (sdmi_ssim); parity with skimage itself is unpinned."""
+    x, y = torch.as_tensor(x), torch.as_tensor(y)
+    _need_gpu(x)
+    _need_gpu(y)
+    assert x.shape == y.shape and x.dim() == 4
+    B, Cc, H, W = x.shape
+    xf = (x.float() * 255.0).contiguous()
+    yf = (y.float() * 255.0).contiguous()
+    out = torch.empty((B * Cc,), dtype=torch.float64, device=x.device)
+    _lib.call('sdmi_ssim', torch.cuda.current_stream().cuda_stream, x=xf.data_ptr(), y=yf.data_ptr(),
+              out=out.data_ptr(), P=B * Cc, H=H, W=W, data_range=255.0)
+    return float(out.view(B, Cc).mean(1).mean().cpu())        # mean over channels, then over images
+
+
+def shuffle_slots(slots):
+    """Compositional generation (video_based/test_comp_gen.py:25-31): slot i of every item is taken
+    from the item i places further along the batch, so each new scene mixes objects of N scenes.
+    slots [B,T,N,C] or [B,N,C] -> a new tensor of the same shape (the input is left untouched)."""
+    nd = slots.dim()
+    assert nd in (3, 4)
+    B, N = slots.shape[0], slots.shape[-2]
+    src = (torch.arange(B, device=slots.device)[:, None] + torch.arange(N, device=slots.device)[None]) % B
+    slot_ix = torch.arange(N, device=slots.device)[None].expand(B, N)
+    if nd == 3:
+        return slots[src, slot_ix]
+    return slots[src, :, slot_ix].permute(0, 2, 1, 3).contiguous()

@@ -139,18 +139,25 @@ class LDM(_Owned):
         B = img.shape[0]
         with torch.no_grad():
             x0 = engine.vae_encode(r.K(), r._to_nhwc(img), r.ed, scale_factor=r.z_scale)
-            if t is None:
-                t = torch.randint(0, self.num_timesteps, (B,), device=img.device).long()
-            if noise is None:
-                noise = torch.randn(B, 3, x0.shape[1], x0.shape[2], device=img.device)
-            nz = ops.nchw_to_nhwc(noise, torch.float32, 4)
-            ca = self.sqrt_alphas_bar[t].contiguous()
-            cb = self.sqrt_one_minus_alphas_bar[t].contiguous()
+            tf = None
+            if t is None and noise is None:
+                # the reference's two draws (ldm.py:65-69) + the schedule gathers in ONE launch of
+                # the counter-based generator (keyed on the run seed and the per-step seed word, so a
+                # graph replay draws new values); explicit t / noise (fixtures) take the path below
+                t, tf, ca, cb, nz = self._draw_tn(B, x0.shape[1], x0.shape[2], img.device)
+            else:
+                if t is None:
+                    t = torch.randint(0, self.num_timesteps, (B,), device=img.device).long()
+                if noise is None:
+                    noise = torch.randn(B, 3, x0.shape[1], x0.shape[2], device=img.device)
+                nz = ops.nchw_to_nhwc(noise, torch.float32, 4)
+                ca = self.sqrt_alphas_bar[t].contiguous()
+                cb = self.sqrt_one_minus_alphas_bar[t].contiguous()
             xt = ops.row_lincomb(x0, nz, ca, cb)
         grad = torch.is_grad_enabled() and (slots.requires_grad or r.training)
         Kp = r.KG() if grad else r.K()
         with torch.set_grad_enabled(grad):
-            pred = r._unet_eps(xt, t.float(), slots, Kp)
+            pred = r._unet_eps(xt, tf if tf is not None else t.float(), slots, Kp)
             # the 4th (zero pad) channel adds no error but is counted in n: rescale 4/3
             if self.pred_target == 'eps':                      # ldm.py:71-79
                 gt = nz
@@ -163,6 +170,21 @@ class LDM(_Owned):
             else:
                 loss = (ops.mse(pred, gt) * (4.0 / 3.0)).reshape(())
         return {'denoise_loss': loss}
+
+    def _draw_tn(self, B, h, w, device):
+        r = self.root
+        hw = h * w
+        t = torch.empty((B,), dtype=torch.int64, device=device)
+        tf, ca, cb = (torch.empty((B,), dtype=torch.float32, device=device) for _ in range(3))
+        nz = torch.empty((B, hw, 4), dtype=torch.float32, device=device)
+        seed_dev = getattr(r, 'step_seed', None)
+        kern.call('sdmi_draw_tn', torch.cuda.current_stream().cuda_stream, t=t.data_ptr(),
+                  tf=tf.data_ptr(), ca=ca.data_ptr(), cb=cb.data_ptr(), noise=nz.data_ptr(),
+                  tab_a=self.sqrt_alphas_bar.data_ptr(), tab_b=self.sqrt_one_minus_alphas_bar.data_ptr(),
+                  B=B, T=self.num_timesteps, per=hw * 4,
+                  seed=(int(getattr(r, 'seed', 0)) * 7919 + int(os.environ.get('RANK', 0)) * 104729 + 17),
+                  seed_dev=(seed_dev.data_ptr() if seed_dev is not None else 0))
+        return t, tf, ca, cb, nz.view(B, h, w, 4)
 
     # -- a12/a13 -------------------------------------------------------------------------
     @torch.no_grad()

@@ -33,6 +33,16 @@ def _need_gpu(*ts):
             raise _lib.SdmiError('libsdmi kernels need device tensors (no CPU fallback)')
 
 
+def zero_(t):
+    """Stream-ordered zero fill of a contiguous tensor (memset node in a graph; no framework kernel)."""
+    call('sdmi_memset0', _stream(), ptr=_p(t), bytes=t.numel() * t.element_size())
+    return t
+
+
+def zeros(shape, dtype, device):
+    return zero_(torch.empty(shape, dtype=dtype, device=device))
+
+
 # ------------------------------------------------------------------------------------------
 # implicit GEMM
 # ------------------------------------------------------------------------------------------
@@ -63,7 +73,9 @@ def conv2d(x, w, bias=None, *, kh=3, kw=3, stride=1, pad=(1, 1, 1, 1), ups=False
     odt = out_dtype or x.dtype
     ldc = ldc or N
     if out is None:
-        out = (torch.zeros if ldc != N else torch.empty)((B, Ho, Wo, ldc), dtype=odt, device=x.device)
+        out = torch.empty((B, Ho, Wo, ldc), dtype=odt, device=x.device)
+        if ldc != N:                      # channel-pad columns must read as zeros downstream
+            zero_(out)
     M = B * Ho * Wo
     ws = splitk_workspace(M, N, K, x.element_size(), x.device) if split_k != 1 else None
     call('sdmi_igemm', _stream(), a=_p(x), w=_p(w), out=_p(out), bias=_p(bias), rowvec=_p(rowvec),
@@ -254,11 +266,12 @@ def cast2d(src, dst_dtype, cols=None, out=None, ldd=None):
     cols = cols or lds
     rows = src.numel() // lds
     ldd = ldd or cols
+    zpad = 0
     if out is None:
-        out = (torch.zeros if ldd != cols else torch.empty)(src.shape[:-1] + (ldd,),
-                                                            dtype=dst_dtype, device=src.device)
+        out = torch.empty(src.shape[:-1] + (ldd,), dtype=dst_dtype, device=src.device)
+        zpad = int(ldd != cols)           # the kernel writes the pad columns itself
     call('sdmi_cast2d', _stream(), src=_p(src), dst=_p(out), src_dtype=_dt(src),
-         dst_dtype=_DT[dst_dtype], rows=rows, cols=cols, lds=lds, ldd=ldd)
+         dst_dtype=_DT[dst_dtype], rows=rows, cols=cols, lds=lds, ldd=ldd, zpad=zpad)
     return out
 
 
@@ -334,12 +347,13 @@ def softmax_rows_bwd_(p, dp, scale=1.0):
     return dp
 
 
-def mse(pred, target, want_grad=False, gscale=1.0, l1=False):
+def mse(pred, target, want_grad=False, gscale=1.0, l1=False, oscale=0.0):
     n = pred.numel()
     nblk = max(1, min(1024, (n + 2047) // 2048))
     partial = torch.empty((nblk,), dtype=torch.float32, device=pred.device)
     out = torch.empty((1,), dtype=torch.float32, device=pred.device)
     dpred = torch.empty_like(pred) if want_grad else None
     call('sdmi_mse', _stream(), pred=_p(pred), target=_p(target), out=_p(out), dpred=_p(dpred),
-         partial=_p(partial), dtype=_dt(pred), n=n, nblk=nblk, gscale=gscale, l1=int(l1))
+         partial=_p(partial), dtype=_dt(pred), n=n, nblk=nblk, gscale=gscale, l1=int(l1),
+         oscale=float(oscale))
     return (out, dpred) if want_grad else out

@@ -57,7 +57,11 @@ class FusedAdam:
         return 0.5 * (1. + math.cos(math.pi * min(1.0, prog)))
 
     def zero_grad(self):
-        self.model.grad_arena().zero_()
+        g = self.model.grad_arena()
+        if g.is_cuda:
+            call('sdmi_memset0', torch.cuda.current_stream().cuda_stream, ptr=_p(g), bytes=g.numel() * 4)
+        else:
+            g.zero_()
 
     def state_dict(self):
         """Everything a resumed run needs: moments, step (bias correction + schedule position)."""
@@ -96,7 +100,7 @@ class FusedAdam:
         g = m.grad_arena()
         st = torch.cuda.current_stream().cuda_stream
         if capturable:          # host bookkeeping (step_count, lr) is the replaying caller's job
-            self.step_dev.add_(1)
+            call('sdmi_counters_inc', st, step=_p(self.step_dev))
         else:
             self.set_lr_for_next_step()
             self.step_count += 1
@@ -209,7 +213,7 @@ class GraphedTrainStep:
     # -- pieces ---------------------------------------------------------------------------
     def _forward_loss(self):
         m = self.model
-        m.grad_arena().zero_()           # (the model's forward starts a new dropout step itself)
+        self.opt.zero_grad()             # (the model's forward starts a new dropout step itself)
         out = m(self.static)
         loss = m.calc_train_loss(self.static, out)[self.loss_key]
         if self.loss_weight != 1.0:

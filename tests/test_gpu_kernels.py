@@ -375,3 +375,73 @@ def test_eval_metrics_on_device():
     assert abs(MT.mse_metric(x.cuda(), y.cuda()) - O.mse_metric(x, y)) <= 1e-6 * O.mse_metric(x, y)
     with pytest.raises(RuntimeError):
         MT.ARI_metric(gt, pred)           # CPU tensors: no fallback
+
+
+def test_training_step_helpers():
+    """The small stream-ordered helpers that keep framework kernels out of the training step:
+    sdmi_draw_tn (timestep / noise draws + schedule gathers), sdmi_memset0, sdmi_scale_dev,
+    sdmi_counters_inc, the zero-padding cast."""
+    from slotdiffusion_amd import _lib
+    ops = _ops()
+    st = torch.cuda.current_stream().cuda_stream
+    B, hw, T = 4096, 64, 1000
+    tab_a = torch.linspace(1.0, 0.1, T, device=DEV)
+    tab_b = torch.linspace(0.0, 0.9, T, device=DEV)
+    seed_dev = torch.full((1,), 3, dtype=torch.int64, device=DEV)
+
+    def draw(seed):
+        t = torch.empty(B, dtype=torch.int64, device=DEV)
+        tf, ca, cb = (torch.empty(B, device=DEV) for _ in range(3))
+        nz = torch.empty(B, hw, 4, device=DEV)
+        _lib.call('sdmi_draw_tn', st, t=t.data_ptr(), tf=tf.data_ptr(), ca=ca.data_ptr(), cb=cb.data_ptr(),
+                  noise=nz.data_ptr(), tab_a=tab_a.data_ptr(), tab_b=tab_b.data_ptr(), B=B, T=T, per=hw * 4,
+                  seed=seed, seed_dev=seed_dev.data_ptr())
+        return t.cpu(), tf.cpu(), ca.cpu(), cb.cpu(), nz.cpu()
+    t, tf, ca, cb, nz = draw(11)
+    assert int(t.min()) >= 0 and int(t.max()) < T and torch.equal(tf, t.float())
+    assert torch.equal(ca, tab_a.cpu()[t]) and torch.equal(cb, tab_b.cpu()[t])
+    hist = torch.bincount(t // 100, minlength=10).float() / B          # uniform over the schedule
+    assert float((hist - 0.1).abs().max()) < 0.02, hist
+    z = nz[..., :3]
+    assert float(nz[..., 3].abs().max()) == 0.0
+    assert abs(float(z.mean())) < 5e-3 and abs(float(z.std()) - 1.0) < 5e-3
+    assert abs(float((z ** 4).mean()) - 3.0) < 0.06 and float(z.abs().max()) > 4.0     # Gaussian tails
+    t2, _, _, _, nz2 = draw(11)
+    assert torch.equal(t, t2) and torch.equal(nz, nz2)                 # same seed word: reproducible
+    _lib.call('sdmi_counters_inc', st, seed=seed_dev.data_ptr())
+    assert int(seed_dev) == 4
+    t3, _, _, _, nz3 = draw(11)
+    assert not torch.equal(t, t3) and float((nz3 - nz).abs().mean()) > 0.5
+    step = torch.zeros(1, dtype=torch.int32, device=DEV)
+    _lib.call('sdmi_counters_inc', st, step=step.data_ptr(), seed=seed_dev.data_ptr())
+    assert int(step) == 1 and int(seed_dev) == 5
+    # memset / scale / zero-padding cast
+    x = torch.randn(1000, 5, device=DEV)
+    y = ops.cast2d(x, torch.bfloat16, cols=3, ldd=8)
+    assert y.shape == (1000, 8) and float(y[:, 3:].float().abs().max()) == 0.0
+    assert torch.equal(y[:, :3], x[:, :3].bfloat16())
+    assert float(ops.zeros((777,), torch.float32, DEV).abs().max()) == 0.0
+    s = torch.tensor([0.25], device=DEV)
+    for dt in (torch.float32, torch.bfloat16):
+        xs = torch.randn(3333, device=DEV).to(dt)
+        out = torch.empty_like(xs)
+        _lib.call('sdmi_scale_dev', st, x=xs.data_ptr(), y=out.data_ptr(), s=s.data_ptr(),
+                  dtype=(_lib.BF16 if dt == torch.bfloat16 else _lib.F32), n=xs.numel())
+        assert torch.equal(out, xs * 0.25)
+
+
+def test_ssim_on_device_matches_oracle():
+    """sdmi_ssim (fp64 windows on the device) against the oracle's scipy restatement (skimage itself
+    is absent: parity unpinned at that boundary), incl. ragged sizes and identical images."""
+    from oracle import slotdiff_oracle as O
+    from slotdiffusion_amd import metrics
+    g = torch.Generator().manual_seed(9)
+    for B, H, W in ((2, 128, 128), (3, 37, 53), (1, 11, 11)):
+        x = torch.rand(B, 3, H, W, generator=g)
+        y = (x + 0.05 * torch.randn(B, 3, H, W, generator=g)).clamp(0, 1)
+        ref = O.ssim_metric(x.numpy(), y.numpy())
+        got = metrics.ssim_metric(x.to(DEV), y.to(DEV))
+        assert abs(got - ref) < 1e-6, (got, ref)
+    assert abs(metrics.ssim_metric(x.to(DEV), x.to(DEV)) - 1.0) < 1e-9
+    slots = torch.randn(6, 3, 7, 16, generator=g)
+    assert torch.equal(metrics.shuffle_slots(slots.to(DEV)).cpu(), O.shuffle_slots(slots))

@@ -441,6 +441,7 @@ def test_groupnorm_fanout_and_fused_dropout(B, HW, C, dtype):
             _offsets = {'n.weight': (0, C), 'n.bias': (C, C)}
         t = {'n.weight': gam.cuda(), 'n.bias': bet.cuda()}
         g = torch.zeros(2 * C, device='cuda')
+        defer_colsum = False
 
         @staticmethod
         def f(k):
@@ -552,6 +553,7 @@ def test_layernorm_and_gemm_fanout(dtype):
             _offsets = {'n.weight': (0, C), 'n.bias': (C, C)}
         t = {'n.weight': gam.cuda(), 'n.bias': bet.cuda()}
         g = torch.zeros(2 * C, device='cuda')
+        defer_colsum = False
 
         @staticmethod
         def f(k):

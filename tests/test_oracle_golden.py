@@ -409,3 +409,46 @@ def test_vqvae_training_gradients_oracle_matches_reference():
             for n in ('quantize.embedding.weight', 'decoder.mid.attn_1.k.weight'):
                 ref = V['grad/' + n]
                 assert float((W[n].grad - ref).abs().max()) <= 2e-3 * float(ref.abs().max()) + 1e-9, n
+
+
+def test_ssim_restatement_and_slot_shuffling():
+    """SSIM (parity unpinned: skimage is absent): the oracle's scipy restatement against a direct
+    evaluation of the published definition, its basic properties, and the compositional-generation
+    slot shuffling against the reference's in-place loop (test_comp_gen.py:25-31)."""
+    import numpy as np
+    g = torch.Generator().manual_seed(4)
+    x = torch.rand(2, 3, 24, 20, generator=g).numpy()
+    y = np.clip(x + 0.1 * torch.randn(2, 3, 24, 20, generator=g).numpy(), 0, 1)
+    s = O.ssim_metric(x, y)
+    # direct definition: 11x11 outer-product Gaussian window at every interior pixel
+    w = np.exp(-0.5 * (np.arange(-5, 6) ** 2) / 1.5 ** 2)
+    w /= w.sum()
+    W2 = np.outer(w, w)
+    C1, C2 = (0.01 * 255) ** 2, (0.03 * 255) ** 2
+    vals = []
+    for i in range(2):
+        ch = []
+        for c in range(3):
+            a, b = x[i, c] * 255., y[i, c] * 255.
+            acc = []
+            for cy in range(5, 24 - 5):
+                for cx in range(5, 20 - 5):
+                    pa, pb = a[cy - 5:cy + 6, cx - 5:cx + 6], b[cy - 5:cy + 6, cx - 5:cx + 6]
+                    ux, uy = (W2 * pa).sum(), (W2 * pb).sum()
+                    vx, vy = (W2 * pa * pa).sum() - ux * ux, (W2 * pb * pb).sum() - uy * uy
+                    vxy = (W2 * pa * pb).sum() - ux * uy
+                    acc.append(((2 * ux * uy + C1) * (2 * vxy + C2)) / ((ux ** 2 + uy ** 2 + C1) * (vx + vy + C2)))
+            ch.append(np.mean(acc))
+        vals.append(np.mean(ch))
+    assert abs(s - float(np.mean(vals))) < 1e-8
+    assert abs(O.ssim_metric(x, x) - 1.0) < 1e-12 and 0.0 < s < 1.0
+    assert O.ssim_metric(x, y) == O.ssim_metric(y, x)
+    # slot shuffling: the reference's in-place loop
+    slots = torch.randn(5, 2, 7, 4, generator=g)
+    ref = slots.clone()
+    for i in range(7):
+        ref[:, :, i] = torch.cat([ref[i:, :, i], ref[:i, :, i]])
+    assert torch.equal(O.shuffle_slots(slots), ref)
+    from slotdiffusion_amd import metrics
+    assert torch.equal(metrics.shuffle_slots(slots), ref)
+    assert torch.equal(metrics.shuffle_slots(slots[:, 0]), O.shuffle_slots(slots[:, 0]))

@@ -1,14 +1,53 @@
-"""Which Python lines of the train step launch ATen (non-libsdmi) device kernels?  (GPU box, dev tool)
+"""Which Python lines of the train step run ATen (non-libsdmi) device work?  (GPU box, dev tool)
     python tools/find_aten.py
-Eager step under torch.profiler with stacks; kernels are attributed to the innermost frame inside
-this repository."""
+Python-level wrappers around the usual suspects (zeros / zero_ / fill_ / copying contiguous() /
+casts / arithmetic / RNG / indexing) count calls per call site inside this repository during one
+eager step; accumulations done by the autograd engine itself are what remains of the profiler's
+ATen kernel count."""
 import collections
 import os
 import sys
+import traceback
 import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import bench
-from torch.profiler import ProfilerActivity, profile
+
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+hits = collections.Counter()
+ON = [False]
+
+
+def site():
+    for fr in reversed(traceback.extract_stack()[:-2]):
+        if fr.filename.startswith(root) and 'tools/find_aten' not in fr.filename:
+            return f'{fr.filename.replace(root + "/", "")}:{fr.lineno}'
+    return 'outside'
+
+
+def wrap(obj, name, cond=None, tag=None):
+    orig = getattr(obj, name)
+
+    def f(*a, **k):
+        if ON[0] and (cond is None or cond(*a, **k)):
+            hits[(tag or name, site())] += 1
+        return orig(*a, **k)
+    setattr(obj, name, f)
+
+
+T = torch.Tensor
+wrap(torch, 'zeros'); wrap(torch, 'randn'); wrap(torch, 'randint'); wrap(torch, 'full'); wrap(torch, 'ones')
+wrap(torch, 'stack'); wrap(torch, 'cat'); wrap(torch, 'tensor')
+for n in ('zero_', 'fill_', 'add_', 'mul_', 'copy_', 'clone', 'float', 'long', 'to', '__add__', '__mul__',
+          '__sub__', '__neg__', '__getitem__', 'sum', 'expand', 'repeat'):
+    c = None
+    if n in ('float', 'long', 'to'):
+        c = lambda self, *a, **k: self.is_cuda
+    if n == '__getitem__':
+        c = lambda self, idx: self.is_cuda and torch.is_tensor(idx)
+    if n in ('expand',):
+        c = lambda *a, **k: False
+    wrap(T, n, c)
+wrap(T, 'contiguous', lambda self, *a, **k: self.is_cuda and not self.is_contiguous(), 'contiguous(copy)')
 
 model, cfg = bench.build_model(torch.bfloat16)
 model = model.cuda().train()
@@ -29,18 +68,9 @@ def step():
 for _ in range(2):
     step()
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
-    step()
-    torch.cuda.synchronize()
-root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-agg = collections.Counter()
-for ev in prof.events():
-    if ev.device_type == torch.autograd.DeviceType.CPU and ev.name.startswith('aten::') and ev.kernels:
-        site = 'unknown'
-        for fr in ev.stack:
-            if root in fr and 'tools/find_aten' not in fr:
-                site = fr.replace(root + '/', '')
-                break
-        agg[(ev.name, site[:110])] += len(ev.kernels)
-for (name, site), n in sorted(agg.items(), key=lambda kv: -kv[1]):
-    print(f'{n:4d}  {name:28s} {site}')
+ON[0] = True
+step()
+ON[0] = False
+torch.cuda.synchronize()
+for (name, s), n in sorted(hits.items(), key=lambda kv: -kv[1]):
+    print(f'{n:4d}  {name:18s} {s}')
