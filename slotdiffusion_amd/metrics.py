@@ -184,7 +184,9 @@ def shuffle_slots(slots):
     nd = slots.dim()
     assert nd in (3, 4)
     B, N = slots.shape[0], slots.shape[-2]
-    src = (torch.arange(B, device=slots.device)[:, None] + torch.arange(N, device=slots.device)[None]) % B
+    shift = torch.arange(N, device=slots.device)
+    shift = torch.where(shift < B, shift, torch.zeros_like(shift))     # slots[i:] is empty for i >= B
+    src = (torch.arange(B, device=slots.device)[:, None] + shift[None]) % B
     slot_ix = torch.arange(N, device=slots.device)[None].expand(B, N)
     if nd == 3:
         return slots[src, slot_ix]
