@@ -63,9 +63,40 @@ def resnet_encoder(W, img, plan, prefix='encoder'):
     return x
 
 
+def dino_vit_forward(W, img, meta, prefix='encoder.dino'):
+    """DINOEncoder.forward (video_based/models/dino.py:43-55): transformers' ViTModel (third party,
+    pinned 4.27.4 by the reference; the architecture is restated from its published definition and
+    pinned by a fixture generated with the installed transformers' ViTModel class on the same weights):
+    patch embedding (conv p x p, stride p), [CLS] + learnt positions, pre-LN blocks -- biased q/k/v,
+    softmax(q k^T / sqrt(d)) v, output projection, GELU(erf) MLP -- final LayerNorm, eps 1e-12, CLS
+    dropped, -> [B, hidden, H/p, W/p]."""
+    p, hid, heads = prefix, meta['hidden'], meta['heads']
+    hd = hid // heads
+    e = p + '.embeddings'
+    x = F.conv2d(img, W[e + '.patch_embeddings.projection.weight'], W[e + '.patch_embeddings.projection.bias'],
+                 stride=meta['patch'])
+    B, _, gh, gw = x.shape
+    x = x.flatten(2).transpose(1, 2)
+    x = torch.cat([W[e + '.cls_token'].expand(B, -1, -1), x], 1) + W[e + '.position_embeddings']
+    S = x.shape[1]
+    ln = lambda name, t: F.layer_norm(t, (hid,), W[name + '.weight'], W[name + '.bias'], 1e-12)
+    for i in range(meta['layers']):
+        l = f'{p}.encoder.layer.{i}'
+        h = ln(l + '.layernorm_before', x)
+        sp = lambda t: t.view(B, S, heads, hd).permute(0, 2, 1, 3)
+        q, k, v = (sp(_lin(W, f'{l}.attention.attention.{n}', h)) for n in ('query', 'key', 'value'))
+        att = (torch.einsum('bhid,bhjd->bhij', q, k) * hd ** -0.5).softmax(-1)
+        ctx = torch.einsum('bhij,bhjd->bhid', att, v).permute(0, 2, 1, 3).reshape(B, S, hid)
+        x = x + _lin(W, l + '.attention.output.dense', ctx)
+        h = F.gelu(_lin(W, l + '.intermediate.dense', ln(l + '.layernorm_after', x)))
+        x = x + _lin(W, l + '.output.dense', h)
+    x = ln(p + '.layernorm', x)[:, 1:, :]
+    return x.reshape(B, gh, gw, hid).permute(0, 3, 1, 2)
+
+
 def encoder_out(W, img, plan):
     """img_based/models/slot_attention.py:305-316 + models/utils.py:60-63."""
-    feat = resnet_encoder(W, img, plan)
+    feat = dino_vit_forward(W, img, plan) if isinstance(plan, dict) else resnet_encoder(W, img, plan)
     pos = _lin(W, 'encoder_pos_embedding.dense', W['encoder_pos_embedding.grid'])   # [1,h,w,C]
     feat = feat + pos.permute(0, 3, 1, 2)
     x = feat.flatten(2, 3).permute(0, 2, 1)                                        # [B,HW,C]

@@ -313,7 +313,8 @@ __global__ __launch_bounds__(256) void sat_fwd_kernel(SdmiSaAttendArgs p, int ti
     }
   }
   __syncthreads();
-  // phase B: thread d owns channel d: upd_partial[n][d] = sum_m w[m][n] v[m][d]; threads D..D+N-1: den
+  // phase B: thread d owns channel d: upd_partial[n][d] = sum_m w[m][n] v[m][d]; the last N threads
+  // (idle when D < 256, shared with a channel when D == 256): den
   float* wsu = p.workspace + ((long long)b * tiles + tile) * N * (D + 1);
   if (tid < D) {
     float acc[NP];
@@ -332,8 +333,9 @@ __global__ __launch_bounds__(256) void sat_fwd_kernel(SdmiSaAttendArgs p, int ti
 #pragma unroll
     for (int n = 0; n < NP; ++n)
       if (n < N) wsu[n * D + tid] = acc[n];
-  } else if (tid < D + N) {
-    const int n = tid - D;
+  }
+  if (tid >= 256 - N) {
+    const int n = tid - (256 - N);
     float s = 0.f;
     for (int m = 0; m < mvalid; ++m) s += w_s[m * NP + n];
     wsu[N * D + n] = s;

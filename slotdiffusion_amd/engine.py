@@ -46,10 +46,57 @@ def position_embedding(K, name='encoder_pos_embedding'):
     return pos
 
 
+# ------------------------------------------------------------------------------------------
+# frozen DINO ViT encoder (video_based/models/dino.py:21-60 -> transformers ViTModel: patch
+# embedding, CLS + learnt positions, pre-LN blocks with biased q/k/v, GELU MLP, final LayerNorm)
+# ------------------------------------------------------------------------------------------
+def dino_encoder(K, img_nhwc, meta, prefix='encoder.dino'):
+    """img [B,H,W,Cpad] compute dtype -> patch features [B, (H/p)*(W/p), hidden] (CLS dropped).
+    No autograd: the ViT is frozen (dino.py:39-41).  Attention over the 785 tokens runs as batched
+    MFMA GEMMs per head (S = q k^T, row softmax, O = P v) -- head dim 64."""
+    wb = K.wb
+    hid, heads, p_ = meta['hidden'], meta['heads'], meta['patch']
+    hd = hid // heads
+    dt = img_nhwc.dtype
+    with torch.no_grad():
+        Kf = K if not K.training else K.wb.model.K()          # frozen: plain launches
+        e = prefix + '.embeddings'
+        pat = Kf.conv(img_nhwc, e + '.patch_embeddings.projection.weight',
+                      e + '.patch_embeddings.projection.bias', kh=p_, kw=p_, stride=p_, pad=(0, 0, 0, 0))
+        B, gh, gw, _ = pat.shape
+        S = gh * gw + 1
+        x = ops.zeros((B, S, hid), dt, pat.device)                                        # token 0 = 0
+        ops.cast2d(pat.view(B, gh * gw * hid), dt, out=x.view(B, S * hid)[:, hid:], ldd=S * hid)   # 1..
+        key = prefix + '/pos+cls'            # positions with the CLS token folded into row 0 (frozen)
+        if key not in wb.cache:
+            pc = wb.f(e + '.position_embeddings').view(S, hid).clone()
+            ops.lincomb(1.0, pc[0], 1.0, wb.f(e + '.cls_token').view(hid), out=pc[0])
+            wb.cache[key] = pc
+        x = ops.add_pos(x, wb.cache[key])
+        for i in range(meta['layers']):
+            l = f'{prefix}.encoder.layer.{i}'
+            a = l + '.attention.attention'
+            h = Kf.ln(x, l + '.layernorm_before', eps=1e-12)
+            qkv = Kf.linear(h, (a + '.query.weight', a + '.key.weight', a + '.value.weight'),
+                            (a + '.query.bias', a + '.key.bias', a + '.value.bias'))
+            ctx = ops.attention_long(qkv[..., :hid], qkv[..., hid:2 * hid], qkv[..., 2 * hid:], heads, hd)
+            x = Kf.linear(ctx, l + '.attention.output.dense.weight', l + '.attention.output.dense.bias',
+                          residual=x)
+            h = Kf.ln(x, l + '.layernorm_after', eps=1e-12)
+            h = Kf.linear(h, l + '.intermediate.dense.weight', l + '.intermediate.dense.bias', act='gelu')
+            x = Kf.linear(h, l + '.output.dense.weight', l + '.output.dense.bias', residual=x)
+        x = Kf.ln(x, prefix + '.layernorm', eps=1e-12)
+        return x[:, 1:, :].contiguous(), (gh, gw)
+
+
 def encoder_out(K, img_nhwc, plan):
     """-> tokens [B, h*w, enc_out] in compute dtype."""
-    feat = resnet_encoder(K, img_nhwc, plan)
-    B, h, w, C = feat.shape
+    if isinstance(plan, dict):            # DINO ViT features (already [B, h*w, C] tokens)
+        feat, (h, w) = dino_encoder(K, img_nhwc, plan)
+        B, _, C = feat.shape
+    else:
+        feat = resnet_encoder(K, img_nhwc, plan)
+        B, h, w, C = feat.shape
     tok = K.add_pos(feat.view(B, h * w, C), position_embedding(K))
     tok = K.ln(tok, 'encoder_out_layer.0')
     tok = K.linear(tok, 'encoder_out_layer.1.weight', 'encoder_out_layer.1.bias', act='relu')

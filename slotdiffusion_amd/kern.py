@@ -205,8 +205,23 @@ class WeightBank:
         self._join_queued = False
 
     def invalidate(self):
-        self.cache.clear()
+        """The master weights changed (optimiser step / checkpoint load): derived operands of
+        TRAINABLE parameters are dropped; those of frozen ones (VQ-VAE, DINO ViT) stay valid."""
+        fz = self._frozen_names()
+        keep = {}
+        for key, val in self.cache.items():
+            names = key[0] if (isinstance(key, tuple) and isinstance(key[0], tuple)) else \
+                (key[1] if (isinstance(key, tuple) and key[0] == 'bias') else None)
+            if names is not None and all(n in fz for n in names):
+                keep[key] = val
+        self.cache = keep
         self._wd_stale = True
+
+    def _frozen_names(self):
+        fz = getattr(self, '_fz', None)
+        if fz is None:
+            fz = self._fz = {p.name for p in getattr(self.model, '_spec', []) if not p.trainable}
+        return fz
 
     def f(self, name):
         return self.t[name]
@@ -410,11 +425,13 @@ class Kern:
              B=B, N=N, HW=H * W_, ldo=ld)
         return recon, masks
 
-    def ln(self, x, name):
-        return ops.layer_norm(x, self.wb.f(name + '.weight'), self.wb.f(name + '.bias'))
+    def ln(self, x, name, eps=1e-5):
+        return ops.layer_norm(x, self.wb.f(name + '.weight'), self.wb.f(name + '.bias'), eps=eps)
 
     def attn_self(self, qkv, heads, head_dim=32):
         C = heads * head_dim
+        if qkv.shape[1] > ops.ATTN_LDS_MAX_KV:          # e.g. 28 x 28 tokens of the 224^2 configs
+            return ops.attention_long(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], heads, head_dim)
         return ops.attention(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], heads,
                              head_dim=head_dim)
 
@@ -862,6 +879,43 @@ class AttnFn(torch.autograd.Function):
              scale=hd ** -0.5, head_dim=hd)
         _dbg(f'attn Sq={Sq} Skv={Skv}', dout=dout, da=da, dkv=dkv)
         return da, dkv, None, None
+
+
+class LongAttnFn(torch.autograd.Function):
+    """Self-attention over sequences beyond the LDS-resident kernels (ops.attention_long) with its
+    backward as batched GEMMs per head:  dP = dO v^T,  dv = P^T dO,  dS = softmax'(P, dP),
+    dq = dS k,  dk = dS^T q  (the score / probability matrices live in HBM).  qkv [B,S,3C]."""
+
+    @staticmethod
+    def forward(ctx, qkv, heads, head_dim):
+        C = heads * head_dim
+        assert qkv.shape[1] % ops.vec_of(qkv.dtype) == 0, 'sequence length must keep 16-byte rows'
+        out, P = ops.attention_long(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], heads, head_dim,
+                                    keep_p=True)
+        ctx.save_for_backward(qkv, P)
+        ctx.heads, ctx.hd = heads, head_dim
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, P = ctx.saved_tensors
+        heads, hd = ctx.heads, ctx.hd
+        C = heads * hd
+        B, S, _ = qkv.shape
+        dout = dout.contiguous()
+        dqkv = torch.empty_like(qkv)
+        dp = torch.empty((B, S, S), dtype=qkv.dtype, device=qkv.device)
+        for h in range(heads):
+            q, k, v = (qkv[..., j * C + h * hd:j * C + (h + 1) * hd] for j in range(3))
+            dq, dk, dv = (dqkv[..., j * C + h * hd:j * C + (h + 1) * hd] for j in range(3))
+            do = dout[..., h * hd:(h + 1) * hd]
+            p = P[h]
+            ops.bmm_nt(do, v, dp)                                            # dP = dO v^T
+            ops.bmm_nt(ops.transpose2d(p), ops.transpose2d(do), dv)          # dv = P^T dO
+            ops.softmax_rows_bwd_(p, dp, scale=float(hd) ** -0.5)            # dp <- dS
+            ops.bmm_nt(dp, ops.transpose2d(k), dq)                           # dq = dS k
+            ops.bmm_nt(ops.transpose2d(dp), ops.transpose2d(q), dk)          # dk = dS^T q
+        return dqkv, None, None
 
 
 class GegluFn(torch.autograd.Function):
@@ -1368,6 +1422,8 @@ class KernGrad(Kern):
         return LayerNormFn.apply(x, self.wb.anchor_for(name), self.wb, name)
 
     def attn_self(self, qkv, heads, head_dim=32):
+        if qkv.shape[1] > ops.ATTN_LDS_MAX_KV:
+            return LongAttnFn.apply(qkv, heads, head_dim)
         return AttnFn.apply(qkv, None, heads, head_dim)
 
     def attn_cross(self, q, kv, heads):

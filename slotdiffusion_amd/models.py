@@ -324,13 +324,11 @@ class SADiffusion(SlotModelBase):
         self.num_slots = slot_dict['num_slots']
         self.slot_size = slot_dict['slot_size']
         self.num_iterations = slot_dict['num_iterations']
-        div = 8 if enc_dict['use_layer4'] else 4
-        self.visual_resolution = tuple(r // div for r in self.resolution)
+        self.rplan, self.visual_resolution = spec.encoder_plan(self.resolution, enc_dict)
         self.latent_res = tuple(dec_dict['resolution'])
         self.ed = dec_dict['vae_dict']['enc_dec_dict']
         self.z_scale = float(dd.get('z_scale_factor', 1.))
         self.vq_key = 'dm_decoder.vae.vqvae.quantize.embedding.weight'
-        self.rplan = spec.resnet18_plan(enc_dict['use_layer4'])
         self.unet_cfg = dec_dict['unet_dict']
         self.testing = False
         # ResBlock dropout (unet_dict['dropout']); parity tests switch it off (RNG streams differ)
@@ -682,10 +680,8 @@ class SA(SlotModelBase):
         self.num_slots = slot_dict['num_slots']
         self.slot_size = slot_dict['slot_size']
         self.num_iterations = slot_dict['num_iterations']
-        div = 8 if enc_dict['use_layer4'] else 4
-        self.visual_resolution = tuple(r // div for r in self.resolution)
+        self.rplan, self.visual_resolution = spec.encoder_plan(self.resolution, enc_dict)
         self.dec_resolution = tuple(dec_dict['dec_resolution'])
-        self.rplan = spec.resnet18_plan(enc_dict['use_layer4'])
         self.dplan = spec.sa_decoder_plan(self.resolution, dec_dict)
         self.testing = False
         self.compute_dtype = compute_dtype or default_compute_dtype()

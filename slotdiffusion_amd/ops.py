@@ -150,7 +150,7 @@ def group_norm(x, gamma, beta, *, eps, act=None, groups=32, residual=None, out=N
     return (out, stats) if return_stats else out
 
 
-def layer_norm(x, gamma, beta, *, eps=1e-5, out=None, stats=None):
+def layer_norm(x, gamma, beta, *, eps=1e-5, out=None, stats=None):  # noqa: D401
     _need_gpu(x)
     C = x.shape[-1]
     rows = x.numel() // C
@@ -162,9 +162,11 @@ def layer_norm(x, gamma, beta, *, eps=1e-5, out=None, stats=None):
 
 
 def softmax_rows_(x, scale=1.0):
+    """In-place row softmax over the last dim; rows may be padded (uniform row pitch x.stride(-2))."""
     cols = x.shape[-1]
+    ld = x.stride(-2) if x.dim() > 1 else cols
     call('sdmi_softmax_rows', _stream(), x=_p(x), dtype=_dt(x), rows=x.numel() // cols, cols=cols,
-         ld=cols, scale=scale)
+         ld=ld, scale=scale)
     return x
 
 
@@ -339,12 +341,41 @@ def transpose2d(x, out=None):
 
 
 def softmax_rows_bwd_(p, dp, scale=1.0):
-    """dp <- scale * p * (dp - rowsum(dp * p)) in place (p = softmax output, rows of the last dim)."""
+    """dp <- scale * p * (dp - rowsum(dp * p)) in place (p = softmax output, rows of the last dim;
+    p and dp share the row pitch)."""
     _need_gpu(p, dp)
     cols = p.shape[-1]
+    ld = p.stride(-2) if p.dim() > 1 else cols
+    assert dp.stride(-2) == ld
     call('sdmi_softmax_rows_bwd', _stream(), p=_p(p), dp=_p(dp), dtype=_dt(p), rows=p.numel() // cols,
-         cols=cols, ld=cols, scale=scale)
+         cols=cols, ld=ld, scale=scale)
     return dp
+
+
+ATTN_LDS_MAX_KV = 400       # longer key sequences do not fit the LDS-resident attention kernels
+
+
+def attention_long(q, k, v, heads, head_dim, keep_p=False):
+    """Multi-head attention for key sequences beyond the LDS-resident kernels (DINO ViT: 785 tokens of
+    head dim 64; the UNet's 28 x 28 self-attention of the 224^2 configs: 784 tokens): per head,
+    batched MFMA GEMMs S = q k^T -> row softmax -> O = P v, with the score matrix in HBM (288 GB make
+    that affordable; a flash-style kernel is the known next step).  q [B,Sq,*], k / v [B,Skv,*] views
+    with head h at channel h * head_dim.  -> out [B,Sq,heads*hd] (, P [heads][B,Sq,Sp] if keep_p)."""
+    _need_gpu(q, k, v)
+    B, Sq, Skv, hd = q.shape[0], q.shape[1], k.shape[1], head_dim
+    vec = vec_of(q.dtype)
+    Sp = (Skv + vec - 1) // vec * vec                 # key pitch of the score matrix
+    out = torch.empty((B, Sq, heads * hd), dtype=q.dtype, device=q.device)
+    P = zeros((heads if keep_p else 1, B, Sq, Sp), q.dtype, q.device)     # pad columns stay zero
+    vt = zeros((B, hd, Sp), q.dtype, q.device)
+    for h in range(heads):
+        sl = slice(h * hd, (h + 1) * hd)
+        sc = P[h if keep_p else 0]
+        bmm_nt(q[..., sl], k[..., sl], sc[..., :Skv])
+        softmax_rows_(sc[..., :Skv], scale=float(hd) ** -0.5)
+        transpose2d(v[..., sl], out=vt[..., :Skv])
+        bmm_nt(sc, vt, out[..., sl])
+    return (out, P) if keep_p else out
 
 
 def mse(pred, target, want_grad=False, gscale=1.0, l1=False, oscale=0.0):

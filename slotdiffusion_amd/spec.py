@@ -80,6 +80,17 @@ def resnet18_gn(prefix='encoder', use_layer4=False):
     return out
 
 
+def encoder_plan(resolution, enc_dict):
+    """-> (plan for engine.encoder_out, visual resolution): the ResNet block list, or the DINO ViT's
+    geometry dict (slot_attention.py:180-211)."""
+    if enc_dict.get('dino', False):
+        _, meta = dino_vit('encoder.dino', enc_dict.get('small_size', True), enc_dict['patch_size'],
+                           resolution[0])
+        return meta, tuple(r // enc_dict['patch_size'] for r in resolution)
+    div = 8 if enc_dict['use_layer4'] else 4
+    return resnet18_plan(enc_dict['use_layer4']), tuple(r // div for r in resolution)
+
+
 def resnet18_plan(use_layer4=False):
     """Structural plan mirrored by engine + oracle: list of (block, cin, cout, stride, has_ds)."""
     plan = []
@@ -91,6 +102,39 @@ def resnet18_plan(use_layer4=False):
             plan.append((f'layer{li}.{bi}', cin, planes, s, s != 1 or cin != planes))
             cin = planes
     return plan
+
+
+def dino_vit(prefix='encoder.dino', small=True, patch=8, image=224):
+    """Frozen DINO ViT of the DINOSAUR-style configs (video_based/models/dino.py:21-60 wraps
+    transformers.ViTModel.from_pretrained('facebook/dino-vit{s,b}{8,16}')).  Key names and order are
+    those of transformers 4.27.4's ViTModel (the version the reference pins, environment.yml:216) --
+    recalled, not verifiable offline (the installed 5.x renames them; tools/gen_golden.py maps).  All
+    tensors are frozen; the pooler exists in the checkpoint but is never evaluated."""
+    hid, heads, mlp, layers = (384, 6, 1536, 12) if small else (768, 12, 3072, 12)
+    ntok = (image // patch) ** 2 + 1
+    fz = dict(trainable=False)
+    out = [_p(f'{prefix}.embeddings.cls_token', (1, 1, hid), 'n01', **fz),
+           _p(f'{prefix}.embeddings.position_embeddings', (1, ntok, hid), 'n01', **fz),
+           _p(f'{prefix}.embeddings.patch_embeddings.projection.weight', (hid, 3, patch, patch), 'lin',
+              3 * patch * patch, **fz),
+           _p(f'{prefix}.embeddings.patch_embeddings.projection.bias', (hid,), 'lin', 3 * patch * patch, **fz)]
+
+    def lin(name, cin, cout):
+        return [_p(f'{name}.weight', (cout, cin), 'lin', cin, **fz), _p(f'{name}.bias', (cout,), 'lin', cin, **fz)]
+
+    def ln(name):
+        return [_p(f'{name}.weight', (hid,), 'one', **fz), _p(f'{name}.bias', (hid,), 'zero', **fz)]
+    for i in range(layers):
+        l = f'{prefix}.encoder.layer.{i}'
+        for n in ('query', 'key', 'value'):
+            out += lin(f'{l}.attention.attention.{n}', hid, hid)
+        out += lin(f'{l}.attention.output.dense', hid, hid)
+        out += lin(f'{l}.intermediate.dense', hid, mlp)
+        out += lin(f'{l}.output.dense', mlp, hid)
+        out += ln(f'{l}.layernorm_before') + ln(f'{l}.layernorm_after')
+    out += ln(f'{prefix}.layernorm')
+    out += lin(f'{prefix}.pooler.dense', hid, hid)
+    return out, dict(hidden=hid, heads=heads, mlp=mlp, layers=layers, patch=patch, ntok=ntok)
 
 
 def soft_pos_embed(name, hidden, res):
@@ -336,15 +380,27 @@ def ldm(prefix, dec_dict):
 # whole models
 # --------------------------------------------------------------------------
 def sa_encoder_side(resolution, slot_dict, enc_dict):
-    assert enc_dict.get('resnet') == 'resnet18', 'hot path covers the ResNet-18 encoder'
-    use_l4 = enc_dict['use_layer4']
-    vis_ch = 512 if use_l4 else 256
-    div = 8 if use_l4 else 4
-    vis_res = tuple(r // div for r in resolution)
+    dino = bool(enc_dict.get('dino', False))
+    assert dino or enc_dict.get('resnet') == 'resnet18', \
+        'hot path covers the ResNet-18 and the frozen DINO ViT encoders (the plain nerv CNN encoder of ' \
+        'the MOVi-Solid / MOVi-Tex configs is out of scope: SURVEY section 8(f) row 4)'
     d = slot_dict['slot_size']
     out = [_p('init_latents', (1, slot_dict['num_slots'], d), 'n01')]
     out += slot_attention('slot_attention', enc_dict['enc_out_channels'], d,
                           slot_dict['slot_mlp_size'])
+    if dino:               # slot_attention.py:196-211: features [B, 384 | 768, H/patch, W/patch]
+        patch = enc_dict['patch_size']
+        assert patch in (8, 16) and resolution[0] == resolution[1]
+        vit, meta = dino_vit('encoder.dino', enc_dict.get('small_size', True), patch, resolution[0])
+        vis_ch, vis_res = meta['hidden'], tuple(r // patch for r in resolution)
+        out += vit
+        out += soft_pos_embed('encoder_pos_embedding', vis_ch, vis_res)
+        out += encoder_head('encoder_out_layer', vis_ch, enc_dict['enc_out_channels'])
+        return out, vis_ch, vis_res
+    use_l4 = enc_dict['use_layer4']
+    vis_ch = 512 if use_l4 else 256
+    div = 8 if use_l4 else 4
+    vis_res = tuple(r // div for r in resolution)
     out += resnet18_gn('encoder', use_l4)
     out += soft_pos_embed('encoder_pos_embedding', vis_ch, vis_res)
     out += encoder_head('encoder_out_layer', vis_ch, enc_dict['enc_out_channels'])

@@ -145,6 +145,28 @@ def movid_cfg(num_slots=11, clip_len=6):
     return cfg
 
 
+def dino_coco_cfg():
+    """img_based/configs/sa_ldm/sa_ldm_dino_coco_params-res224.py (BASELINE config 5) from its dumped
+    values (tests/golden/configs): 224 x 224, DINO ViT-S/8 features 28 x 28 x 384, 7 slots of 256,
+    latent 56 x 56."""
+    with open(os.path.join(GOLD, 'configs', 'img_based__sa_ldm_dino_coco_params-res224.json')) as f:
+        d = json.load(f)
+    return {k: d[k] for k in ('resolution', 'slot_dict', 'enc_dict', 'dec_dict', 'loss_dict')}
+
+
+def dino_inputs():
+    g = torch.Generator().manual_seed(21)
+    img = (torch.randn(1, 3, 224, 224, generator=g) * 0.5).clamp(-1, 1)
+    noise = torch.randn(1, 3, 56, 56, generator=g)
+    return img, noise
+
+
+def oracle_weights_generic(sp):
+    """{key: fp32 CPU tensor} for a spec list with tests/detfill.py values (buffers: grid / schedule
+    are filled by the caller where needed)."""
+    return {p.name: det_value(p.name, p.shape, i) for i, p in enumerate(sp) if not p.init.startswith('buf:')}
+
+
 def oracle_weights_video(cfg, seed=1234):
     from slotdiffusion_amd.module import build_grid, ddpm_schedule
     sp = spec.savi_diffusion(cfg['resolution'], cfg['slot_dict'], cfg['enc_dict'], cfg['dec_dict'],

@@ -575,3 +575,75 @@ def test_vqvae_stage1_training_gradients():
     assert REPORT['vqvae_train_loss_err'] <= 1e-6 and REPORT['vqvae_train_grad_norm_max_rel'] <= 5e-3
     assert worst <= 5e-3 and REPORT['vqvae_train_l1_grad_norm_max_rel'] <= 5e-3
     assert REPORT['vqvae_train_bf16_grad_norm_median_rel'] <= 0.1
+
+
+def test_dino_coco_config_fp32():
+    """SURVEY 8(f) row 4 / BASELINE config 5: img_based SADiffusion with the frozen DINO ViT-S/8 encoder
+    (224 x 224, 785 tokens through the long-sequence GEMM attention, 28 x 28 x 384 features), 7 slots
+    of 256, latent 56 x 56 with the UNet's 28 x 28 self-attention (784 keys: ops.attention_long and
+    its backward) -- against the reference run in tests/golden/sadiff_dino_b1.npz."""
+    from slotdiffusion_amd.models import SADiffusion
+    from slotdiffusion_amd import ops, engine
+    cfg = C.dino_coco_cfg()
+    G = C.load_golden('sadiff_dino_b1.npz')
+    m = SADiffusion(cfg['resolution'], cfg['slot_dict'], cfg['enc_dict'], cfg['dec_dict'],
+                    cfg['loss_dict'], compute_dtype=torch.float32)
+    det_fill_(m.state_dict().items(), skip=is_buffer_name)
+    m.train_dropout = 0.0
+    m = m.cuda()
+    m.use_graph = False
+    img, noise = C.dino_inputs()
+    img = img.cuda()
+    with torch.no_grad():
+        feat, (gh, gw) = engine.dino_encoder(m.K(), m._to_nhwc(img), m.rplan)
+    feat = feat.view(1, gh, gw, -1).permute(0, 3, 1, 2)
+    R = {'dino_feat_maxerr': maxerr(feat[:, ::8], G['dino_feat_sub']),
+         'dino_feat_scale': float(G['dino_feat_sub'].abs().max())}
+    m.train()
+    m.grad_arena().zero_()
+    out = m(dict(img=img))
+    R['slots_maxerr'] = maxerr(out['slots'], G['slots'])
+    R['masks_train_argmax_agree'] = float(
+        (out['masks'].cpu().argmax(1) == G['masks_train_argmax'].long()).float().mean())
+    x0 = m.dm_decoder.vae.encode(img)
+    R['x0_maxerr'] = maxerr(x0, G['x0'])
+    loss = m.calc_train_loss(dict(img=img, t=G['t'].cuda(), noise=noise.cuda()), out)['denoise_loss']
+    loss.backward()
+    R['loss'], R['loss_ref'] = float(loss), float(G['train_loss'])
+    named = dict(m.named_parameters())
+    names = [str(n) for n in G['grad_norms_names']]
+    mine = torch.tensor([float(named[n].grad.norm()) for n in names])
+    big = G['grad_norms'] > 1e-6 * float(G['grad_norms'].max())
+    rel = ((mine - G['grad_norms']).abs() / (G['grad_norms'].abs() + 1e-12))[big]
+    R['grad_norm_max_rel'], R['grad_norm_median_rel'] = float(rel.max()), float(rel.median())
+    assert all(named[n].grad is None or not named[n].requires_grad for n in named
+               if n.startswith('encoder.dino.'))                      # the ViT is frozen
+    m.eval()
+    with torch.no_grad():
+        xt = m._latent_nhwc(C_xt(G, x0, noise).cuda())
+        eps = ops.nhwc_to_nchw(m._unet_eps(xt, G['t'].float().cuda(), G['slots'].cuda()), 3)
+        R['eps_maxerr'] = maxerr(eps, G['eps_pred'])
+        oe = m(dict(img=img))
+    R['masks_eval_argmax_agree'] = float(
+        (oe['masks'].cpu().argmax(1) == G['masks_eval_argmax'].long()).float().mean())
+    REPORT['dino_coco224'] = R
+    _dump()
+    assert R['dino_feat_maxerr'] <= 2e-4 * max(1.0, R['dino_feat_scale'])
+    assert R['slots_maxerr'] <= 2e-4 and R['masks_train_argmax_agree'] == 1.0
+    assert R['x0_maxerr'] <= 1e-4 and R['eps_maxerr'] <= 2e-4
+    assert abs(R['loss'] - R['loss_ref']) <= 1e-4 * max(1.0, R['loss_ref'])
+    assert R['masks_eval_argmax_agree'] > 0.9995
+    assert R['grad_norm_max_rel'] <= 2e-2 and R['grad_norm_median_rel'] <= 2e-3
+
+
+def C_xt(G, x0, noise):
+    """x_t = sqrt(acp[t]) x0 + sqrt(1 - acp[t]) noise with the linear-beta DDPM schedule of the config."""
+    from slotdiffusion_amd.module import ddpm_schedule
+    cfg = C.dino_coco_cfg()
+    dd = {k: v for k, v in cfg['dec_dict']['diffusion_dict'].items()
+          if k in ('timesteps', 'beta_schedule', 'linear_start', 'linear_end')}
+    s = ddpm_schedule(**dd)
+    t = int(G['t'][0])
+    a = torch.tensor(s['sqrt_alphas_bar'], dtype=torch.float32)[t]
+    b = torch.tensor(s['sqrt_one_minus_alphas_bar'], dtype=torch.float32)[t]
+    return a * G['x0'] + b * noise

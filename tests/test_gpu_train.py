@@ -626,8 +626,38 @@ def test_attention_bwd_kernel(cfg, dtype):
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('B,heads,S,hd', [(2, 4, 784, 32), (1, 6, 785, 64), (2, 2, 408, 32)])
+def test_long_sequence_attention(B, heads, S, hd, dtype):
+    """Key sequences beyond the LDS-resident kernels (28 x 28 UNet tokens of the 224^2 configs, the
+    785 DINO tokens): per-head batched-GEMM attention, forward and (for 16-byte-aligned S) the
+    autograd backward, against torch."""
+    from slotdiffusion_amd import ops
+    from slotdiffusion_amd.kern import LongAttnFn
+    C = heads * hd
+    g = torch.Generator().manual_seed(S + hd)
+    qkv = (torch.randn(B, S, 3 * C, generator=g) * 0.7).to(dtype).float().requires_grad_(True)
+    dout = torch.randn(B, S, C, generator=g).to(dtype).float()
+    sp = lambda t: t.view(B, S, heads, hd).permute(0, 2, 1, 3)
+    q, k, v = (sp(qkv[..., j * C:(j + 1) * C]) for j in range(3))
+    ref = (torch.einsum('bhid,bhjd->bhij', q, k) * hd ** -0.5).softmax(-1) @ v
+    ref = ref.permute(0, 2, 1, 3).reshape(B, S, C)
+    ref.backward(dout)
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    rel = lambda a, b: float((a.float().cpu() - b).norm() / b.norm())
+    xd = qkv.detach().to(dtype).cuda()
+    out = ops.attention_long(xd[..., :C], xd[..., C:2 * C], xd[..., 2 * C:], heads, hd)
+    assert rel(out, ref.detach()) <= tol
+    if S % ops.vec_of(dtype) == 0:
+        xd.requires_grad_(True)
+        o = LongAttnFn.apply(xd, heads, hd)
+        assert rel(o.detach(), ref.detach()) <= tol
+        o.backward(dout.to(dtype).cuda())
+        assert rel(xd.grad, qkv.grad) <= (tol if dtype == torch.float32 else 3e-2)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize('B,M,N,D', [(2, 1024, 7, 192), (3, 200, 5, 192), (2, 130, 8, 128),
-                                     (2, 1024, 15, 192), (2, 300, 11, 192), (1, 784, 16, 256)])
+                                     (2, 1024, 15, 192), (2, 300, 11, 192), (1, 784, 16, 256), (2, 784, 7, 256)])
 def test_sa_attend_tiled_matches_reference(B, M, N, D, dtype):
     """Token-tiled Slot-Attention pass (forward and backward) against torch autograd of the
     reference formula (sa_diffusion.py:40-58) and against the one-workgroup-per-image kernels."""

@@ -452,3 +452,32 @@ def test_ssim_restatement_and_slot_shuffling():
     from slotdiffusion_amd import metrics
     assert torch.equal(metrics.shuffle_slots(slots), ref)
     assert torch.equal(metrics.shuffle_slots(slots[:, 0]), O.shuffle_slots(slots[:, 0]))
+
+
+def test_dino_coco_config_oracle_matches_reference():
+    """SURVEY 8(f) row 4 / BASELINE config 5 (COCO 224^2, DINO ViT-S/8 encoder, 7 slots of 256, latent
+    56^2): the oracle's ViT restatement + the usual slot / VQ-VAE / UNet path against the reference run
+    in tests/golden/sadiff_dino_b1.npz (tools/gen_golden.py dino: the reference model with
+    transformers' ViTModel class standing in for the hub download)."""
+    cfg = C.dino_coco_cfg()
+    G = C.load_golden('sadiff_dino_b1.npz')
+    W = C.oracle_weights(cfg)
+    img, noise = C.dino_inputs()
+    assert torch.equal(torch.stack([img.double().sum(), (img.double() ** 2).sum()]), G['img_checksum'])
+    assert torch.equal(noise, G['noise'])
+    meta, vres = spec.encoder_plan(cfg['resolution'], cfg['enc_dict'])
+    assert vres == (28, 28) and meta['ntok'] == 785
+    with torch.no_grad():
+        feat = O.dino_vit_forward(W, img, meta)
+        close(feat[:, ::8], G['dino_feat_sub'], 2e-4)
+        slots, masks = O.sa_encode(W, img, meta, cfg['slot_dict']['num_iterations'], training=True)
+        close(slots, G['slots'], 2e-4)
+        assert torch.equal(masks.argmax(1), G['masks_train_argmax'].long())
+        _, me = O.sa_encode(W, img, meta, cfg['slot_dict']['num_iterations'], training=False)
+        assert float((me.argmax(1) == G['masks_eval_argmax'].long()).float().mean()) > 0.9995
+        plan = spec.unet_plan(cfg['dec_dict']['unet_dict'])
+        ed = cfg['dec_dict']['vae_dict']['enc_dec_dict']
+        loss, pred, x0 = O.ldm_loss(W, plan, ed, img, G['slots'], G['t'].long(), noise)
+    close(x0, G['x0'], 2e-4)
+    close(pred, G['eps_pred'], 5e-4)
+    assert abs(float(loss) - float(G['train_loss'])) <= 1e-4 * max(1.0, float(G['train_loss']))

@@ -344,6 +344,101 @@ def main_vpred():
     print('wrote vpred_b1t2.npz', {k: tuple(np.asarray(v).shape) for k, v in arrs.items()})
 
 
+def dino_name_map(key):
+    """transformers 4.27 ViTModel key (the reference era, used by this repository's checkpoints) ->
+    the key of the installed transformers 5.x ViTModel."""
+    k = key.replace('.encoder.layer.', '.layers.')
+    for a, b in (('.attention.attention.query.', '.attention.q_proj.'), ('.attention.attention.key.', '.attention.k_proj.'),
+                 ('.attention.attention.value.', '.attention.v_proj.'), ('.attention.output.dense.', '.attention.o_proj.'),
+                 ('.intermediate.dense.', '.mlp.fc1.'), ('.output.dense.', '.mlp.fc2.')):
+        k = k.replace(a, b)
+    return k
+
+
+def main_dino():
+    """tests/golden/sadiff_dino_b1.npz (SURVEY 8(f) row 4 + BASELINE config 5): the reference
+    img_based SADiffusion with the DINO ViT-S/8 encoder config (sa_ldm_dino_coco_params-res224:
+    224 x 224 images, 28 x 28 feature tokens, 7 slots of 256, latent 56 x 56), B = 1.
+    `ViTModel.from_pretrained` needs the HF hub: it is replaced by `ViTModel(ViTConfig(...))` of the
+    installed transformers with the dino-vits8 architecture (hidden 384, 12 layers, 6 heads, MLP 1536,
+    patch 8, qkv bias) -- random architecture-true weights, overwritten by the deterministic fill."""
+    from transformers import ViTConfig, ViTModel            # the REAL classes, before the harness mocks the module
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    im = rh.ref_models('img_based')
+    import slotdiffusion.img_based.models.dino as rdino
+    import slotdiffusion.video_based.models.dino as vdino      # (the class img_based actually builds)
+
+    class _ViT:
+        @staticmethod
+        def from_pretrained(name):
+            assert name == 'facebook/dino-vits8', name
+            return ViTModel(ViTConfig(hidden_size=384, num_hidden_layers=12, num_attention_heads=6,
+                                      intermediate_size=1536, patch_size=8, image_size=224, qkv_bias=True))
+    rdino.ViTModel = vdino.ViTModel = _ViT
+    P = rh.ref_params('img_based', 'sa_ldm', 'sa_ldm_dino_coco_params-res224')
+    model = im.build_model(P)
+    det_fill_(model.state_dict().items(), skip=is_buffer_name)
+    # this repository's model (4.27 key names): same fill recipe; its DINO values go into the HF module
+    from slotdiffusion_amd import compat
+    from slotdiffusion_amd.models import build_model as my_build
+    mine = my_build(compat.Params(**{k: getattr(P, k) for k in ('model', 'resolution', 'slot_dict', 'enc_dict',
+                                                                 'dec_dict', 'loss_dict')}))
+    det_fill_(mine.state_dict().items(), skip=is_buffer_name)
+    ref_sd = model.state_dict()
+    my_sd = mine.state_dict()
+    assert len(ref_sd) == len(my_sd), (len(ref_sd), len(my_sd))
+    n_dino = 0
+    with torch.no_grad():
+        for k, v in my_sd.items():
+            rk = dino_name_map(k) if k.startswith('encoder.dino.') else k
+            assert rk in ref_sd and ref_sd[rk].shape == v.shape, (k, rk)
+            if k.startswith('encoder.dino.'):
+                ref_sd[rk].copy_(v)
+                n_dino += 1
+            elif not is_buffer_name(k):
+                assert torch.equal(ref_sd[rk], v), k           # same fill everywhere else
+    assert n_dino == 200
+    g = torch.Generator().manual_seed(21)
+    img = (torch.randn(1, 3, 224, 224, generator=g) * 0.5).clamp(-1, 1)
+    t = torch.tensor([437])
+    noise = torch.randn(1, 3, 56, 56, generator=g)
+    G = dict(t=t, noise=noise, img_checksum=torch.stack([img.double().sum(), (img.double() ** 2).sum()]))
+    model.train()
+    dm = model.dm_decoder
+    dm.model.eval()
+    with torch.no_grad():
+        feat = model.encoder(img)                           # [1, 384, 28, 28]
+    G['dino_feat_sub'] = feat[:, ::8].contiguous()
+    for p in model.parameters():
+        p.grad = None
+    out = model(dict(img=img))
+    G['slots'], G['masks_train_argmax'] = out['slots'].detach(), out['masks'].detach().argmax(1)
+    with torch.no_grad():
+        x0 = dm.vae.encode(img)
+    G['x0'] = x0
+    xt = dm._sample_xt_from_x0(x0=x0, t=t, noise=noise)
+    pred = dm.forward(xt, t, context=out['slots'])
+    loss = torch.nn.functional.mse_loss(pred, noise)
+    loss.backward()
+    G['eps_pred'], G['train_loss'] = pred.detach(), loss.detach()
+    named = dict(model.named_parameters())
+    names = sorted(n for n, p in named.items() if p.grad is not None)[::8]
+    G['grad_norms_names'] = np.array(names)
+    G['grad_norms'] = torch.tensor([float(named[n].grad.norm()) for n in names])
+    assert all(named[n].grad is None for n in named if n.startswith('encoder.dino.'))
+    model.eval()
+    with torch.no_grad():
+        oe = model(dict(img=img))
+    G['masks_eval_argmax'] = oe['masks'].argmax(1)
+    arrs = {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else v) for k, v in G.items()}
+    for k in list(arrs):
+        if arrs[k].dtype == np.int64 and k != 't':
+            arrs[k] = arrs[k].astype(np.int16)
+    np.savez_compressed(os.path.join(OUT, 'sadiff_dino_b1.npz'), **arrs)
+    print('wrote sadiff_dino_b1.npz', {k: tuple(np.asarray(v).shape) for k, v in arrs.items()})
+
+
 def metric_inputs():
     """Synthetic id maps for the metric fixtures: B=4 images 32x32; blobs of ids 0..5 (gt) against
     shifted / merged / split predictions; image 2 holds only background; image 3 has fewer
@@ -599,6 +694,9 @@ if __name__ == '__main__':
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'anc':
         main_anc()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'dino':
+        main_dino()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'vpred':
         main_vpred()
