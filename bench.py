@@ -14,8 +14,11 @@ mode=sample: one 20-NFE DPM-Solver++ sampling pass over B images' slots (20 x (U
 conversion + VQ quantise) + solver updates); value = N * B * 20 * K / seconds.  Inputs are resident
 in HBM; for N > 1 every rank works on its own B images (weak scaling), time is the max over ranks
 between barriers.
-Extra JSON objects: roofline (MFMA, dominant kernel sdmi_igemm, measured live with HIP events on
-the launch stream) and cpu_baseline (the CPU oracle on this box's host cores, bounded sample).
+Extra JSON objects: roofline (MFMA, dominant kernel family sdmi_igemm) and roofline_hbm (GroupNorm
+family): algorithmic flops / bytes per launch counted from the launch arguments, durations from a
+rocprofv3 --kernel-trace of THIS command's graph-replayed timed region (a child run on the same box,
+see replayed_trace(); falls back to a live eager HIP-event pass, labelled, if rocprofv3 is not
+usable); cpu_baseline (the CPU oracle on this box's host cores, bounded sample).
 """
 import argparse
 import json
@@ -111,20 +114,87 @@ def cpu_baseline(cfg, mode, quick=False):
                        f'of {cores} cores, {dt:.1f}s')
 
 
-def pmc_traffic(which):
-    """HBM traffic / MFMA utilisation of the igemm kernels from the committed rocprofv3 PMC passes
-    (profiles/r01_<which>_pmc_by_kernel.csv; separate --pmc runs of this same command, see
-    DESIGN.md section 5).  FETCH_SIZE is doubled (gfx950 counts 128-byte requests as 64 bytes)."""
+# kernels behind the C-ABI entry points the roofline legs price (csrc/igemm.hip, norm.hip, norm_bwd.hip)
+FAMILIES = {
+    'sdmi_igemm': ('igemm_kernel', 'igemm_kernel_tall', 'igemm_dma_kernel', 'conv3x3_c64_kernel',
+                   'splitk_epilogue_kernel'),
+    'sdmi_wgrad': ('wgrad_kernel', 'wgrad_tr_kernel', 'wgrad_group_kernel', 'wgrad_group_reduce_kernel',
+                   'wgrad_reduce_kernel'),
+    'sdmi_groupnorm': ('gn_fused_kernel', 'gn_stats_kernel', 'gn_apply_kernel'),
+    'sdmi_groupnorm_bwd': ('gn_bwd_fused_kernel', 'gn_bwd_stats_kernel', 'gn_bwd_apply_kernel'),
+}
+MARK = 'sqerr_rows_kernel'      # a kernel no train / sampling step launches: brackets the timed region
+
+
+def kernel_base_name(k):
+    import re
+    k = re.sub(r'\(anonymous namespace\)::', '', k)
+    k = re.sub(r'^void ', '', k)
+    return re.sub(r'[<(].*', '', k).strip()
+
+
+def replayed_trace(argv, steps):
+    """Per-kernel durations of the graph-replayed timed region: runs this same command (same box,
+    same flags, --mark) under `rocprofv3 --kernel-trace` and keeps the kernels between the two
+    marker launches = exactly the K timed steps.  -> ({kernel base name: [calls/step, ms/step]},
+    note) or (None, reason)."""
     import csv
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles',
-                        f'r01_{which}_pmc_by_kernel.csv')
-    if not os.path.exists(path):
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which('rocprofv3') or '/opt/rocm/bin/rocprofv3'
+    if not os.path.exists(exe):
+        return None, 'rocprofv3 not found'
+    d = tempfile.mkdtemp(prefix='sdmi_trace_', dir='/tmp')
+    env = dict(os.environ, TMPDIR='/tmp')
+    cmd = [exe, '--kernel-trace', '--output-format', 'csv', '-d', d, '-o', 't', '--', sys.executable,
+           os.path.abspath(__file__)] + argv + ['--mark', '--no-roofline', '--no-cpu-baseline',
+                                                '--big-batch', '0', '--only-train']
+    try:
+        r = subprocess.run(cmd, cwd='/tmp', env=env, capture_output=True, text=True, timeout=900)
+        files = glob.glob(os.path.join(d, '**', '*kernel_trace.csv'), recursive=True)
+        if r.returncode != 0 or not files:
+            return None, f'rocprofv3 child failed (rc {r.returncode}): {(r.stderr or "")[-300:]}'
+        rows = []
+        with open(files[0]) as f:
+            for q in csv.DictReader(f):
+                rows.append((int(q['Start_Timestamp']), int(q['End_Timestamp']), q['Kernel_Name']))
+        rows.sort()
+        marks = [i for i, q in enumerate(rows) if kernel_base_name(q[2]) == MARK]
+        if len(marks) < 2:
+            return None, 'markers not found in the trace'
+        seg = rows[marks[-2] + 1:marks[-1]]
+        agg = {}
+        for a, b, k in seg:
+            v = agg.setdefault(kernel_base_name(k), [0.0, 0.0])
+            v[0] += 1.0 / steps
+            v[1] += (b - a) / 1e6 / steps
+        span = (seg[-1][1] - seg[0][0]) / 1e6 / steps if seg else 0.0
+        agg['__span_ms_per_step__'] = [len(seg) / steps, span]
+        return agg, 'rocprofv3 --kernel-trace of the graph-replayed timed region (child run of this command, same box)'
+    except Exception as e:              # noqa: BLE001 -- instrumentation must not take the bench down
+        return None, f'{type(e).__name__}: {e}'
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
+def pmc_traffic(which):
+    """HBM traffic / MFMA utilisation of the igemm kernels from the COMMITTED rocprofv3 PMC passes
+    (profiles/r0N_<which>_pmc_by_kernel.csv; separate --pmc runs of this same command on an earlier
+    box) -- replayed numbers, labelled as such in the JSON, never observed by
+    the run that prints them.  FETCH_SIZE is doubled (gfx950 counts 128-byte requests as 64 bytes)."""
+    import csv
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles')
+    path = next((q for q in (os.path.join(root, f'r02_{which}_pmc_by_kernel.csv'),
+                             os.path.join(root, f'r01_{which}_pmc_by_kernel.csv')) if os.path.exists(q)), None)
+    if path is None:
         return {}
     f = w = n = act = busy = 0.0
     have_tcc = True
     with open(path) as fh:
         for r in csv.DictReader(fh):
-            if r['kernel'].startswith('igemm_kernel'):
+            if kernel_base_name(r['kernel']) in FAMILIES['sdmi_igemm']:
                 n += float(r['dispatches'])
                 have_tcc = have_tcc and 'FETCH_SIZE' in r and 'WRITE_SIZE' in r
                 if have_tcc:
@@ -157,6 +227,8 @@ def main():
                          'full at the configured B = 64')
     ap.add_argument('--only-train', action='store_true',
                     help='profiling aid: skip the sampling leg of --mode train')
+    ap.add_argument('--mark', action='store_true',
+                    help='internal (replayed_trace): bracket the timed region with marker kernels')
     args = ap.parse_args()
 
     # --gpus N is the number of ranks (one per GPU).  Started without a launcher it re-executes
@@ -210,15 +282,24 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed(fn, steps, warmup):
+    def mark():
+        if args.mark:           # (outside the timed region: before t0 / after the closing barrier)
+            from slotdiffusion_amd import metrics
+            metrics._sqerr(torch.zeros(1, 8, device=dev), torch.ones(1, 8, device=dev))
+
+    def timed(fn, steps, warmup, marked=False):
         for _ in range(warmup):
             fn()
+        if marked:
+            mark()
         barrier()
         t0 = time.perf_counter()
         for _ in range(steps):
             fn()
         barrier()
         dt = time.perf_counter() - t0
+        if marked:
+            mark()
         if dist is not None:
             tt = torch.tensor([dt], device=dev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -237,7 +318,7 @@ def main():
         if args.only_train and args.mode == 'train':
             sample_step = lambda: None
         dt_s = timed(sample_step, args.steps if args.mode == 'sample' else max(2, args.steps // 2),
-                     args.warmup if args.mode == 'sample' else 1)
+                     args.warmup if args.mode == 'sample' else 1, marked=args.mode == 'sample')
         n_s = args.steps if args.mode == 'sample' else max(2, args.steps // 2)
         denoise_rate = world * B * nfe * n_s / dt_s
         big_rate = None
@@ -280,7 +361,7 @@ def main():
             graphed = GraphedTrainStep(model, opt, dict(img=img),
                                        allreduce=(True if dist is not None else None), world=world)
             run_step = lambda: graphed(dict(img=img))
-        dt_t = timed(run_step, args.steps, args.warmup)
+        dt_t = timed(run_step, args.steps, args.warmup, marked=True)
         train_rate = world * B * args.steps / dt_t
         if dist is not None:
             # the exchange by itself (all ranks idle otherwise) and what of it the step exposes:
@@ -333,30 +414,66 @@ def main():
             step()
             with KernelTimer() as kt:
                 step()
-            summ = kt.summary()
+            summ = kt.summary()           # launch counts + algorithmic flops / bytes per entry point
             model.bank().overlap_wgrad = overlap
             model.use_graph = not args.no_graph
-            ig = dict(summ['sdmi_igemm'])       # dominant kernel: the implicit-GEMM conv/linear
-            fam = dict(ig)
-            if 'sdmi_wgrad' in summ:            # MFMA GEMM family = forward/dgrad igemm + wgrad
-                for k in ('calls', 'ms', 'flops'):
-                    fam[k] += summ['sdmi_wgrad'][k]
-            total_ms = sum(v['ms'] for v in summ.values())
-            ach = ig['flops'] / (ig['ms'] * 1e-3) / 1e12
             peak = PEAK_TFLOPS[args.dtype]
+            # durations: the graph-replayed timed region itself (rocprofv3 child run on this box);
+            # eager HIP events only as the labelled fallback
+            trace, tnote = (None, 'not taken (--no-graph or N > 1)') if (args.no_graph or world > 1) else \
+                replayed_trace([a for a in sys.argv[1:] if a != '--mark'], args.steps)
+
+            def fam_ms(entry):
+                if trace is None:
+                    return summ[entry]['ms'], summ[entry]['calls']
+                ms = sum(trace[k][1] for k in FAMILIES[entry] if k in trace)
+                n = sum(trace[k][0] for k in FAMILIES[entry] if k in trace)
+                return ms, n
+            ig = summ['sdmi_igemm']
+            ig_ms, ig_kernels = fam_ms('sdmi_igemm')
+            ach = ig['flops'] / (ig_ms * 1e-3) / 1e12
+            fam_flops = ig['flops'] + summ.get('sdmi_wgrad', {}).get('flops', 0.0)
+            fam_time = ig_ms + (fam_ms('sdmi_wgrad')[0] if 'sdmi_wgrad' in summ else 0.0)
             pmc = pmc_traffic('train' if args.mode == 'train' else 'sample')
-            out['roofline'] = {'bound': 'mfma', 'kernel': 'igemm_kernel (sdmi_igemm: implicit-GEMM conv/linear fwd + dgrad)',
-                               'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak,
-                               'traffic': pmc.get('bytes_per_launch'), 'traffic_unit': 'HBM bytes per launch',
-                               'traffic_source': pmc.get('source'),
-                               'mfma_util_pmc': pmc.get('mfma_util'),
-                               'algorithmic_gflop_per_launch': ig['flops'] / ig['calls'] / 1e9,
-                               'launches_per_step': ig['calls'],
-                               'avg_launch_us': 1e3 * ig['ms'] / ig['calls'],
-                               'igemm_ms_per_step': ig['ms'],
-                               'gemm_family_tflops_incl_wgrad': fam['flops'] / (fam['ms'] * 1e-3) / 1e12,
-                               'all_kernels_ms_per_step_eager': total_ms,
-                               'algorithmic_gflop_per_step': fam['flops'] / 1e9}
+            src = ('replayed from ' + pmc['source'] + ' (committed PMC pass of an earlier run of this command; '
+                   'NOT observed by this run)') if pmc else None
+            out['roofline'] = {
+                'bound': 'mfma', 'kernel': 'igemm family (sdmi_igemm: implicit-GEMM conv/linear fwd + dgrad): '
+                                           + ', '.join(FAMILIES['sdmi_igemm']),
+                'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak,
+                'timing_source': tnote if trace is not None else f'eager HIP-event pass (fallback: {tnote})',
+                'driver_observed': trace is not None,
+                'launches_per_step': ig['calls'], 'kernels_per_step': ig_kernels,
+                'family_ms_per_step': ig_ms, 'avg_launch_us': 1e3 * ig_ms / ig['calls'],
+                'algorithmic_gflop_per_launch': ig['flops'] / ig['calls'] / 1e9,
+                'algorithmic_gflop_per_step': ig['flops'] / 1e9,
+                'algorithmic_bytes_per_launch': ig['bytes'] / ig['calls'],
+                'traffic': pmc.get('bytes_per_launch'), 'traffic_unit': 'HBM bytes per launch',
+                'traffic_source': src, 'mfma_util_pmc': pmc.get('mfma_util'), 'mfma_util_pmc_source': src,
+                'gemm_family_tflops_incl_wgrad': fam_flops / (fam_time * 1e-3) / 1e12,
+                'gemm_family_gflop_per_step_incl_wgrad': fam_flops / 1e9,
+                'whole_step_tflops': fam_flops / (ms * 1e-3) / 1e12,
+                'eager_event_pass': {'igemm_ms': ig['ms'], 'tflops': ig['flops'] / (ig['ms'] * 1e-3) / 1e12,
+                                     'all_kernels_ms': sum(v['ms'] for v in summ.values())}}
+            if trace is not None:
+                out['roofline']['kernels_in_timed_region_per_step'] = trace['__span_ms_per_step__'][0]
+                out['roofline']['kernel_span_ms_per_step'] = trace['__span_ms_per_step__'][1]
+            # the HBM-bound family that costs the most time: GroupNorm (+SiLU/residual/dropout) passes
+            hb = {}
+            for entry in ('sdmi_groupnorm', 'sdmi_groupnorm_bwd'):
+                if entry in summ and summ[entry]['bytes']:
+                    t_ms, n_k = fam_ms(entry)
+                    gbs = summ[entry]['bytes'] / (t_ms * 1e-3) / 1e9
+                    hb[entry] = {'achieved': gbs, 'frac': gbs / 8000.0, 'launches_per_step': summ[entry]['calls'],
+                                 'family_ms_per_step': t_ms,
+                                 'algorithmic_bytes_per_launch': summ[entry]['bytes'] / summ[entry]['calls'],
+                                 'avg_launch_us': 1e3 * t_ms / summ[entry]['calls']}
+            if hb:
+                worst = min(hb, key=lambda k: hb[k]['frac'])
+                out['roofline_hbm'] = dict(hb[worst], bound='hbm', peak=8000.0, unit='GB/s',
+                                           kernel=f'{worst}: ' + ', '.join(FAMILIES[worst]),
+                                           timing_source=out['roofline']['timing_source'], traffic=None,
+                                           families=hb)
             out['kernel_breakdown_ms'] = {k: round(v['ms'], 3) for k, v in
                                           sorted(summ.items(), key=lambda kv: -kv[1]['ms'])}
         if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -74,6 +74,18 @@ typedef struct {
    * input-pixel parity, each with the filter taps of that parity -- written interleaved this
    * way (no multiply-adds on inserted zeros, unlike `zins`).  No residual / split-K in this mode. */
   int oH, oW, osy, osx, ooy, oox;
+  /* Fused LayerNorm prologue (inference; 1x1 / linear only): the GEMM runs on the RAW rows x of A
+   * with weights pre-multiplied by the norm's gamma, W'[n][k] = W[n][k] * gamma[k]; the kernel takes
+   * the row statistics from the operand registers and finishes
+   *   out[m][n] = act( rstd[m] * (acc[m][n] - mean[m] * ln_colsum[n]) + bias[n] )
+   * with ln_colsum[n] = sum_k W'[n][k] (of the ROUNDED operand) and bias[n] = sum_k W[n][k] beta[k]
+   * (+ the layer's own bias), mean / rstd over the K entries of row m (eps = ln_eps).  Replaces
+   * nn.LayerNorm + nn.Linear pairs: attention.py:238-240,246-251 (norm1/2/3 -> to_q/k/v, ff). */
+  const float* ln_colsum; /* [N] (GEGLU: [2N]) or NULL */
+  float ln_eps;
+  /* geglu != 0: W has 2N rows (value rows 0..N-1, gate rows N..2N-1), bias / ln_colsum 2N entries;
+   * out[m][n] = value[m][n] * gelu(gate[m][n]), N columns (attention.py:44-48 GEGLU.forward). */
+  int geglu;
 } SdmiGemmArgs;
 int sdmi_igemm(const SdmiGemmArgs* a, void* stream);
 

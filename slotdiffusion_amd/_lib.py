@@ -134,11 +134,27 @@ class KernelTimer:
 
 
 def _meta(fname, kw):
+    """Algorithmic work of one launch (bench.py's roofline legs): flops of the GEMM-shaped entry
+    points; algorithmic HBM bytes (every operand read once, every result written once)."""
+    elt = 2 if kw.get('dtype', F32) == BF16 else 4
     if fname == 'sdmi_igemm':
         b = max(1, kw.get('batch', 1))
-        return dict(flops=2.0 * kw['M'] * kw['N'] * kw['K'] * b)
+        oelt = 2 if kw.get('out_dtype', F32) == BF16 else 4
+        src = kw['B'] * kw['H'] * kw['W'] * kw['Cin']          # the image, not its im2col expansion
+        wts = kw['N'] * kw['K'] * (b if kw.get('sw', 0) else 1)
+        out = kw['M'] * kw['N'] * (2 if kw.get('residual', 0) else 1)
+        return dict(flops=2.0 * kw['M'] * kw['N'] * kw['K'] * b,
+                    bytes=float(b * src * elt + wts * elt + b * out * oelt))
     if fname == 'sdmi_wgrad':
         return dict(flops=2.0 * kw['M'] * kw['N'] * kw['K'])
+    if fname == 'sdmi_groupnorm':          # x in, y out (+ residual in)
+        n = kw['B'] * kw['HW'] * kw['C']
+        return dict(bytes=float(n * elt * (3 if kw.get('residual', 0) else 2)))
+    if fname == 'sdmi_groupnorm_bwd':      # x, dy in; dx out (+ residual-branch gradient, extras)
+        n = kw['B'] * kw['HW'] * kw['C']
+        k = 3 + (1 if kw.get('residual', 0) else 0) + (1 if kw.get('dresidual', 0) else 0) + \
+            (1 if kw.get('dextra0', 0) else 0) + (1 if kw.get('dextra1', 0) else 0)
+        return dict(bytes=float(n * elt * k))
     return {}
 
 

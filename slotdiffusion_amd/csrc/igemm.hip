@@ -174,7 +174,73 @@ __device__ __forceinline__ void wave_epilogue(const SdmiGemmArgs& p, f32x16 (&ac
     }
 }
 
-template <typename T, int BM, int BN, int BKB, int MODE>
+
+// Fused LayerNorm-fold / GEGLU epilogue of one MFMA wave's block (sdmi.h: ln_colsum, geglu; 1x1 /
+// linear problems only).  EPI bit 0: the GEMM ran on raw rows with gamma-scaled weights, sx / sxx are
+// this lane's partial sums (its 16 bytes of every 32-byte k-step) of row (lane & 31) of row tile i:
+//   out = rstd * (acc - mean * colsum[n]) + bias[n]
+// EPI bit 1: column tiles j < TN/2 hold value columns, j + TN/2 the matching gate columns:
+//   out[m][n] = value * gelu(gate).
+typedef __bf16 sdmi_bf16x2 __attribute__((ext_vector_type(2)));
+
+template <int TM, int TN, int EPI>
+__device__ __forceinline__ void fused_epilogue(const SdmiGemmArgs& p, f32x16 (&acc)[TM][TN],
+                                               const float (&sx)[TM], const float (&sxx)[TM], int mw0,
+                                               int nw0, int lane) {
+  constexpr bool LNF = (EPI & 1) != 0, GEGLU = (EPI & 2) != 0;
+  constexpr int NOUT = GEGLU ? TN / 2 : TN;
+  // C layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+  const int col_l = lane & 31, row_l = (lane >> 5) * 4;
+  const bool out_bf16 = p.out_dtype == SDMI_BF16;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    float mean = 0.f, rstd = 1.f;
+    if constexpr (LNF) {
+      const float tot = sx[i] + __shfl_xor(sx[i], 32, 64), tot2 = sxx[i] + __shfl_xor(sxx[i], 32, 64);
+      const float inv_k = 1.f / (float)p.K;
+      mean = tot * inv_k;
+      rstd = rsqrtf(fmaxf(tot2 * inv_k - mean * mean, 0.f) + p.ln_eps);      // lane l: row l & 31
+    }
+    // per-column epilogue operands first (NOUT columns per lane), then row by row: the row's
+    // statistics are fetched from their owner lane when needed (no 32-register staging arrays)
+    float c0[NOUT], s0[NOUT], c1[NOUT], s1[NOUT];
+    int ncol[NOUT];
+#pragma unroll
+    for (int j = 0; j < NOUT; ++j) {
+      const int n = nw0 + j * 32 + col_l;
+      ncol[j] = n;
+      const int nc = n < p.N ? n : p.N - 1;
+      c0[j] = p.bias ? p.bias[nc] : 0.f;
+      s0[j] = LNF ? p.ln_colsum[nc] : 0.f;
+      c1[j] = (GEGLU && p.bias) ? p.bias[p.N + nc] : 0.f;
+      s1[j] = (GEGLU && LNF) ? p.ln_colsum[p.N + nc] : 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int rr = (r & 3) + 8 * (r >> 2) + row_l;
+      const float mu = LNF ? __shfl(mean, rr, 64) : 0.f;
+      const float rs = LNF ? __shfl(rstd, rr, 64) : 1.f;
+      const int m = mw0 + i * 32 + rr;
+#pragma unroll
+      for (int j = 0; j < NOUT; ++j) {
+        float v = rs * (acc[i][j][r] * p.alpha - mu * s0[j]) + c0[j];
+        if constexpr (GEGLU) {
+          const float g = rs * (acc[i][j + TN / 2][r] * p.alpha - mu * s1[j]) + c1[j];
+          v *= act_apply(g, SDMI_ACT_GELU);
+        } else {
+          v = act_apply(v, p.act);
+        }
+        if (ncol[j] < p.N && m < p.M) {
+          const long long o = (long long)m * p.ldc + ncol[j];
+          if (out_bf16) ((bf16_t*)p.out)[o] = f32_to_bf16(v);
+          else ((float*)p.out)[o] = v;
+        }
+      }
+    }
+  }
+}
+
+template <typename T, int BM, int BN, int BKB, int MODE, int EPI = 0>
 __device__ __forceinline__ void igemm_body(const SdmiGemmArgs& p, int tiles_m, int tiles_n,
                                            int kt_per_split, int hw_shift) {
   // MODE: 0 = general gather (nearest-x2 fold, zero insertion, K tiles that straddle filter taps),
@@ -183,6 +249,9 @@ __device__ __forceinline__ void igemm_body(const SdmiGemmArgs& p, int tiles_m, i
   //       adds, two compares and one 64-bit multiply-add
   constexpr bool IS1X1 = MODE == 1;
   constexpr bool TAPU = MODE == 2;
+  constexpr bool LNF = (EPI & 1) != 0, GEGLU = (EPI & 2) != 0;
+  static_assert(EPI == 0 || MODE == 1, "fused LayerNorm / GEGLU epilogues: 1x1 / linear only");
+  static_assert(!GEGLU || (BN / 2) % 64 == 0, "GEGLU pairs value and gate tiles inside a wave");
   constexpr int VEC = 16 / sizeof(T);
   constexpr int BK = BKB / sizeof(T);
   constexpr int VPR = BKB / 16;
@@ -206,7 +275,7 @@ __device__ __forceinline__ void igemm_body(const SdmiGemmArgs& p, int tiles_m, i
     const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (vb >> 3);
     const int tm = id / tiles_n;
     m0 = tm * BM;
-    n0 = (id - tm * tiles_n) * BN;
+    n0 = (id - tm * tiles_n) * (GEGLU ? BN / 2 : BN);     // GEGLU: BN/2 output columns per tile
   };
   const int my_tiles = ((int)blockIdx.x < nwg) ? (nwg - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
   const int zb = blockIdx.y / p.split_k;
@@ -298,7 +367,16 @@ __device__ __forceinline__ void igemm_body(const SdmiGemmArgs& p, int tiles_m, i
 #pragma unroll
       for (int i = 0; i < B_VECS; ++i) {
         const int row = (tid + i * 256) / VPR;
-        const int n = min(n0 + row, p.N - 1);
+        int n;
+        if constexpr (GEGLU) {
+          // B-tile row -> weight row: each wave's BN/2 rows are [value columns | their gate columns]
+          constexpr int HW_ = BN / 4;                       // output columns per wave
+          const int wnr = row / (BN / 2), rem = row - wnr * (BN / 2);
+          const int jg = rem / HW_, c = rem - jg * HW_;
+          n = jg * p.N + min(n0 + wnr * HW_ + c, p.N - 1);
+        } else {
+          n = min(n0 + row, p.N - 1);
+        }
         b_row[i] = n;
         b_vo[i] = ((unsigned)n * (unsigned)p.ldw + kc * VEC) * (unsigned)sizeof(T);
         b_cur[i] = b_vo[i];
@@ -391,19 +469,25 @@ __device__ __forceinline__ void igemm_body(const SdmiGemmArgs& p, int tiles_m, i
         *reinterpret_cast<u32x4*>(st_b + stage_off + i * RSTEP * ROWB) = rb[i];
     };
 
-    u32x4 ra0[A_VECS], rb0[B_VECS], ra1[A_VECS], rb1[B_VECS];
     // flat pipeline over (output tile, K tile) steps: while the MFMA waves finish a tile and run
-    // its epilogue, the first K tiles of the next one are already staged / in flight
-    if (total > 0) load_tile(ra0, rb0);
-    if (total > 1) load_tile(ra1, rb1);
-    for (int g = 0; g < total; g += 2) {
-      store_tile(0, ra0, rb0);
-      if (g + 2 < total) load_tile(ra0, rb0);
-      __syncthreads();
-      if (g + 1 < total) {
-        store_tile(BUF_BYTES, ra1, rb1);
-        if (g + 3 < total) load_tile(ra1, rb1);
-        __syncthreads();
+    // its epilogue, the first K tiles of the next one are already staged / in flight.  DEPTH K tiles
+    // of global loads are in flight in registers (16 vectors per thread: 2 tiles of the 128 x 128 x
+    // 128-byte configuration, 4 - 8 of the small-tile ones, whose launches are bound by the memory
+    // latency of each K step rather than by bandwidth); the LDS image stays double buffered.
+    constexpr int DEPTH_ = 16 / (A_VECS + B_VECS);
+    constexpr int DEPTH = DEPTH_ >= 8 ? 8 : (DEPTH_ >= 4 ? 4 : 2);
+    u32x4 ra[DEPTH][A_VECS], rb[DEPTH][B_VECS];
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d)
+      if (total > d) load_tile(ra[d], rb[d]);
+    for (int g = 0; g < total; g += DEPTH) {
+#pragma unroll
+      for (int d = 0; d < DEPTH; ++d) {
+        if (g + d < total) {
+          store_tile((d & 1) * BUF_BYTES, ra[d], rb[d]);
+          if (g + d + DEPTH < total) load_tile(ra[d], rb[d]);
+          __syncthreads();
+        }
       }
     }
     return;
@@ -437,6 +521,9 @@ __device__ __forceinline__ void igemm_body(const SdmiGemmArgs& p, int tiles_m, i
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  float sx[TM], sxx[TM];                 // LayerNorm fold: row sums taken from the A fragments
+#pragma unroll
+  for (int i = 0; i < TM; ++i) sx[i] = sxx[i] = 0.f;
   for (int t = 0; t < n_kt; ++t, ++g) {
     __syncthreads();                 // stage g & 1 holds this K tile
     const char* base = smem + (g & 1) * BUF_BYTES;
@@ -448,6 +535,32 @@ __device__ __forceinline__ void igemm_body(const SdmiGemmArgs& p, int tiles_m, i
     for (int ks = 0; ks < KSTEPS; ++ks) {
       if (ks + 1 < KSTEPS) read_frags(As, Bs, ks + 1, fa[(ks + 1) & 1], fb[(ks + 1) & 1]);
       __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ahead of this k-step's MFMAs
+      if constexpr (LNF) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const u32x4 a4 = fa[ks & 1][i];
+          if constexpr (sizeof(T) == 2) {
+            // (explicit lanes: indexing the vector inside an unrolled loop was miscompiled to lane 0)
+            const sdmi_bf16x2 ones = __builtin_bit_cast(sdmi_bf16x2, 0x3F803F80u);
+            const bf16x8 a8 = __builtin_bit_cast(bf16x8, a4);
+            const sdmi_bf16x2 v0 = {a8[0], a8[1]}, v1 = {a8[2], a8[3]}, v2 = {a8[4], a8[5]},
+                              v3 = {a8[6], a8[7]};
+            sx[i] = __builtin_amdgcn_fdot2_f32_bf16(v0, ones, sx[i], false);
+            sxx[i] = __builtin_amdgcn_fdot2_f32_bf16(v0, v0, sxx[i], false);
+            sx[i] = __builtin_amdgcn_fdot2_f32_bf16(v1, ones, sx[i], false);
+            sxx[i] = __builtin_amdgcn_fdot2_f32_bf16(v1, v1, sxx[i], false);
+            sx[i] = __builtin_amdgcn_fdot2_f32_bf16(v2, ones, sx[i], false);
+            sxx[i] = __builtin_amdgcn_fdot2_f32_bf16(v2, v2, sxx[i], false);
+            sx[i] = __builtin_amdgcn_fdot2_f32_bf16(v3, ones, sx[i], false);
+            sxx[i] = __builtin_amdgcn_fdot2_f32_bf16(v3, v3, sxx[i], false);
+          } else {
+            const float f0 = __uint_as_float(a4.x), f1 = __uint_as_float(a4.y),
+                        f2 = __uint_as_float(a4.z), f3 = __uint_as_float(a4.w);
+            sx[i] += (f0 + f1) + (f2 + f3);
+            sxx[i] = fmaf(f0, f0, fmaf(f1, f1, fmaf(f2, f2, fmaf(f3, f3, sxx[i]))));
+          }
+        }
+      }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -466,7 +579,10 @@ __device__ __forceinline__ void igemm_body(const SdmiGemmArgs& p, int tiles_m, i
     }
   }
 
-  wave_epilogue<TM, TN>(p, acc, m0 + wm * WTM, n0 + wn * WTN, zb, hw_shift, lane);
+  if constexpr (EPI == 0)
+    wave_epilogue<TM, TN>(p, acc, m0 + wm * WTM, n0 + wn * WTN, zb, hw_shift, lane);
+  else
+    fused_epilogue<TM, TN, EPI>(p, acc, sx, sxx, m0 + wm * WTM, n0 + wn * (GEGLU ? WTN / 2 : WTN), lane);
   }  // tiles of this workgroup
 }
 
@@ -861,10 +977,10 @@ __global__ __launch_bounds__(256) void conv3x3_c64_kernel(SdmiGemmArgs p, int hw
 
 // Two entry points over the same body: <= 128 VGPRs (two workgroups per CU) for the tiles whose
 // double-buffered LDS image allows it, unconstrained for the 256-row tile (92 KB of LDS).
-template <typename T, int BM, int BN, int BKB, int MODE>
+template <typename T, int BM, int BN, int BKB, int MODE, int EPI = 0>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void igemm_kernel(
     SdmiGemmArgs p, int tiles_m, int tiles_n, int kt_per_split, int hw_shift) {
-  igemm_body<T, BM, BN, BKB, MODE>(p, tiles_m, tiles_n, kt_per_split, hw_shift);
+  igemm_body<T, BM, BN, BKB, MODE, EPI>(p, tiles_m, tiles_n, kt_per_split, hw_shift);
 }
 template <typename T, int BM, int BN, int BKB, int MODE>
 __global__ __launch_bounds__(512) void igemm_kernel_tall(SdmiGemmArgs p, int tiles_m, int tiles_n,
@@ -902,14 +1018,15 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(SdmiGemmArgs p, in
 
 static int device_cus();
 
-template <typename T, int BM, int BN, int BKB, int MODE>
+template <typename T, int BM, int BN, int BKB, int MODE, int EPI = 0>
 int launch_cfg(const SdmiGemmArgs& p, int split_k, int hw_shift, hipStream_t st) {
   constexpr int BK = BKB / sizeof(T);
   constexpr int smem = 2 * (BM + BN) * (BKB + 16);
+  constexpr int BN_OUT = (EPI & 2) ? BN / 2 : BN;          // GEGLU: value + gate rows per output column
   static bool attr_done = false;
   void (*kern)(SdmiGemmArgs, int, int, int, int);
   if constexpr (BM > 128) kern = igemm_kernel_tall<T, BM, BN, BKB, MODE>;
-  else kern = igemm_kernel<T, BM, BN, BKB, MODE>;
+  else kern = igemm_kernel<T, BM, BN, BKB, MODE, EPI>;
   if (!attr_done) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem) !=
         hipSuccess) {
@@ -920,7 +1037,7 @@ int launch_cfg(const SdmiGemmArgs& p, int split_k, int hw_shift, hipStream_t st)
   }
   SdmiGemmArgs q = p;
   q.split_k = split_k;
-  const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+  const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN_OUT - 1) / BN_OUT;
   const int nk = (p.K + BK - 1) / BK;
   const int ktps = (nk + split_k - 1) / split_k;
   // persistent workgroups: at most what the chip holds at once (registers / LDS allow 2 workgroups
@@ -1052,8 +1169,37 @@ int dispatch(const SdmiGemmArgs& p, hipStream_t st) {
   // the scalar-offset loaders (MODE 1 / 2) address operands with 31-bit byte offsets
   const long long a_bytes =
       ((long long)p.B * p.H * p.W + (long long)(p.KH + 1) * p.W) * p.lda * (long long)sizeof(T);
-  const long long w_bytes = (long long)p.N * p.ldw * (long long)sizeof(T);
+  const long long w_bytes = (long long)p.N * (p.geglu ? 2 : 1) * p.ldw * (long long)sizeof(T);
   const bool fits31 = a_bytes < (1ll << 31) && w_bytes < (1ll << 31);
+  // fused LayerNorm-fold / GEGLU epilogues (sdmi.h: ln_colsum, geglu): 1x1 / linear problems only
+  {
+    const int epi = (p.ln_colsum ? 1 : 0) | (p.geglu ? 2 : 0);
+    if (epi) {
+      if (!is1x1 || !fits31 || batch != 1 || p.osy != 0 || p.split_k > 1 || p.bias_m || p.residual || p.rowvec) {
+        sdmi_set_error("igemm: LayerNorm-fold / GEGLU epilogues need a plain 1x1 problem without residual / rowvec");
+        return SDMI_EUNSUPPORTED;
+      }
+      static int lnf_tile = -1;
+      if (lnf_tile < 0) {
+        const char* e = getenv("SDMI_LNF_TILE");
+        lnf_tile = e ? atoi(e) : 0;
+      }
+      // GEGLU pairs tiles inside a 64-column wave block: 128 x 128 only
+      const bool t128 = (epi & 2) || (shape == T128x128 && lnf_tile != 64);
+#define SDMI_EPI(E)                                                                              \
+  do {                                                                                           \
+    if (t128) return wide ? launch_cfg<T, 128, 128, 128, 1, E>(p, 1, hw_shift, st)               \
+                          : launch_cfg<T, 128, 128, 64, 1, E>(p, 1, hw_shift, st);               \
+    if constexpr (((E) & 2) == 0)                                                                \
+      return wide ? launch_cfg<T, 64, 64, 128, 1, E>(p, 1, hw_shift, st)                         \
+                  : launch_cfg<T, 64, 64, 64, 1, E>(p, 1, hw_shift, st);                         \
+  } while (0)
+      if (epi == 1) SDMI_EPI(1);
+      if (epi == 2) SDMI_EPI(2);
+      SDMI_EPI(3);
+#undef SDMI_EPI
+    }
+  }
   // LDS-DMA kernels (one workgroup per CU, 3-4 LDS stages): deep-K 1x1 / plain convolutions with
   // wide outputs, no split-K
   {

@@ -199,19 +199,17 @@ class UNetRunner:
         tok = K.linear(h.view(B, H * W, C), n + '.proj_in.weight', n + '.proj_in.bias')
         t = n + '.transformer_blocks.0'
         # self attention
-        n1, tres = K.ln_fan(tok, t + '.norm1')
-        qkv = K.linear(n1, (t + '.attn1.to_q.weight', t + '.attn1.to_k.weight',
-                            t + '.attn1.to_v.weight'))
+        qkv, tres = K.ln_linear_fan(tok, t + '.norm1', (t + '.attn1.to_q.weight', t + '.attn1.to_k.weight',
+                                                        t + '.attn1.to_v.weight'))
         a = K.attn_self(qkv, heads)
         tok = K.linear(a, t + '.attn1.to_out.0.weight', t + '.attn1.to_out.0.bias', residual=tres)
         # slot cross attention (K/V precomputed per sample call)
-        n2, tres = K.ln_fan(tok, t + '.norm2')
-        q = K.linear(n2, t + '.attn2.to_q.weight')
+        q, tres = K.ln_linear_fan(tok, t + '.norm2', t + '.attn2.to_q.weight')
         a = K.attn_cross(q, kv, heads)
         tok = K.linear(a, t + '.attn2.to_out.0.weight', t + '.attn2.to_out.0.bias', residual=tres)
         # GEGLU feed-forward
-        n3, tres = K.ln_fan(tok, t + '.norm3')
-        g = K.geglu(K.linear(n3, t + '.ff.net.0.proj.weight', t + '.ff.net.0.proj.bias'))
+        g, tres = K.ln_linear_fan(tok, t + '.norm3', t + '.ff.net.0.proj.weight', t + '.ff.net.0.proj.bias',
+                                  geglu=True)
         tok = K.linear(g, t + '.ff.net.2.weight', t + '.ff.net.2.bias', residual=tres)
         out = K.linear(tok, n + '.proj_out.weight', n + '.proj_out.bias',
                        residual=xres.view(B, H * W, C))

@@ -41,6 +41,9 @@ def _dbg(tag, **tensors):
         print(f'[bwd] {tag}: {msg}', flush=True)
 
 
+_LN_FOLD = os.environ.get('SDMI_LN_FOLD', '1') != '0'
+
+
 class WeightBank:
     """name(s) -> GEMM operand [N, K] in the requested dtype (K padded to the vector width)."""
 
@@ -67,7 +70,7 @@ class WeightBank:
         self._join_queued = False
         # grouped weight gradients: 1x1 / linear bf16 problems are queued and launched together
         # (sdmi_wgrad_group) once their tiles can fill the chip -- see queue_wgrad()
-        self.group_wgrad = os.environ.get('SDMI_WGRAD_GROUP', '1') != '0'
+        self.group_wgrad = os.environ.get('SDMI_WGRAD_GROUP', '0') != '0'
         self._wq, self._wq_keep, self._wq_items, self._wq_bytes = [], [], 0, 0
         self.defer_colsum = os.environ.get('SDMI_DEFER_COLSUM', '1') != '0'
         # dgrad operands: key -> [buffer, epoch, (stable source view | None, geometry)]
@@ -292,6 +295,24 @@ class WeightBank:
         self.cache[key] = out
         return out
 
+    def ln_folded(self, ln_name, wnames, bnames, dtype):
+        """Operands of a LayerNorm folded into the linear layer behind it (sdmi.h: ln_colsum):
+        W' = W * gamma in `dtype`, colsum[n] = sum_k W'[n][k] of the rounded W', bias' = W beta + b.
+        Weight preparation, once per weight update (cached like the bf16 operand shadows)."""
+        if isinstance(wnames, str):
+            wnames = (wnames,)
+        key = ('lnfold', ln_name, wnames, dtype)
+        if key not in self.cache:
+            with torch.no_grad():
+                g, be = self.t[ln_name + '.weight'].float(), self.t[ln_name + '.bias'].float()
+                W = torch.cat([self.t[n].float().reshape(-1, g.numel()) for n in wnames])
+                Wp = (W * g).to(dtype).contiguous()
+                bias = W @ be
+                if bnames is not None:
+                    bias = bias + self.b(bnames).float()
+                self.cache[key] = (Wp, Wp.float().sum(1).contiguous(), bias.contiguous())
+        return self.cache[key]
+
     def b(self, names):
         """fp32 bias vector, fused across names (view when adjacent)."""
         if names is None:
@@ -404,6 +425,17 @@ class Kern:
 
     def ln_fan(self, x, name):
         return self.ln(x, name), x
+
+    def ln_linear_fan(self, x, ln_name, wnames, bnames=None, *, act=None, geglu=False, eps=1e-5):
+        """linear(LayerNorm(x)) (-> GEGLU) in ONE launch at inference: the norm is folded into the
+        GEMM (sdmi.h: ln_colsum), the gated activation into its epilogue.  -> (out, x for the
+        residual branch).  bf16 (throughput) path only: the fp32 path keeps the reference's kernel
+        sequence for the parity tests.  SDMI_LN_FOLD=0: the unfused sequence everywhere."""
+        if not _LN_FOLD or x.dtype != torch.bfloat16:
+            h = self.linear(self.ln(x, ln_name, eps), wnames, bnames, act=act)
+            return (self.geglu(h) if geglu else h), x
+        w, colsum, bias = self.wb.ln_folded(ln_name, wnames, bnames, x.dtype)
+        return ops.linear(x, w, bias, act=act, ln_colsum=colsum, ln_eps=eps, geglu=geglu), x
 
     def conv_fan(self, x, wname, bname=None, **kw):
         return self.conv(x, wname, bname, **kw), x
@@ -1403,6 +1435,11 @@ class KernGrad(Kern):
 
     def ln_fan(self, x, name):
         return LayerNormFn.apply(x, self.wb.anchor_for(name), self.wb, name, 1)
+
+    def ln_linear_fan(self, x, ln_name, wnames, bnames=None, *, act=None, geglu=False, eps=1e-5):
+        n, xres = self.ln_fan(x, ln_name)          # (training keeps the normalised rows for wgrad)
+        h = self.linear(n, wnames, bnames, act=act)
+        return (self.geglu(h) if geglu else h), xres
 
     def conv_fan(self, x, wname, bname=None, *, kh=3, kw=3, stride=1, pad=(1, 1, 1, 1), ups=False,
                  rowvec=None, residual=None, out_dtype=None, ldc=None):

@@ -89,27 +89,31 @@ def conv2d(x, w, bias=None, *, kh=3, kw=3, stride=1, pad=(1, 1, 1, 1), ups=False
 
 
 def linear(x, w, bias=None, *, act=None, residual=None, out=None, out_dtype=None, n=None,
-           alpha=1.0, lda=None, k=None):
-    """x [..., K] (last dim contiguous; row pitch lda) ; w [N, K] -> [..., N]."""
+           alpha=1.0, lda=None, k=None, ln_colsum=None, ln_eps=0.0, geglu=False):
+    """x [..., K] (last dim contiguous; row pitch lda) ; w [N, K] -> [..., N].
+    ln_colsum: fused LayerNorm prologue (w pre-scaled by gamma, bias = W beta + b; see sdmi.h);
+    geglu: w [2N, K] (value rows, gate rows) -> value * gelu(gate), N columns."""
     _need_gpu(x, w)
     K = k or x.shape[-1]
     lda = lda or x.stride(-2) if x.dim() > 1 else K
     M = x.numel() // x.shape[-1]
-    N = n if n is not None else w.numel() // K
+    N = n if n is not None else w.numel() // K // (2 if geglu else 1)
     odt = out_dtype or x.dtype
     if out is None:
         out = torch.empty(x.shape[:-1] + (N,), dtype=odt, device=x.device)
     ws = None
     t64 = ((M + 63) // 64) * ((N + 63) // 64)
     t128 = ((M + 127) // 128) * ((N + 127) // 128)
-    if not (N > 64 and t128 >= 192) and t64 < 384 and K * x.element_size() >= 2048:
+    if not (N > 64 and t128 >= 192) and t64 < 384 and K * x.element_size() >= 2048 and \
+            ln_colsum is None and not geglu:
         ws = torch.empty((16 * M * N,), dtype=torch.float32, device=x.device)
     call('sdmi_igemm', _stream(), a=_p(x), w=_p(w), out=_p(out), bias=_p(bias),
          residual=_p(residual), workspace=_p(ws), dtype=_dt(x), out_dtype=_DT[odt], M=M, N=N, K=K,
          lda=lda, ldw=K, ldc=out.stride(-2) if out.dim() > 1 else N,
          ldr=(residual.stride(-2) if residual is not None else 0), B=M, H=1, W=1, Cin=K, Ho=1,
          Wo=1, KH=1, KW=1, stride=1, pad_t=0, pad_l=0, ups=0, act=ACT[act], alpha=alpha,
-         bias_m=0, split_k=(0 if ws is not None else 1), batch=1)
+         bias_m=0, split_k=(0 if ws is not None else 1), batch=1, ln_colsum=_p(ln_colsum),
+         ln_eps=float(ln_eps), geglu=int(geglu))
     return out
 
 

@@ -135,6 +135,45 @@ def test_igemm_linear(mnk, dtype):
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('geglu', [False, True])
+@pytest.mark.parametrize('mnk', [(1024, 1536, 512), (4096, 384, 384), (16384, 256, 256), (448, 64, 192),
+                                 (70, 200, 136), (1000, 96, 264)])
+def test_igemm_layernorm_fold_and_geglu(mnk, geglu, dtype):
+    """Register-resident GEMM with the fused epilogues (sdmi.h: ln_colsum / geglu):
+    linear(LayerNorm(x)) [-> value * gelu(gate)] in one launch, the norm folded into pre-scaled
+    weights + a per-row (mean, rstd) correction, against torch's LayerNorm -> Linear -> GEGLU."""
+    ops = _ops()
+    M, N, K = mnk
+    g = torch.Generator().manual_seed(M + N + K)
+    x = q(torch.randn(M, K, generator=g) * 1.5 + 0.7 * torch.randn(M, 1, generator=g), dtype)
+    NW = 2 * N if geglu else N
+    w = torch.randn(NW, K, generator=g) / math.sqrt(K)
+    b = torch.randn(NW, generator=g)
+    gamma, beta = 1 + 0.3 * torch.randn(K, generator=g), 0.2 * torch.randn(K, generator=g)
+    eps = 1e-5
+    wp = q(w * gamma, dtype)                                # the operand the kernel multiplies with
+    # reference: exact LayerNorm statistics, the same rounded operand (the fold is an identity then)
+    mu, var = x.double().mean(1, keepdim=True), x.double().var(1, unbiased=False, keepdim=True)
+    n = (x.double() - mu) / (var + eps).sqrt()
+    ref = (n @ wp.double().t() + (w.double() @ beta.double() + b.double())).float()
+    if geglu:
+        ref = ref[:, :N] * F.gelu(ref[:, N:])
+    out = ops.linear(x.to(dtype).to(DEV), wp.to(dtype).to(DEV), (w @ beta + b).to(DEV),
+                     ln_colsum=wp.sum(1).to(DEV), ln_eps=eps, geglu=geglu)
+    assert out.shape == (M, N)
+    check(out, ref, dtype, f'ln-fold {mnk} geglu={geglu}')
+    if not geglu:        # GEGLU epilogue alone (no norm), relu epilogue with the fold
+        w2 = q(torch.randn(2 * N, K, generator=g) / math.sqrt(K), dtype)
+        b2 = torch.randn(2 * N, generator=g)
+        h = F.linear(x, w2, b2)
+        out2 = ops.linear(x.to(dtype).to(DEV), w2.to(dtype).to(DEV), b2.to(DEV), geglu=True)
+        check(out2, h[:, :N] * F.gelu(h[:, N:]), dtype, f'geglu {mnk}')
+        out3 = ops.linear(x.to(dtype).to(DEV), wp.to(dtype).to(DEV), (w @ beta + b).to(DEV),
+                          ln_colsum=wp.sum(1).to(DEV), ln_eps=eps, act='relu', out_dtype=torch.float32)
+        check(out3, F.relu(ref), dtype, f'ln-fold relu {mnk}')
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 def test_bmm_nt_and_softmax(dtype):
     ops = _ops()
     g = torch.Generator().manual_seed(5)

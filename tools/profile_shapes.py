@@ -23,23 +23,43 @@ def timed(fname, stream, **kw):
     recs.append((fname, kw, e0, e1))
 
 
+TRAIN = len(sys.argv) > 3 and sys.argv[3] == 'train'
+if TRAIN:
+    model.train()
+    model.bank().overlap_wgrad = False
+    img = bench.synth_batch(B, 0, 'cuda')
+
+    def step():
+        model.grad_arena().zero_()
+        out = model(dict(img=img))
+        model.calc_train_loss(dict(img=img), out)['denoise_loss'].backward()
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    _lib._call = timed
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    _lib._call = orig
 with torch.no_grad():
+    if TRAIN:
+        sys.argv = sys.argv[:1]
     img = bench.synth_batch(B, 0, 'cuda')
     slots, _ = model.encode(img)
     x = ops.nchw_to_nhwc(torch.randn(B, 3, 32, 32).cuda(), torch.float32, 4)
     t = torch.full((B,), 500., device='cuda')
-    for _ in range(2):
+    for _ in range(0 if TRAIN else 2):
         model._unet_eps(x, t, slots)
     torch.cuda.synchronize()
     _lib._call = timed
-    for _ in range(3):
+    for _ in range(0 if TRAIN else 3):
         model._unet_eps(x, t, slots)
     torch.cuda.synchronize()
     _lib._call = orig
 agg = {}
 for fname, kw, e0, e1 in recs:
     if fname == 'sdmi_igemm':
-        key = (fname, kw['M'], kw['N'], kw['K'], kw['KH'], kw['stride'], kw['ups'], kw.get('batch', 1))
+        key = (fname, kw['M'], kw['N'], kw['K'], kw['KH'], kw['stride'], kw.get('ups', 0), kw.get('batch', 1))
         fl = 2.0 * kw['M'] * kw['N'] * kw['K'] * max(1, kw.get('batch', 1))
     else:
         key = (fname,)
@@ -49,7 +69,7 @@ for fname, kw, e0, e1 in recs:
     d[1] += e0.elapsed_time(e1)
     d[2] += fl
 tot = sum(d[1] for d in agg.values())
-print(f'total {tot / 3:.3f} ms per UNet eval (B={B}, {dtype})')
-for key, d in sorted(agg.items(), key=lambda kv: -kv[1][1])[:45]:
+print(f'total {tot / 3:.3f} ms per {"train step" if TRAIN else "UNet eval"} (B={B}, {dtype})')
+for key, d in sorted(agg.items(), key=lambda kv: -kv[1][1])[:70]:
     tf = d[2] / (d[1] * 1e-3) / 1e12 if d[1] > 0 else 0
     print(f'{d[1] / 3:8.3f} ms  n={d[0] // 3:3d}  {tf:7.1f} TF/s  {key}')
