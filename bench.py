@@ -33,13 +33,15 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK_TFLOPS = {'bf16': 2500.0, 'fp32': 157.3}      # MI355X dense MFMA peaks (MI355X_MICROARCH.md)
+PEAK_TFLOPS = {'bf16': 2500.0, 'fp32': 157.3, 'fp8': 5000.0}      # MI355X dense MFMA peaks (MI355X_MICROARCH.md)
 
 
-def build_model(dtype, seed=1234):
+def build_model(dtype, seed=1234, config='clevrtex128'):
     from slotdiffusion_amd.models import SADiffusion
-    from tests.common import clevrtex_cfg
-    cfg = clevrtex_cfg(num_slots=7)
+    from tests.common import clevrtex_cfg, dino_coco_cfg
+    # clevrtex128 = BASELINE configs[1] (the metric's configuration); coco224 = configs[4]: DINO ViT-S/8
+    # encoder, 224 x 224 images, latent 56 x 56 (reference config values: tests/golden/configs)
+    cfg = dino_coco_cfg() if config == 'coco224' else clevrtex_cfg(num_slots=7)
     m = SADiffusion(cfg['resolution'], cfg['slot_dict'], cfg['enc_dict'], cfg['dec_dict'],
                     cfg['loss_dict'], compute_dtype=dtype, seed=seed)
     g = torch.Generator().manual_seed(seed)
@@ -51,9 +53,9 @@ def build_model(dtype, seed=1234):
     return m, cfg
 
 
-def synth_batch(B, rank, device):
+def synth_batch(B, rank, device, res=128):
     g = torch.Generator().manual_seed(1234 + rank)
-    img = (torch.randn(B, 3, 128, 128, generator=g) * 0.5).clamp(-1, 1)
+    img = (torch.randn(B, 3, res, res, generator=g) * 0.5).clamp(-1, 1)
     return img.to(device)
 
 
@@ -216,8 +218,12 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--batch', type=int, default=64)
-    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
+    ap.add_argument('--batch', type=int, default=0, help='images per GPU (default 64; coco224: 16)')
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32', 'fp8'],
+                    help="fp8 = bf16 storage + e4m3fn operands on the denoiser's 3x3 convolutions "
+                         '(sampling path only this round)')
+    ap.add_argument('--config', default='clevrtex128', choices=['clevrtex128', 'coco224'],
+                    help='clevrtex128 = BASELINE configs[1] (the metric); coco224 = configs[4]')
     ap.add_argument('--mode', default='train', choices=['train', 'sample'])
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -236,6 +242,9 @@ def main():
     # torch.distributed.launch --nproc_per_node=$GPUS, scripts/sbatch_run.sh:36-39); a mismatch
     # between --gpus and the world the launcher set up, or fewer visible devices than ranks, is an
     # error -- never a silent single-GPU measurement.
+    if args.dtype == 'fp8' and args.mode != 'sample':
+        sys.exit('bench.py: --dtype fp8 covers the sampling path (--mode sample); the train step keeps '
+                 'bf16 operands')
     n_vis = torch.cuda.device_count()
     if args.gpus > n_vis:
         sys.exit(f'bench.py: --gpus {args.gpus} requested but only {n_vis} GPU(s) are visible on this box')
@@ -262,13 +271,17 @@ def main():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29511')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
-    dtype = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
+    dtype = torch.float32 if args.dtype == 'fp32' else torch.bfloat16
 
-    model, cfg = build_model(dtype)
+    model, cfg = build_model(dtype, config=args.config)
     model = model.to(dev)
+    if args.dtype == 'fp8':
+        model.set_compute_dtype('fp8')
     model.use_graph = not args.no_graph
-    B = args.batch
-    img = synth_batch(B, rank, dev)
+    res = cfg['resolution'][0]
+    lat = res // 4
+    B = args.batch if args.batch > 0 else (64 if args.config == 'clevrtex128' else 16)
+    img = synth_batch(B, rank, dev, res)
     from slotdiffusion_amd import ops, parallel
     if dist is not None:                      # every rank starts from rank 0's parameters
         parallel.broadcast_parameters(model.arena())
@@ -311,7 +324,7 @@ def main():
     with torch.no_grad():
         slots, _ = model.encode(img)
         g = torch.Generator(device='cpu').manual_seed(77 + rank)
-        x_T = ops.nchw_to_nhwc(torch.randn(B, 3, 32, 32, generator=g).to(dev), torch.float32, 4)
+        x_T = ops.nchw_to_nhwc(torch.randn(B, 3, lat, lat, generator=g).to(dev), torch.float32, 4)
 
         def sample_step():
             return model._dpm_sample(x_T, slots)[0]
@@ -322,12 +335,13 @@ def main():
         n_s = args.steps if args.mode == 'sample' else max(2, args.steps // 2)
         denoise_rate = world * B * nfe * n_s / dt_s
         big_rate = None
-        if args.big_batch and args.big_batch != B and world == 1 and not args.only_train:
+        if args.big_batch and args.big_batch != B and world == 1 and not args.only_train and \
+                args.config == 'clevrtex128':
             # informational: the same sampler at a batch that fills the chip better
             Bb = args.big_batch
             slots_b = slots[:1].expand(Bb, -1, -1).contiguous() + 0.01 * torch.randn(
                 Bb, slots.shape[1], slots.shape[2], device=dev)
-            xT_b = ops.nchw_to_nhwc(torch.randn(Bb, 3, 32, 32, device=dev), torch.float32, 4)
+            xT_b = ops.nchw_to_nhwc(torch.randn(Bb, 3, lat, lat, device=dev), torch.float32, 4)
             big = lambda: model._dpm_sample(xT_b, slots_b)[0]
             dt_b = timed(big, 2, 1)
             big_rate = Bb * nfe * 2 / dt_b
@@ -392,6 +406,11 @@ def main():
             metric = 'DPM-Solver denoise-steps/sec, 128^2 7-slot'
             work = ('img_based SlotDiffusion CLEVRTex 128x128 7 slots: 20-NFE DPM-Solver++ '
                     'sampling (UNet eps + VQ per NFE)')
+        if args.config == 'coco224':
+            metric = metric.replace('128^2 7-slot', '224^2 7-slot (COCO / DINO config, BASELINE configs[4])')
+            work = work.replace('CLEVRTex 128x128', 'COCO 224x224 (DINO ViT-S/8 encoder, latent 56x56)')
+        if args.dtype == 'fp8':
+            work += "; e4m3fn operands on the UNet's 3x3 convolutions (fp8 MFMA), bf16 elsewhere"
         out = {
             'metric': metric, 'value': value, 'unit': unit, 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': ms, 'higher_is_better': True,
@@ -477,7 +496,7 @@ def main():
             out['kernel_breakdown_ms'] = {k: round(v['ms'], 3) for k, v in
                                           sorted(summ.items(), key=lambda kv: -kv[1]['ms'])}
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(cfg, args.mode)
+            out['cpu_baseline'] = cpu_baseline(cfg, args.mode) if args.config == 'clevrtex128' else None
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -24,7 +24,7 @@ extern "C" {
 
 #define SDMI_VERSION 100
 
-enum { SDMI_F32 = 0, SDMI_BF16 = 1 };
+enum { SDMI_F32 = 0, SDMI_BF16 = 1, SDMI_FP8 = 2 /* OCP e4m3fn; sdmi_igemm operands / sdmi_quant_fp8 output only */ };
 enum { SDMI_ACT_NONE = 0, SDMI_ACT_RELU = 1, SDMI_ACT_SILU = 2, SDMI_ACT_GELU = 3 };
 enum { SDMI_OK = 0, SDMI_EINVAL = -1, SDMI_ELAUNCH = -2, SDMI_EUNSUPPORTED = -3 };
 
@@ -42,7 +42,10 @@ const char* sdmi_last_error(void);
  *   video_based/models/unet/unet.py:222,249,255-259,408,542 (ResBlock/in/out convs),
  *   unet.py:108-121,165-179 (Up/Downsample), attention.py:44-48,175-180 (Linear),
  *   vqvae/modules.py:23-48,71-91 (VQ-VAE convs, asymmetric pad), resnet.py:12-35.
- * dtype: SDMI_BF16 -> v_mfma_f32_32x32x16_bf16; SDMI_F32 -> v_mfma_f32_32x32x2_f32 (exact fp32).
+ * dtype: SDMI_BF16 -> v_mfma_f32_32x32x16_bf16; SDMI_F32 -> v_mfma_f32_32x32x2_f32 (exact fp32);
+ *        SDMI_FP8 (e4m3fn operands from sdmi_quant_fp8, the BASELINE "fp8 MFMA UNet" configuration) ->
+ *        v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales; the per-tensor quantisation scales
+ *        of A and W are undone through `alpha` = 1 / (scale_a * scale_w).
  * Accumulation is always fp32.  Epilogue tensors bias/rowvec are fp32.
  * split_k > 1: partial sums go to `workspace` (fp32, split_k*M*N) and a second kernel reduces.
  * batch > 1 (1x1 only): grid.z batches with element strides sa/sw/sc/sr (attention GEMMs).
@@ -140,6 +143,11 @@ typedef struct {
   float drop_p;
   long long drop_seed;
   const long long* drop_seed_dev;
+  /* optional (bf16 input): the activated output is ALSO quantised to e4m3fn bytes at y8 (same
+   * [B][HW][C] indexing, y8_scale as in sdmi_quant_fp8) -- the operand of the fp8 convolution
+   * behind the norm; y may then be NULL (inference: the bf16 copy has no other reader). */
+  void* y8;
+  float y8_scale;
 } SdmiGroupNormArgs;
 int sdmi_groupnorm_stats(const SdmiGroupNormArgs* a, void* stream);
 int sdmi_groupnorm_apply(const SdmiGroupNormArgs* a, void* stream);
@@ -292,6 +300,14 @@ typedef struct {
   int zpad;      /* != 0: columns [cols, ldd) of dst are written with zeros (channel padding) */
 } SdmiCast2dArgs;
 int sdmi_cast2d(const SdmiCast2dArgs* a, void* stream);
+/* Per-tensor fp8 quantisation of a strided 2-D view: dst[r][c] = e4m3fn(clamp(src[r][c] * scale, +-448)),
+ * columns [cols, ldd) zero (K padding).  src fp32 / bf16; dst bytes, row pitch ldd (multiple of 16).
+ * Feeds the SDMI_FP8 operands of sdmi_igemm (activations with a fixed scale, weights with
+ * scale = 448 / amax at weight-preparation time). */
+typedef struct {
+  const void* src; void* dst; int src_dtype; long long rows; int cols, lds, ldd; float scale;
+} SdmiQuantFp8Args;
+int sdmi_quant_fp8(const SdmiQuantFp8Args* a, void* stream);
 
 /* Small stream-ordered helpers that keep the training step free of framework kernels:
  *   sdmi_memset0 ...... zero `bytes` bytes (gradient arena, padded buffers) -- a memset node in a graph

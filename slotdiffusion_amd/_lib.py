@@ -58,7 +58,7 @@ def parse_header(path=HEADER):
 
 
 STRUCTS, FUNCS, ENUMS = parse_header()
-F32, BF16 = ENUMS['SDMI_F32'], ENUMS['SDMI_BF16']
+F32, BF16, FP8 = ENUMS['SDMI_F32'], ENUMS['SDMI_BF16'], ENUMS['SDMI_FP8']
 ACT = {None: 0, 'none': 0, 'relu': ENUMS['SDMI_ACT_RELU'], 'silu': ENUMS['SDMI_ACT_SILU'],
        'gelu': ENUMS['SDMI_ACT_GELU']}
 
@@ -136,7 +136,7 @@ class KernelTimer:
 def _meta(fname, kw):
     """Algorithmic work of one launch (bench.py's roofline legs): flops of the GEMM-shaped entry
     points; algorithmic HBM bytes (every operand read once, every result written once)."""
-    elt = 2 if kw.get('dtype', F32) == BF16 else 4
+    elt = {BF16: 2, FP8: 1}.get(kw.get('dtype', F32), 4)
     if fname == 'sdmi_igemm':
         b = max(1, kw.get('batch', 1))
         oelt = 2 if kw.get('out_dtype', F32) == BF16 else 4
@@ -144,7 +144,7 @@ def _meta(fname, kw):
         wts = kw['N'] * kw['K'] * (b if kw.get('sw', 0) else 1)
         out = kw['M'] * kw['N'] * (2 if kw.get('residual', 0) else 1)
         return dict(flops=2.0 * kw['M'] * kw['N'] * kw['K'] * b,
-                    bytes=float(b * src * elt + wts * elt + b * out * oelt))
+                    bytes=float(b * src * elt + wts * elt + b * out * oelt), fp8=int(elt == 1))
     if fname == 'sdmi_wgrad':
         return dict(flops=2.0 * kw['M'] * kw['N'] * kw['K'])
     if fname == 'sdmi_groupnorm':          # x in, y out (+ residual in)

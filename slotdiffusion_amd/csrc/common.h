@@ -36,6 +36,19 @@ __device__ __forceinline__ uint32_t f32x2_to_bf16x2(float lo, float hi) {
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(sdmi_f32x2{lo, hi}, sdmi_bf16x2));
 }
 
+typedef unsigned char fp8_t;     // raw OCP e4m3fn bits (gfx950's native fp8)
+// four floats -> four e4m3fn bytes (round to nearest even), saturating at +-448 (the cvt itself
+// would produce NaN beyond the format's range)
+__device__ __forceinline__ uint32_t f32x4_to_fp8x4(float a, float b, float c, float d) {
+  a = fminf(fmaxf(a, -448.f), 448.f);
+  b = fminf(fmaxf(b, -448.f), 448.f);
+  c = fminf(fmaxf(c, -448.f), 448.f);
+  d = fminf(fmaxf(d, -448.f), 448.f);
+  int v = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+  v = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, v, true);
+  return (uint32_t)v;
+}
+
 template <typename T> struct Elem;
 template <> struct Elem<float> {
   static constexpr int VEC = 4;  // elements per 16-byte vector

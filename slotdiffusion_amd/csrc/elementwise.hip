@@ -77,6 +77,33 @@ __global__ void cast2d_kernel(SdmiCast2dArgs p) {
   }
 }
 
+// per-tensor fp8 (e4m3fn) quantisation, 16 values per thread (one 16-byte store)
+template <typename S>
+__global__ void quant_fp8_kernel(SdmiQuantFp8Args p) {
+  const int vpr = p.ldd / 16;                       // 16-byte output vectors per row
+  const long long n = p.rows * vpr;
+  GRID_STRIDE(i, n) {
+    const long long r = i / vpr;
+    const int c0 = (int)(i - r * vpr) * 16;
+    const S* src = (const S*)p.src + r * p.lds + c0;
+    float f[16];
+    if (c0 + 16 <= p.cols && (p.lds % Elem<S>::VEC) == 0) {
+#pragma unroll
+      for (int q = 0; q < 16 / Elem<S>::VEC; ++q)
+        unpack16<S>(*reinterpret_cast<const uint4*>(src + q * Elem<S>::VEC), f + q * Elem<S>::VEC);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) f[j] = c0 + j < p.cols ? Elem<S>::ld(src + j) : 0.f;
+    }
+    uint4 o;
+    o.x = f32x4_to_fp8x4(f[0] * p.scale, f[1] * p.scale, f[2] * p.scale, f[3] * p.scale);
+    o.y = f32x4_to_fp8x4(f[4] * p.scale, f[5] * p.scale, f[6] * p.scale, f[7] * p.scale);
+    o.z = f32x4_to_fp8x4(f[8] * p.scale, f[9] * p.scale, f[10] * p.scale, f[11] * p.scale);
+    o.w = f32x4_to_fp8x4(f[12] * p.scale, f[13] * p.scale, f[14] * p.scale, f[15] * p.scale);
+    *reinterpret_cast<uint4*>((fp8_t*)p.dst + r * p.ldd + c0) = o;
+  }
+}
+
 template <typename T>
 __global__ void scale_dev_kernel(SdmiScaleDevArgs p) {
   const float s = p.s[0];
@@ -385,6 +412,15 @@ extern "C" int sdmi_cast2d(const SdmiCast2dArgs* a, void* stream) {
   else if (db) hipLaunchKernelGGL((cast2d_kernel<float, bf16_t>), dim3(g), dim3(EW_THREADS), 0, ST, *a);
   else hipLaunchKernelGGL((cast2d_kernel<float, float>), dim3(g), dim3(EW_THREADS), 0, ST, *a);
   return sdmi_check_launch("cast2d");
+}
+extern "C" int sdmi_quant_fp8(const SdmiQuantFp8Args* a, void* stream) {
+  SDMI_REQUIRE(a && a->src && a->dst, "null pointer");
+  SDMI_REQUIRE(a->ldd % 16 == 0 && a->ldd >= a->cols && ((uintptr_t)a->dst & 15) == 0, "dst rows are 16-byte vectors");
+  SDMI_REQUIRE(a->src_dtype == SDMI_F32 || a->src_dtype == SDMI_BF16, "bad src_dtype");
+  const int g = ew_blocks(a->rows * (a->ldd / 16));
+  if (a->src_dtype == SDMI_BF16) hipLaunchKernelGGL(quant_fp8_kernel<bf16_t>, dim3(g), dim3(EW_THREADS), 0, ST, *a);
+  else hipLaunchKernelGGL(quant_fp8_kernel<float>, dim3(g), dim3(EW_THREADS), 0, ST, *a);
+  return sdmi_check_launch("quant_fp8");
 }
 extern "C" int sdmi_memset0(const SdmiMemsetArgs* a, void* stream) {
   SDMI_REQUIRE(a && a->ptr && a->bytes >= 0, "bad args");

@@ -529,6 +529,29 @@ __device__ __forceinline__ void igemm_body(const SdmiGemmArgs& p, int tiles_m, i
     const char* base = smem + (g & 1) * BUF_BYTES;
     const char* As = base + (wm * WTM + frag_row) * ROWB + frag_kb;
     const char* Bs = base + BM * ROWB + (wn * WTN + frag_row) * ROWB + frag_kb;
+    if constexpr (sizeof(T) == 1) {
+      // fp8 (e4m3fn): one v_mfma_scale_f32_32x32x64_f8f6f4 (unit block scales) per 64 bytes of K
+      // = two 32-byte k-steps; a lane's 32 operand bytes are its 16 bytes of each of the two
+      // steps (the same K subset for A and B, so the contraction is unchanged)
+      typedef int i32x8 __attribute__((ext_vector_type(8)));
+#pragma unroll
+      for (int kp = 0; kp < KSTEPS / 2; ++kp) {
+        u32x4 fa0[TM], fa1[TM], fb0[TN], fb1[TN];
+        read_frags(As, Bs, 2 * kp, fa0, fb0);
+        read_frags(As, Bs, 2 * kp + 1, fa1, fb1);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const i32x8 a8 = {(int)fa0[i].x, (int)fa0[i].y, (int)fa0[i].z, (int)fa0[i].w,
+                              (int)fa1[i].x, (int)fa1[i].y, (int)fa1[i].z, (int)fa1[i].w};
+            const i32x8 b8 = {(int)fb0[j].x, (int)fb0[j].y, (int)fb0[j].z, (int)fb0[j].w,
+                              (int)fb1[j].x, (int)fb1[j].y, (int)fb1[j].z, (int)fb1[j].w};
+            acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, acc[i][j], 0, 0, 0, 127,
+                                                                        0, 127);
+          }
+      }
+    } else {
     u32x4 fa[2][TM], fb[2][TN];
     read_frags(As, Bs, 0, fa[0], fb[0]);
 #pragma unroll
@@ -576,6 +599,7 @@ __device__ __forceinline__ void igemm_body(const SdmiGemmArgs& p, int tiles_m, i
                   __uint_as_float(a4[c]), __uint_as_float(b4[c]), acc[i][j], 0, 0, 0);
           }
         }
+    }
     }
   }
 
@@ -1175,7 +1199,7 @@ int dispatch(const SdmiGemmArgs& p, hipStream_t st) {
   {
     const int epi = (p.ln_colsum ? 1 : 0) | (p.geglu ? 2 : 0);
     if (epi) {
-      if (!is1x1 || !fits31 || batch != 1 || p.osy != 0 || p.split_k > 1 || p.bias_m || p.residual || p.rowvec) {
+      if (sizeof(T) == 1 || !is1x1 || !fits31 || batch != 1 || p.osy != 0 || p.split_k > 1 || p.bias_m || p.residual || p.rowvec) {
         sdmi_set_error("igemm: LayerNorm-fold / GEGLU epilogues need a plain 1x1 problem without residual / rowvec");
         return SDMI_EUNSUPPORTED;
       }
@@ -1208,7 +1232,7 @@ int dispatch(const SdmiGemmArgs& p, hipStream_t st) {
       const char* e = getenv("SDMI_IGEMM_DMA");
       dma_env = e ? atoi(e) : SDMI_IGEMM_DMA;
     }
-    const bool dma_ok = dma_env && wide && kbytes >= 8 * 128 && split_k == 1 && p.N > 64 && fits31 &&
+    const bool dma_ok = sizeof(T) != 1 && dma_env && wide && kbytes >= 8 * 128 && split_k == 1 && p.N > 64 && fits31 &&
                         (is1x1 || (plain && p.Cin % (128 / (int)sizeof(T)) == 0)) && p.KH * p.KW <= 32;
     if (dma_ok) {
       const long long t256 = ((p.M + 255) / 256) * ((p.N + 127) / 128) * batch;
@@ -1241,9 +1265,11 @@ int dispatch(const SdmiGemmArgs& p, hipStream_t st) {
 
 extern "C" int sdmi_igemm(const SdmiGemmArgs* a, void* stream) {
   SDMI_REQUIRE(a && a->a && a->w && a->out, "null pointer");
-  SDMI_REQUIRE(a->dtype == SDMI_F32 || a->dtype == SDMI_BF16, "bad dtype");
+  SDMI_REQUIRE(a->dtype == SDMI_F32 || a->dtype == SDMI_BF16 || a->dtype == SDMI_FP8, "bad dtype");
   SDMI_REQUIRE(a->out_dtype == SDMI_F32 || a->out_dtype == SDMI_BF16, "bad out_dtype");
-  const int vec = a->dtype == SDMI_BF16 ? 8 : 4;
+  const int vec = a->dtype == SDMI_FP8 ? 16 : (a->dtype == SDMI_BF16 ? 8 : 4);
+  SDMI_REQUIRE(a->dtype != SDMI_FP8 || (a->split_k <= 1 && !(a->batch > 1) && !a->ups && a->zins <= 1),
+               "fp8 operands: plain convolution / linear only (no split-K, batch, upsample fold)");
   SDMI_REQUIRE(a->M > 0 && a->N > 0 && a->K > 0, "empty problem");
   SDMI_REQUIRE(a->K == a->KH * a->KW * a->Cin, "K != KH*KW*Cin");
   SDMI_REQUIRE(a->Cin % vec == 0 && a->lda % vec == 0 && a->ldw % vec == 0,
@@ -1261,5 +1287,6 @@ extern "C" int sdmi_igemm(const SdmiGemmArgs* a, void* stream) {
                "sub-sampled output: the residual shares the output's layout");
   SDMI_REQUIRE(a->osy == 0 || (!a->rowvec && !a->act && !a->bias_m), "sub-sampled output: plain epilogue only");
   hipStream_t st = (hipStream_t)stream;
+  if (a->dtype == SDMI_FP8) return dispatch<fp8_t>(*a, st);
   return a->dtype == SDMI_BF16 ? dispatch<bf16_t>(*a, st) : dispatch<float>(*a, st);
 }

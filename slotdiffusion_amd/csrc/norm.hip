@@ -57,6 +57,15 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(SdmiGroupNormArgs p) {
   }
 }
 
+// e4m3fn copy of 8 activated outputs (one 8-byte store): the fp8 convolution's operand
+__device__ __forceinline__ void gn_store_fp8(const SdmiGroupNormArgs& p, long long elem, const float* f) {
+  uint2 o;
+  const float s = p.y8_scale;
+  o.x = f32x4_to_fp8x4(f[0] * s, f[1] * s, f[2] * s, f[3] * s);
+  o.y = f32x4_to_fp8x4(f[4] * s, f[5] * s, f[6] * s, f[7] * s);
+  *reinterpret_cast<uint2*>((fp8_t*)p.y8 + elem) = o;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void gn_apply_kernel(SdmiGroupNormArgs p, int rows_per) {
   constexpr int VEC = Elem<T>::VEC;
@@ -125,7 +134,10 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(SdmiGroupNormArgs p, int 
       for (int j = 0; j < VEC; ++j) f[j] = act_apply(f[j] * sc[j] + sh[j], p.act);
     }
     if (drop) sdmi_drop_apply<VEC>(f, dseed, (base + o) / VEC, thr16, dinv);
-    *reinterpret_cast<uint4*>(yb + o) = pack16<T>(f);
+    if (p.y) *reinterpret_cast<uint4*>(yb + o) = pack16<T>(f);
+    if constexpr (VEC == 8) {
+      if (p.y8) gn_store_fp8(p, base + o, f);
+    }
   }
 }
 
@@ -239,7 +251,10 @@ __global__ __launch_bounds__(THREADS) void gn_fused_kernel(SdmiGroupNormArgs p) 
         for (int j = 0; j < VEC; ++j) f[j] = act_apply(f[j] * sc[j] + sh[j], p.act);
       }
       if (drop) sdmi_drop_apply<VEC>(f, dseed, (base + o) / VEC, thr16, dinv);
-      *reinterpret_cast<uint4*>(yb + o) = pack16<T>(f);
+      if (p.y) *reinterpret_cast<uint4*>(yb + o) = pack16<T>(f);
+      if constexpr (VEC == 8) {
+        if (p.y8) gn_store_fp8(p, base + o, f);
+      }
     }
   }
 }
@@ -370,7 +385,8 @@ extern "C" int sdmi_groupnorm_stats(const SdmiGroupNormArgs* a, void* stream) {
 extern "C" int sdmi_groupnorm_apply(const SdmiGroupNormArgs* a, void* stream) {
   int rc = gn_validate(a);
   if (rc) return rc;
-  SDMI_REQUIRE(a->y && a->partial, "null output / partial");
+  SDMI_REQUIRE((a->y || a->y8) && a->partial, "null output / partial");
+  SDMI_REQUIRE(!a->y8 || a->dtype == SDMI_BF16, "fp8 output: bf16 input only");
   hipStream_t st = (hipStream_t)stream;
   // ~32 KiB of activations per workgroup, at least one row-sweep each
   const long long row_bytes = (long long)a->C * (a->dtype == SDMI_BF16 ? 2 : 4);
@@ -388,7 +404,8 @@ extern "C" int sdmi_groupnorm_apply(const SdmiGroupNormArgs* a, void* stream) {
 extern "C" int sdmi_groupnorm(const SdmiGroupNormArgs* a, void* stream) {
   int rc = gn_validate(a);
   if (rc) return rc;
-  SDMI_REQUIRE(a->y, "null output");
+  SDMI_REQUIRE(a->y || a->y8, "null output");
+  SDMI_REQUIRE(!a->y8 || a->dtype == SDMI_BF16, "fp8 output: bf16 input only");
   const int vec = a->dtype == SDMI_BF16 ? 8 : 4;
   // single-pass kernel when the image (or a whole-group channel chunk of it) fits a workgroup's registers
   {

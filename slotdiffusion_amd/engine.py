@@ -180,10 +180,12 @@ class UNetRunner:
         n = self.P + name
         off, cout = self.emb_off[name]
         rv = rowvecs[:, off:off + cout]            # strided view; the kernel takes its row pitch
-        outs = K.gn_fan(x, n + '.in_layers.0', eps=1e-5, act='silu', n_alias=2 if want_cat else 1)
+        outs = K.gn_fan(x, n + '.in_layers.0', eps=1e-5, act='silu', n_alias=2 if want_cat else 1,
+                        for_conv=n + '.in_layers.2.weight')
         h, skip = outs[0], outs[1]
         h = K.conv(h, n + '.in_layers.2.weight', n + '.in_layers.2.bias', rowvec=rv)
-        h = K.gn(h, n + '.out_layers.0', eps=1e-5, act='silu', dropout='unet')   # training only
+        h = K.gn(h, n + '.out_layers.0', eps=1e-5, act='silu', dropout='unet',      # (dropout: training only)
+                 for_conv=n + '.out_layers.3.weight')
         if (n + '.skip_connection.weight') in K.wb.t:
             skip = K.conv(skip, n + '.skip_connection.weight', n + '.skip_connection.bias', kh=1, kw=1,
                           pad=(0, 0, 0, 0))

@@ -41,6 +41,7 @@ def _dbg(tag, **tensors):
         print(f'[bwd] {tag}: {msg}', flush=True)
 
 
+FP8_ACT_SCALE = 8.0        # activations -> e4m3fn: +-56 representable, 2^-9 resolution near zero
 _LN_FOLD = os.environ.get('SDMI_LN_FOLD', '1') != '0'
 
 
@@ -295,6 +296,22 @@ class WeightBank:
         self.cache[key] = out
         return out
 
+    def w8(self, name):
+        """e4m3fn operand of a conv / linear weight with its per-tensor scale: (bytes [N][K],
+        1 / scale), scale = 448 / amax.  Weight preparation (inference: once per weight update); the
+        amax read-back synchronises, so the first use must precede any graph capture (the samplers'
+        warm-up pass does)."""
+        key = ('fp8', name)
+        if key not in self.cache:
+            p = self.t[name]
+            flat = self._flat(name, torch.float32)
+            if flat is None:
+                raise _lib.SdmiError(f'{name}: fp8 operands need 16-byte input-channel rows')
+            amax = float(p.detach().abs().max())
+            scale = 448.0 / max(amax, 1e-12)
+            self.cache[key] = (ops.quant_fp8(flat.float().contiguous(), scale), 1.0 / scale)
+        return self.cache[key]
+
     def ln_folded(self, ln_name, wnames, bnames, dtype):
         """Operands of a LayerNorm folded into the linear layer behind it (sdmi.h: ln_colsum):
         W' = W * gamma in `dtype`, colsum[n] = sum_k W'[n][k] of the rounded W', bias' = W beta + b.
@@ -402,26 +419,46 @@ class Kern:
 
     def conv(self, x, wname, bname=None, *, kh=3, kw=3, stride=1, pad=(1, 1, 1, 1), ups=False,
              rowvec=None, residual=None, out_dtype=None, ldc=None):
+        if x.dtype == torch.uint8 or self.fp8_ok(x, wname, kh * kw, ups):
+            # BASELINE "fp8 MFMA UNet": e4m3fn operands (activations at a fixed scale -- written by
+            # the GroupNorm in front when there is one -- weights at 448 / amax), fp32 accumulation,
+            # the scales undone in the epilogue's alpha
+            w8, inv = self.wb.w8(wname)
+            x8 = x if x.dtype == torch.uint8 else ops.quant_fp8(x, FP8_ACT_SCALE)
+            return ops.conv2d(x8, w8, self.wb.b(bname), kh=kh, kw=kw,
+                              stride=stride, pad=pad, rowvec=rowvec, residual=residual,
+                              out_dtype=out_dtype or self.wb.dtype, ldc=ldc, alpha=inv / FP8_ACT_SCALE)
         return ops.conv2d(x, self.wb.w(wname, x.dtype), self.wb.b(bname), kh=kh, kw=kw,
                           stride=stride, pad=pad, ups=ups, rowvec=rowvec, residual=residual,
                           out_dtype=out_dtype, ldc=ldc)
+
+    def fp8_ok(self, x, wname, taps, ups):
+        """fp8 operands for the UNet's 3x3 convolutions (bf16 storage path, >= 64 input channels in
+        16-byte rows); everything else -- 1x1 / linear layers, attention, the 3 / 4-channel
+        in / out convolutions, the VQ-VAE and the slot encoder -- stays bf16."""
+        return (getattr(self.wb.model, 'fp8_unet', False) and x.dtype == torch.bfloat16 and taps > 1
+                and not ups and x.shape[-1] % 16 == 0 and x.shape[-1] >= 64
+                and wname.startswith(self.wb.model.fp8_prefix))
 
     def linear(self, x, wnames, bnames=None, *, act=None, residual=None, out_dtype=None):
         return ops.linear(x, self.wb.w(wnames, x.dtype), self.wb.b(bnames), act=act,
                           residual=residual, out_dtype=out_dtype)
 
-    def gn(self, x, name, *, eps, act=None, residual=None, dropout=None):
-        """dropout = site name: training-mode dropout behind the activation (no-op at inference)."""
+    def gn(self, x, name, *, eps, act=None, residual=None, dropout=None, for_conv=None):
+        """dropout = site name: training-mode dropout behind the activation (no-op at inference).
+        for_conv = weight name of the 3x3 convolution that is the output's only reader: in the fp8
+        configuration the norm writes that convolution's e4m3fn operand directly."""
+        f8 = FP8_ACT_SCALE if (for_conv and self.fp8_ok(x, for_conv, 9, False)) else None
         return ops.group_norm(x, self.wb.f(name + '.weight'), self.wb.f(name + '.bias'), eps=eps,
-                              act=act, residual=residual)
+                              act=act, residual=residual, fp8_scale=f8)
 
     def linear_multi(self, x, wname_list):
         """Several bias-free projections of one input -> tuple of outputs."""
         return tuple(self.linear(x, n) for n in wname_list)
 
     # fan-out forms: (result, alias(es) of x for x's other consumers) -- plain x at inference
-    def gn_fan(self, x, name, *, eps, act=None, residual=None, n_alias=1):
-        return (self.gn(x, name, eps=eps, act=act, residual=residual),) + (x,) * n_alias
+    def gn_fan(self, x, name, *, eps, act=None, residual=None, n_alias=1, for_conv=None):
+        return (self.gn(x, name, eps=eps, act=act, residual=residual, for_conv=for_conv),) + (x,) * n_alias
 
     def ln_fan(self, x, name):
         return self.ln(x, name), x
@@ -1413,7 +1450,7 @@ class KernGrad(Kern):
                          (0, 0, 1, (0, 0, 0, 0), False), out_dtype, None)
         return ActFn.apply(y, act) if act else y
 
-    def gn(self, x, name, *, eps, act=None, residual=None, dropout=None):
+    def gn(self, x, name, *, eps, act=None, residual=None, dropout=None, for_conv=None):
         drop = None
         if dropout is not None:
             p = self._p_drop(dropout)
@@ -1422,7 +1459,7 @@ class KernGrad(Kern):
                 drop = (p, (self.seed << 20) + self._drop_ctr, getattr(self.wb.model, 'step_seed', None))
         return GroupNormFn.apply(x, residual, self.wb.anchor_for(name), self.wb, name, eps, act, 0, drop)
 
-    def gn_fan(self, x, name, *, eps, act=None, residual=None, n_alias=1):
+    def gn_fan(self, x, name, *, eps, act=None, residual=None, n_alias=1, for_conv=None):
         return GroupNormFn.apply(x, residual, self.wb.anchor_for(name), self.wb, name, eps, act, n_alias)
 
     def linear_fan(self, x, wnames, bnames=None):

@@ -241,7 +241,15 @@ class SlotModelBase(FlatModule):
     def dtype(self):
         return self.init_latents.dtype
 
+    # 'fp8': bf16 storage with e4m3fn operands on the denoiser's 3x3 convolutions at inference
+    # (BASELINE config 5, "fp8 MFMA UNet"; kern.Kern.conv); training keeps bf16 operands
+    fp8_unet = False
+    fp8_prefix = 'dm_decoder.model.'
+
     def set_compute_dtype(self, dt):
+        self.fp8_unet = isinstance(dt, str) and dt.lower() == 'fp8'
+        if self.fp8_unet:
+            dt = 'bf16'
         self.compute_dtype = _DTYPES[dt] if isinstance(dt, str) else dt
         self.invalidate_weights()
         return self

@@ -6,9 +6,9 @@ stream; every FLOP happens in the hand-written kernels of ``csrc/``.  All activa
 import torch
 
 from . import _lib
-from ._lib import ACT, BF16, F32, call
+from ._lib import ACT, BF16, F32, FP8, call
 
-_DT = {torch.float32: F32, torch.bfloat16: BF16}
+_DT = {torch.float32: F32, torch.bfloat16: BF16, torch.uint8: FP8}   # uint8 = raw e4m3fn bytes
 
 
 def _stream():
@@ -56,11 +56,25 @@ def splitk_workspace(M, N, K, elt, device):
     return None
 
 
+def quant_fp8(x, scale, out=None):
+    """Per-tensor e4m3fn quantisation of a contiguous [..., C] tensor (C % 16 == 0): uint8 bytes of
+    clamp(x * scale, +-448).  Operands of the SDMI_FP8 igemm path."""
+    _need_gpu(x)
+    C = x.shape[-1]
+    assert x.is_contiguous() and C % 16 == 0
+    if out is None:
+        out = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+    call('sdmi_quant_fp8', _stream(), src=_p(x), dst=_p(out), src_dtype=_dt(x), rows=x.numel() // C,
+         cols=C, lds=C, ldd=C, scale=float(scale))
+    return out
+
+
 def conv2d(x, w, bias=None, *, kh=3, kw=3, stride=1, pad=(1, 1, 1, 1), ups=False, cout=None,
            rowvec=None, residual=None, act=None, out=None, out_dtype=None, ldc=None,
-           split_k=0):
+           split_k=0, alpha=1.0):
     """x [B,H,W,Cin] NHWC; w [Cout][kh][kw][Cin] (flat or 4-D channels_last view).
-    pad = (top, bottom, left, right).  Returns [B,Ho,Wo,ldc or Cout]."""
+    pad = (top, bottom, left, right).  Returns [B,Ho,Wo,ldc or Cout].
+    uint8 x / w = e4m3fn operands (quant_fp8): out_dtype is required, alpha undoes the scales."""
     _need_gpu(x, w)
     B, H, W, Cin = x.shape
     assert x.is_contiguous()
@@ -77,12 +91,15 @@ def conv2d(x, w, bias=None, *, kh=3, kw=3, stride=1, pad=(1, 1, 1, 1), ups=False
         if ldc != N:                      # channel-pad columns must read as zeros downstream
             zero_(out)
     M = B * Ho * Wo
+    if x.dtype == torch.uint8:
+        assert out_dtype is not None and w.dtype == torch.uint8
+        split_k = 1
     ws = splitk_workspace(M, N, K, x.element_size(), x.device) if split_k != 1 else None
     call('sdmi_igemm', _stream(), a=_p(x), w=_p(w), out=_p(out), bias=_p(bias), rowvec=_p(rowvec),
          residual=_p(residual), workspace=_p(ws), dtype=_dt(x), out_dtype=_DT[odt], M=M, N=N, K=K,
          lda=Cin, ldw=K, ldc=ldc, ldr=(residual.shape[-1] if residual is not None else 0),
          B=B, H=H, W=W, Cin=Cin, Ho=Ho, Wo=Wo, KH=kh, KW=kw, stride=stride, pad_t=pad[0],
-         pad_l=pad[2], ups=int(ups), act=ACT[act], alpha=1.0, bias_m=0,
+         pad_l=pad[2], ups=int(ups), act=ACT[act], alpha=float(alpha), bias_m=0,
          ldrv=(rowvec.stride(0) if rowvec is not None else 0),
          split_k=(split_k if ws is not None or split_k == 1 else 1), batch=1)
     return out
@@ -134,18 +151,24 @@ def bmm_nt(a, b, out, *, alpha=1.0, bias_m=None):
 # normalisation
 # ------------------------------------------------------------------------------------------
 def group_norm(x, gamma, beta, *, eps, act=None, groups=32, residual=None, out=None,
-               return_stats=False, drop=None):
+               return_stats=False, drop=None, fp8_scale=None):
     """x [B,H,W,C] (or [B,HW,C]) NHWC -> same shape; fp32 statistics.  drop = (p, seed, seed_dev):
-    inverted dropout fused behind the activation (training-mode ResBlocks)."""
+    inverted dropout fused behind the activation (training-mode ResBlocks).  fp8_scale: the output
+    is written as e4m3fn bytes (uint8 tensor) for the fp8 convolution behind the norm."""
     _need_gpu(x)
     B, C = x.shape[0], x.shape[-1]
     HW = x.numel() // (B * C)
     nsplit = max(1, min(16, HW // 64))
     partial = torch.empty((B * nsplit * groups * 2,), dtype=torch.float32, device=x.device)
     stats = torch.empty((B, groups, 2), dtype=torch.float32, device=x.device)
-    if out is None:
-        out = torch.empty_like(x)
-    kw = dict(x=_p(x), y=_p(out), gamma=_p(gamma), beta=_p(beta), stats=_p(stats),
+    if fp8_scale is not None:
+        out = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+        kw = dict(y=0, y8=_p(out), y8_scale=float(fp8_scale))
+    else:
+        if out is None:
+            out = torch.empty_like(x)
+        kw = dict(y=_p(out))
+    kw.update(x=_p(x), gamma=_p(gamma), beta=_p(beta), stats=_p(stats),
               partial=_p(partial), dtype=_dt(x), B=B, HW=HW, C=C, groups=groups, eps=eps,
               act=ACT[act], nsplit=nsplit, residual=_p(residual))
     if drop is not None and drop[0] > 0.0:

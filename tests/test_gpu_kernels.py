@@ -173,6 +173,43 @@ def test_igemm_layernorm_fold_and_geglu(mnk, geglu, dtype):
         check(out3, F.relu(ref), dtype, f'ln-fold relu {mnk}')
 
 
+def _e4m3(t):
+    """fp32 -> nearest e4m3fn value (saturating at +-448), via torch's own float8 type on the CPU."""
+    return t.clamp(-448, 448).to(torch.float8_e4m3fn).float()
+
+
+@pytest.mark.parametrize('case', [(2, 16, 16, 64, 96, 3, 1), (2, 28, 28, 128, 128, 3, 1), (1, 14, 14, 256, 320, 3, 2),
+                                  (64, 8, 8, 128, 64, 1, 1), (3, 9, 11, 80, 72, 3, 1)])
+def test_igemm_fp8_operands(case):
+    """SDMI_FP8: e4m3fn operands (sdmi_quant_fp8) through v_mfma_scale_f32_32x32x64_f8f6f4.  The
+    quantiser must equal torch's e4m3fn rounding bit for bit; the convolution must equal the fp32
+    convolution of the DEQUANTISED operands (fp32 accumulation: only summation order differs)."""
+    ops = _ops()
+    B, H, W, Cin, Cout, k, stride = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(B, Cin, H, W, generator=g) * 1.3
+    w = torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k)
+    b = torch.randn(Cout, generator=g)
+    sx, sw = 8.0, 448.0 / float(w.abs().max())
+    xq = ops.quant_fp8(x.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(DEV), sx)
+    wq = ops.quant_fp8(w.permute(0, 2, 3, 1).reshape(Cout, -1).contiguous().to(DEV), sw)
+    x_ref = _e4m3(x.to(torch.bfloat16).float() * sx)
+    w_ref = _e4m3(w * sw)
+    assert torch.equal(xq.cpu().view(torch.float8_e4m3fn).float(), x_ref.permute(0, 2, 3, 1))
+    assert torch.equal(wq.cpu().view(torch.float8_e4m3fn).float().view(Cout, k, k, Cin), w_ref.permute(0, 2, 3, 1))
+    pad = k // 2
+    ref = F.conv2d(x_ref, w_ref, None, stride=stride, padding=pad) / (sx * sw) + b.view(1, -1, 1, 1)
+    out = ops.conv2d(xq, wq, b.to(DEV), kh=k, kw=k, stride=stride, pad=(pad,) * 4, out_dtype=torch.float32,
+                     alpha=1.0 / (sx * sw))
+    # (the f8f6f4 MFMA adds its 64 products per instruction with a bounded-width adder tree: a few
+    # 1e-5 relative to the output scale, against 2e-5 for the fp32-accumulating bf16 / fp32 paths)
+    o, scale = out.permute(0, 3, 1, 2).float().cpu(), float(ref.abs().max())
+    assert float((o - ref).abs().max()) <= 1e-4 * scale, f'fp8 conv {case}'
+    # and it stays close to the unquantised convolution (e4m3: 3 mantissa bits per operand)
+    full = F.conv2d(x, w, b, stride=stride, padding=pad)
+    assert rel_l2(out.permute(0, 3, 1, 2), full) <= 6e-2
+
+
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 def test_bmm_nt_and_softmax(dtype):
     ops = _ops()

@@ -647,3 +647,42 @@ def C_xt(G, x0, noise):
     a = torch.tensor(s['sqrt_alphas_bar'], dtype=torch.float32)[t]
     b = torch.tensor(s['sqrt_one_minus_alphas_bar'], dtype=torch.float32)[t]
     return a * G['x0'] + b * noise
+
+
+def test_fp8_unet_coco_config_deviation():
+    """BASELINE config 5 ("fp8 MFMA UNet"): the COCO-224 DINO model with e4m3fn operands on the
+    denoiser's 3x3 convolutions (compute 'fp8' = bf16 storage + fp8 conv operands) against the
+    reference run in sadiff_dino_b1.npz, next to the plain bf16 path: deviations reported and
+    bounded (the fp8 bound leaves ~1.5x head-room over the value measured on MI355X)."""
+    from slotdiffusion_amd.models import SADiffusion
+    from slotdiffusion_amd import ops
+    cfg = C.dino_coco_cfg()
+    G = C.load_golden('sadiff_dino_b1.npz')
+    img, noise = C.dino_inputs()
+    R = {}
+    for mode in ('bf16', 'fp8'):
+        m = SADiffusion(cfg['resolution'], cfg['slot_dict'], cfg['enc_dict'], cfg['dec_dict'],
+                        cfg['loss_dict'], compute_dtype=torch.bfloat16)
+        det_fill_(m.state_dict().items(), skip=is_buffer_name)
+        m = m.cuda().eval()
+        m.set_compute_dtype(mode)
+        m.use_graph = False
+        assert m.fp8_unet == (mode == 'fp8') and m.compute_dtype == torch.bfloat16
+        with torch.no_grad():
+            xt = m._latent_nhwc(C_xt(G, None, noise).cuda())
+            eps = ops.nhwc_to_nchw(m._unet_eps(xt, G['t'].float().cuda(), G['slots'].cuda()), 3)
+        R[mode + '_eps_rel_l2'] = float((eps.cpu() - G['eps_pred']).norm() / G['eps_pred'].norm())
+        if mode == 'fp8':
+            from slotdiffusion_amd import _lib
+            with _lib.KernelTimer() as kt:
+                with torch.no_grad():
+                    m._unet_eps(xt, G['t'].float().cuda(), G['slots'].cuda())
+            torch.cuda.synchronize()
+            R['fp8_igemm_launches'] = sum(1 for r in kt.records if r[0] == 'sdmi_igemm' and r[3].get('fp8'))
+            R['fp8_quant_launches'] = sum(1 for r in kt.records if r[0] == 'sdmi_quant_fp8')
+    REPORT['fp8_coco224'] = R
+    _dump()
+    # the ResBlock convolutions really ran on fp8 operands, written by the GroupNorms in front of them
+    assert R['fp8_igemm_launches'] >= 40 and R['fp8_quant_launches'] <= 8
+    assert R['bf16_eps_rel_l2'] < 0.03
+    assert R['fp8_eps_rel_l2'] < 0.10
