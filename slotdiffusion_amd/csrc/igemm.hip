@@ -1268,8 +1268,8 @@ extern "C" int sdmi_igemm(const SdmiGemmArgs* a, void* stream) {
   SDMI_REQUIRE(a->dtype == SDMI_F32 || a->dtype == SDMI_BF16 || a->dtype == SDMI_FP8, "bad dtype");
   SDMI_REQUIRE(a->out_dtype == SDMI_F32 || a->out_dtype == SDMI_BF16, "bad out_dtype");
   const int vec = a->dtype == SDMI_FP8 ? 16 : (a->dtype == SDMI_BF16 ? 8 : 4);
-  SDMI_REQUIRE(a->dtype != SDMI_FP8 || (a->split_k <= 1 && !(a->batch > 1) && !a->ups && a->zins <= 1),
-               "fp8 operands: plain convolution / linear only (no split-K, batch, upsample fold)");
+  SDMI_REQUIRE(a->dtype != SDMI_FP8 || (!(a->batch > 1) && !a->ups && a->zins <= 1),
+               "fp8 operands: plain convolution / linear only (no batch, upsample fold)");
   SDMI_REQUIRE(a->M > 0 && a->N > 0 && a->K > 0, "empty problem");
   SDMI_REQUIRE(a->K == a->KH * a->KW * a->Cin, "K != KH*KW*Cin");
   SDMI_REQUIRE(a->Cin % vec == 0 && a->lda % vec == 0 && a->ldw % vec == 0,

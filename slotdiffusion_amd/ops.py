@@ -93,7 +93,6 @@ def conv2d(x, w, bias=None, *, kh=3, kw=3, stride=1, pad=(1, 1, 1, 1), ups=False
     M = B * Ho * Wo
     if x.dtype == torch.uint8:
         assert out_dtype is not None and w.dtype == torch.uint8
-        split_k = 1
     ws = splitk_workspace(M, N, K, x.element_size(), x.device) if split_k != 1 else None
     call('sdmi_igemm', _stream(), a=_p(x), w=_p(w), out=_p(out), bias=_p(bias), rowvec=_p(rowvec),
          residual=_p(residual), workspace=_p(ws), dtype=_dt(x), out_dtype=_DT[odt], M=M, N=N, K=K,
