@@ -66,7 +66,7 @@ __device__ __forceinline__ void gn_store_fp8(const SdmiGroupNormArgs& p, long lo
   *reinterpret_cast<uint2*>((fp8_t*)p.y8 + elem) = o;
 }
 
-template <typename T>
+template <typename T, bool F8 = false>
 __global__ __launch_bounds__(256) void gn_apply_kernel(SdmiGroupNormArgs p, int rows_per) {
   constexpr int VEC = Elem<T>::VEC;
   __shared__ float s_stats[128][2];
@@ -134,10 +134,8 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(SdmiGroupNormArgs p, int 
       for (int j = 0; j < VEC; ++j) f[j] = act_apply(f[j] * sc[j] + sh[j], p.act);
     }
     if (drop) sdmi_drop_apply<VEC>(f, dseed, (base + o) / VEC, thr16, dinv);
-    if (p.y) *reinterpret_cast<uint4*>(yb + o) = pack16<T>(f);
-    if constexpr (VEC == 8) {
-      if (p.y8) gn_store_fp8(p, base + o, f);
-    }
+    if constexpr (F8) gn_store_fp8(p, base + o, f);
+    else *reinterpret_cast<uint4*>(yb + o) = pack16<T>(f);
   }
 }
 
@@ -148,7 +146,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(SdmiGroupNormArgs p, int 
 // across the lanes that share a vector column with xor-butterflies, so the LDS combine (fp64) only
 // walks one entry per wave.  Wide workgroups keep whole 128-byte lines per row segment even when the
 // image needs many row passes (THREADS / CVp rows per pass).
-template <typename T, int THREADS, int NV>
+template <typename T, int THREADS, int NV, bool F8 = false>
 __global__ __launch_bounds__(THREADS) void gn_fused_kernel(SdmiGroupNormArgs p) {
   constexpr int VEC = Elem<T>::VEC;
   extern __shared__ __attribute__((aligned(16))) float gn_smem[];
@@ -198,13 +196,20 @@ __global__ __launch_bounds__(THREADS) void gn_fused_kernel(SdmiGroupNormArgs p) 
   __syncthreads();
   const int cpg = p.C / p.groups;
   const int gs = p.groups / S;               // groups of this chunk
-  if ((int)threadIdx.x < 2 * gs) {           // 2 threads per group: (sum | sumsq), fp64 combine
+  // two-stage fp64 combine (fixed order): one thread per (channel, sum) folds the RR row entries,
+  // then 2 threads per group fold the group's channels
+  for (int t = threadIdx.x; t < CV * VEC * 2; t += THREADS) {      // one thread per (channel, sum | sumsq)
+    const int ccv = t / (VEC * 2), j = (t >> 1) % VEC, which = t & 1;
+    double a = 0.0;
+    for (int r = 0; r < RR; ++r) a += (double)part[r * CVp + ccv][j][which];
+    // entry 0 of the column is only read by this thread's own fold: safe to overwrite after it
+    part[ccv][j][which] = (float)a;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < 2 * gs) {
     const int g = threadIdx.x >> 1, which = threadIdx.x & 1;
     double acc = 0.0;
-    for (int c = g * cpg; c < (g + 1) * cpg; ++c) {      // c: channel inside the chunk
-      const int ccv = c / VEC, j = c % VEC;
-      for (int r = 0; r < RR; ++r) acc += (double)part[r * CVp + ccv][j][which];
-    }
+    for (int c = g * cpg; c < (g + 1) * cpg; ++c) acc += (double)part[c / VEC][c % VEC][which];
     const double other = __shfl_xor(acc, 1, 64);
     const double sum = which ? other : acc, sq = which ? acc : other;
     const double n = (double)p.HW * cpg;
@@ -251,10 +256,10 @@ __global__ __launch_bounds__(THREADS) void gn_fused_kernel(SdmiGroupNormArgs p) 
         for (int j = 0; j < VEC; ++j) f[j] = act_apply(f[j] * sc[j] + sh[j], p.act);
       }
       if (drop) sdmi_drop_apply<VEC>(f, dseed, (base + o) / VEC, thr16, dinv);
-      if (p.y) *reinterpret_cast<uint4*>(yb + o) = pack16<T>(f);
-      if constexpr (VEC == 8) {
-        if (p.y8) gn_store_fp8(p, base + o, f);
-      }
+      // (the e4m3fn output is its own instantiation: as a run-time branch it pushed the 16-vector
+      // variants of the plain kernel into scratch)
+      if constexpr (F8) gn_store_fp8(p, base + o, f);
+      else *reinterpret_cast<uint4*>(yb + o) = pack16<T>(f);
     }
   }
 }
@@ -394,7 +399,9 @@ extern "C" int sdmi_groupnorm_apply(const SdmiGroupNormArgs* a, void* stream) {
   if (rows_per < 4) rows_per = 4;
   if (rows_per > a->HW) rows_per = a->HW;
   dim3 grid((a->HW + rows_per - 1) / rows_per, a->B);
-  if (a->dtype == SDMI_BF16)
+  if (a->dtype == SDMI_BF16 && a->y8)
+    hipLaunchKernelGGL((gn_apply_kernel<bf16_t, true>), grid, dim3(256), 0, st, *a, rows_per);
+  else if (a->dtype == SDMI_BF16)
     hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, grid, dim3(256), 0, st, *a, rows_per);
   else
     hipLaunchKernelGGL(gn_apply_kernel<float>, grid, dim3(256), 0, st, *a, rows_per);
@@ -419,27 +426,37 @@ extern "C" int sdmi_groupnorm(const SdmiGroupNormArgs* a, void* stream) {
       while (cvp < cv) cvp <<= 1;
       const int RR = cvp < 64 ? gg.T / 64 : gg.T / cvp;
       const size_t smem = ((size_t)RR * cvp * vec * 2 + 2 * 128) * sizeof(float);
-#define GN_GO2(T_, TH, NV_)                                                                        \
+#define GN_GO3(T_, TH, NV_, F8_)                                                                   \
   do {                                                                                             \
     static bool attr = false;                                                                      \
     if (!attr) {                                                                                   \
-      (void)hipFuncSetAttribute((const void*)gn_fused_kernel<T_, TH, NV_>,                         \
+      (void)hipFuncSetAttribute((const void*)gn_fused_kernel<T_, TH, NV_, F8_>,                    \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);            \
       attr = true;                                                                                 \
     }                                                                                              \
-    hipLaunchKernelGGL((gn_fused_kernel<T_, TH, NV_>), grid, dim3(TH), smem, st, *a);              \
+    hipLaunchKernelGGL((gn_fused_kernel<T_, TH, NV_, F8_>), grid, dim3(TH), smem, st, *a);         \
   } while (0)
+#define GN_GO2(T_, TH, NV_) GN_GO3(T_, TH, NV_, false)
       // fewest registers that hold the slab: more workgroups per CU
 #define GN_GO(T_, TH)                                                                              \
   do {                                                                                             \
     if (gg.need <= 4) GN_GO2(T_, TH, 4); else if (gg.need <= 8) GN_GO2(T_, TH, 8); else GN_GO2(T_, TH, 16); \
   } while (0)
-      if (a->dtype == SDMI_BF16) {
+      if (a->dtype == SDMI_BF16 && a->y8) {           // e4m3fn output (inference)
+#define GN_GO8(TH)                                                                                 \
+  do {                                                                                             \
+    if (gg.need <= 4) GN_GO3(bf16_t, TH, 4, true); else if (gg.need <= 8) GN_GO3(bf16_t, TH, 8, true); \
+    else GN_GO3(bf16_t, TH, 16, true);                                                             \
+  } while (0)
+        if (gg.T == 1024) GN_GO8(1024); else if (gg.T == 512) GN_GO8(512); else GN_GO8(256);
+#undef GN_GO8
+      } else if (a->dtype == SDMI_BF16) {
         if (gg.T == 1024) GN_GO(bf16_t, 1024); else if (gg.T == 512) GN_GO(bf16_t, 512); else GN_GO(bf16_t, 256);
       } else {
         if (gg.T == 1024) GN_GO(float, 1024); else if (gg.T == 512) GN_GO(float, 512); else GN_GO(float, 256);
       }
 #undef GN_GO2
+#undef GN_GO3
 #undef GN_GO
       return sdmi_check_launch("groupnorm (fused)");
     }
