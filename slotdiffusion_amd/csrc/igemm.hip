@@ -552,16 +552,24 @@ __device__ __forceinline__ void igemm_body(const SdmiGemmArgs& p, int tiles_m, i
           }
       }
     } else {
-    u32x4 fa[2][TM], fb[2][TN];
-    read_frags(As, Bs, 0, fa[0], fb[0]);
+    // fragments double buffered, except in the fused-epilogue variants of the 128 x 128 tile: their
+    // row-sum registers and epilogue operands do not fit next to 64 accumulators + two fragment
+    // sets under the 128-VGPR budget (the spills cost more than the exposed LDS latency)
+    constexpr int NFB = (EPI != 0 && TM * TN >= 4) ? 1 : 2;
+    u32x4 fa[NFB][TM], fb[NFB][TN];
+    if constexpr (NFB == 2) read_frags(As, Bs, 0, fa[0], fb[0]);
 #pragma unroll
     for (int ks = 0; ks < KSTEPS; ++ks) {
-      if (ks + 1 < KSTEPS) read_frags(As, Bs, ks + 1, fa[(ks + 1) & 1], fb[(ks + 1) & 1]);
+      if constexpr (NFB == 2) {
+        if (ks + 1 < KSTEPS) read_frags(As, Bs, ks + 1, fa[(ks + 1) & 1], fb[(ks + 1) & 1]);
+      } else {
+        read_frags(As, Bs, ks, fa[0], fb[0]);
+      }
       __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ahead of this k-step's MFMAs
       if constexpr (LNF) {
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-          const u32x4 a4 = fa[ks & 1][i];
+          const u32x4 a4 = fa[ks & (NFB - 1)][i];
           if constexpr (sizeof(T) == 2) {
             // (explicit lanes: indexing the vector inside an unrolled loop was miscompiled to lane 0)
             const sdmi_bf16x2 ones = __builtin_bit_cast(sdmi_bf16x2, 0x3F803F80u);
@@ -588,7 +596,7 @@ __device__ __forceinline__ void igemm_body(const SdmiGemmArgs& p, int tiles_m, i
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-          const u32x4 a4 = fa[ks & 1][i], b4 = fb[ks & 1][j];
+          const u32x4 a4 = fa[ks & (NFB - 1)][i], b4 = fb[ks & (NFB - 1)][j];
           if constexpr (sizeof(T) == 2) {
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
                 __builtin_bit_cast(bf16x8, a4), __builtin_bit_cast(bf16x8, b4), acc[i][j], 0, 0, 0);
