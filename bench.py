@@ -25,6 +25,7 @@ import json
 import os
 
 os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')   # dmabuf IPC (RCCL across processes)
+os.environ.setdefault('DEBUG_HIP_FORCE_GRAPH_QUEUES', '2')  # see slotdiffusion_amd/__init__.py
 import sys
 import time
 

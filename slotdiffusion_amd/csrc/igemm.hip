@@ -1160,6 +1160,22 @@ int dispatch(const SdmiGemmArgs& p, hipStream_t st) {
     // with K = 576 the prologue / epilogue of each tile is no longer hidden by a neighbour)
     if (tm128 * batch >= 192) shape = T128x64;
   }
+  {
+    // experiment knob: shallow-K 1x1 problems on 64x64 tiles (more, shorter workgroups)
+    static int t64_kb = -1;
+    if (t64_kb < 0) {
+      const char* e = getenv("SDMI_IGEMM_T64_MAXKB");
+      t64_kb = e ? atoi(e) : 0;
+    }
+    if (t64_kb > 0 && is1x1 && p.K * (int)sizeof(T) <= t64_kb && shape == T128x128) shape = T64x64;
+    // experiment knob: 128x64 tiles when 128x128 gives fewer than this many workgroups
+    static int t12864 = -1;
+    if (t12864 < 0) {
+      const char* e = getenv("SDMI_IGEMM_T128X64_BELOW");
+      t12864 = e ? atoi(e) : 0;
+    }
+    if (t12864 > 0 && shape == T128x128 && t128 < t12864 && !is1x1) shape = T128x64;
+  }
   const bool big = shape != T64x64;
   // K tile: 128 bytes of K per row when K is deep enough, else 64
   const int kbytes = p.K * (int)sizeof(T);

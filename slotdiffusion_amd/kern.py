@@ -42,6 +42,7 @@ def _dbg(tag, **tensors):
 
 
 FP8_ACT_SCALE = 8.0        # activations -> e4m3fn: +-56 representable, 2^-9 resolution near zero
+_WG_MAIN_BELOW = float(os.environ.get('SDMI_WGRAD_MAIN_BELOW_GF', '0')) * 1e9
 _LN_FOLD = os.environ.get('SDMI_LN_FOLD', '1') != '0'
 
 
@@ -657,8 +658,12 @@ class GemmFn(torch.autograd.Function):
                                 K=K, lda=lda, ldy=ldy, B=B, H=H, W=W_, Cin=Cin, Ho=Ho, Wo=Wo, KH=1, KW=1,
                                 stride=1, pad_t=0, pad_l=0, ups=0, accumulate=1),
                            (x, dy), tiles, (M + 63) // 64, (x.numel() + dy.numel()) * 2)
+        elif os.environ.get('SDMI_EXP_SKIP_WGRAD') == '1':
+            pass            # measurement only (wrong gradients): the step without weight gradients
         else:
             side = wb.side_stream(names[0])
+            if side is not None and 2.0 * M * N * K < _WG_MAIN_BELOW:
+                side = None                  # small contraction: not worth a cross-stream edge
             if side is not None:
                 ev = torch.cuda.Event()
                 ev.record()
@@ -757,6 +762,13 @@ class GemmFn(torch.autograd.Function):
                 btmp = torch.empty((N,), dtype=torch.float32, device=x.device)
                 if acc:
                     ops.zero_(btmp)
+        if os.environ.get('SDMI_EXP_WGRAD_TINY') == '1':   # measurement only: same launches, ~no work
+            if is_conv:
+                B, Ho = 1, min(Ho, max(1, 64 // Wo))
+                M = B * Ho * Wo
+            else:
+                M = B = min(M, 64)
+            splits = 1
         call('sdmi_wgrad', _st(), a=_p(x), dy=_p(dy), dw=_p(dwbuf), dbias=_p(btmp),
              workspace=_p(ws), dtype=_DT[dt], M=M, N=N, K=K,
              lda=(Cin if is_conv else x.stride(-2)), ldy=ldy, B=B, H=H, W=W_,

@@ -61,6 +61,9 @@ for fname, kw, e0, e1 in recs:
     if fname == 'sdmi_igemm':
         key = (fname, kw['M'], kw['N'], kw['K'], kw['KH'], kw['stride'], kw.get('ups', 0), kw.get('batch', 1))
         fl = 2.0 * kw['M'] * kw['N'] * kw['K'] * max(1, kw.get('batch', 1))
+    elif fname == 'sdmi_wgrad':
+        key = (fname, kw['M'], kw['N'], kw['K'], kw['KH'], kw['stride'], kw.get('splits', 1))
+        fl = 2.0 * kw['M'] * kw['N'] * kw['K']
     else:
         key = (fname,)
         fl = 0
