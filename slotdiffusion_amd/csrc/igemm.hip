@@ -1161,11 +1161,13 @@ int dispatch(const SdmiGemmArgs& p, hipStream_t st) {
     if (tm128 * batch >= 192) shape = T128x64;
   }
   {
-    // experiment knob: shallow-K 1x1 problems on 64x64 tiles (more, shorter workgroups)
+    // shallow-K 1x1 problems (<= 512 bytes of K per row: two K tiles) on 64x64 tiles: more, shorter
+    // workgroups.  Slower per launch in isolation (10.4 vs 9.7 us at 16384 x 256 x 256), faster inside
+    // the sampler (same-box A/B twice: 104.2 / 104.6 vs 105.1 / 105.2 ms per 20-NFE pass); train neutral.
     static int t64_kb = -1;
     if (t64_kb < 0) {
       const char* e = getenv("SDMI_IGEMM_T64_MAXKB");
-      t64_kb = e ? atoi(e) : 0;
+      t64_kb = e ? atoi(e) : 512;
     }
     if (t64_kb > 0 && is1x1 && p.K * (int)sizeof(T) <= t64_kb && shape == T128x128) shape = T64x64;
     // experiment knob: 128x64 tiles when 128x128 gives fewer than this many workgroups
