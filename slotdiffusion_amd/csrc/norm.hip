@@ -202,14 +202,21 @@ __global__ __launch_bounds__(THREADS) void gn_fused_kernel(SdmiGroupNormArgs p) 
     const int ccv = t / (VEC * 2), j = (t >> 1) % VEC, which = t & 1;
     double a = 0.0;
     for (int r = 0; r < RR; ++r) a += (double)part[r * CVp + ccv][j][which];
-    // entry 0 of the column is only read by this thread's own fold: safe to overwrite after it
-    part[ccv][j][which] = (float)a;
+    // the column's entries are only read by this thread's own fold: entry 0 / 1 take the sum as a
+    // (hi, lo) float pair -- the fp64 precision of the fold survives to the group stage (mean and
+    // E[x^2] cancel in the variance)
+    const float hi = (float)a;
+    part[ccv][j][which] = hi;
+    if (RR > 1) part[CVp + ccv][j][which] = (float)(a - (double)hi);
   }
   __syncthreads();
   if ((int)threadIdx.x < 2 * gs) {
     const int g = threadIdx.x >> 1, which = threadIdx.x & 1;
     double acc = 0.0;
-    for (int c = g * cpg; c < (g + 1) * cpg; ++c) acc += (double)part[c / VEC][c % VEC][which];
+    for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+      acc += (double)part[c / VEC][c % VEC][which];
+      if (RR > 1) acc += (double)part[CVp + c / VEC][c % VEC][which];
+    }
     const double other = __shfl_xor(acc, 1, 64);
     const double sum = which ? other : acc, sq = which ? acc : other;
     const double n = (double)p.HW * cpg;
