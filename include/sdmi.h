@@ -412,6 +412,14 @@ int sdmi_pool2x2_sum(const SdmiPool2x2Args* a, void* stream);
 /* y = x + z elementwise in `dtype` (gradient accumulation at residual / skip joins) */
 typedef struct { const void* x; const void* z; void* y; int dtype; long long n; } SdmiAddArgs;
 int sdmi_add(const SdmiAddArgs* a, void* stream);
+/* dst_i[0 .. count_i) += src_i[0 .. count_i) for up to 32 fp32 segments in ONE launch: the weight
+ * gradient of a GEMM that was fused across parameters which are not adjacent in the gradient arena
+ * (the 22 time-embedding projections of the UNet run as one GEMM; unet.py:233-236, 268) goes back
+ * to its parameters this way.  `items` is a HOST array of n SdmiScatterItem; the launch carries the
+ * table by value (graph-capturable). */
+typedef struct { const float* src; float* dst; long long count; } SdmiScatterItem;
+typedef struct { const void* items; int n; } SdmiScatterAddArgs;
+int sdmi_scatter_add(const SdmiScatterAddArgs* a, void* stream);
 /* EMA of the denoiser weights (LitEma.forward, ddpm/ema.py:29-52):
  * shadow[i] -= one_minus_decay * (shadow[i] - p[i]) over a contiguous fp32 arena range. */
 typedef struct { float* shadow; const float* p; long long n; float one_minus_decay; } SdmiEmaArgs;

@@ -139,6 +139,23 @@ __global__ void add_kernel(SdmiAddArgs p) {
     Elem<T>::st((T*)p.y + i, Elem<T>::ld((const T*)p.x + i) + Elem<T>::ld((const T*)p.z + i));
 }
 
+// grid (blocks, segment): segment blockIdx.y of the table, float4 body + scalar tail
+constexpr int SCATTER_MAX = 32;
+struct ScatterTable { SdmiScatterItem it[SCATTER_MAX]; };
+__global__ __launch_bounds__(256) void scatter_add_kernel(ScatterTable t) {
+  const SdmiScatterItem s = t.it[blockIdx.y];
+  const bool vec = ((((uintptr_t)s.src) | ((uintptr_t)s.dst)) & 15) == 0;
+  const long long nv = vec ? s.count / 4 : 0;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nv; i += (long long)gridDim.x * 256) {
+    f32x4 a = reinterpret_cast<const f32x4*>(s.src)[i];
+    a += reinterpret_cast<const f32x4*>(s.dst)[i];
+    reinterpret_cast<f32x4*>(s.dst)[i] = a;
+  }
+  for (long long i = nv * 4 + (long long)blockIdx.x * 256 + threadIdx.x; i < s.count;
+       i += (long long)gridDim.x * 256)
+    s.dst[i] += s.src[i];
+}
+
 template <typename T>
 __global__ void split_kernel(SdmiSplitArgs p) {
   constexpr int VEC = Elem<T>::VEC;
@@ -289,6 +306,22 @@ extern "C" int sdmi_add(const SdmiAddArgs* a, void* stream) {
   SDMI_REQUIRE(a && a->x && a->z && a->y, "null pointer");
   DISPATCH_T(add_kernel, dim3(nblocks(a->n / 4 + 1)), a);
   return sdmi_check_launch("add");
+}
+extern "C" int sdmi_scatter_add(const SdmiScatterAddArgs* a, void* stream) {
+  SDMI_REQUIRE(a && a->items && a->n >= 1 && a->n <= SCATTER_MAX, "1 .. 32 segments");
+  const SdmiScatterItem* it = (const SdmiScatterItem*)a->items;
+  ScatterTable t;
+  long long mx = 0;
+  for (int i = 0; i < a->n; ++i) {
+    SDMI_REQUIRE(it[i].src && it[i].dst && it[i].count >= 0, "bad segment");
+    t.it[i] = it[i];
+    if (it[i].count > mx) mx = it[i].count;
+  }
+  long long blocks = (mx / 4 + 255) / 256;
+  if (blocks < 1) blocks = 1;
+  if (blocks > 256) blocks = 256;
+  hipLaunchKernelGGL(scatter_add_kernel, dim3((unsigned)blocks, a->n), dim3(256), 0, (hipStream_t)stream, t);
+  return sdmi_check_launch("scatter_add");
 }
 extern "C" int sdmi_split_channels(const SdmiSplitArgs* a, void* stream) {
   SDMI_REQUIRE(a && a->y && a->a && a->b, "null pointer");

@@ -778,26 +778,42 @@ class GemmFn(torch.autograd.Function):
         # the direct path does: a parameter used several times per step (per-frame modules,
         # gradient accumulation over micro-batches) keeps every contribution
         if not direct:
+            import ctypes
             g = wb.model.grad_arena()
-            o = 0
+            taps = kh * kw
+            o, segs, keep = 0, [], []
             for nme in names:
                 off, cnt = wb.model._offsets[nme]
                 rows = wb.t[nme].shape[0]
-                taps = kh * kw
                 ci_true = cnt // (rows * taps)
-                # [rows*taps, Cin(pad)] -> [rows*taps, ci_true]
-                tmp = ops.cast2d(dwbuf[o:o + rows].reshape(rows * taps, Cin), torch.float32,
-                                 cols=ci_true, ldd=ci_true)
-                call('sdmi_add', _st(), x=_p(g[off:]), z=_p(tmp), y=_p(g[off:]), dtype=_lib.F32, n=cnt)
+                src = dwbuf[o:o + rows]
+                if ci_true != Cin:                     # channel-padded Cin: [rows*taps, Cin(pad)] -> true Cin
+                    src = ops.cast2d(src.reshape(rows * taps, Cin), torch.float32, cols=ci_true, ldd=ci_true)
+                    keep.append(src)
+                segs.append((_p(src), _p(g[off:]), cnt))
                 o += rows
+            Item = _lib.CSTRUCT['SdmiScatterItem']
+            for c0 in range(0, len(segs), 32):         # one launch per 32 destinations
+                chunk = segs[c0:c0 + 32]
+                arr = (Item * len(chunk))()
+                for a_, (sp, dp, cnt) in zip(arr, chunk):
+                    a_.src, a_.dst, a_.count = sp, dp, cnt
+                call('sdmi_scatter_add', _st(), items=ctypes.addressof(arr), n=len(chunk))
         if stage_bias:
+            import ctypes
             g = wb.model.grad_arena()
-            o = 0
+            o, segs = 0, []
             for nme in (bnames if not isinstance(bnames, str) else (bnames,)):
                 off, cnt = wb.model._offsets[nme]
-                call('sdmi_add', _st(), x=_p(g[off:]), z=_p(btmp[o:]), y=_p(g[off:]), dtype=_lib.F32,
-                     n=cnt)
+                segs.append((_p(btmp[o:]), _p(g[off:]), cnt))
                 o += cnt
+            Item = _lib.CSTRUCT['SdmiScatterItem']
+            for c0 in range(0, len(segs), 32):
+                chunk = segs[c0:c0 + 32]
+                arr = (Item * len(chunk))()
+                for a_, (sp, dp, cnt) in zip(arr, chunk):
+                    a_.src, a_.dst, a_.count = sp, dp, cnt
+                call('sdmi_scatter_add', _st(), items=ctypes.addressof(arr), n=len(chunk))
 
 
 class MultiLinearFn(torch.autograd.Function):
