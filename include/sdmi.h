@@ -106,8 +106,14 @@ typedef struct {
   int B, H, W, Cin, Ho, Wo, KH, KW, stride, pad_t, pad_l, ups;
   int splits;
   int accumulate;
+  int defer_fold;   /* != 0 with splits > 1: leave the split partials in `workspace`; the caller folds
+                       them later with sdmi_wgrad_fold_group (one launch for up to 16 layers) */
 } SdmiWgradArgs;
 int sdmi_wgrad(const SdmiWgradArgs* a, void* stream);
+/* Fold the split partials of up to 16 earlier sdmi_wgrad(defer_fold = 1) launches into their dw / dbias
+ * (+= when accumulate) in ONE launch.  `problems` (see SdmiWgradGroupArgs below) is a HOST array of the
+ * same SdmiWgradArgs (dw, dbias, workspace, N, K, splits, accumulate are read); destinations must be
+ * distinct within a call.  Results equal the immediate folds bit for bit (split order). */
 
 /* Grouped weight gradients: up to 16 independent 1x1 / linear bf16 problems (the eight Linear layers
  * of a transformer block, attention.py:182-251) in ONE launch.  Each problem alone has too few output
@@ -117,6 +123,7 @@ int sdmi_wgrad(const SdmiWgradArgs* a, void* stream);
  * second launch.  Results equal n sdmi_wgrad calls bit for bit. */
 typedef struct { const void* problems; int n; } SdmiWgradGroupArgs;
 int sdmi_wgrad_group(const SdmiWgradGroupArgs* a, void* stream);
+int sdmi_wgrad_fold_group(const SdmiWgradGroupArgs* a, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * GroupNorm (+ fused activation) on NHWC, statistics in fp32.

@@ -847,6 +847,26 @@ extern "C" int sdmi_wgrad_group(const SdmiWgradGroupArgs* ga, void* stream) {
   return sdmi_check_launch("wgrad group reduce");
 }
 
+extern "C" int sdmi_wgrad_fold_group(const SdmiWgradGroupArgs* ga, void* stream) {
+  SDMI_REQUIRE(ga && ga->problems && ga->n >= 1 && ga->n <= WG_MAX, "1 .. 16 problems");
+  const SdmiWgradArgs* ps = (const SdmiWgradArgs*)ga->problems;
+  WgradGroup g;
+  g.n = ga->n;
+  int red = 0;
+  for (int i = 0; i < ga->n; ++i) {
+    SDMI_REQUIRE(ps[i].dw && ps[i].workspace && ps[i].splits > 1 && ps[i].N > 0 && ps[i].K > 0 &&
+                 ((long long)ps[i].N * ps[i].K) % 4 == 0, "bad problem");
+    g.p[i] = ps[i];
+    g.item_begin[i] = 0;
+    g.red_begin[i] = red;
+    long long blocks = ((long long)ps[i].N * ps[i].K / 4 + 255) / 256;
+    red += (int)(blocks > 512 ? 512 : blocks);
+  }
+  for (int i = ga->n; i <= WG_MAX; ++i) { g.item_begin[i] = 0; g.red_begin[i] = red; }
+  hipLaunchKernelGGL(wgrad_group_reduce_kernel, dim3(red), dim3(256), 0, (hipStream_t)stream, g);
+  return sdmi_check_launch("wgrad fold group");
+}
+
 extern "C" int sdmi_wgrad(const SdmiWgradArgs* a, void* stream) {
   SDMI_REQUIRE(a && a->a && a->dy && a->dw && a->workspace, "null pointer");
   SDMI_REQUIRE(a->dtype == SDMI_F32 || a->dtype == SDMI_BF16, "bad dtype");
@@ -859,7 +879,7 @@ extern "C" int sdmi_wgrad(const SdmiWgradArgs* a, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   int rc;
   rc = a->dtype == SDMI_BF16 ? dispatch_wgrad_bf16(*a, st) : dispatch_wgrad_f32(*a, st);
-  if (rc || a->splits == 1) return rc;
+  if (rc || a->splits == 1 || a->defer_fold) return rc;
   const long long total = (long long)a->N * a->K;     // K % 4 == 0 (Cin % vec == 0)
   int blocks = (int)((total / 4 + 255) / 256);
   if (blocks > 4096) blocks = 4096;

@@ -481,6 +481,23 @@ def test_groupnorm_fanout_and_fused_dropout(B, HW, C, dtype):
     assert float(((yd2 != 0) != (yd != 0)).float().mean()) > 0.1
 
 
+def test_deferred_weight_gradient_folds_match():
+    """WeightBank.defer_fold (sdmi_wgrad defer_fold + sdmi_wgrad_fold_group at the autograd join) gives
+    the same gradient arena as the immediate per-layer folds, bit for bit."""
+    G = C.load_golden()
+    img = C.make_inputs(2)[0].cuda()
+    m = _model(torch.bfloat16)
+    arenas = []
+    for defer in (False, True):
+        m.bank().defer_fold = defer
+        _train_backward(m, G, img)
+        torch.cuda.synchronize()
+        arenas.append(m.grad_arena().clone())
+    m.bank().defer_fold = False
+    assert torch.equal(arenas[0], arenas[1])
+    assert float(arenas[0].abs().sum()) > 0
+
+
 def test_wgrad_group_matches_single_launches():
     """sdmi_wgrad_group: several 1x1 / linear bf16 problems (different shapes, ragged M, with and
     without bias, with and without M-splits) in one launch equal the single-problem launches bit for
