@@ -89,6 +89,11 @@ typedef struct {
   /* geglu != 0: W has 2N rows (value rows 0..N-1, gate rows N..2N-1), bias / ln_colsum 2N entries;
    * out[m][n] = value[m][n] * gelu(gate[m][n]), N columns (attention.py:44-48 GEGLU.forward). */
   int geglu;
+  /* optional second A source (1x1 / linear only): A = [a | a2] along K -- a [M][lda] supplies k < K1,
+   * a2 [M][lda2] the rest (K1 a multiple of 64 elements); the skip-concat's 1x1 convolution reads its
+   * two inputs in place. */
+  const void* a2;
+  int lda2, K1;
 } SdmiGemmArgs;
 int sdmi_igemm(const SdmiGemmArgs* a, void* stream);
 
@@ -155,6 +160,11 @@ typedef struct {
    * behind the norm; y may then be NULL (inference: the bf16 copy has no other reader). */
   void* y8;
   float y8_scale;
+  /* optional second source (inference): the input is the channel concatenation [x | x2] of two
+   * tensors -- x [B][HW][C1], x2 [B][HW][C - C1] -- read in place (the UNet's skip concat,
+   * unet.py:571-573, without materialising it).  C1 is a multiple of the 16-byte vector. */
+  const void* x2;
+  int C1;
 } SdmiGroupNormArgs;
 int sdmi_groupnorm_stats(const SdmiGroupNormArgs* a, void* stream);
 int sdmi_groupnorm_apply(const SdmiGroupNormArgs* a, void* stream);

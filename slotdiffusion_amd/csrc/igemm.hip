@@ -310,6 +310,10 @@ __device__ __forceinline__ void igemm_body(const SdmiGemmArgs& p, int tiles_m, i
     if (TAPU) Abase -= (long long)(p.pad_t * p.W + p.pad_l) * p.lda;
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)Abase, 0, (int)OOB, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)Wg, 0, (int)OOB, 0x00020000);
+    // second A source of a 1x1 problem (A = [a | a2] along K: the skip concat read in place)
+    const __amdgpu_buffer_rsrc_t rsA2 = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.a2 ? p.a2 : p.a), 0, (int)OOB, 0x00020000);
+    unsigned a_vo2[IS1X1 ? A_VECS : 1];
     unsigned a_vo[A_VECS], a_cur[A_VECS], a_inv[A_VECS], b_vo[B_VECS], b_cur[B_VECS];
     int k0 = 0, ci = 0, kh = 0, kw = 0;       // wave-uniform k state of the next K tile (MODE 1/2)
     // MODE 0 (general gather) state
@@ -338,6 +342,7 @@ __device__ __forceinline__ void igemm_body(const SdmiGemmArgs& p, int tiles_m, i
         const int m = min(m0 + row, p.M - 1);
         if (IS1X1) {
           a_vo[i] = ((unsigned)m * (unsigned)p.lda + kc * VEC) * (unsigned)sizeof(T);
+          a_vo2[i] = ((unsigned)m * (unsigned)p.lda2 + kc * VEC) * (unsigned)sizeof(T);
           a_inv[i] = 0;
           a_cur[i] = a_vo[i];
         } else {
@@ -407,9 +412,20 @@ __device__ __forceinline__ void igemm_body(const SdmiGemmArgs& p, int tiles_m, i
           so_a = (unsigned)k0 * (unsigned)sizeof(T);
         }
         const unsigned so_b = (unsigned)k0 * (unsigned)sizeof(T);
+        bool second = false;
+        if constexpr (IS1X1) second = p.a2 != nullptr && k0 >= p.K1;      // wave-uniform
+        if (second) {
+          if constexpr (IS1X1) {
+            const unsigned so2 = (unsigned)(k0 - p.K1) * (unsigned)sizeof(T);
+#pragma unroll
+            for (int i = 0; i < A_VECS; ++i)
+              ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rsA2, (int)a_vo2[i], (int)so2, 0);
+          }
+        } else {
 #pragma unroll
         for (int i = 0; i < A_VECS; ++i)
           ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)a_cur[i], (int)so_a, 0);
+        }
 #pragma unroll
         for (int i = 0; i < B_VECS; ++i)
           rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rsW, (int)b_cur[i], (int)so_b, 0);
@@ -1190,7 +1206,6 @@ int dispatch(const SdmiGemmArgs& p, hipStream_t st) {
     while (t64 * split_k < 384 && split_k * 2 <= nk / 4 && split_k < 16) split_k *= 2;
   }
   if (split_k > 1 && !p.workspace) split_k = 1;
-  (void)VEC;
   const bool plain = !is1x1 && !p.ups && p.zins <= 1;
   // direct 3x3 kernel for the 64 -> 64 channel convolutions at full resolution
   if (sizeof(T) == 2 && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad_t == 1 && p.pad_l == 1 &&
@@ -1221,6 +1236,15 @@ int dispatch(const SdmiGemmArgs& p, hipStream_t st) {
       ((long long)p.B * p.H * p.W + (long long)(p.KH + 1) * p.W) * p.lda * (long long)sizeof(T);
   const long long w_bytes = (long long)p.N * (p.geglu ? 2 : 1) * p.ldw * (long long)sizeof(T);
   const bool fits31 = a_bytes < (1ll << 31) && w_bytes < (1ll << 31);
+  if (p.a2) {       // two-source A (sdmi.h: a2): plain 1x1, whole K tiles on both sides of the seam
+    const int bk = (wide ? 128 : 64) / (int)sizeof(T);
+    const long long a2_bytes = (long long)p.M * p.lda2 * (long long)sizeof(T);
+    if (!is1x1 || batch != 1 || p.osy != 0 || p.ln_colsum || p.geglu || p.K1 <= 0 || p.K1 >= p.K ||
+        p.K1 % bk || (p.K - p.K1) % bk || p.lda2 % VEC || !fits31 || a2_bytes >= (1ll << 31)) {
+      sdmi_set_error("igemm: two-source A needs a plain 1x1 problem with K1 and K - K1 multiples of the K tile");
+      return SDMI_EUNSUPPORTED;
+    }
+  }
   // fused LayerNorm-fold / GEGLU epilogues (sdmi.h: ln_colsum, geglu): 1x1 / linear problems only
   {
     const int epi = (p.ln_colsum ? 1 : 0) | (p.geglu ? 2 : 0);
@@ -1258,7 +1282,7 @@ int dispatch(const SdmiGemmArgs& p, hipStream_t st) {
       const char* e = getenv("SDMI_IGEMM_DMA");
       dma_env = e ? atoi(e) : SDMI_IGEMM_DMA;
     }
-    const bool dma_ok = sizeof(T) != 1 && dma_env && wide && kbytes >= 8 * 128 && split_k == 1 && p.N > 64 && fits31 &&
+    const bool dma_ok = sizeof(T) != 1 && !p.a2 && dma_env && wide && kbytes >= 8 * 128 && split_k == 1 && p.N > 64 && fits31 &&
                         (is1x1 || (plain && p.Cin % (128 / (int)sizeof(T)) == 0)) && p.KH * p.KW <= 32;
     if (dma_ok) {
       const long long t256 = ((p.M + 255) / 256) * ((p.N + 127) / 128) * batch;

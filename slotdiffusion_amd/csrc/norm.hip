@@ -16,6 +16,22 @@ __device__ __forceinline__ int next_pow2(int v) {
   return p;
 }
 
+// Input vector column starting at channel c of image b: pointer to its row 0 and the row pitch
+// (elements) -- one tensor [B][HW][C], or the in-place concatenation [x | x2] (sdmi.h: x2, C1).
+template <typename T>
+__device__ __forceinline__ const T* gn_src(const SdmiGroupNormArgs& p, int b, int c, int& pitch) {
+  if (p.x2) {
+    if (c >= p.C1) {
+      pitch = p.C - p.C1;
+      return (const T*)p.x2 + (long long)b * p.HW * pitch + (c - p.C1);
+    }
+    pitch = p.C1;
+    return (const T*)p.x + (long long)b * p.HW * pitch + c;
+  }
+  pitch = p.C;
+  return (const T*)p.x + (long long)b * p.HW * p.C + c;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void gn_stats_kernel(SdmiGroupNormArgs p) {
   constexpr int VEC = Elem<T>::VEC;
@@ -32,9 +48,10 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(SdmiGroupNormArgs p) {
 #pragma unroll
   for (int j = 0; j < VEC; ++j) s[j] = ss[j] = 0.f;
   if (cv < CV) {
-    const T* xb = (const T*)p.x + (long long)b * p.HW * p.C + cv * VEC;
+    int xp;
+    const T* xb = gn_src<T>(p, b, cv * VEC, xp);
     for (int row = row_begin + r0; row < row_end; row += R) {
-      const uint4 v = *reinterpret_cast<const uint4*>(xb + (long long)row * p.C);
+      const uint4 v = *reinterpret_cast<const uint4*>(xb + (long long)row * xp);
       float f[VEC];
       unpack16<T>(v, f);
 #pragma unroll
@@ -112,7 +129,8 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(SdmiGroupNormArgs p, int 
     sh[j] = p.beta[c] - mean * sc[j];
   }
   const long long base = (long long)b * p.HW * p.C + cv * VEC;
-  const T* xb = (const T*)p.x + base;
+  int xp;
+  const T* xb = gn_src<T>(p, b, cv * VEC, xp);
   T* yb = (T*)p.y + base;
   const T* rb = p.residual ? (const T*)p.residual + base : nullptr;
   const bool drop = p.drop_p > 0.f;
@@ -121,7 +139,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(SdmiGroupNormArgs p, int 
   const float dinv = 1.f / (1.f - p.drop_p);
   for (int row = row_begin + r0; row < row_end; row += R) {
     const long long o = (long long)row * p.C;
-    const uint4 v = *reinterpret_cast<const uint4*>(xb + o);
+    const uint4 v = *reinterpret_cast<const uint4*>(xb + (long long)row * xp);
     float f[VEC];
     unpack16<T>(v, f);
     if (rb) {
@@ -161,7 +179,8 @@ __global__ __launch_bounds__(THREADS) void gn_fused_kernel(SdmiGroupNormArgs p) 
   const int cv = threadIdx.x % CVp, r0 = threadIdx.x / CVp;
   const bool act_c = cv < CV;
   const long long base = (long long)b * p.HW * p.C + c_lo + (act_c ? cv : 0) * VEC;
-  const T* xb = (const T*)p.x + base;
+  int xp;
+  const T* xb = gn_src<T>(p, b, c_lo + (act_c ? cv : 0) * VEC, xp);
   uint4 xr[NV];
   float s[VEC], ss[VEC];
 #pragma unroll
@@ -169,7 +188,7 @@ __global__ __launch_bounds__(THREADS) void gn_fused_kernel(SdmiGroupNormArgs p) 
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int row = r0 + i * R;
-    if (act_c && row < p.HW) xr[i] = *reinterpret_cast<const uint4*>(xb + (long long)row * p.C);
+    if (act_c && row < p.HW) xr[i] = *reinterpret_cast<const uint4*>(xb + (long long)row * xp);
   }
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
@@ -420,6 +439,9 @@ extern "C" int sdmi_groupnorm(const SdmiGroupNormArgs* a, void* stream) {
   if (rc) return rc;
   SDMI_REQUIRE(a->y || a->y8, "null output");
   SDMI_REQUIRE(!a->y8 || a->dtype == SDMI_BF16, "fp8 output: bf16 input only");
+  SDMI_REQUIRE(!a->x2 || (a->C1 > 0 && a->C1 < a->C && a->C1 % (a->dtype == SDMI_BF16 ? 8 : 4) == 0 &&
+                          (a->C - a->C1) % (a->dtype == SDMI_BF16 ? 8 : 4) == 0 && a->y != a->x),
+               "two-source input: C1 splits the channels on 16-byte vectors; not in place");
   const int vec = a->dtype == SDMI_BF16 ? 8 : 4;
   // single-pass kernel when the image (or a whole-group channel chunk of it) fits a workgroup's registers
   {

@@ -189,6 +189,8 @@ class UNetRunner:
         if (n + '.skip_connection.weight') in K.wb.t:
             skip = K.conv(skip, n + '.skip_connection.weight', n + '.skip_connection.bias', kh=1, kw=1,
                           pad=(0, 0, 0, 0))
+        elif hasattr(skip, 'materialize'):             # (a lazy concat that keeps its channel count)
+            skip = skip.materialize()
         out = K.conv(h, n + '.out_layers.3.weight', n + '.out_layers.3.bias', residual=skip)
         return out, (outs[2] if want_cat else None)
 

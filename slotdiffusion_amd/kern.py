@@ -43,6 +43,24 @@ def _dbg(tag, **tensors):
 
 FP8_ACT_SCALE = 8.0        # activations -> e4m3fn: +-56 representable, 2^-9 resolution near zero
 _WG_MAIN_BELOW = float(os.environ.get('SDMI_WGRAD_MAIN_BELOW_GF', '0')) * 1e9
+_LAZY_CAT = os.environ.get('SDMI_LAZY_CAT', '1') != '0'
+
+
+class CatPair:
+    """Two NHWC tensors standing for their channel concatenation (inference: read in place)."""
+
+    def __init__(self, a, b):
+        self.a, self.b = a, b
+        self.shape = tuple(a.shape[:-1]) + (a.shape[-1] + b.shape[-1],)
+        self.dtype, self.device = a.dtype, a.device
+
+    def dim(self):
+        return self.a.dim()
+
+    def materialize(self):
+        return ops.concat_channels(self.a, self.b)
+
+
 _LN_FOLD = os.environ.get('SDMI_LN_FOLD', '1') != '0'
 
 
@@ -456,6 +474,11 @@ class Kern:
 
     def conv(self, x, wname, bname=None, *, kh=3, kw=3, stride=1, pad=(1, 1, 1, 1), ups=False,
              rowvec=None, residual=None, out_dtype=None, ldc=None):
+        if isinstance(x, CatPair):
+            if kh == 1 and kw == 1 and stride == 1 and not ups:
+                return ops.conv2d(x.a, self.wb.w(wname, x.dtype), self.wb.b(bname), kh=1, kw=1, pad=pad,
+                                  rowvec=rowvec, residual=residual, out_dtype=out_dtype, ldc=ldc, x2=x.b)
+            x = x.materialize()
         if x.dtype == torch.uint8 or self.fp8_ok(x, wname, kh * kw, ups):
             # BASELINE "fp8 MFMA UNet": e4m3fn operands (activations at a fixed scale -- written by
             # the GroupNorm in front when there is one -- weights at 448 / amax), fp32 accumulation,
@@ -482,6 +505,13 @@ class Kern:
                           residual=residual, out_dtype=out_dtype)
 
     def gn(self, x, name, *, eps, act=None, residual=None, dropout=None, for_conv=None):
+        if isinstance(x, CatPair):
+            f8 = FP8_ACT_SCALE if (for_conv and self.fp8_ok(x, for_conv, 9, False)) else None
+            return ops.group_norm(x.a, self.wb.f(name + '.weight'), self.wb.f(name + '.bias'), eps=eps,
+                                  act=act, residual=residual, fp8_scale=f8, x2=x.b)
+        return self._gn(x, name, eps=eps, act=act, residual=residual, dropout=dropout, for_conv=for_conv)
+
+    def _gn(self, x, name, *, eps, act=None, residual=None, dropout=None, for_conv=None):
         """dropout = site name: training-mode dropout behind the activation (no-op at inference).
         for_conv = weight name of the 3x3 convolution that is the output's only reader: in the fp8
         configuration the norm writes that convolution's e4m3fn operand directly."""
@@ -552,6 +582,11 @@ class Kern:
         return ops.add_pos(x, pos)
 
     def concat(self, a, b):
+        """Channel concatenation for the UNet's skip connections.  At inference the two readers of the
+        result -- the ResBlock's first GroupNorm and its 1x1 skip convolution -- take the two tensors
+        in place (CatPair: sdmi.h x2 / a2), so nothing is materialised."""
+        if _LAZY_CAT and a.dim() == 4 and a.shape[-1] % 64 == 0 and b.shape[-1] % 64 == 0:
+            return CatPair(a, b)
         return ops.concat_channels(a, b)
 
     def cast(self, x, dtype):

@@ -71,13 +71,17 @@ def quant_fp8(x, scale, out=None):
 
 def conv2d(x, w, bias=None, *, kh=3, kw=3, stride=1, pad=(1, 1, 1, 1), ups=False, cout=None,
            rowvec=None, residual=None, act=None, out=None, out_dtype=None, ldc=None,
-           split_k=0, alpha=1.0):
+           split_k=0, alpha=1.0, x2=None):
     """x [B,H,W,Cin] NHWC; w [Cout][kh][kw][Cin] (flat or 4-D channels_last view).
     pad = (top, bottom, left, right).  Returns [B,Ho,Wo,ldc or Cout].
     uint8 x / w = e4m3fn operands (quant_fp8): out_dtype is required, alpha undoes the scales."""
     _need_gpu(x, w)
     B, H, W, Cin = x.shape
     assert x.is_contiguous()
+    C1 = Cin
+    if x2 is not None:          # 1x1 over the channel concatenation [x | x2], read in place (sdmi.h: a2)
+        assert kh == 1 and kw == 1 and stride == 1 and x2.is_contiguous() and x2.shape[:3] == x.shape[:3]
+        Cin = C1 + x2.shape[-1]
     Hs, Ws = (2 * H, 2 * W) if ups else (H, W)
     Ho = (Hs + pad[0] + pad[1] - kh) // stride + 1
     Wo = (Ws + pad[2] + pad[3] - kw) // stride + 1
@@ -96,7 +100,8 @@ def conv2d(x, w, bias=None, *, kh=3, kw=3, stride=1, pad=(1, 1, 1, 1), ups=False
     ws = splitk_workspace(M, N, K, x.element_size(), x.device) if split_k != 1 else None
     call('sdmi_igemm', _stream(), a=_p(x), w=_p(w), out=_p(out), bias=_p(bias), rowvec=_p(rowvec),
          residual=_p(residual), workspace=_p(ws), dtype=_dt(x), out_dtype=_DT[odt], M=M, N=N, K=K,
-         lda=Cin, ldw=K, ldc=ldc, ldr=(residual.shape[-1] if residual is not None else 0),
+         lda=C1, ldw=K, ldc=ldc, ldr=(residual.shape[-1] if residual is not None else 0),
+         a2=_p(x2), lda2=(x2.shape[-1] if x2 is not None else 0), K1=(C1 if x2 is not None else 0),
          B=B, H=H, W=W, Cin=Cin, Ho=Ho, Wo=Wo, KH=kh, KW=kw, stride=stride, pad_t=pad[0],
          pad_l=pad[2], ups=int(ups), act=ACT[act], alpha=float(alpha), bias_m=0,
          ldrv=(rowvec.stride(0) if rowvec is not None else 0),
@@ -150,23 +155,30 @@ def bmm_nt(a, b, out, *, alpha=1.0, bias_m=None):
 # normalisation
 # ------------------------------------------------------------------------------------------
 def group_norm(x, gamma, beta, *, eps, act=None, groups=32, residual=None, out=None,
-               return_stats=False, drop=None, fp8_scale=None):
+               return_stats=False, drop=None, fp8_scale=None, x2=None):
     """x [B,H,W,C] (or [B,HW,C]) NHWC -> same shape; fp32 statistics.  drop = (p, seed, seed_dev):
     inverted dropout fused behind the activation (training-mode ResBlocks).  fp8_scale: the output
     is written as e4m3fn bytes (uint8 tensor) for the fp8 convolution behind the norm."""
     _need_gpu(x)
     B, C = x.shape[0], x.shape[-1]
     HW = x.numel() // (B * C)
+    C1 = 0
+    if x2 is not None:          # input = channel concatenation [x | x2], read in place (sdmi.h: x2)
+        assert x.is_contiguous() and x2.is_contiguous() and x2.shape[:-1] == x.shape[:-1] and out is None
+        C1, C = C, C + x2.shape[-1]
     nsplit = max(1, min(16, HW // 64))
     partial = torch.empty((B * nsplit * groups * 2,), dtype=torch.float32, device=x.device)
     stats = torch.empty((B, groups, 2), dtype=torch.float32, device=x.device)
+    oshape = x.shape[:-1] + (C,)
     if fp8_scale is not None:
-        out = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+        out = torch.empty(oshape, dtype=torch.uint8, device=x.device)
         kw = dict(y=0, y8=_p(out), y8_scale=float(fp8_scale))
     else:
         if out is None:
-            out = torch.empty_like(x)
+            out = torch.empty(oshape, dtype=x.dtype, device=x.device)
         kw = dict(y=_p(out))
+    if x2 is not None:
+        kw.update(x2=_p(x2), C1=C1)
     kw.update(x=_p(x), gamma=_p(gamma), beta=_p(beta), stats=_p(stats),
               partial=_p(partial), dtype=_dt(x), B=B, HW=HW, C=C, groups=groups, eps=eps,
               act=ACT[act], nsplit=nsplit, residual=_p(residual))

@@ -211,6 +211,33 @@ def test_igemm_fp8_operands(case):
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('case', [(2, 16, 16, 256, 128), (3, 8, 8, 384, 384), (2, 32, 32, 128, 64), (1, 64, 64, 64, 64),
+                                  (64, 4, 4, 512, 512)])
+def test_two_source_groupnorm_and_1x1_conv(case, dtype):
+    """The UNet's skip concat read in place (sdmi.h: x2 / a2): GroupNorm(+SiLU) and the 1x1 skip
+    convolution over [a | b] without materialising the concatenation -- identical bits to the same
+    kernels on the concatenated tensor."""
+    ops = _ops()
+    B, H, W, Ca, Cb = case
+    g = torch.Generator().manual_seed(sum(case))
+    a = q(torch.randn(B, H, W, Ca, generator=g), dtype).to(dtype).to(DEV)
+    b = q(torch.randn(B, H, W, Cb, generator=g) * 1.7 + 0.3, dtype).to(dtype).to(DEV)
+    cat = ops.concat_channels(a, b)
+    C = Ca + Cb
+    gamma, beta = (1 + 0.2 * torch.randn(C, generator=g)).to(DEV), (0.1 * torch.randn(C, generator=g)).to(DEV)
+    y_ref = ops.group_norm(cat, gamma, beta, eps=1e-5, act='silu')
+    y_two = ops.group_norm(a, gamma, beta, eps=1e-5, act='silu', x2=b)
+    assert y_two.shape == cat.shape and torch.equal(y_ref, y_two)
+    N = 192
+    w = q(torch.randn(N, C, generator=g) / math.sqrt(C), dtype).to(dtype).to(DEV)
+    bias = torch.randn(N, generator=g).to(DEV)
+    o_ref = ops.conv2d(cat, w, bias, kh=1, kw=1, pad=(0, 0, 0, 0))
+    o_two = ops.conv2d(a, w, bias, kh=1, kw=1, pad=(0, 0, 0, 0), x2=b)
+    assert torch.equal(o_ref, o_two)
+    check(o_two, F.linear(cat.float().cpu(), w.float().cpu(), bias.cpu()), dtype, f'two-source 1x1 {case}')
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 def test_bmm_nt_and_softmax(dtype):
     ops = _ops()
     g = torch.Generator().manual_seed(5)
