@@ -94,6 +94,13 @@ typedef struct {
    * two inputs in place. */
   const void* a2;
   int lda2, K1;
+  /* softmax8 = S in 1..7 (with ln_colsum): the epilogue finishes with a softmax over every aligned group
+   * of 8 output columns of which the first S are scores (the others are pads: treated as -inf, written
+   * as 0) -- the S slot scores of one attention head.  With batch > 1, ln_colsum / bias advance by s_colsum / s_bias entries per batch:
+   * slot cross-attention as two per-image GEMMs (attention.py:182-206 with the 7 keys folded into the
+   * query weights, the values into the output projection; see engine.UNetRunner.cross_fold). */
+  int softmax8;
+  long long s_colsum, s_bias;
 } SdmiGemmArgs;
 int sdmi_igemm(const SdmiGemmArgs* a, void* stream);
 
@@ -325,6 +332,14 @@ typedef struct {
   const void* src; void* dst; int src_dtype; long long rows; int cols, lds, ldd; float scale;
 } SdmiQuantFp8Args;
 int sdmi_quant_fp8(const SdmiQuantFp8Args* a, void* stream);
+/* Head-expanded slot keys / values for the folded cross-attention (engine.UNetRunner.cross_fold):
+ * kv [B][S][ldkv] holds K in columns [0, C) and V in [C, 2C); row h * 8 + j (j < S <= 7) of
+ * kexp / vexp [B][heads * 8][C] is slot j's key (times `scale`) / value restricted to the channels of
+ * head h, zero elsewhere; rows j >= S are zero. */
+typedef struct {
+  const void* kv; void* kexp; void* vexp; int dtype; int B, S, C, heads, ldkv; float scale;
+} SdmiExpandHeadsArgs;
+int sdmi_expand_heads(const SdmiExpandHeadsArgs* a, void* stream);
 
 /* Small stream-ordered helpers that keep the training step free of framework kernels:
  *   sdmi_memset0 ...... zero `bytes` bytes (gradient arena, padded buffers) -- a memset node in a graph

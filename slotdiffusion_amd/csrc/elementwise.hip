@@ -105,6 +105,26 @@ __global__ void quant_fp8_kernel(SdmiQuantFp8Args p) {
 }
 
 template <typename T>
+__global__ void expand_heads_kernel(SdmiExpandHeadsArgs p) {
+  const int R = p.heads * 8, hd = p.C / p.heads;
+  const long long n = (long long)p.B * R * p.C;
+  GRID_STRIDE(i, n) {
+    const int c = (int)(i % p.C);
+    const long long br = i / p.C;
+    const int row = (int)(br % R), b = (int)(br / R);
+    const int h = row >> 3, j = row & 7;
+    float k = 0.f, v = 0.f;
+    if (j < p.S && c / hd == h) {
+      const T* src = (const T*)p.kv + ((long long)b * p.S + j) * p.ldkv;
+      k = Elem<T>::ld(src + c) * p.scale;
+      v = Elem<T>::ld(src + p.C + c);
+    }
+    Elem<T>::st((T*)p.kexp + i, k);
+    Elem<T>::st((T*)p.vexp + i, v);
+  }
+}
+
+template <typename T>
 __global__ void scale_dev_kernel(SdmiScaleDevArgs p) {
   const float s = p.s[0];
   GRID_STRIDE(i, p.n) Elem<T>::st((T*)p.y + i, Elem<T>::ld((const T*)p.x + i) * s);
@@ -412,6 +432,14 @@ extern "C" int sdmi_cast2d(const SdmiCast2dArgs* a, void* stream) {
   else if (db) hipLaunchKernelGGL((cast2d_kernel<float, bf16_t>), dim3(g), dim3(EW_THREADS), 0, ST, *a);
   else hipLaunchKernelGGL((cast2d_kernel<float, float>), dim3(g), dim3(EW_THREADS), 0, ST, *a);
   return sdmi_check_launch("cast2d");
+}
+extern "C" int sdmi_expand_heads(const SdmiExpandHeadsArgs* a, void* stream) {
+  SDMI_REQUIRE(a && a->kv && a->kexp && a->vexp, "null pointer");
+  SDMI_REQUIRE(a->S >= 1 && a->S <= 7 && a->heads > 0 && a->C % a->heads == 0, "1 .. 7 slots, C = heads * head_dim");
+  const int g = ew_blocks((long long)a->B * a->heads * 8 * a->C);
+  if (a->dtype == SDMI_BF16) hipLaunchKernelGGL(expand_heads_kernel<bf16_t>, dim3(g), dim3(EW_THREADS), 0, ST, *a);
+  else hipLaunchKernelGGL(expand_heads_kernel<float>, dim3(g), dim3(EW_THREADS), 0, ST, *a);
+  return sdmi_check_launch("expand_heads");
 }
 extern "C" int sdmi_quant_fp8(const SdmiQuantFp8Args* a, void* stream) {
   SDMI_REQUIRE(a && a->src && a->dst, "null pointer");

@@ -186,8 +186,11 @@ typedef __bf16 sdmi_bf16x2 __attribute__((ext_vector_type(2)));
 template <int TM, int TN, int EPI>
 __device__ __forceinline__ void fused_epilogue(const SdmiGemmArgs& p, f32x16 (&acc)[TM][TN],
                                                const float (&sx)[TM], const float (&sxx)[TM], int mw0,
-                                               int nw0, int lane) {
-  constexpr bool LNF = (EPI & 1) != 0, GEGLU = (EPI & 2) != 0;
+                                               int nw0, int lane, int zb = 0) {
+  constexpr bool LNF = (EPI & 1) != 0, GEGLU = (EPI & 2) != 0, SM8 = (EPI & 4) != 0;
+  const float* bias_p = p.bias ? p.bias + (long long)zb * p.s_bias : nullptr;
+  const float* colsum_p = p.ln_colsum ? p.ln_colsum + (long long)zb * p.s_colsum : nullptr;
+  const long long zc = (long long)zb * p.sc;
   constexpr int NOUT = GEGLU ? TN / 2 : TN;
   // C layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
   const int col_l = lane & 31, row_l = (lane >> 5) * 4;
@@ -210,10 +213,10 @@ __device__ __forceinline__ void fused_epilogue(const SdmiGemmArgs& p, f32x16 (&a
       const int n = nw0 + j * 32 + col_l;
       ncol[j] = n;
       const int nc = n < p.N ? n : p.N - 1;
-      c0[j] = p.bias ? p.bias[nc] : 0.f;
-      s0[j] = LNF ? p.ln_colsum[nc] : 0.f;
-      c1[j] = (GEGLU && p.bias) ? p.bias[p.N + nc] : 0.f;
-      s1[j] = (GEGLU && LNF) ? p.ln_colsum[p.N + nc] : 0.f;
+      c0[j] = bias_p ? bias_p[nc] : 0.f;
+      s0[j] = LNF ? colsum_p[nc] : 0.f;
+      c1[j] = (GEGLU && bias_p) ? bias_p[p.N + nc] : 0.f;
+      s1[j] = (GEGLU && LNF) ? colsum_p[p.N + nc] : 0.f;
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -227,11 +230,25 @@ __device__ __forceinline__ void fused_epilogue(const SdmiGemmArgs& p, f32x16 (&a
         if constexpr (GEGLU) {
           const float g = rs * (acc[i][j + TN / 2][r] * p.alpha - mu * s1[j]) + c1[j];
           v *= act_apply(g, SDMI_ACT_GELU);
+        } else if constexpr (SM8) {
+          // softmax over the aligned 8-column group (softmax8 slot scores + pad columns): the group's lanes
+          // are 8 neighbours of this 32-lane half, every lane takes part
+          const float x = ((ncol[j] & 7) >= p.softmax8) ? -INFINITY : v;
+          float mx = x;
+          mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
+          mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
+          mx = fmaxf(mx, __shfl_xor(mx, 4, 64));
+          const float e = __expf(x - mx);
+          float sm = e;
+          sm += __shfl_xor(sm, 1, 64);
+          sm += __shfl_xor(sm, 2, 64);
+          sm += __shfl_xor(sm, 4, 64);
+          v = e / sm;
         } else {
           v = act_apply(v, p.act);
         }
         if (ncol[j] < p.N && m < p.M) {
-          const long long o = (long long)m * p.ldc + ncol[j];
+          const long long o = zc + (long long)m * p.ldc + ncol[j];
           if (out_bf16) ((bf16_t*)p.out)[o] = f32_to_bf16(v);
           else ((float*)p.out)[o] = v;
         }
@@ -630,7 +647,7 @@ __device__ __forceinline__ void igemm_body(const SdmiGemmArgs& p, int tiles_m, i
   if constexpr (EPI == 0)
     wave_epilogue<TM, TN>(p, acc, m0 + wm * WTM, n0 + wn * WTN, zb, hw_shift, lane);
   else
-    fused_epilogue<TM, TN, EPI>(p, acc, sx, sxx, m0 + wm * WTM, n0 + wn * (GEGLU ? WTN / 2 : WTN), lane);
+    fused_epilogue<TM, TN, EPI>(p, acc, sx, sxx, m0 + wm * WTM, n0 + wn * (GEGLU ? WTN / 2 : WTN), lane, zb);
   }  // tiles of this workgroup
 }
 
@@ -1247,9 +1264,18 @@ int dispatch(const SdmiGemmArgs& p, hipStream_t st) {
   }
   // fused LayerNorm-fold / GEGLU epilogues (sdmi.h: ln_colsum, geglu): 1x1 / linear problems only
   {
-    const int epi = (p.ln_colsum ? 1 : 0) | (p.geglu ? 2 : 0);
-    if (epi) {
-      if (sizeof(T) == 1 || !is1x1 || !fits31 || batch != 1 || p.osy != 0 || p.split_k > 1 || p.bias_m || p.residual || p.rowvec) {
+    const int epi = (p.ln_colsum ? 1 : 0) | (p.geglu ? 2 : 0) | (p.softmax8 ? 4 : 0);
+    if (epi == 5) {            // LayerNorm fold + softmax over 8-column groups (per-image batches allowed)
+      if (sizeof(T) == 1 || !is1x1 || !fits31 || p.osy != 0 || p.split_k > 1 || p.bias_m || p.residual ||
+          p.rowvec || (p.N & 7)) {
+        sdmi_set_error("igemm: softmax8 epilogue needs a plain 1x1 problem with N a multiple of 8");
+        return SDMI_EUNSUPPORTED;
+      }
+      if constexpr (sizeof(T) != 1)
+        return wide ? launch_cfg<T, 64, 64, 128, 1, 5>(p, 1, hw_shift, st)
+                    : launch_cfg<T, 64, 64, 64, 1, 5>(p, 1, hw_shift, st);
+    } else if (epi) {
+      if (sizeof(T) == 1 || (epi & 4) || !is1x1 || !fits31 || batch != 1 || p.osy != 0 || p.split_k > 1 || p.bias_m || p.residual || p.rowvec) {
         sdmi_set_error("igemm: LayerNorm-fold / GEGLU epilogues need a plain 1x1 problem without residual / rowvec");
         return SDMI_EUNSUPPORTED;
       }

@@ -151,6 +151,7 @@ class UNetRunner:
             o += c
         self.emb_total = o
         self.st_names = [l[1] for blk in blocks for l in blk if l[0] == 'st']
+        self.heads_of = {l[1]: l[3] for blk in blocks for l in blk if l[0] == 'st'}
 
     # -- per-call invariants -------------------------------------------------------------
     def time_rowvecs(self, K, t):
@@ -170,7 +171,13 @@ class UNetRunner:
         """ctx [B,N,Dc] compute dtype -> {st name: kv [B,N,2C]}; constant across all NFEs."""
         names = [(self.P + n + '.transformer_blocks.0.attn2.to_k.weight',
                   self.P + n + '.transformer_blocks.0.attn2.to_v.weight') for n in self.st_names]
-        return dict(zip(self.st_names, K.linear_multi(ctx, names)))
+        kvs = dict(zip(self.st_names, K.linear_multi(ctx, names)))
+        if hasattr(K, 'cross_prepare') and not K.training:       # inference: fold the slots into the weights
+            for n in self.st_names:
+                fold = K.cross_prepare(kvs[n], self.P + n + '.transformer_blocks.0', self.heads_of[n])
+                if fold is not None:
+                    kvs[n] = {'kv': kvs[n], 'fold': fold}
+        return kvs
 
     # -- blocks ---------------------------------------------------------------------------
     def _res(self, K, name, x, rowvecs, want_cat=False):
@@ -208,9 +215,7 @@ class UNetRunner:
         a = K.attn_self(qkv, heads)
         tok = K.linear(a, t + '.attn1.to_out.0.weight', t + '.attn1.to_out.0.bias', residual=tres)
         # slot cross attention (K/V precomputed per sample call)
-        q, tres = K.ln_linear_fan(tok, t + '.norm2', t + '.attn2.to_q.weight')
-        a = K.attn_cross(q, kv, heads)
-        tok = K.linear(a, t + '.attn2.to_out.0.weight', t + '.attn2.to_out.0.bias', residual=tres)
+        tok = K.cross_block(tok, t, kv, heads)
         # GEGLU feed-forward
         g, tres = K.ln_linear_fan(tok, t + '.norm3', t + '.ff.net.0.proj.weight', t + '.ff.net.0.proj.bias',
                                   geglu=True)

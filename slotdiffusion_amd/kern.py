@@ -61,6 +61,7 @@ class CatPair:
         return ops.concat_channels(self.a, self.b)
 
 
+_CROSS_FOLD = os.environ.get('SDMI_CROSS_FOLD', '1') != '0'
 _LN_FOLD = os.environ.get('SDMI_LN_FOLD', '1') != '0'
 
 
@@ -367,6 +368,20 @@ class WeightBank:
             self.cache[key] = (ops.quant_fp8(flat.float().contiguous(), scale), 1.0 / scale)
         return self.cache[key]
 
+    def cross_fold_weights(self, t, dtype):
+        """Weight-side operands of the folded slot cross-attention of transformer block `t`
+        (engine.UNetRunner.cross_fold): (W_q * gamma_norm2)^T [C_k, C_d], (W_q beta_norm2) [1, C_d],
+        ones [1, C_k] in `dtype`.  Weight preparation, cached until the weights change."""
+        key = ('crossfold', t, dtype)
+        if key not in self.cache:
+            with torch.no_grad():
+                g, be = self.t[t + '.norm2.weight'].float(), self.t[t + '.norm2.bias'].float()
+                wq = self.t[t + '.attn2.to_q.weight'].float()
+                self.cache[key] = ((wq * g).t().contiguous().to(dtype).unsqueeze(0),
+                                   (wq @ be).to(dtype).view(1, 1, -1).contiguous(),
+                                   torch.ones((1, 1, wq.shape[1]), dtype=dtype, device=wq.device))
+        return self.cache[key]
+
     def ln_folded(self, ln_name, wnames, bnames, dtype):
         """Operands of a LayerNorm folded into the linear layer behind it (sdmi.h: ln_colsum):
         W' = W * gamma in `dtype`, colsum[n] = sum_k W'[n][k] of the rounded W', bias' = W beta + b.
@@ -574,6 +589,38 @@ class Kern:
     def attn_cross(self, q, kv, heads):
         C = heads * 32
         return ops.attention(q, kv[..., :C], kv[..., C:], heads)
+
+    def cross_prepare(self, kv, t, heads):
+        """Once per sampling call (slots and weights are fixed over the NFEs): the 7 slot keys folded
+        into the query projection, the values into the output projection -- per image
+          Wq[b] = (scale K_b restricted per head) (W_q gamma)   [heads*8, C]   (+ LayerNorm-fold terms)
+          W2[b] = W_o (V_b restricted per head)^T               [C, heads*8]
+        so that slot cross-attention is two small per-image GEMMs per evaluation (cross_block)."""
+        if not (_CROSS_FOLD and kv.dtype == torch.bfloat16 and kv.shape[1] <= 7):
+            return None
+        wt, tb, ones = self.wb.cross_fold_weights(t, kv.dtype)
+        B, C = kv.shape[0], kv.shape[-1] // 2
+        R = heads * 8
+        kexp, vexp = ops.expand_heads(kv, heads, float(C // heads) ** -0.5)
+        wq = ops.bmm_nt(kexp, wt, torch.empty((B, R, C), dtype=kv.dtype, device=kv.device))
+        colsum = ops.bmm_nt(wq, ones, torch.empty((B, R, 1), dtype=torch.float32, device=kv.device))
+        biasq = ops.bmm_nt(kexp, tb, torch.empty((B, R, 1), dtype=torch.float32, device=kv.device))
+        wo = self.wb.w(t + '.attn2.to_out.0.weight', kv.dtype)
+        w2 = ops.bmm_nt(wo.view(1, C, C).expand(B, -1, -1), vexp,
+                        torch.empty((B, C, R), dtype=kv.dtype, device=kv.device))
+        return dict(wq=wq, colsum=colsum.view(B, R), biasq=biasq.view(B, R), w2=w2, slots=kv.shape[1])
+
+    def cross_block(self, tok, t, kvp, heads):
+        """norm2 -> slot cross-attention -> to_out + residual of transformer block `t` -> new tok."""
+        fold = kvp.get('fold') if isinstance(kvp, dict) else None
+        if fold is not None:
+            P = ops.cross_scores(tok, fold['wq'], fold['colsum'], fold['biasq'], 1e-5, fold['slots'])
+            return ops.bmm_nt(P, fold['w2'], torch.empty_like(tok), bias=self.wb.b(t + '.attn2.to_out.0.bias'),
+                              residual=tok)
+        kv = kvp['kv'] if isinstance(kvp, dict) else kvp
+        q, tres = self.ln_linear_fan(tok, t + '.norm2', t + '.attn2.to_q.weight')
+        a = self.attn_cross(q, kv, heads)
+        return self.linear(a, t + '.attn2.to_out.0.weight', t + '.attn2.to_out.0.bias', residual=tres)
 
     def geglu(self, h):
         return ops.geglu(h)

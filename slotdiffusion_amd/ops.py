@@ -138,16 +138,48 @@ def linear(x, w, bias=None, *, act=None, residual=None, out=None, out_dtype=None
     return out
 
 
-def bmm_nt(a, b, out, *, alpha=1.0, bias_m=None):
-    """Batched out[z] = alpha * a[z] @ b[z]^T (+ bias_m[:, None]); a [Z,M,K], b [Z,N,K]."""
+def bmm_nt(a, b, out, *, alpha=1.0, bias_m=None, bias=None, residual=None):
+    """Batched out[z] = alpha * a[z] @ b[z]^T (+ bias_m[:, None] | + bias[None, :]) (+ residual[z]);
+    a [Z,M,K] (stride(0) may be 0: shared), b [Z,N,K] or [1,N,K] (shared)."""
     _need_gpu(a, b, out)
     Z, M, K = a.shape
     N = b.shape[1]
-    call('sdmi_igemm', _stream(), a=_p(a), w=_p(b), out=_p(out), bias=_p(bias_m), dtype=_dt(a),
-         out_dtype=_dt(out), M=M, N=N, K=K, lda=a.stride(1), ldw=b.stride(1), ldc=out.stride(1),
+    assert bias_m is None or bias is None
+    call('sdmi_igemm', _stream(), a=_p(a), w=_p(b), out=_p(out), bias=_p(bias_m if bias_m is not None else bias),
+         dtype=_dt(a), out_dtype=_dt(out), M=M, N=N, K=K, lda=a.stride(1), ldw=b.stride(1), ldc=out.stride(1),
          B=M, H=1, W=1, Cin=K, Ho=1, Wo=1, KH=1, KW=1, stride=1, act=0, alpha=alpha,
          bias_m=int(bias_m is not None), split_k=1, batch=Z, sa=a.stride(0),
-         sw=(b.stride(0) if b.shape[0] == Z and Z > 1 else 0), sc=out.stride(0))
+         sw=(b.stride(0) if b.shape[0] == Z and Z > 1 else 0), sc=out.stride(0),
+         residual=_p(residual), ldr=(residual.stride(1) if residual is not None else 0),
+         sr=(residual.stride(0) if residual is not None else 0))
+    return out
+
+
+def expand_heads(kv, heads, scale):
+    """kv [B,S,2C] (K | V) -> (kexp, vexp) [B, heads*8, C]: slot j's key (scaled) / value restricted to
+    head h's channels in row h*8+j, zeros elsewhere (sdmi.h: sdmi_expand_heads)."""
+    _need_gpu(kv)
+    B, S, C2 = kv.shape
+    C = C2 // 2
+    kexp = torch.empty((B, heads * 8, C), dtype=kv.dtype, device=kv.device)
+    vexp = torch.empty_like(kexp)
+    call('sdmi_expand_heads', _stream(), kv=_p(kv), kexp=_p(kexp), vexp=_p(vexp), dtype=_dt(kv), B=B, S=S,
+         C=C, heads=heads, ldkv=kv.stride(1), scale=float(scale))
+    return kexp, vexp
+
+
+def cross_scores(tok, wq, colsum, biasq, eps, slots=7):
+    """Attention probabilities of the folded slot cross-attention: softmax over each head's 7 slots of
+    LayerNorm(tok[b]) @ wq[b]^T, the norm folded into the GEMM (sdmi.h: ln_colsum, softmax8).
+    tok [B,HW,C]; wq [B,R,C] (R = heads*8); colsum / biasq [B,R] fp32 -> P [B,HW,R]."""
+    _need_gpu(tok, wq)
+    B, HW, C = tok.shape
+    R = wq.shape[1]
+    out = torch.empty((B, HW, R), dtype=tok.dtype, device=tok.device)
+    call('sdmi_igemm', _stream(), a=_p(tok), w=_p(wq), out=_p(out), bias=_p(biasq), dtype=_dt(tok),
+         out_dtype=_dt(out), M=HW, N=R, K=C, lda=tok.stride(1), ldw=C, ldc=R, B=HW, H=1, W=1, Cin=C, Ho=1,
+         Wo=1, KH=1, KW=1, stride=1, act=0, alpha=1.0, bias_m=0, split_k=1, batch=B, sa=tok.stride(0),
+         sw=R * C, sc=HW * R, ln_colsum=_p(colsum), ln_eps=float(eps), s_colsum=R, s_bias=R, softmax8=int(slots))
     return out
 
 

@@ -548,3 +548,47 @@ def test_ssim_on_device_matches_oracle():
     assert abs(metrics.ssim_metric(x.to(DEV), x.to(DEV)) - 1.0) < 1e-9
     slots = torch.randn(6, 3, 7, 16, generator=g)
     assert torch.equal(metrics.shuffle_slots(slots.to(DEV)).cpu(), O.shuffle_slots(slots))
+
+
+def test_folded_slot_cross_attention_block():
+    """Slot cross-attention with the 7 keys folded into the query weights and the values into the
+    output projection (kern.Kern.cross_prepare / cross_block: sdmi_expand_heads, batched igemm with the
+    LayerNorm-fold + softmax8 epilogue, batched igemm with bias + residual) against the plain sequence
+    LayerNorm -> to_q -> softmax(q k^T / sqrt(d)) v -> to_out + residual in fp32 torch."""
+    ops = _ops()
+    dtype = torch.bfloat16
+    for (B, HW, C, heads, S) in [(3, 256, 256, 8, 7), (2, 64, 384, 12, 7), (4, 16, 512, 16, 5)]:
+        g = torch.Generator().manual_seed(B + HW + C)
+        hd = C // heads
+        tok = q(torch.randn(B, HW, C, generator=g) * 1.2 + 0.4, dtype)
+        kv = q(torch.randn(B, S, 2 * C, generator=g), dtype)
+        wq = torch.randn(C, C, generator=g) / math.sqrt(C)
+        wo = q(torch.randn(C, C, generator=g) / math.sqrt(C), dtype)
+        bo = torch.randn(C, generator=g)
+        gamma, beta = 1 + 0.2 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
+        # reference
+        n = F.layer_norm(tok, (C,), gamma, beta, 1e-5)
+        qq = (n @ wq.t()).view(B, HW, heads, hd).permute(0, 2, 1, 3)
+        kk = kv[..., :C].view(B, S, heads, hd).permute(0, 2, 1, 3)
+        vv = kv[..., C:].view(B, S, heads, hd).permute(0, 2, 1, 3)
+        att = ((qq @ kk.transpose(-1, -2)) * hd ** -0.5).softmax(-1) @ vv
+        ref = att.permute(0, 2, 1, 3).reshape(B, HW, C) @ wo.t() + bo + tok
+        # folded path (weight-side operands as WeightBank.cross_fold_weights builds them)
+        kvd, tokd = kv.to(dtype).to(DEV), tok.to(dtype).to(DEV)
+        wt = (wq * gamma).t().contiguous().to(dtype).to(DEV).unsqueeze(0)
+        tb = (wq @ beta).to(dtype).view(1, 1, -1).to(DEV)
+        ones = torch.ones(1, 1, C, dtype=dtype, device=DEV)
+        R = heads * 8
+        kexp, vexp = ops.expand_heads(kvd, heads, hd ** -0.5)
+        wqe = ops.bmm_nt(kexp, wt, torch.empty(B, R, C, dtype=dtype, device=DEV))
+        colsum = ops.bmm_nt(wqe, ones, torch.empty(B, R, 1, dtype=torch.float32, device=DEV)).view(B, R)
+        biasq = ops.bmm_nt(kexp, tb, torch.empty(B, R, 1, dtype=torch.float32, device=DEV)).view(B, R)
+        w2 = ops.bmm_nt(wo.to(dtype).to(DEV).view(1, C, C).expand(B, -1, -1), vexp,
+                        torch.empty(B, C, R, dtype=dtype, device=DEV))
+        P = ops.cross_scores(tokd, wqe, colsum, biasq, 1e-5, S)
+        Pf = P.float().cpu().view(B, HW, heads, 8)
+        assert float(Pf[..., S:].abs().max()) == 0.0                       # pad / absent slots get no mass
+        assert float((Pf.sum(-1) - 1).abs().max()) < 2e-2
+        out = ops.bmm_nt(P, w2, torch.empty_like(tokd), bias=bo.to(DEV), residual=tokd)
+        e = rel_l2(out, ref)
+        assert e <= 2e-2, (B, HW, C, e)
