@@ -46,12 +46,16 @@ def zeros(shape, dtype, device):
 # ------------------------------------------------------------------------------------------
 # implicit GEMM
 # ------------------------------------------------------------------------------------------
+_SPLITK_BELOW = int(__import__('os').environ.get('SDMI_SPLITK_BELOW', '384'))     # output tiles (64 x 64)
+_SPLITK_MINKB = int(__import__('os').environ.get('SDMI_SPLITK_MINKB', '2048'))    # bytes of K per row
+
+
 def splitk_workspace(M, N, K, elt, device):
     """fp32 partial-sum workspace for skinny problems (few output tiles, deep K) or None: the
     launcher then picks the K split itself (igemm.hip: dispatch)."""
     t64 = ((M + 63) // 64) * ((N + 63) // 64)
     t128 = ((M + 127) // 128) * ((N + 127) // 128)
-    if not (N > 64 and t128 >= 192) and t64 < 384 and K * elt >= 2048:
+    if not (N > 64 and t128 >= 192) and t64 < _SPLITK_BELOW and K * elt >= _SPLITK_MINKB:
         return torch.empty((16 * M * N,), dtype=torch.float32, device=device)
     return None
 
