@@ -436,7 +436,9 @@ typedef struct { const void* descs; int n_desc; int dtype; int total_blocks; } S
 int sdmi_pack_dgrad_batch(const SdmiPackBatchArgs* a, void* stream);
 /* out[g][n] = sum over the `rows_per` consecutive rows of group g of x[m][n] (fp32 out):
  * gradient of the per-image time-embedding row vector, bias gradients (rows_per = M). */
-typedef struct { const void* x; float* out; int dtype; int groups, rows_per, N, ldx; } SdmiRowGroupSumArgs;
+typedef struct { const void* x; float* out; int dtype; int groups, rows_per, N, ldx;
+                 int ldo; /* row pitch of out (0 = N): results written into a column slice of a wider matrix */
+} SdmiRowGroupSumArgs;
 int sdmi_rowgroup_sum(const SdmiRowGroupSumArgs* a, void* stream);
 /* y[b][y][x][c] = sum of the 2x2 block of x (backward of the nearest x2 upsample folded into a conv) */
 typedef struct { const void* x; void* y; int dtype; int B, H, W, C; } SdmiPool2x2Args;

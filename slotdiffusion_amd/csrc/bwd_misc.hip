@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void rowgroup_sum_kernel(SdmiRowGroupSumArgs p
     s3 += Elem<T>::ld(x + (long long)(r + 3) * p.ldx);
   }
   for (; r < p.rows_per; ++r) s0 += Elem<T>::ld(x + (long long)r * p.ldx);
-  p.out[(long long)g * p.N + n] = (s0 + s1) + (s2 + s3);
+  p.out[(long long)g * (p.ldo ? p.ldo : p.N) + n] = (s0 + s1) + (s2 + s3);
 }
 
 template <typename T>

@@ -185,8 +185,7 @@ class UNetRunner:
         consumers (GroupNorm, skip branch, skip-concat): the aliases route their gradients into
         the GroupNorm backward kernel."""
         n = self.P + name
-        off, cout = self.emb_off[name]
-        rv = rowvecs[:, off:off + cout]            # strided view; the kernel takes its row pitch
+        rv = rowvecs[name]                         # strided view; the kernel takes its row pitch
         outs = K.gn_fan(x, n + '.in_layers.0', eps=1e-5, act='silu', n_alias=2 if want_cat else 1,
                         for_conv=n + '.in_layers.2.weight')
         h, skip = outs[0], outs[1]
@@ -249,6 +248,8 @@ class UNetRunner:
 
     def forward(self, K, x, rowvecs, ctx_kv):
         """x [B,h,w,Cpad] compute dtype -> eps [B,h,w,4] fp32 (3 channels + zero pad)."""
+        names = [n for n, _ in self.res_names]
+        rowvecs = dict(zip(names, K.rowvec_slices(rowvecs, [self.emb_off[n] for n in names])))
         hs = []
         h = x
         # every input-block output has two consumers, the next block and a skip-concat: the next

@@ -628,6 +628,10 @@ class Kern:
     def add_pos(self, x, pos):
         return ops.add_pos(x, pos)
 
+    def rowvec_slices(self, rowvecs, bounds):
+        """[B, total] -> {i: rowvecs[:, off:off+c]} (strided views; the kernels take the row pitch)."""
+        return [rowvecs[:, off:off + c] for off, c in bounds]
+
     def concat(self, a, b):
         """Channel concatenation for the UNet's skip connections.  At inference the two readers of the
         result -- the ResBlock's first GroupNorm and its 1x1 skip convolution -- take the two tensors
@@ -679,6 +683,47 @@ def _grads_of(wb, names):
     return g[offs[0][0]:offs[-1][0] + offs[-1][1]]
 
 
+class _RowvecSink:
+    """Gradient matrix [B, total] shared by the column slices RowvecSplitFn hands out: every consumer
+    writes its slice (rowgroup_sum with an output pitch); allocated at the first write of a backward."""
+
+    def __init__(self, B, total):
+        self.B, self.total, self.buf = B, total, None
+
+    def buffer(self, device):
+        if self.buf is None:
+            self.buf = torch.empty((self.B, self.total), dtype=torch.float32, device=device)
+        return self.buf
+
+
+class RowvecSplitFn(torch.autograd.Function):
+    """rowvecs [B, total] -> its column slices (one per ResBlock: the time-embedding rows).  Plain
+    slicing costs three framework kernels per slice in backward (zeros, copy, accumulate): here the
+    consumers' backward kernels write straight into one shared gradient matrix, which this backward
+    just returns.  The slices must tile [0, total) and each be consumed exactly once."""
+
+    @staticmethod
+    def forward(ctx, rowvecs, bounds):
+        B, total = rowvecs.shape
+        assert bounds[0][0] == 0 and bounds[-1][0] + bounds[-1][1] == total
+        sink = _RowvecSink(B, total)
+        ctx.sink = sink
+        outs = []
+        for off, c in bounds:
+            v = rowvecs[:, off:off + c]
+            outs.append(v)
+        ctx.set_materialize_grads(False)
+        ctx.n = len(bounds)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        sink = ctx.sink
+        assert sink.buf is not None and all(g is not None for g in grads), 'every slice needs its consumer'
+        buf, sink.buf = sink.buf, None
+        return buf, None
+
+
 class GemmFn(torch.autograd.Function):
     """out = conv/linear(x, W) + bias (+ rowvec[b]) (+ residual).  Activation-free."""
 
@@ -698,6 +743,7 @@ class GemmFn(torch.autograd.Function):
         ctx.save_for_backward(x)
         ctx.cfg = (wb, wnames, bnames, geom, rowvec is not None, residual is not None,
                    rowvec.shape if rowvec is not None else None)
+        ctx.rv_sink = getattr(rowvec, '_sdmi_sink', None)      # (RowvecSplitFn: shared gradient matrix)
         ctx.set_materialize_grads(False)
         if n_alias:
             return out, x.view_as(x)
@@ -713,9 +759,15 @@ class GemmFn(torch.autograd.Function):
                                                        ctx.needs_input_grad[0], dalias)
         drv = None
         if has_rv and ctx.needs_input_grad[1]:
-            drv = torch.empty(rv_shape, dtype=torch.float32, device=x.device)
-            call('sdmi_rowgroup_sum', _st(), x=_p(dy), out=_p(drv), dtype=_DT[dt], groups=B,
-                 rows_per=Ho * Wo, N=N, ldx=ldy)
+            if ctx.rv_sink is not None:        # a column slice of the shared [B, total] gradient matrix
+                sink, off = ctx.rv_sink
+                drv = sink.buffer(x.device)[:, off:off + N]
+                call('sdmi_rowgroup_sum', _st(), x=_p(dy), out=_p(drv), dtype=_DT[dt], groups=B,
+                     rows_per=Ho * Wo, N=N, ldx=ldy, ldo=drv.stride(0))
+            else:
+                drv = torch.empty(rv_shape, dtype=torch.float32, device=x.device)
+                call('sdmi_rowgroup_sum', _st(), x=_p(dy), out=_p(drv), dtype=_DT[dt], groups=B,
+                     rows_per=Ho * Wo, N=N, ldx=ldy)
         dres = None
         if has_res and ctx.needs_input_grad[2]:
             dres = dy if dy.shape[-1] == N else None
@@ -1610,6 +1662,15 @@ class KernGrad(Kern):
                 self._drop_ctr += 1
                 drop = (p, (self.seed << 20) + self._drop_ctr, getattr(self.wb.model, 'step_seed', None))
         return GroupNormFn.apply(x, residual, self.wb.anchor_for(name), self.wb, name, eps, act, 0, drop)
+
+    def rowvec_slices(self, rowvecs, bounds):
+        if not rowvecs.requires_grad:
+            return [rowvecs[:, off:off + c] for off, c in bounds]
+        outs = RowvecSplitFn.apply(rowvecs, tuple(bounds))
+        sink = outs[0].grad_fn.sink if hasattr(outs[0].grad_fn, 'sink') else None
+        for v, (off, c) in zip(outs, bounds):
+            v._sdmi_sink = (sink, off)
+        return list(outs)
 
     def gn_fan(self, x, name, *, eps, act=None, residual=None, n_alias=1, for_conv=None):
         return GroupNormFn.apply(x, residual, self.wb.anchor_for(name), self.wb, name, eps, act, n_alias)
