@@ -431,6 +431,10 @@ typedef struct {
   const void* src; void* dst;
   int Cout, KH, KW, Cin, CoutPad;
   int block_begin;
+  /* optional tap selection (nkh > 0): dst holds only the taps kh' = kh0 + i*kstep (i < nkh),
+   * kw' = kw0 + j*kstep (j < nkw) of the flipped filter, [Cin][nkh][nkw][CoutPad] -- the parity
+   * sub-filters of a strided convolution's data gradient; the operand takes nkh*nkw tap slices. */
+  int kh0, kw0, kstep, nkh, nkw;
 } SdmiPackDesc;
 typedef struct { const void* descs; int n_desc; int dtype; int total_blocks; } SdmiPackBatchArgs;
 int sdmi_pack_dgrad_batch(const SdmiPackBatchArgs* a, void* stream);

@@ -49,10 +49,14 @@ __global__ __launch_bounds__(256) void pack_dgrad_batch_kernel(SdmiPackBatchArgs
   const int ci0 = (w % tci) * 64;
   w /= tci;
   const int co0 = (w % tco) * 64;
-  const int tap = w / tco;                       // destination tap (kh', kw')
-  const int kh = tap / d.KW, kw = tap - kh * d.KW;
+  const int tap = w / tco;                       // destination tap slot
+  const bool sel = d.nkh > 0;                    // tap selection (parity sub-filter) or the whole filter
+  const int nkw = sel ? d.nkw : d.KW;
+  const int ti = tap / nkw, tj = tap - ti * nkw;
+  const int kh = sel ? d.kh0 + ti * d.kstep : ti, kw = sel ? d.kw0 + tj * d.kstep : tj;   // (kh', kw')
   const int stap = (d.KH - 1 - kh) * d.KW + (d.KW - 1 - kw);
-  const int taps = d.KH * d.KW;
+  const int taps = d.KH * d.KW;                  // source taps
+  const int dtaps = sel ? d.nkh * d.nkw : taps;  // destination taps
   const T* src = (const T*)d.src;
   T* dst = (T*)d.dst;
   for (int i = threadIdx.x; i < 64 * VPR; i += 256) {
@@ -74,7 +78,7 @@ __global__ __launch_bounds__(256) void pack_dgrad_batch_kernel(SdmiPackBatchArgs
     T* e = reinterpret_cast<T*>(&v);
 #pragma unroll
     for (int j = 0; j < VEC; ++j) e[j] = tile[c + j][r];   // rows co >= Cout hold zeros
-    *reinterpret_cast<uint4*>(dst + ((long long)ci * taps + tap) * d.CoutPad + co) = v;
+    *reinterpret_cast<uint4*>(dst + ((long long)ci * dtaps + tap) * d.CoutPad + co) = v;
   }
 }
 

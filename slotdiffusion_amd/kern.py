@@ -447,6 +447,48 @@ class WeightBank:
             self._wd_table = None          # new member: rebuild the descriptor table
         return dst
 
+    @staticmethod
+    def _fill_desc(d, e, blk):
+        w, n, kh, kw, cin, npad = e[2][:6]
+        d.src, d.dst = w.data_ptr(), e[0].data_ptr()
+        d.Cout, d.KH, d.KW, d.Cin, d.CoutPad, d.block_begin = n, kh, kw, cin, npad, blk
+        taps = kh * kw
+        if len(e[2]) > 6:                       # parity sub-filter: selected taps only
+            d.kh0, d.kw0, d.kstep, d.nkh, d.nkw = e[2][6]
+            taps = d.nkh * d.nkw
+        return blk + taps * ((n + 63) // 64) * ((cin + 63) // 64)
+
+    def wd_sub(self, names, dtype, kh, kw, cin_x, kh0, kw0, step):
+        """Parity sub-filter of the dgrad operand (taps kh0::step, kw0::step of the flipped filter,
+        [Cin][nkh][nkw][CoutPad]) for the data gradient of a strided convolution; kept and re-packed
+        with the other dgrad operands (one sdmi_pack_dgrad_batch launch per optimiser step)."""
+        names = names if not isinstance(names, str) else (names,)
+        key = ('dgradsub', names, dtype, kh0, kw0, step)
+        if self._wd_stale:
+            self._repack_all()
+        ent = self._wd.get(key)
+        if ent is not None and ent[1] == self._wd_epoch:
+            return ent[0]
+        w = self.w(names, dtype)
+        n = w.shape[0]
+        vec = ops.vec_of(dtype)
+        npad = (n + vec - 1) // vec * vec
+        nkh, nkw = len(range(kh0, kh, step)), len(range(kw0, kw, step))
+        dst = ent[0] if ent is not None else \
+            (torch.zeros if npad != n else torch.empty)((cin_x * nkh * nkw, npad), dtype=dtype, device=w.device)
+        stable = self._in_arena(w)
+        e = [dst, self._wd_epoch, (w if stable else None, n, kh, kw, cin_x, npad, (kh0, kw0, step, nkh, nkw))]
+        # (first use / unstable operand: a one-entry table -- eager only, it copies the table to the device)
+        Desc = _lib.CSTRUCT['SdmiPackDesc']
+        arr = (Desc * 1)()
+        blocks = self._fill_desc(arr[0], [dst, 0, (w,) + e[2][1:]], 0)
+        dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(w.device)
+        call('sdmi_pack_dgrad_batch', _st(), descs=_p(dev), n_desc=1, dtype=_DT[dtype], total_blocks=blocks)
+        self._wd[key] = e
+        if stable:
+            self._wd_table = None
+        return dst
+
     def _in_arena(self, t):
         m = self.model
         for a in (m.arena(), m.shadow_arena() if m.compute_dtype != torch.float32 else None):
@@ -458,17 +500,14 @@ class WeightBank:
         self._wd_stale = False
         self._wd_epoch += 1
         for dtype in {k[2] for k, e in self._wd.items() if e[2][0] is not None}:
-            items = [e for k, e in self._wd.items() if k[2] == dtype and e[2][0] is not None]
+            items = [e for k, e in self._wd.items() if k[2] == dtype and e[2][0] is not None]   # full + sub-filters
             tab = self._wd_table.get(dtype) if self._wd_table else None
             if tab is None:
                 Desc = _lib.CSTRUCT['SdmiPackDesc']
                 arr = (Desc * len(items))()
                 blk = 0
                 for d, e in zip(arr, items):
-                    w, n, kh, kw, cin, npad = e[2]
-                    d.src, d.dst = w.data_ptr(), e[0].data_ptr()
-                    d.Cout, d.KH, d.KW, d.Cin, d.CoutPad, d.block_begin = n, kh, kw, cin, npad, blk
-                    blk += kh * kw * ((n + 63) // 64) * ((cin + 63) // 64)
+                    blk = self._fill_desc(d, e, blk)
                 dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(
                     items[0][0].device)
                 tab = (dev, len(items), blk)
@@ -848,8 +887,9 @@ class GemmFn(torch.autograd.Function):
         if need_dx:
             wd = wb.wd(wnames, dt, kh, kw, Cin)
             if is_conv and stride > 1 and not ups:
-                dx, dalias = GemmFn._dgrad_strided(dy, wd, B, H, W_, Ho, Wo, Cin, ldy, kh, kw, stride,
-                                                   pad, dt, dalias)
+                dx, dalias = GemmFn._dgrad_strided(
+                    dy, wd, B, H, W_, Ho, Wo, Cin, ldy, kh, kw, stride, pad, dt, dalias,
+                    sub_of=lambda a0, b0: wb.wd_sub(wnames, dt, kh, kw, Cin, a0, b0, stride))
             elif is_conv:
                 Hs, Ws = (2 * H, 2 * W_) if ups else (H, W_)
                 out = torch.empty((B, Hs, Ws, Cin), dtype=dt, device=x.device)
@@ -880,7 +920,7 @@ class GemmFn(torch.autograd.Function):
         return dx, dy, (N, ldy, B, Ho, Wo, dt)
 
     @staticmethod
-    def _dgrad_strided(dy, wd, B, H, W_, Ho, Wo, Cin, ldy, kh, kw, s, pad, dt, extra=None):
+    def _dgrad_strided(dy, wd, B, H, W_, Ho, Wo, Cin, ldy, kh, kw, s, pad, dt, extra=None, sub_of=None):
         """Data gradient of a stride-s convolution as s*s plain stride-1 convolutions over dy, one
         per input-pixel parity (py, px): only the filter taps kh = (py + pad_t) mod s (+ s, ...)
         reach that parity, so each launch uses its sub-filter (a strided slice of the flipped
@@ -904,7 +944,8 @@ class GemmFn(torch.autograd.Function):
                 ws_ = len(range(px, W_, s))
                 if nky == 0 or nkx == 0 or hs == 0 or ws_ == 0:
                     continue
-                sub = w4[:, (kh - 1 - ay) % s::s, (kw - 1 - ax) % s::s, :].contiguous()
+                sub = sub_of((kh - 1 - ay) % s, (kw - 1 - ax) % s) if sub_of is not None else \
+                    w4[:, (kh - 1 - ay) % s::s, (kw - 1 - ax) % s::s, :].contiguous()
                 K = nky * nkx * ldy
                 call('sdmi_igemm', _st(), a=_p(dy), w=_p(sub), out=_p(dx), dtype=_DT[dt],
                      out_dtype=_DT[dt], M=B * hs * ws_, N=Cin, K=K, lda=ldy, ldw=K, ldc=Cin, B=B,
