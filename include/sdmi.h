@@ -458,6 +458,12 @@ int sdmi_add(const SdmiAddArgs* a, void* stream);
 typedef struct { const float* src; float* dst; long long count; } SdmiScatterItem;
 typedef struct { const void* items; int n; } SdmiScatterAddArgs;
 int sdmi_scatter_add(const SdmiScatterAddArgs* a, void* stream);
+/* Up to 32 plain device-to-device copies in ONE launch (`items`: HOST array of n SdmiCopyItem, table by
+ * value): the fused operand / bias of a GEMM over parameters that are not adjacent in the arena is
+ * re-gathered after every optimiser step this way (22 blocks -> 1 launch instead of 44). */
+typedef struct { const void* src; void* dst; long long bytes; } SdmiCopyItem;
+typedef struct { const void* items; int n; } SdmiCopyGroupArgs;
+int sdmi_copy_group(const SdmiCopyGroupArgs* a, void* stream);
 /* EMA of the denoiser weights (LitEma.forward, ddpm/ema.py:29-52):
  * shadow[i] -= one_minus_decay * (shadow[i] - p[i]) over a contiguous fp32 arena range. */
 typedef struct { float* shadow; const float* p; long long n; float one_minus_decay; } SdmiEmaArgs;

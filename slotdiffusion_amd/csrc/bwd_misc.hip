@@ -160,6 +160,20 @@ __global__ __launch_bounds__(256) void scatter_add_kernel(ScatterTable t) {
     s.dst[i] += s.src[i];
 }
 
+struct CopyTable { SdmiCopyItem it[SCATTER_MAX]; };
+__global__ __launch_bounds__(256) void copy_group_kernel(CopyTable t) {
+  const SdmiCopyItem s = t.it[blockIdx.y];
+  const char* src = (const char*)s.src;
+  char* dst = (char*)s.dst;
+  const bool vec = ((((uintptr_t)src) | ((uintptr_t)dst)) & 15) == 0;
+  const long long nv = vec ? s.bytes / 16 : 0;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nv; i += (long long)gridDim.x * 256)
+    reinterpret_cast<uint4*>(dst)[i] = reinterpret_cast<const uint4*>(src)[i];
+  for (long long i = nv * 16 + (long long)blockIdx.x * 256 + threadIdx.x; i < s.bytes;
+       i += (long long)gridDim.x * 256)
+    dst[i] = src[i];
+}
+
 template <typename T>
 __global__ void split_kernel(SdmiSplitArgs p) {
   constexpr int VEC = Elem<T>::VEC;
@@ -326,6 +340,22 @@ extern "C" int sdmi_scatter_add(const SdmiScatterAddArgs* a, void* stream) {
   if (blocks > 256) blocks = 256;
   hipLaunchKernelGGL(scatter_add_kernel, dim3((unsigned)blocks, a->n), dim3(256), 0, (hipStream_t)stream, t);
   return sdmi_check_launch("scatter_add");
+}
+extern "C" int sdmi_copy_group(const SdmiCopyGroupArgs* a, void* stream) {
+  SDMI_REQUIRE(a && a->items && a->n >= 1 && a->n <= SCATTER_MAX, "1 .. 32 copies");
+  const SdmiCopyItem* it = (const SdmiCopyItem*)a->items;
+  CopyTable t;
+  long long mx = 0;
+  for (int i = 0; i < a->n; ++i) {
+    SDMI_REQUIRE(it[i].src && it[i].dst && it[i].bytes >= 0, "bad item");
+    t.it[i] = it[i];
+    if (it[i].bytes > mx) mx = it[i].bytes;
+  }
+  long long blocks = (mx / 16 + 255) / 256;
+  if (blocks < 1) blocks = 1;
+  if (blocks > 256) blocks = 256;
+  hipLaunchKernelGGL(copy_group_kernel, dim3((unsigned)blocks, a->n), dim3(256), 0, (hipStream_t)stream, t);
+  return sdmi_check_launch("copy_group");
 }
 extern "C" int sdmi_split_channels(const SdmiSplitArgs* a, void* stream) {
   SDMI_REQUIRE(a && a->y && a->a && a->b, "null pointer");

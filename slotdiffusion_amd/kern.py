@@ -65,6 +65,18 @@ _CROSS_FOLD = os.environ.get('SDMI_CROSS_FOLD', '1') != '0'
 _LN_FOLD = os.environ.get('SDMI_LN_FOLD', '1') != '0'
 
 
+def _copy_group(items):
+    """[(src ptr, dst ptr, bytes)] -> sdmi_copy_group launches of up to 32 copies each."""
+    import ctypes
+    Item = _lib.CSTRUCT['SdmiCopyItem']
+    for c0 in range(0, len(items), 32):
+        chunk = items[c0:c0 + 32]
+        arr = (Item * len(chunk))()
+        for a, (sp, dp, nb) in zip(arr, chunk):
+            a.src, a.dst, a.bytes = sp, dp, nb
+        call('sdmi_copy_group', _st(), items=ctypes.addressof(arr), n=len(chunk))
+
+
 class WeightBank:
     """name(s) -> GEMM operand [N, K] in the requested dtype (K padded to the vector width)."""
 
@@ -325,6 +337,16 @@ class WeightBank:
                 base = self.model.arena() if dtype == torch.float32 else self.model.shadow_arena()
                 o = self.model._offsets[names[0]][0]
                 out = base[o:o + n * k].view(n, k)
+        if out is None and all(p is not None for p in parts) and len({p.shape[1] for p in parts}) == 1:
+            # operand views exist but are not adjacent (the 22 time-embedding projections): gather them
+            # with ONE grouped copy instead of a cast + a copy per part
+            out = torch.empty((sum(p.shape[0] for p in parts), parts[0].shape[1]), dtype=dtype,
+                              device=parts[0].device)
+            o, items = 0, []
+            for p in parts:
+                items.append((_p(p), _p(out[o:]), p.numel() * p.element_size()))
+                o += p.shape[0]
+            _copy_group(items)
         if out is None:
             mats = []
             vec = ops.vec_of(dtype)
@@ -412,6 +434,14 @@ class WeightBank:
         parts = [self.t[n] for n in names]
         out = torch.empty((sum(p.numel() for p in parts),), dtype=torch.float32,
                           device=parts[0].device)
+        if all(p.dtype == torch.float32 and p.is_contiguous() for p in parts):
+            o, items = 0, []
+            for p in parts:
+                items.append((_p(p), _p(out[o:]), p.numel() * 4))
+                o += p.numel()
+            _copy_group(items)
+            self.cache[key] = out
+            return out
         o = 0
         for p in parts:
             ops.cast2d(p.view(-1, 1), torch.float32, out=out[o:o + p.numel()].view(-1, 1))
