@@ -201,12 +201,18 @@ typedef struct {
   float drop_p;         /* the forward's fused dropout (mask regenerated from the seed) */
   long long drop_seed;
   const long long* drop_seed_dev;
+  float* dxsum;         /* optional [B][ld_dxsum]: dxsum[b][c] = sum over the image's pixels of dx[b][.][c]
+                           (single-pass kernel only; sdmi_groupnorm_bwd_fused tells) -- the gradient of a
+                           per-image row vector that was added to x (ResBlock time embedding, unet.py:268) */
+  int ld_dxsum;
   int defer_colsum;     /* != 0: leave the per-image channel sums in `partial` ([B*nsplit][C][2]); the
                            caller folds them into dbeta / dgamma later with sdmi_colsum_group */
 } SdmiGroupNormBwdArgs;
 int sdmi_groupnorm_bwd(const SdmiGroupNormBwdArgs* a, void* stream);
 /* number of [C][2] entries sdmi_groupnorm_bwd leaves in `partial` for this geometry (B for the
  * single-pass kernels, B * nsplit for the two-pass ones); no launch.  Returns the count (> 0). */
+/* query: 1 if sdmi_groupnorm_bwd runs this geometry as the single-pass kernel (and fills dxsum) */
+int sdmi_groupnorm_bwd_fused(const SdmiGroupNormBwdArgs* a, void* unused);
 int sdmi_groupnorm_bwd_entries(const SdmiGroupNormBwdArgs* a, void* stream);
 
 /* LayerNorm over the last dim (eps 1e-5 default): attention.py:238-240, savi.py:38-54. */

@@ -193,8 +193,11 @@ __global__ __launch_bounds__(THREADS) void gn_bwd_fused_kernel(SdmiGroupNormBwdA
     gsum[g][1] = (float)s2;
   }
   __syncthreads();
-  if (!act_c) return;
   const float inv_n = 1.f / ((float)p.HW * (float)cpg);
+  float sd[VEC];                        // per-channel sums of dx over this thread's rows (dxsum)
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) sd[j] = 0.f;
+  if (act_c) {
   float s1[VEC], s2[VEC];
 #pragma unroll
   for (int j = 0; j < VEC; ++j) {
@@ -231,8 +234,32 @@ __global__ __launch_bounds__(THREADS) void gn_bwd_fused_kernel(SdmiGroupNormBwdA
 #pragma unroll
         for (int j = 0; j < VEC; ++j) dx[j] += ex[j];
       }
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) sd[j] += dx[j];
       *reinterpret_cast<uint4*>(dxb + o) = pack16<T>(dx);
       if (drb) *reinterpret_cast<uint4*>(drb + o) = dr[i];
+    }
+  }
+  }
+  if (p.dxsum) {                         // (uniform: every thread of the workgroup takes this path)
+    for (int off = CVp; off < 64; off <<= 1) {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) sd[j] += __shfl_xor(sd[j], off, 64);
+    }
+    __syncthreads();                     // `part` is free again (group sums were read above)
+    if (CVp >= 64 || (int)(threadIdx.x & 63) < CVp) {
+      const int slot = CVp < 64 ? (threadIdx.x >> 6) * CVp + cv : threadIdx.x;
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) part[slot][j][0] = sd[j];
+    }
+    __syncthreads();
+    if (r0 == 0 && act_c) {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        float t = 0.f;
+        for (int r = 0; r < RR; ++r) t += part[r * CVp + cv][j][0];
+        p.dxsum[(long long)b * p.ld_dxsum + c_lo + cv * VEC + j] = t;
+      }
     }
   }
 }
@@ -513,6 +540,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(SdmiLayerNormBwdArgs p, int
   }
 }
 }  // namespace
+
+extern "C" int sdmi_groupnorm_bwd_fused(const SdmiGroupNormBwdArgs* a, void*) {
+  if (!a || a->C <= 0 || a->groups <= 0) return 0;
+  const int vec = a->dtype == SDMI_BF16 ? 8 : 4;
+  int nv_of_T[3] = {16, 16, a->dtype == SDMI_BF16 ? 4 : 8};
+  return gn_pick(a->B, a->HW, a->C, a->groups, vec, nv_of_T).T ? 1 : 0;
+}
 
 extern "C" int sdmi_groupnorm_bwd_entries(const SdmiGroupNormBwdArgs* a, void*) {
   if (!a || a->C <= 0 || a->groups <= 0) return 0;

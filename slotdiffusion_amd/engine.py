@@ -191,7 +191,7 @@ class UNetRunner:
         h, skip = outs[0], outs[1]
         h = K.conv(h, n + '.in_layers.2.weight', n + '.in_layers.2.bias', rowvec=rv)
         h = K.gn(h, n + '.out_layers.0', eps=1e-5, act='silu', dropout='unet',      # (dropout: training only)
-                 for_conv=n + '.out_layers.3.weight')
+                 for_conv=n + '.out_layers.3.weight', rowsum_of=rv)
         if (n + '.skip_connection.weight') in K.wb.t:
             skip = K.conv(skip, n + '.skip_connection.weight', n + '.skip_connection.bias', kh=1, kw=1,
                           pad=(0, 0, 0, 0))

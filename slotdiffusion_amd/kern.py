@@ -588,7 +588,7 @@ class Kern:
         return ops.linear(x, self.wb.w(wnames, x.dtype), self.wb.b(bnames), act=act,
                           residual=residual, out_dtype=out_dtype)
 
-    def gn(self, x, name, *, eps, act=None, residual=None, dropout=None, for_conv=None):
+    def gn(self, x, name, *, eps, act=None, residual=None, dropout=None, for_conv=None, rowsum_of=None):
         if isinstance(x, CatPair):
             f8 = FP8_ACT_SCALE if (for_conv and self.fp8_ok(x, for_conv, 9, False)) else None
             return ops.group_norm(x.a, self.wb.f(name + '.weight'), self.wb.f(name + '.bias'), eps=eps,
@@ -758,6 +758,7 @@ class _RowvecSink:
 
     def __init__(self, B, total):
         self.B, self.total, self.buf = B, total, None
+        self.filled = set()        # offsets whose slice a GroupNorm backward has written already
 
     def buffer(self, device):
         if self.buf is None:
@@ -790,6 +791,7 @@ class RowvecSplitFn(torch.autograd.Function):
         sink = ctx.sink
         assert sink.buf is not None and all(g is not None for g in grads), 'every slice needs its consumer'
         buf, sink.buf = sink.buf, None
+        sink.filled.clear()
         return buf, None
 
 
@@ -831,8 +833,9 @@ class GemmFn(torch.autograd.Function):
             if ctx.rv_sink is not None:        # a column slice of the shared [B, total] gradient matrix
                 sink, off = ctx.rv_sink
                 drv = sink.buffer(x.device)[:, off:off + N]
-                call('sdmi_rowgroup_sum', _st(), x=_p(dy), out=_p(drv), dtype=_DT[dt], groups=B,
-                     rows_per=Ho * Wo, N=N, ldx=ldy, ldo=drv.stride(0))
+                if off not in sink.filled:     # (else: the GroupNorm behind this conv summed its dx already)
+                    call('sdmi_rowgroup_sum', _st(), x=_p(dy), out=_p(drv), dtype=_DT[dt], groups=B,
+                         rows_per=Ho * Wo, N=N, ldx=ldy, ldo=drv.stride(0))
             else:
                 drv = torch.empty(rv_shape, dtype=torch.float32, device=x.device)
                 call('sdmi_rowgroup_sum', _st(), x=_p(dy), out=_p(drv), dtype=_DT[dt], groups=B,
@@ -1092,8 +1095,11 @@ class MultiLinearFn(torch.autograd.Function):
 
 class GroupNormFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, residual, anchor, wb, name, eps, act, n_alias=0, drop=None):
-        """drop = (p, seed, seed_dev): dropout fused behind the activation (the mask is regenerated
+    def forward(ctx, x, residual, anchor, wb, name, eps, act, n_alias=0, drop=None, rsink=None):
+        """rsink = (sink, offset): x = conv(.) + a per-image row vector whose gradient -- the pixel sums
+        of this norm's dx -- goes into that slice of the shared row-vector gradient matrix (written
+        by the backward kernel itself: no separate reduction launch).
+        drop = (p, seed, seed_dev): dropout fused behind the activation (the mask is regenerated
         from the seed in backward).  n_alias aliases of x are returned next to y for x's other consumers (ResBlock skip,
         UNet skip-concat, SpatialTransformer residual): their gradients come back into this
         backward and are summed by the GroupNorm backward kernel (dextra0/1) -- no separate
@@ -1104,6 +1110,7 @@ class GroupNormFn(torch.autograd.Function):
         ctx.save_for_backward(x, stats, residual)
         ctx.cfg = (wb, name, act)
         ctx.drop = drop if (drop is not None and drop[0] > 0.0) else None
+        ctx.rsink = rsink
         ctx.set_materialize_grads(False)
         if n_alias:
             return (y,) + tuple(x.view_as(x) for _ in range(n_alias))
@@ -1119,7 +1126,7 @@ class GroupNormFn(torch.autograd.Function):
             dx = extras[0]
             for e in extras[1:]:
                 dx = AddFn.apply(dx, e)
-            return dx, None, None, None, None, None, None, None, None
+            return dx, None, None, None, None, None, None, None, None, None
         dy = dy.contiguous()
         B, C = x.shape[0], x.shape[-1]
         HW = x.numel() // (B * C)
@@ -1135,15 +1142,26 @@ class GroupNormFn(torch.autograd.Function):
         defer = wb.defer_colsum
         if defer:          # the dbeta / dgamma folds of the whole step run in a few grouped launches
             wb.queue_colsum(partial, _lib.query('sdmi_groupnorm_bwd_entries', **geo), C, db, dg)
+        rs_kw, rs_view = {}, None
+        if ctx.rsink is not None and not extras:
+            sink, off = ctx.rsink
+            rs_view = sink.buffer(x.device)[:, off:off + C]
+            if _lib.query('sdmi_groupnorm_bwd_fused', **geo):
+                rs_kw = dict(dxsum=_p(rs_view), ld_dxsum=rs_view.stride(0))
         call('sdmi_groupnorm_bwd', _st(), x=_p(x), dy=_p(dy), dx=_p(dx), gamma=_p(wb.f(name + '.weight')),
              beta=_p(wb.f(name + '.bias')), stats=_p(stats), dgamma=_p(dg), dbeta=_p(db),
-             partial=_p(partial), defer_colsum=int(defer), **geo,
+             partial=_p(partial), defer_colsum=int(defer), **geo, **rs_kw,
              act=_lib.ACT[act], residual=_p(residual), dresidual=_p(dres), accumulate=1,
              dextra0=(_p(extras[0]) if extras else 0), dextra1=(_p(extras[1]) if len(extras) > 1 else 0),
              **(dict(drop_p=float(ctx.drop[0]), drop_seed=int(ctx.drop[1]), drop_seed_dev=_p(ctx.drop[2]))
                 if ctx.drop else {}))
+        if rs_view is not None:
+            if not rs_kw:              # two-pass geometry: the sums take their own launch after all
+                call('sdmi_rowgroup_sum', _st(), x=_p(dx), out=_p(rs_view), dtype=_DT[dx.dtype], groups=B,
+                     rows_per=HW, N=C, ldx=C, ldo=rs_view.stride(0))
+            ctx.rsink[0].filled.add(ctx.rsink[1])
         _dbg(f'gn {name}', dy=dy, dx=dx, dres=dres)
-        return dx, dres, None, None, None, None, None, None, None
+        return dx, dres, None, None, None, None, None, None, None, None
 
 
 class LayerNormFn(torch.autograd.Function):
@@ -1725,14 +1743,15 @@ class KernGrad(Kern):
                          (0, 0, 1, (0, 0, 0, 0), False), out_dtype, None)
         return ActFn.apply(y, act) if act else y
 
-    def gn(self, x, name, *, eps, act=None, residual=None, dropout=None, for_conv=None):
+    def gn(self, x, name, *, eps, act=None, residual=None, dropout=None, for_conv=None, rowsum_of=None):
         drop = None
         if dropout is not None:
             p = self._p_drop(dropout)
             if p > 0.0:          # fused behind the activation: same seed scheme as DropoutFn
                 self._drop_ctr += 1
                 drop = (p, (self.seed << 20) + self._drop_ctr, getattr(self.wb.model, 'step_seed', None))
-        return GroupNormFn.apply(x, residual, self.wb.anchor_for(name), self.wb, name, eps, act, 0, drop)
+        return GroupNormFn.apply(x, residual, self.wb.anchor_for(name), self.wb, name, eps, act, 0, drop,
+                                 getattr(rowsum_of, '_sdmi_sink', None))
 
     def rowvec_slices(self, rowvecs, bounds):
         if not rowvecs.requires_grad:
