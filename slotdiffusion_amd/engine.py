@@ -218,9 +218,7 @@ class UNetRunner:
         # GEGLU feed-forward
         g, tres = K.ln_linear_fan(tok, t + '.norm3', t + '.ff.net.0.proj.weight', t + '.ff.net.0.proj.bias',
                                   geglu=True)
-        tok = K.linear(g, t + '.ff.net.2.weight', t + '.ff.net.2.bias', residual=tres)
-        out = K.linear(tok, n + '.proj_out.weight', n + '.proj_out.bias',
-                       residual=xres.view(B, H * W, C))
+        out = K.ff_out_proj(g, tres, xres.view(B, H * W, C), t, n)
         return out.view(B, H, W, C)
 
     def _run(self, K, layers, h, rowvecs, ctx_kv, want_cat=False):

@@ -61,6 +61,7 @@ class CatPair:
         return ops.concat_channels(self.a, self.b)
 
 
+_FF_MERGE = os.environ.get('SDMI_FF_MERGE', '1') != '0'
 _CROSS_FOLD = os.environ.get('SDMI_CROSS_FOLD', '1') != '0'
 _LN_FOLD = os.environ.get('SDMI_LN_FOLD', '1') != '0'
 
@@ -390,6 +391,21 @@ class WeightBank:
             self.cache[key] = (ops.quant_fp8(flat.float().contiguous(), scale), 1.0 / scale)
         return self.cache[key]
 
+    def ffout_proj_weights(self, t, n, dtype):
+        """Feed-forward output and proj_out of a SpatialTransformer are two linear layers with only a
+        residual add in between (attention.py:250-251, 305-308):
+            out = (g Wff^T + bff + tres) Wpo^T + bpo + xres = [g | tres] [Wpo Wff | Wpo]^T + (Wpo bff + bpo) + xres
+        -> combined weight [C, 4C + C] in `dtype` and fp32 bias (weight preparation, cached)."""
+        key = ('ffoutproj', t, dtype)
+        if key not in self.cache:
+            with torch.no_grad():
+                wff, bff = self.t[t + '.ff.net.2.weight'].float(), self.t[t + '.ff.net.2.bias'].float()
+                wpo = self.t[n + '.proj_out.weight'].float().reshape(wff.shape[0], -1)
+                bpo = self.t[n + '.proj_out.bias'].float()
+                w = torch.cat([wpo @ wff, wpo], 1).to(dtype).contiguous()
+                self.cache[key] = (w, (wpo @ bff + bpo).contiguous())
+        return self.cache[key]
+
     def cross_fold_weights(self, t, dtype):
         """Weight-side operands of the folded slot cross-attention of transformer block `t`
         (engine.UNetRunner.cross_fold): (W_q * gamma_norm2)^T [C_k, C_d], (W_q beta_norm2) [1, C_d],
@@ -658,6 +674,18 @@ class Kern:
     def attn_cross(self, q, kv, heads):
         C = heads * 32
         return ops.attention(q, kv[..., :C], kv[..., C:], heads)
+
+    def ff_out_proj(self, g, tres, xres, t, n):
+        """ff.net.2 (+ token residual) followed by proj_out (+ block residual): ONE GEMM over the two
+        sources [g | tres] with pre-multiplied weights at bf16 inference, the two launches otherwise."""
+        if _FF_MERGE and g.dtype == torch.bfloat16 and g.shape[-1] % 64 == 0 and tres.shape[-1] % 64 == 0:
+            w, b = self.wb.ffout_proj_weights(t, n, g.dtype)
+            B, HW, C = tres.shape
+            out = ops.conv2d(g.view(B, HW, 1, g.shape[-1]), w, b, kh=1, kw=1, pad=(0, 0, 0, 0),
+                             residual=xres.view(B, HW, 1, C), x2=tres.view(B, HW, 1, C))
+            return out.view(B, HW, C)
+        tok = self.linear(g, t + '.ff.net.2.weight', t + '.ff.net.2.bias', residual=tres)
+        return self.linear(tok, n + '.proj_out.weight', n + '.proj_out.bias', residual=xres)
 
     def cross_prepare(self, kv, t, heads):
         """Once per sampling call (slots and weights are fixed over the NFEs): the 7 slot keys folded
@@ -1752,6 +1780,10 @@ class KernGrad(Kern):
                 drop = (p, (self.seed << 20) + self._drop_ctr, getattr(self.wb.model, 'step_seed', None))
         return GroupNormFn.apply(x, residual, self.wb.anchor_for(name), self.wb, name, eps, act, 0, drop,
                                  getattr(rowsum_of, '_sdmi_sink', None))
+
+    def ff_out_proj(self, g, tres, xres, t, n):
+        tok = self.linear(g, t + '.ff.net.2.weight', t + '.ff.net.2.bias', residual=tres)
+        return self.linear(tok, n + '.proj_out.weight', n + '.proj_out.bias', residual=xres)
 
     def rowvec_slices(self, rowvecs, bounds):
         if not rowvecs.requires_grad:
