@@ -244,8 +244,7 @@ __device__ __forceinline__ void store_col(bf16_t* rp, const f32x16& acc, float s
   }
 }
 
-__global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(SdmiAttnBwdArgs p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void attn_bwd_dq_mfma_body(const SdmiAttnBwdArgs& p, char* smem, int bx) {
   const int nkb = (p.Skv + 31) / 32, skv_pad = nkb * 32;
   char* K80 = smem;
   char* K64 = K80 + skv_pad * P80;
@@ -267,7 +266,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(SdmiAttnBwdArgs p
     }
   }
   __syncthreads();
-  const int q0 = (blockIdx.x * 4 + wave) * 32;
+  const int q0 = (bx * 4 + wave) * 32;
   if (q0 >= p.Sq) return;
   const int ql = lane & 31, hh = lane >> 5;
   const int qi = q0 + ql, qc = qi < p.Sq ? qi : p.Sq - 1;
@@ -321,8 +320,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(SdmiAttnBwdArgs p
     store_col((bf16_t*)p.dq + ((long long)b * p.Sq + qi) * p.ldq + h * 32 + 4 * hh, dq, p.scale);
 }
 
-__global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(SdmiAttnBwdArgs p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void attn_bwd_dkv_mfma_body(const SdmiAttnBwdArgs& p, char* smem, int bx) {
   const int nqb = (p.Sq + 31) / 32, sq_pad = nqb * 32;
   char* Q80 = smem;
   char* Q64 = Q80 + sq_pad * P80;
@@ -362,7 +360,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(SdmiAttnBwdArgs 
     }
   }
   __syncthreads();
-  const int k0 = (blockIdx.x * 4 + wave) * 32;
+  const int k0 = (bx * 4 + wave) * 32;
   if (k0 >= p.Skv) return;
   const int kl = lane & 31, hh = lane >> 5;
   const int kj = k0 + kl, kc = kj < p.Skv ? kj : p.Skv - 1;
@@ -421,20 +419,26 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(SdmiAttnBwdArgs 
   }
 }
 
+// dq and dk / dv of one attention in ONE launch: workgroups [0, nqx) take query blocks, the rest key
+// blocks (two dependent-free halves of the same backward: one launch instead of two)
+__global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(SdmiAttnBwdArgs p, int nqx) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  if ((int)blockIdx.x < nqx) attn_bwd_dq_mfma_body(p, smem, blockIdx.x);
+  else attn_bwd_dkv_mfma_body(p, smem, (int)blockIdx.x - nqx);
+}
+
 int launch_attn_bwd_mfma(const SdmiAttnBwdArgs& a, hipStream_t st) {
   static bool done = false;
   if (!done) {
-    (void)hipFuncSetAttribute((const void*)attn_bwd_dq_mfma_kernel,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_mfma_kernel,
+    (void)hipFuncSetAttribute((const void*)attn_bwd_mfma_kernel,
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     done = true;
   }
   const int skv_pad = (a.Skv + 31) / 32 * 32, sq_pad = (a.Sq + 31) / 32 * 32;
-  hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel, dim3((a.Sq + 127) / 128, a.heads, a.B), dim3(256),
-                     skv_pad * (2 * P80 + P64), st, a);
-  hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel, dim3((a.Skv + 127) / 128, a.heads, a.B), dim3(256),
-                     sq_pad * (2 * P80 + 2 * P64 + 8), st, a);
+  const int smem_q = skv_pad * (2 * P80 + P64), smem_k = sq_pad * (2 * P80 + 2 * P64 + 8);
+  const int nqx = (a.Sq + 127) / 128, nkx = (a.Skv + 127) / 128;
+  hipLaunchKernelGGL(attn_bwd_mfma_kernel, dim3(nqx + nkx, a.heads, a.B), dim3(256),
+                     smem_q > smem_k ? smem_q : smem_k, st, a, nqx);
   return sdmi_check_launch("attention_bwd (mfma)");
 }
 
