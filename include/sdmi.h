@@ -89,11 +89,17 @@ typedef struct {
   /* geglu != 0: W has 2N rows (value rows 0..N-1, gate rows N..2N-1), bias / ln_colsum 2N entries;
    * out[m][n] = value[m][n] * gelu(gate[m][n]), N columns (attention.py:44-48 GEGLU.forward). */
   int geglu;
-  /* optional second A source (1x1 / linear only): A = [a | a2] along K -- a [M][lda] supplies k < K1,
-   * a2 [M][lda2] the rest (K1 a multiple of 64 elements); the skip-concat's 1x1 convolution reads its
-   * two inputs in place. */
+  /* optional extra A sources appended along K (1x1 / linear, or a stride-1 "same" convolution): the
+   * first K1 = KH*KW*Cin columns of A come from `a` as usual, columns [K1, K2) are a2[m][k - K1] (row
+   * pitch lda2) and columns [K2, K) a3[m][k - K2] (row pitch lda3; K2 = 0: no third source) -- i.e. 1x1
+   * taps at the output pixel.  K1, K2 - K1, K - K2 are multiples of the K tile (64 elements).  Uses:
+   * the skip concat's 1x1 convolution reads its two inputs in place; a ResBlock's second 3x3
+   * convolution and its 1x1 skip convolution run as ONE GEMM ([im2col(h) | x] or [im2col(h) | xa | xb],
+   * weights concatenated along K; unet.py:255-259,268-269). */
   const void* a2;
   int lda2, K1;
+  const void* a3;
+  int lda3, K2;
   /* softmax8 = S in 1..7 (with ln_colsum): the epilogue finishes with a softmax over every aligned group
    * of 8 output columns of which the first S are scores (the others are pads: treated as -inf, written
    * as 0) -- the S slot scores of one attention head.  With batch > 1, ln_colsum / bias advance by s_colsum / s_bias entries per batch:

@@ -257,7 +257,7 @@ __device__ __forceinline__ void fused_epilogue(const SdmiGemmArgs& p, f32x16 (&a
   }
 }
 
-template <typename T, int BM, int BN, int BKB, int MODE, int EPI = 0>
+template <typename T, int BM, int BN, int BKB, int MODE, int EPI = 0, bool XS = false>
 __device__ __forceinline__ void igemm_body(const SdmiGemmArgs& p, int tiles_m, int tiles_n,
                                            int kt_per_split, int hw_shift) {
   // MODE: 0 = general gather (nearest-x2 fold, zero insertion, K tiles that straddle filter taps),
@@ -327,10 +327,11 @@ __device__ __forceinline__ void igemm_body(const SdmiGemmArgs& p, int tiles_m, i
     if (TAPU) Abase -= (long long)(p.pad_t * p.W + p.pad_l) * p.lda;
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)Abase, 0, (int)OOB, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)Wg, 0, (int)OOB, 0x00020000);
-    // second A source of a 1x1 problem (A = [a | a2] along K: the skip concat read in place)
-    const __amdgpu_buffer_rsrc_t rsA2 = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(p.a2 ? p.a2 : p.a), 0, (int)OOB, 0x00020000);
-    unsigned a_vo2[IS1X1 ? A_VECS : 1];
+    // extra A sources appended along K (sdmi.h: a2 / a3): 1x1 taps at the output pixel
+    constexpr bool XSRC = XS && (IS1X1 || TAPU);      // (its own instantiation: 8 more loader VGPRs)
+    // (their buffer descriptors are built per K tile from the pointer: three more live descriptors
+    // pushed the loaders' scalar state into scratch)
+    unsigned a_vo2[XSRC ? A_VECS : 1], a_vo3[XSRC ? A_VECS : 1];
     unsigned a_vo[A_VECS], a_cur[A_VECS], a_inv[A_VECS], b_vo[B_VECS], b_cur[B_VECS];
     int k0 = 0, ci = 0, kh = 0, kw = 0;       // wave-uniform k state of the next K tile (MODE 1/2)
     // MODE 0 (general gather) state
@@ -357,9 +358,12 @@ __device__ __forceinline__ void igemm_body(const SdmiGemmArgs& p, int tiles_m, i
       for (int i = 0; i < A_VECS; ++i) {
         const int row = (tid + i * 256) / VPR;
         const int m = min(m0 + row, p.M - 1);
+        if constexpr (XSRC) {      // (stride-1 "same" convolutions: output pixel m = input pixel m)
+          a_vo2[i] = ((unsigned)m * (unsigned)p.lda2 + kc * VEC) * (unsigned)sizeof(T);
+          a_vo3[i] = ((unsigned)m * (unsigned)p.lda3 + kc * VEC) * (unsigned)sizeof(T);
+        }
         if (IS1X1) {
           a_vo[i] = ((unsigned)m * (unsigned)p.lda + kc * VEC) * (unsigned)sizeof(T);
-          a_vo2[i] = ((unsigned)m * (unsigned)p.lda2 + kc * VEC) * (unsigned)sizeof(T);
           a_inv[i] = 0;
           a_cur[i] = a_vo[i];
         } else {
@@ -429,19 +433,19 @@ __device__ __forceinline__ void igemm_body(const SdmiGemmArgs& p, int tiles_m, i
           so_a = (unsigned)k0 * (unsigned)sizeof(T);
         }
         const unsigned so_b = (unsigned)k0 * (unsigned)sizeof(T);
-        bool second = false;
-        if constexpr (IS1X1) second = p.a2 != nullptr && k0 >= p.K1;      // wave-uniform
-        if (second) {
-          if constexpr (IS1X1) {
-            const unsigned so2 = (unsigned)(k0 - p.K1) * (unsigned)sizeof(T);
+        // which source this K tile reads (wave-uniform): selects, not branches -- separate load loops per
+        // source pushed the loaders' register arrays into scratch
+        const bool s1 = XSRC && p.a2 != nullptr && k0 >= p.K1;
+        const bool s2 = s1 && p.a3 != nullptr && k0 >= p.K2;
+        const unsigned so_x = s2 ? (unsigned)(k0 - p.K2) * (unsigned)sizeof(T)
+                                 : (s1 ? (unsigned)(k0 - p.K1) * (unsigned)sizeof(T) : so_a);
+        const void* base_x = s2 ? p.a3 : (s1 ? p.a2 : (const void*)Abase);
+        const __amdgpu_buffer_rsrc_t rs_x =
+            XSRC ? __builtin_amdgcn_make_buffer_rsrc((void*)base_x, 0, (int)OOB, 0x00020000) : rsA;
 #pragma unroll
-            for (int i = 0; i < A_VECS; ++i)
-              ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rsA2, (int)a_vo2[i], (int)so2, 0);
-          }
-        } else {
-#pragma unroll
-        for (int i = 0; i < A_VECS; ++i)
-          ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)a_cur[i], (int)so_a, 0);
+        for (int i = 0; i < A_VECS; ++i) {
+          const unsigned vo = s2 ? a_vo3[XSRC ? i : 0] : (s1 ? a_vo2[XSRC ? i : 0] : a_cur[i]);
+          ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)vo, (int)so_x, 0);
         }
 #pragma unroll
         for (int i = 0; i < B_VECS; ++i)
@@ -1042,10 +1046,10 @@ __global__ __launch_bounds__(256) void conv3x3_c64_kernel(SdmiGemmArgs p, int hw
 
 // Two entry points over the same body: <= 128 VGPRs (two workgroups per CU) for the tiles whose
 // double-buffered LDS image allows it, unconstrained for the 256-row tile (92 KB of LDS).
-template <typename T, int BM, int BN, int BKB, int MODE, int EPI = 0>
+template <typename T, int BM, int BN, int BKB, int MODE, int EPI = 0, bool XS = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void igemm_kernel(
     SdmiGemmArgs p, int tiles_m, int tiles_n, int kt_per_split, int hw_shift) {
-  igemm_body<T, BM, BN, BKB, MODE, EPI>(p, tiles_m, tiles_n, kt_per_split, hw_shift);
+  igemm_body<T, BM, BN, BKB, MODE, EPI, XS>(p, tiles_m, tiles_n, kt_per_split, hw_shift);
 }
 template <typename T, int BM, int BN, int BKB, int MODE>
 __global__ __launch_bounds__(512) void igemm_kernel_tall(SdmiGemmArgs p, int tiles_m, int tiles_n,
@@ -1083,7 +1087,7 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(SdmiGemmArgs p, in
 
 static int device_cus();
 
-template <typename T, int BM, int BN, int BKB, int MODE, int EPI = 0>
+template <typename T, int BM, int BN, int BKB, int MODE, int EPI = 0, bool XS = false>
 int launch_cfg(const SdmiGemmArgs& p, int split_k, int hw_shift, hipStream_t st) {
   constexpr int BK = BKB / sizeof(T);
   constexpr int smem = 2 * (BM + BN) * (BKB + 16);
@@ -1091,7 +1095,7 @@ int launch_cfg(const SdmiGemmArgs& p, int split_k, int hw_shift, hipStream_t st)
   static bool attr_done = false;
   void (*kern)(SdmiGemmArgs, int, int, int, int);
   if constexpr (BM > 128) kern = igemm_kernel_tall<T, BM, BN, BKB, MODE>;
-  else kern = igemm_kernel<T, BM, BN, BKB, MODE, EPI>;
+  else kern = igemm_kernel<T, BM, BN, BKB, MODE, EPI, XS>;
   if (!attr_done) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem) !=
         hipSuccess) {
@@ -1226,7 +1230,7 @@ int dispatch(const SdmiGemmArgs& p, hipStream_t st) {
   const bool plain = !is1x1 && !p.ups && p.zins <= 1;
   // direct 3x3 kernel for the 64 -> 64 channel convolutions at full resolution
   if (sizeof(T) == 2 && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad_t == 1 && p.pad_l == 1 &&
-      !p.ups && p.zins <= 1 && p.osy == 0 && p.Cin == 64 && p.N <= 64 && p.N > 32 && batch == 1 &&
+      !p.a2 && !p.ups && p.zins <= 1 && p.osy == 0 && p.Cin == 64 && p.N <= 64 && p.N > 32 && batch == 1 &&
       p.split_k <= 1 && p.H == p.Ho && p.W == p.Wo && p.W % 64 == 0 && p.H % 4 == 0 &&
       p.out_dtype == SDMI_BF16 && p.ldc % 8 == 0 && p.N % 8 == 0 && !p.bias_m &&
       (!p.residual || p.ldr % 8 == 0) &&
@@ -1253,12 +1257,33 @@ int dispatch(const SdmiGemmArgs& p, hipStream_t st) {
       ((long long)p.B * p.H * p.W + (long long)(p.KH + 1) * p.W) * p.lda * (long long)sizeof(T);
   const long long w_bytes = (long long)p.N * (p.geglu ? 2 : 1) * p.ldw * (long long)sizeof(T);
   const bool fits31 = a_bytes < (1ll << 31) && w_bytes < (1ll << 31);
-  if (p.a2) {       // two-source A (sdmi.h: a2): plain 1x1, whole K tiles on both sides of the seam
+  if (p.a2) {       // extra A sources (sdmi.h: a2 / a3): 1x1, or a stride-1 "same" convolution on the fast path
     const int bk = (wide ? 128 : 64) / (int)sizeof(T);
     const long long a2_bytes = (long long)p.M * p.lda2 * (long long)sizeof(T);
-    if (!is1x1 || batch != 1 || p.osy != 0 || p.ln_colsum || p.geglu || p.K1 <= 0 || p.K1 >= p.K ||
-        p.K1 % bk || (p.K - p.K1) % bk || p.lda2 % VEC || !fits31 || a2_bytes >= (1ll << 31)) {
-      sdmi_set_error("igemm: two-source A needs a plain 1x1 problem with K1 and K - K1 multiples of the K tile");
+    const long long a3_bytes = p.a3 ? (long long)p.M * p.lda3 * (long long)sizeof(T) : 0;
+    const int kend2 = p.a3 ? p.K2 : p.K;
+    const bool same = p.stride == 1 && p.H == p.Ho && p.W == p.Wo && !p.ups && p.zins <= 1;
+    const bool conv_ok = plain && same && p.KH * p.KW <= 32 && p.Cin % bk == 0;
+    if (!(is1x1 || conv_ok) || batch != 1 || p.osy != 0 || p.ln_colsum || p.geglu ||
+        p.K1 != p.KH * p.KW * p.Cin || kend2 <= p.K1 || (p.a3 && p.K <= p.K2) || p.K1 % bk || (kend2 - p.K1) % bk ||
+        (p.K - kend2) % bk || p.lda2 % VEC || (p.a3 && p.lda3 % VEC) || !fits31 || a2_bytes >= (1ll << 31) ||
+        a3_bytes >= (1ll << 31)) {
+      sdmi_set_error("igemm: extra A sources need a 1x1 / stride-1 same-size problem with whole K tiles per segment");
+      return SDMI_EUNSUPPORTED;
+    }
+    // their own instantiations (128-byte K tile; 128 x 128 or 64 x 64 output tiles)
+    if constexpr (sizeof(T) != 1) {
+      if (!wide || shape == T128x64) {
+        sdmi_set_error("igemm: extra A sources need K >= 512 bytes per row and N > 64");
+        return SDMI_EUNSUPPORTED;
+      }
+      if (shape == T128x128)
+        return is1x1 ? launch_cfg<T, 128, 128, 128, 1, 0, true>(p, split_k, hw_shift, st)
+                     : launch_cfg<T, 128, 128, 128, 2, 0, true>(p, split_k, hw_shift, st);
+      return is1x1 ? launch_cfg<T, 64, 64, 128, 1, 0, true>(p, split_k, hw_shift, st)
+                   : launch_cfg<T, 64, 64, 128, 2, 0, true>(p, split_k, hw_shift, st);
+    } else {
+      sdmi_set_error("igemm: extra A sources: bf16 / fp32 operands only");
       return SDMI_EUNSUPPORTED;
     }
   }
@@ -1347,7 +1372,8 @@ extern "C" int sdmi_igemm(const SdmiGemmArgs* a, void* stream) {
   SDMI_REQUIRE(a->dtype != SDMI_FP8 || (!(a->batch > 1) && !a->ups && a->zins <= 1),
                "fp8 operands: plain convolution / linear only (no batch, upsample fold)");
   SDMI_REQUIRE(a->M > 0 && a->N > 0 && a->K > 0, "empty problem");
-  SDMI_REQUIRE(a->K == a->KH * a->KW * a->Cin, "K != KH*KW*Cin");
+  SDMI_REQUIRE(a->a2 ? (a->K1 == a->KH * a->KW * a->Cin && a->K > a->K1) : a->K == a->KH * a->KW * a->Cin,
+               "K != KH*KW*Cin (+ extra sources)");
   SDMI_REQUIRE(a->Cin % vec == 0 && a->lda % vec == 0 && a->ldw % vec == 0,
                "Cin/lda/ldw must be multiples of the 16-byte vector width");
   SDMI_REQUIRE(((uintptr_t)a->a & 15) == 0 && ((uintptr_t)a->w & 15) == 0, "unaligned operand");

@@ -192,12 +192,7 @@ class UNetRunner:
         h = K.conv(h, n + '.in_layers.2.weight', n + '.in_layers.2.bias', rowvec=rv)
         h = K.gn(h, n + '.out_layers.0', eps=1e-5, act='silu', dropout='unet',      # (dropout: training only)
                  for_conv=n + '.out_layers.3.weight', rowsum_of=rv)
-        if (n + '.skip_connection.weight') in K.wb.t:
-            skip = K.conv(skip, n + '.skip_connection.weight', n + '.skip_connection.bias', kh=1, kw=1,
-                          pad=(0, 0, 0, 0))
-        elif hasattr(skip, 'materialize'):             # (a lazy concat that keeps its channel count)
-            skip = skip.materialize()
-        out = K.conv(h, n + '.out_layers.3.weight', n + '.out_layers.3.bias', residual=skip)
+        out = K.res_tail(h, n, skip)
         return out, (outs[2] if want_cat else None)
 
     def _st(self, K, name, x, heads, kv):

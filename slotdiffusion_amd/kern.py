@@ -61,6 +61,7 @@ class CatPair:
         return ops.concat_channels(self.a, self.b)
 
 
+_RES_MERGE = os.environ.get('SDMI_RES_MERGE', '1') != '0'
 _FF_MERGE = os.environ.get('SDMI_FF_MERGE', '1') != '0'
 _CROSS_FOLD = os.environ.get('SDMI_CROSS_FOLD', '1') != '0'
 _LN_FOLD = os.environ.get('SDMI_LN_FOLD', '1') != '0'
@@ -391,6 +392,19 @@ class WeightBank:
             self.cache[key] = (ops.quant_fp8(flat.float().contiguous(), scale), 1.0 / scale)
         return self.cache[key]
 
+    def conv_skip_weights(self, n, dtype):
+        """[W_out3 (3x3, tap-major K) | W_skip (1x1)] along K and the summed bias of ResBlock `n`: its second
+        convolution and its skip convolution as ONE implicit GEMM (sdmi.h: a2 / a3).  Cached."""
+        key = ('convskip', n, dtype)
+        if key not in self.cache:
+            with torch.no_grad():
+                w2 = self.w(n + '.out_layers.3.weight', dtype)
+                ws = self.w(n + '.skip_connection.weight', dtype)
+                w = torch.cat([w2.reshape(w2.shape[0], -1), ws.reshape(ws.shape[0], -1)], 1).contiguous()
+                b = (self.t[n + '.out_layers.3.bias'].float() + self.t[n + '.skip_connection.bias'].float())
+                self.cache[key] = (w, b.contiguous())
+        return self.cache[key]
+
     def ffout_proj_weights(self, t, n, dtype):
         """Feed-forward output and proj_out of a SpatialTransformer are two linear layers with only a
         residual add in between (attention.py:250-251, 305-308):
@@ -674,6 +688,24 @@ class Kern:
     def attn_cross(self, q, kv, heads):
         C = heads * 32
         return ops.attention(q, kv[..., :C], kv[..., C:], heads)
+
+    def res_tail(self, h, n, skip):
+        """out = out_layers.3(h) + (skip_connection(skip) if the block changes its channel count else skip).
+        bf16 inference: the 3x3 convolution and the 1x1 skip convolution are ONE implicit GEMM over
+        [im2col(h) | skip] (or [im2col(h) | a | b] for a skip that is a lazy concat)."""
+        has_skip = (n + '.skip_connection.weight') in self.wb.t
+        if has_skip and _RES_MERGE and torch.is_tensor(h) and h.dtype == torch.bfloat16 and h.shape[-1] % 64 == 0:
+            srcs = (skip.a, skip.b) if isinstance(skip, CatPair) else (skip,)
+            if all(t.shape[-1] % 64 == 0 and t.dtype == h.dtype for t in srcs):
+                w, b = self.wb.conv_skip_weights(n, h.dtype)
+                return ops.conv2d(h, w, b, kh=3, kw=3, pad=(1, 1, 1, 1), x2=srcs[0],
+                                  x3=(srcs[1] if len(srcs) > 1 else None))
+        if has_skip:
+            skip = self.conv(skip, n + '.skip_connection.weight', n + '.skip_connection.bias', kh=1, kw=1,
+                             pad=(0, 0, 0, 0))
+        elif hasattr(skip, 'materialize'):             # (a lazy concat that keeps its channel count)
+            skip = skip.materialize()
+        return self.conv(h, n + '.out_layers.3.weight', n + '.out_layers.3.bias', residual=skip)
 
     def ff_out_proj(self, g, tres, xres, t, n):
         """ff.net.2 (+ token residual) followed by proj_out (+ block residual): ONE GEMM over the two
@@ -1784,6 +1816,12 @@ class KernGrad(Kern):
     def ff_out_proj(self, g, tres, xres, t, n):
         tok = self.linear(g, t + '.ff.net.2.weight', t + '.ff.net.2.bias', residual=tres)
         return self.linear(tok, n + '.proj_out.weight', n + '.proj_out.bias', residual=xres)
+
+    def res_tail(self, h, n, skip):
+        if (n + '.skip_connection.weight') in self.wb.t:
+            skip = self.conv(skip, n + '.skip_connection.weight', n + '.skip_connection.bias', kh=1, kw=1,
+                             pad=(0, 0, 0, 0))
+        return self.conv(h, n + '.out_layers.3.weight', n + '.out_layers.3.bias', residual=skip)
 
     def rowvec_slices(self, rowvecs, bounds):
         if not rowvecs.requires_grad:

@@ -75,7 +75,7 @@ def quant_fp8(x, scale, out=None):
 
 def conv2d(x, w, bias=None, *, kh=3, kw=3, stride=1, pad=(1, 1, 1, 1), ups=False, cout=None,
            rowvec=None, residual=None, act=None, out=None, out_dtype=None, ldc=None,
-           split_k=0, alpha=1.0, x2=None):
+           split_k=0, alpha=1.0, x2=None, x3=None):
     """x [B,H,W,Cin] NHWC; w [Cout][kh][kw][Cin] (flat or 4-D channels_last view).
     pad = (top, bottom, left, right).  Returns [B,Ho,Wo,ldc or Cout].
     uint8 x / w = e4m3fn operands (quant_fp8): out_dtype is required, alpha undoes the scales."""
@@ -83,13 +83,18 @@ def conv2d(x, w, bias=None, *, kh=3, kw=3, stride=1, pad=(1, 1, 1, 1), ups=False
     B, H, W, Cin = x.shape
     assert x.is_contiguous()
     C1 = Cin
-    if x2 is not None:          # 1x1 over the channel concatenation [x | x2], read in place (sdmi.h: a2)
-        assert kh == 1 and kw == 1 and stride == 1 and x2.is_contiguous() and x2.shape[:3] == x.shape[:3]
-        Cin = C1 + x2.shape[-1]
+    extra = 0
+    if x2 is not None:          # extra sources appended along K as 1x1 taps (sdmi.h: a2 / a3)
+        assert stride == 1 and not ups and x2.is_contiguous() and x2.shape[:3] == x.shape[:3]
+        assert (kh, kw) == (1, 1) or pad == (kh // 2, kh // 2, kw // 2, kw // 2)
+        extra = x2.shape[-1]
+        if x3 is not None:
+            assert x3.is_contiguous() and x3.shape[:3] == x.shape[:3]
+            extra += x3.shape[-1]
     Hs, Ws = (2 * H, 2 * W) if ups else (H, W)
     Ho = (Hs + pad[0] + pad[1] - kh) // stride + 1
     Wo = (Ws + pad[2] + pad[3] - kw) // stride + 1
-    K = kh * kw * Cin
+    K = kh * kw * Cin + extra
     N = cout if cout is not None else w.numel() // K
     assert w.numel() == N * K, (w.shape, N, K)
     odt = out_dtype or x.dtype
@@ -105,7 +110,9 @@ def conv2d(x, w, bias=None, *, kh=3, kw=3, stride=1, pad=(1, 1, 1, 1), ups=False
     call('sdmi_igemm', _stream(), a=_p(x), w=_p(w), out=_p(out), bias=_p(bias), rowvec=_p(rowvec),
          residual=_p(residual), workspace=_p(ws), dtype=_dt(x), out_dtype=_DT[odt], M=M, N=N, K=K,
          lda=C1, ldw=K, ldc=ldc, ldr=(residual.shape[-1] if residual is not None else 0),
-         a2=_p(x2), lda2=(x2.shape[-1] if x2 is not None else 0), K1=(C1 if x2 is not None else 0),
+         a2=_p(x2), lda2=(x2.shape[-1] if x2 is not None else 0), K1=(kh * kw * C1 if x2 is not None else 0),
+         a3=_p(x3), lda3=(x3.shape[-1] if x3 is not None else 0),
+         K2=(kh * kw * C1 + x2.shape[-1] if x3 is not None else 0),
          B=B, H=H, W=W, Cin=Cin, Ho=Ho, Wo=Wo, KH=kh, KW=kw, stride=stride, pad_t=pad[0],
          pad_l=pad[2], ups=int(ups), act=ACT[act], alpha=float(alpha), bias_m=0,
          ldrv=(rowvec.stride(0) if rowvec is not None else 0),

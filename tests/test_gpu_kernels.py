@@ -211,7 +211,7 @@ def test_igemm_fp8_operands(case):
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize('case', [(2, 16, 16, 256, 128), (3, 8, 8, 384, 384), (2, 32, 32, 128, 64), (1, 64, 64, 64, 64),
+@pytest.mark.parametrize('case', [(2, 16, 16, 256, 128), (3, 8, 8, 384, 384), (2, 32, 32, 128, 128), (1, 64, 64, 192, 64),
                                   (64, 4, 4, 512, 512)])
 def test_two_source_groupnorm_and_1x1_conv(case, dtype):
     """The UNet's skip concat read in place (sdmi.h: x2 / a2): GroupNorm(+SiLU) and the 1x1 skip
@@ -592,3 +592,28 @@ def test_folded_slot_cross_attention_block():
         out = ops.bmm_nt(P, w2, torch.empty_like(tokd), bias=bo.to(DEV), residual=tokd)
         e = rel_l2(out, ref)
         assert e <= 2e-2, (B, HW, C, e)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('case', [(2, 16, 16, 256, 256, 128, 128), (3, 8, 8, 384, 384, 384, 0), (64, 4, 4, 512, 512, 512, 512),
+                                  (2, 32, 32, 128, 128, 256, 0)])
+def test_conv3x3_with_extra_1x1_sources(case, dtype):
+    """sdmi_igemm a2 / a3 on the convolution fast path: a 3x3 "same" convolution over h plus 1x1 taps
+    over one or two more tensors as ONE implicit GEMM (a ResBlock's out_layers.3 + skip_connection),
+    against the two convolutions in torch."""
+    ops = _ops()
+    B, H, W, C, N, Ca, Cb = case
+    g = torch.Generator().manual_seed(sum(case))
+    h = q(torch.randn(B, C, H, W, generator=g), dtype)
+    xa = q(torch.randn(B, Ca, H, W, generator=g), dtype)
+    xb = q(torch.randn(B, Cb, H, W, generator=g), dtype) if Cb else None
+    w2 = q(torch.randn(N, C, 3, 3, generator=g) / math.sqrt(9 * C), dtype)
+    ws = q(torch.randn(N, Ca + Cb, 1, 1, generator=g) / math.sqrt(Ca + Cb), dtype)
+    bias = torch.randn(N, generator=g)
+    xs = xa if xb is None else torch.cat([xa, xb], 1)
+    ref = F.conv2d(h, w2, None, padding=1) + F.conv2d(xs, ws, bias)
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().to(dtype).to(DEV)
+    wk = torch.cat([w2.permute(0, 2, 3, 1).reshape(N, -1), ws.reshape(N, -1)], 1).contiguous().to(dtype).to(DEV)
+    out = ops.conv2d(nhwc(h), wk, bias.to(DEV), kh=3, kw=3, pad=(1, 1, 1, 1), x2=nhwc(xa),
+                     x3=(nhwc(xb) if xb is not None else None))
+    check(out.permute(0, 3, 1, 2), ref, dtype, f'conv3x3 + 1x1 sources {case}')
