@@ -123,106 +123,129 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(SdmiAttnArgs p) {
 typedef short a_s16x4 __attribute__((ext_vector_type(4)));
 typedef short a_s16x8 __attribute__((ext_vector_type(8)));
 #define ATT_LDS_V4(p) ((__attribute__((address_space(3))) a_s16x4*)(p))
-constexpr int ATT_KP = 80;   // K row pitch in LDS: 64 B + 16 (conflict-free ds_read_b128)
 constexpr int ATT_VP = 64;   // V row pitch: = 64 (mod 256), what the transposing read wants
 
 __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
   return (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
 }
 
+// HD = 32 (UNet) or 64 (DINO ViT).  Keys pass through LDS in chunks of CHUNK rows (one chunk covers the
+// UNet's sequences; the ViT's 785 keys x 64 channels take four), the online-softmax state and the
+// output accumulators stay in registers across chunks.  V is kept as HD/32 separate 32-channel images
+// so the transposing read sees the same 64-byte pitch for either head size.
+template <int HD, int CHUNK>
 __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(SdmiAttnArgs p) {
+  constexpr int ND = HD / 32;            // 32-channel groups of the head
+  constexpr int KP = HD * 2 + 16;        // K row pitch in LDS (conflict-free ds_read_b128)
+  constexpr int PIECES = HD / 8;         // 16-byte pieces per row
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int nkb = (p.Skv + 31) / 32, skv_pad = nkb * 32;
+  const int skv_pad = (p.Skv + 31) / 32 * 32;
+  const int cap = skv_pad < CHUNK ? skv_pad : CHUNK;
   char* Ks = smem;
-  char* Vs = smem + skv_pad * ATT_KP;
+  char* Vs = smem + cap * KP;            // image j (channels 32j..32j+31) at Vs + j * cap * ATT_VP
   const int b = blockIdx.z, h = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  {  // stage K, V of this (image, head): 4 16-byte pieces per row each; pad rows zeroed
-    const bf16_t* kb = (const bf16_t*)p.k + (long long)b * p.Skv * p.ldk + h * 32;
-    const bf16_t* vb = (const bf16_t*)p.v + (long long)b * p.Skv * p.ldv + h * 32;
-    const u32x4 zero4 = {0u, 0u, 0u, 0u};
-    for (int i = tid; i < skv_pad * 4; i += 256) {
-      const int row = i >> 2, c = i & 3;
-      const bool ok = row < p.Skv;
-      const u32x4 kv = ok ? *reinterpret_cast<const u32x4*>(kb + (long long)row * p.ldk + c * 8) : zero4;
-      const u32x4 vv = ok ? *reinterpret_cast<const u32x4*>(vb + (long long)row * p.ldv + c * 8) : zero4;
-      *reinterpret_cast<u32x4*>(Ks + row * ATT_KP + c * 16) = kv;
-      *reinterpret_cast<u32x4*>(Vs + row * ATT_VP + c * 16) = vv;
-    }
-  }
-  __syncthreads();
   const int q0 = (blockIdx.x * 4 + wave) * 32;
-  if (q0 >= p.Sq) return;
+  const bool active = q0 < p.Sq;         // idle waves still stage and keep the barriers
   const int ql = lane & 31, hh = lane >> 5;
   const int qi = q0 + ql;
   const int qc = qi < p.Sq ? qi : p.Sq - 1;
   // B operand of S^T: this lane's query row, d = ks*16 + hh*8 .. +8
-  bf16x8 bq[2];
+  bf16x8 bq[2 * ND];
   {
-    const bf16_t* qp = (const bf16_t*)p.q + ((long long)b * p.Sq + qc) * p.ldq + h * 32 + hh * 8;
-    bq[0] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(qp));
-    bq[1] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(qp + 16));
-  }
-  f32x16 o;
+    const bf16_t* qp = (const bf16_t*)p.q + ((long long)b * p.Sq + qc) * p.ldq + h * HD + hh * 8;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) o[r] = 0.f;
+    for (int ks = 0; ks < 2 * ND; ++ks)
+      bq[ks] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(qp + 16 * ks));
+  }
+  f32x16 o[ND];
+#pragma unroll
+  for (int j = 0; j < ND; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[j][r] = 0.f;
   float m = -INFINITY, lsum = 0.f;
   const int g = lane >> 4, t = lane & 15;
-  const char* kfrag = Ks + ql * ATT_KP + hh * 16;
+  const char* kfrag = Ks + ql * KP + hh * 16;
   // transposing read: lane addresses piece (row t>>2, 4 columns at (t&3)*4) of its group's block
   const char* vfrag = Vs + (4 * hh + (t >> 2)) * ATT_VP + ((g & 1) * 16 + (t & 3) * 4) * 2;
-  for (int kb = 0; kb < nkb; ++kb) {
-    f32x16 s;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) s[r] = 0.f;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const u32x4 a = *reinterpret_cast<const u32x4*>(kfrag + kb * 32 * ATT_KP + ks * 32);
-      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), bq[ks], s, 0, 0, 0);
+  const bf16_t* kbase = (const bf16_t*)p.k + (long long)b * p.Skv * p.ldk + h * HD;
+  const bf16_t* vbase = (const bf16_t*)p.v + (long long)b * p.Skv * p.ldv + h * HD;
+  for (int c0 = 0; c0 < skv_pad; c0 += CHUNK) {
+    const int rows = skv_pad - c0 < CHUNK ? skv_pad - c0 : CHUNK;
+    if (c0) __syncthreads();
+    {  // stage K, V rows c0 .. c0+rows of this (image, head); pad rows zeroed
+      const u32x4 zero4 = {0u, 0u, 0u, 0u};
+      for (int i = tid; i < rows * PIECES; i += 256) {
+        const int row = i / PIECES, c = i % PIECES;
+        const bool ok = c0 + row < p.Skv;
+        const u32x4 kv = ok ? *reinterpret_cast<const u32x4*>(kbase + (long long)(c0 + row) * p.ldk + c * 8) : zero4;
+        const u32x4 vv = ok ? *reinterpret_cast<const u32x4*>(vbase + (long long)(c0 + row) * p.ldv + c * 8) : zero4;
+        *reinterpret_cast<u32x4*>(Ks + row * KP + c * 16) = kv;
+        *reinterpret_cast<u32x4*>(Vs + (c >> 2) * cap * ATT_VP + row * ATT_VP + (c & 3) * 16) = vv;
+      }
     }
-    float bmax = -INFINITY;
+    __syncthreads();
+    if (!active) continue;
+    for (int kb = 0; kb < rows / 32; ++kb) {
+      f32x16 s;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-      s[r] = key < p.Skv ? s[r] * p.scale : -INFINITY;
-      bmax = fmaxf(bmax, s[r]);
-    }
-    bmax = fmaxf(bmax, __shfl_xor(bmax, 32, 64));
-    const float m_new = fmaxf(m, bmax);
-    const float alpha = __expf(m - m_new);
-    float psum = 0.f;
+      for (int r = 0; r < 16; ++r) s[r] = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      s[r] = __expf(s[r] - m_new);
-      psum += s[r];
-    }
-    psum += __shfl_xor(psum, 32, 64);
-    lsum = lsum * alpha + psum;
-    m = m_new;
+      for (int ks = 0; ks < 2 * ND; ++ks) {
+        const u32x4 a = *reinterpret_cast<const u32x4*>(kfrag + kb * 32 * KP + ks * 32);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), bq[ks], s, 0, 0, 0);
+      }
+      float bmax = -INFINITY;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) o[r] *= alpha;
+      for (int r = 0; r < 16; ++r) {
+        const int key = c0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        s[r] = key < p.Skv ? s[r] * p.scale : -INFINITY;
+        bmax = fmaxf(bmax, s[r]);
+      }
+      bmax = fmaxf(bmax, __shfl_xor(bmax, 32, 64));
+      const float m_new = fmaxf(m, bmax);
+      const float alpha = __expf(m - m_new);
+      float psum = 0.f;
 #pragma unroll
-    for (int mm = 0; mm < 2; ++mm) {
-      const u32x4 pb = {pack_bf16x2(s[8 * mm + 0], s[8 * mm + 1]), pack_bf16x2(s[8 * mm + 2], s[8 * mm + 3]),
-                        pack_bf16x2(s[8 * mm + 4], s[8 * mm + 5]), pack_bf16x2(s[8 * mm + 6], s[8 * mm + 7])};
-      const char* vp = vfrag + (kb * 32 + 16 * mm) * ATT_VP;
-      const a_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(ATT_LDS_V4(vp));
-      const a_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(ATT_LDS_V4(vp + 8 * ATT_VP));
-      const a_s16x8 av = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-      o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av),
-                                                  __builtin_bit_cast(bf16x8, pb), o, 0, 0, 0);
+      for (int r = 0; r < 16; ++r) {
+        s[r] = __expf(s[r] - m_new);
+        psum += s[r];
+      }
+      psum += __shfl_xor(psum, 32, 64);
+      lsum = lsum * alpha + psum;
+      m = m_new;
+#pragma unroll
+      for (int j = 0; j < ND; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[j][r] *= alpha;
+#pragma unroll
+      for (int mm = 0; mm < 2; ++mm) {
+        const u32x4 pb = {pack_bf16x2(s[8 * mm + 0], s[8 * mm + 1]), pack_bf16x2(s[8 * mm + 2], s[8 * mm + 3]),
+                          pack_bf16x2(s[8 * mm + 4], s[8 * mm + 5]), pack_bf16x2(s[8 * mm + 6], s[8 * mm + 7])};
+#pragma unroll
+        for (int j = 0; j < ND; ++j) {
+          const char* vp = vfrag + j * cap * ATT_VP + (kb * 32 + 16 * mm) * ATT_VP;
+          const a_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(ATT_LDS_V4(vp));
+          const a_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(ATT_LDS_V4(vp + 8 * ATT_VP));
+          const a_s16x8 av = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+          o[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av),
+                                                         __builtin_bit_cast(bf16x8, pb), o[j], 0, 0, 0);
+        }
+      }
     }
   }
-  if (qi < p.Sq) {
+  if (active && qi < p.Sq) {
     const float inv = 1.f / lsum;
-    bf16_t* op = (bf16_t*)p.out + ((long long)b * p.Sq + qi) * p.ldo + h * 32 + 4 * hh;
+    bf16_t* op = (bf16_t*)p.out + ((long long)b * p.Sq + qi) * p.ldo + h * HD + 4 * hh;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {    // d = 8j + 4hh + (0..3)
-      uint2 w;
-      w.x = pack_bf16x2(o[4 * j] * inv, o[4 * j + 1] * inv);
-      w.y = pack_bf16x2(o[4 * j + 2] * inv, o[4 * j + 3] * inv);
-      *reinterpret_cast<uint2*>(op + 8 * j) = w;
-    }
+    for (int jd = 0; jd < ND; ++jd)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {    // d = 32jd + 8j + 4hh + (0..3)
+        uint2 w;
+        w.x = pack_bf16x2(o[jd][4 * j] * inv, o[jd][4 * j + 1] * inv);
+        w.y = pack_bf16x2(o[jd][4 * j + 2] * inv, o[jd][4 * j + 3] * inv);
+        *reinterpret_cast<uint2*>(op + 32 * jd + 8 * j) = w;
+      }
     if (p.lse && hh == 0) p.lse[((long long)b * p.heads + h) * p.Sq + qi] = m + __logf(lsum);
   }
 }
@@ -234,19 +257,41 @@ extern "C" int sdmi_attention(const SdmiAttnArgs* a, void* stream) {
   const int vec = a->dtype == SDMI_BF16 ? 8 : 4;
   SDMI_REQUIRE(a->ldq % vec == 0 && a->ldk % vec == 0 && a->ldv % vec == 0 && a->ldo % vec == 0,
                "row pitches must keep 16-byte alignment");
-  SDMI_REQUIRE(a->Skv >= 1 && a->Skv <= 400, "Skv must be in [1, 400] (K/V staged in LDS)");
+  const int hd = a->head_dim > 0 ? a->head_dim : 32;
+  SDMI_REQUIRE(hd == 32 || hd == 48 || hd == 64,
+               "head_dim must be 32 (UNet), 48 (SAVi predictor) or 64 (DINO ViT, bf16 only)");
   hipStream_t st = (hipStream_t)stream;
+  if (a->dtype == SDMI_BF16 && (hd == 32 || hd == 64)) {
+    // matrix-core kernel.  head_dim 32: K and V of one (image, head) in one LDS image of 144 B per key
+    // (1024 keys = 147 KB of the CU's 160 KB: the 28 x 28 self-attention of the 224^2 configs fits);
+    // head_dim 64: 272 B per key, staged in chunks of 256 keys (two workgroups per CU), any length.
+    static bool big = false;
+    if (!big) {
+      (void)hipFuncSetAttribute((const void*)attn_fwd_mfma_kernel<32, 1024>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 1024 * (32 * 2 + 16 + ATT_VP));
+      (void)hipFuncSetAttribute((const void*)attn_fwd_mfma_kernel<64, 256>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 256 * (64 * 2 + 16 + 2 * ATT_VP));
+      big = true;
+    }
+    const int skv_pad = (a->Skv + 31) / 32 * 32;
+    dim3 g2((a->Sq + 127) / 128, a->heads, a->B);
+    if (hd == 32) {
+      SDMI_REQUIRE(a->Skv >= 1 && a->Skv <= 1024, "Skv must be in [1, 1024] for bf16 / head_dim 32");
+      hipLaunchKernelGGL((attn_fwd_mfma_kernel<32, 1024>), g2, dim3(256), skv_pad * (32 * 2 + 16 + ATT_VP),
+                         st, *a);
+    } else {
+      SDMI_REQUIRE(a->Skv >= 1, "Skv must be positive");
+      const int cap = skv_pad < 256 ? skv_pad : 256;
+      hipLaunchKernelGGL((attn_fwd_mfma_kernel<64, 256>), g2, dim3(256), cap * (64 * 2 + 16 + 2 * ATT_VP),
+                         st, *a);
+    }
+    return sdmi_check_launch("attention (mfma)");
+  }
+  SDMI_REQUIRE(hd != 64, "head_dim 64 is implemented for bf16 only");
+  SDMI_REQUIRE(a->Skv >= 1 && a->Skv <= 400, "Skv must be in [1, 400] (fp32 / head_dim 48: K/V staged whole in LDS)");
   int threads = ((a->Sq + 63) / 64) * 64;
   if (threads > 256) threads = 256;
   dim3 grid((a->Sq + threads - 1) / threads, a->heads, a->B);
-  const int hd = a->head_dim > 0 ? a->head_dim : 32;
-  SDMI_REQUIRE(hd == 32 || hd == 48, "head_dim must be 32 (UNet) or 48 (SAVi predictor)");
-  if (a->dtype == SDMI_BF16 && hd == 32) {
-    const int skv_pad = (a->Skv + 31) / 32 * 32;
-    dim3 g2((a->Sq + 127) / 128, a->heads, a->B);
-    hipLaunchKernelGGL(attn_fwd_mfma_kernel, g2, dim3(256), skv_pad * (ATT_KP + ATT_VP), st, *a);
-    return sdmi_check_launch("attention (mfma)");
-  }
   const int smem = 2 * a->Skv * hd * 4;
 #define ATTN_GO(T, HDV)                                                                      \
   do {                                                                                       \

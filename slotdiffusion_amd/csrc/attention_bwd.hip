@@ -244,30 +244,21 @@ __device__ __forceinline__ void store_col(bf16_t* rp, const f32x16& acc, float s
   }
 }
 
+// Keys (dQ body) / queries (dKV body) pass through LDS in chunks of ATB_CHUNK rows, so sequences beyond
+// one LDS image (the 784 tokens of the 224^2 configs) take the same kernel: the accumulators stay in
+// registers across chunks, only the staged images are replaced between two barriers.
+constexpr int ATB_CHUNK = 512;
+
 __device__ __forceinline__ void attn_bwd_dq_mfma_body(const SdmiAttnBwdArgs& p, char* smem, int bx) {
-  const int nkb = (p.Skv + 31) / 32, skv_pad = nkb * 32;
+  const int skv_pad = (p.Skv + 31) / 32 * 32;
+  const int cap = skv_pad < ATB_CHUNK ? skv_pad : ATB_CHUNK;
   char* K80 = smem;
-  char* K64 = K80 + skv_pad * P80;
-  char* V80 = K64 + skv_pad * P64;
+  char* K64 = K80 + cap * P80;
+  char* V80 = K64 + cap * P64;
   const int b = blockIdx.z, h = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  {
-    const bf16_t* kb = (const bf16_t*)p.k + (long long)b * p.Skv * p.ldk + h * 32;
-    const bf16_t* vb = (const bf16_t*)p.v + (long long)b * p.Skv * p.ldv + h * 32;
-    const u32x4 zero4 = {0u, 0u, 0u, 0u};
-    for (int i = tid; i < skv_pad * 4; i += 256) {
-      const int row = i >> 2, c = i & 3;
-      const bool ok = row < p.Skv;
-      const u32x4 kv = ok ? *reinterpret_cast<const u32x4*>(kb + (long long)row * p.ldk + c * 8) : zero4;
-      const u32x4 vv = ok ? *reinterpret_cast<const u32x4*>(vb + (long long)row * p.ldv + c * 8) : zero4;
-      *reinterpret_cast<u32x4*>(K80 + row * P80 + c * 16) = kv;
-      *reinterpret_cast<u32x4*>(K64 + row * P64 + c * 16) = kv;
-      *reinterpret_cast<u32x4*>(V80 + row * P80 + c * 16) = vv;
-    }
-  }
-  __syncthreads();
   const int q0 = (bx * 4 + wave) * 32;
-  if (q0 >= p.Sq) return;
+  const bool active = q0 < p.Sq;          // idle waves still help staging and keep the barriers
   const int ql = lane & 31, hh = lane >> 5;
   const int qi = q0 + ql, qc = qi < p.Sq ? qi : p.Sq - 1;
   bf16x8 bq[2], bdo[2];
@@ -293,75 +284,66 @@ __device__ __forceinline__ void attn_bwd_dq_mfma_body(const SdmiAttnBwdArgs& p, 
   const char* kfrag = K80 + ql * P80 + hh * 16;
   const char* vfrag = V80 + ql * P80 + hh * 16;
   const char* ktr = K64 + (4 * hh + (t >> 2)) * P64 + ((g & 1) * 16 + (t & 3) * 4) * 2;
-  for (int kb = 0; kb < nkb; ++kb) {
-    f32x16 s, dp;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) s[r] = dp[r] = 0.f;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const u32x4 ak = *reinterpret_cast<const u32x4*>(kfrag + kb * 32 * P80 + ks * 32);
-      const u32x4 av = *reinterpret_cast<const u32x4*>(vfrag + kb * 32 * P80 + ks * 32);
-      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ak), bq[ks], s, 0, 0, 0);
-      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), bdo[ks], dp, 0, 0, 0);
+  const bf16_t* kbase = (const bf16_t*)p.k + (long long)b * p.Skv * p.ldk + h * 32;
+  const bf16_t* vbase = (const bf16_t*)p.v + (long long)b * p.Skv * p.ldv + h * 32;
+  for (int c0 = 0; c0 < skv_pad; c0 += ATB_CHUNK) {
+    const int rows = skv_pad - c0 < ATB_CHUNK ? skv_pad - c0 : ATB_CHUNK;
+    if (c0) __syncthreads();              // everyone is done with the previous chunk's images
+    {
+      const u32x4 zero4 = {0u, 0u, 0u, 0u};
+      for (int i = tid; i < rows * 4; i += 256) {
+        const int row = i >> 2, c = i & 3;
+        const bool ok = c0 + row < p.Skv;
+        const u32x4 kv = ok ? *reinterpret_cast<const u32x4*>(kbase + (long long)(c0 + row) * p.ldk + c * 8) : zero4;
+        const u32x4 vv = ok ? *reinterpret_cast<const u32x4*>(vbase + (long long)(c0 + row) * p.ldv + c * 8) : zero4;
+        *reinterpret_cast<u32x4*>(K80 + row * P80 + c * 16) = kv;
+        *reinterpret_cast<u32x4*>(K64 + row * P64 + c * 16) = kv;
+        *reinterpret_cast<u32x4*>(V80 + row * P80 + c * 16) = vv;
+      }
     }
-    float ds[16];
+    __syncthreads();
+    if (!active) continue;
+    for (int kb = 0; kb < rows / 32; ++kb) {
+      f32x16 s, dp;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-      const float pr = key < p.Skv ? __expf(s[r] * p.scale - lse) : 0.f;
-      ds[r] = pr * (dp[r] - D);
+      for (int r = 0; r < 16; ++r) s[r] = dp[r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const u32x4 ak = *reinterpret_cast<const u32x4*>(kfrag + kb * 32 * P80 + ks * 32);
+        const u32x4 av = *reinterpret_cast<const u32x4*>(vfrag + kb * 32 * P80 + ks * 32);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ak), bq[ks], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), bdo[ks], dp, 0, 0, 0);
+      }
+      float ds[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = c0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        const float pr = key < p.Skv ? __expf(s[r] * p.scale - lse) : 0.f;
+        ds[r] = pr * (dp[r] - D);
+      }
+#pragma unroll
+      for (int mm = 0; mm < 2; ++mm)
+        dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_operand(ktr, kb * 32 + 16 * mm),
+                                                     bpack8(ds + 8 * mm), dq, 0, 0, 0);
     }
-#pragma unroll
-    for (int mm = 0; mm < 2; ++mm)
-      dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_operand(ktr, kb * 32 + 16 * mm),
-                                                   bpack8(ds + 8 * mm), dq, 0, 0, 0);
   }
-  if (qi < p.Sq)
+  if (active && qi < p.Sq)
     store_col((bf16_t*)p.dq + ((long long)b * p.Sq + qi) * p.ldq + h * 32 + 4 * hh, dq, p.scale);
 }
 
 __device__ __forceinline__ void attn_bwd_dkv_mfma_body(const SdmiAttnBwdArgs& p, char* smem, int bx) {
-  const int nqb = (p.Sq + 31) / 32, sq_pad = nqb * 32;
+  const int sq_pad = (p.Sq + 31) / 32 * 32;
+  const int cap = sq_pad < ATB_CHUNK ? sq_pad : ATB_CHUNK;
   char* Q80 = smem;
-  char* Q64 = Q80 + sq_pad * P80;
-  char* O80 = Q64 + sq_pad * P64;
-  char* O64 = O80 + sq_pad * P80;
-  float* lse_s = reinterpret_cast<float*>(O64 + sq_pad * P64);
-  float* D_s = lse_s + sq_pad;
+  char* Q64 = Q80 + cap * P80;
+  char* O80 = Q64 + cap * P64;
+  char* O64 = O80 + cap * P80;
+  float* lse_s = reinterpret_cast<float*>(O64 + cap * P64);
+  float* D_s = lse_s + cap;
   const int b = blockIdx.z, h = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  {
-    const bf16_t* qb = (const bf16_t*)p.q + (long long)b * p.Sq * p.ldq + h * 32;
-    const bf16_t* db = (const bf16_t*)p.dout + (long long)b * p.Sq * p.ldo + h * 32;
-    const u32x4 zero4 = {0u, 0u, 0u, 0u};
-    for (int i = tid; i < sq_pad * 4; i += 256) {
-      const int row = i >> 2, c = i & 3;
-      const bool ok = row < p.Sq;
-      const u32x4 qv = ok ? *reinterpret_cast<const u32x4*>(qb + (long long)row * p.ldq + c * 8) : zero4;
-      const u32x4 dv = ok ? *reinterpret_cast<const u32x4*>(db + (long long)row * p.ldo + c * 8) : zero4;
-      *reinterpret_cast<u32x4*>(Q80 + row * P80 + c * 16) = qv;
-      *reinterpret_cast<u32x4*>(Q64 + row * P64 + c * 16) = qv;
-      *reinterpret_cast<u32x4*>(O80 + row * P80 + c * 16) = dv;
-      *reinterpret_cast<u32x4*>(O64 + row * P64 + c * 16) = dv;
-    }
-    // D_q = dO_q . O_q and lse_q; pad queries get lse = +inf (P = 0) and D = 0
-    const bf16_t* ob = (const bf16_t*)p.out + (long long)b * p.Sq * p.ldo + h * 32;
-    for (int qi = tid; qi < sq_pad; qi += 256) {
-      float d = 0.f, l = INFINITY;
-      if (qi < p.Sq) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-          d += dot8(*reinterpret_cast<const u32x4*>(db + (long long)qi * p.ldo + c * 8),
-                    *reinterpret_cast<const u32x4*>(ob + (long long)qi * p.ldo + c * 8));
-        l = p.lse[((long long)b * p.heads + h) * p.Sq + qi];
-      }
-      D_s[qi] = d;
-      lse_s[qi] = l;
-    }
-  }
-  __syncthreads();
   const int k0 = (bx * 4 + wave) * 32;
-  if (k0 >= p.Skv) return;
+  const bool active = k0 < p.Skv;
   const int kl = lane & 31, hh = lane >> 5;
   const int kj = k0 + kl, kc = kj < p.Skv ? kj : p.Skv - 1;
   bf16x8 bk[2], bv[2];
@@ -382,38 +364,74 @@ __device__ __forceinline__ void attn_bwd_dkv_mfma_body(const SdmiAttnBwdArgs& p,
   const int troff = (4 * hh + (t >> 2)) * P64 + ((g & 1) * 16 + (t & 3) * 4) * 2;
   const char* qtr = Q64 + troff;
   const char* otr = O64 + troff;
-  for (int qb = 0; qb < nqb; ++qb) {
-    f32x16 s, dp;
+  const bf16_t* qb_ = (const bf16_t*)p.q + (long long)b * p.Sq * p.ldq + h * 32;
+  const bf16_t* db = (const bf16_t*)p.dout + (long long)b * p.Sq * p.ldo + h * 32;
+  const bf16_t* ob = (const bf16_t*)p.out + (long long)b * p.Sq * p.ldo + h * 32;
+  for (int c0 = 0; c0 < sq_pad; c0 += ATB_CHUNK) {
+    const int rows = sq_pad - c0 < ATB_CHUNK ? sq_pad - c0 : ATB_CHUNK;
+    if (c0) __syncthreads();
+    {
+      const u32x4 zero4 = {0u, 0u, 0u, 0u};
+      for (int i = tid; i < rows * 4; i += 256) {
+        const int row = i >> 2, c = i & 3;
+        const bool ok = c0 + row < p.Sq;
+        const u32x4 qv = ok ? *reinterpret_cast<const u32x4*>(qb_ + (long long)(c0 + row) * p.ldq + c * 8) : zero4;
+        const u32x4 dv4 = ok ? *reinterpret_cast<const u32x4*>(db + (long long)(c0 + row) * p.ldo + c * 8) : zero4;
+        *reinterpret_cast<u32x4*>(Q80 + row * P80 + c * 16) = qv;
+        *reinterpret_cast<u32x4*>(Q64 + row * P64 + c * 16) = qv;
+        *reinterpret_cast<u32x4*>(O80 + row * P80 + c * 16) = dv4;
+        *reinterpret_cast<u32x4*>(O64 + row * P64 + c * 16) = dv4;
+      }
+      // D_q = dO_q . O_q and lse_q; pad queries get lse = +inf (P = 0) and D = 0
+      for (int r = tid; r < rows; r += 256) {
+        const int qi = c0 + r;
+        float d = 0.f, l = INFINITY;
+        if (qi < p.Sq) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) s[r] = dp[r] = 0.f;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const u32x4 aq = *reinterpret_cast<const u32x4*>(qfrag + qb * 32 * P80 + ks * 32);
-      const u32x4 ao = *reinterpret_cast<const u32x4*>(ofrag + qb * 32 * P80 + ks * 32);
-      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, aq), bk[ks], s, 0, 0, 0);
-      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ao), bv[ks], dp, 0, 0, 0);
-    }
-    float pr[16], ds[16];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {   // rows (queries) qb*32 + 8j + 4hh + i
-      const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + qb * 32 + 8 * j + 4 * hh);
-      const f32x4 d4 = *reinterpret_cast<const f32x4*>(D_s + qb * 32 + 8 * j + 4 * hh);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int r = 4 * j + i;
-        pr[r] = __expf(s[r] * p.scale - l4[i]);
-        ds[r] = pr[r] * (dp[r] - d4[i]);
+          for (int c = 0; c < 4; ++c)
+            d += dot8(*reinterpret_cast<const u32x4*>(db + (long long)qi * p.ldo + c * 8),
+                      *reinterpret_cast<const u32x4*>(ob + (long long)qi * p.ldo + c * 8));
+          l = p.lse[((long long)b * p.heads + h) * p.Sq + qi];
+        }
+        D_s[r] = d;
+        lse_s[r] = l;
       }
     }
+    __syncthreads();
+    if (!active) continue;
+    for (int qb = 0; qb < rows / 32; ++qb) {
+      f32x16 s, dp;
 #pragma unroll
-    for (int mm = 0; mm < 2; ++mm) {
-      dv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_operand(otr, qb * 32 + 16 * mm),
-                                                   bpack8(pr + 8 * mm), dv, 0, 0, 0);
-      dk = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_operand(qtr, qb * 32 + 16 * mm),
-                                                   bpack8(ds + 8 * mm), dk, 0, 0, 0);
+      for (int r = 0; r < 16; ++r) s[r] = dp[r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const u32x4 aq = *reinterpret_cast<const u32x4*>(qfrag + qb * 32 * P80 + ks * 32);
+        const u32x4 ao = *reinterpret_cast<const u32x4*>(ofrag + qb * 32 * P80 + ks * 32);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, aq), bk[ks], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ao), bv[ks], dp, 0, 0, 0);
+      }
+      float pr[16], ds[16];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {   // rows (queries) c0 + qb*32 + 8j + 4hh + i
+        const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + qb * 32 + 8 * j + 4 * hh);
+        const f32x4 d4 = *reinterpret_cast<const f32x4*>(D_s + qb * 32 + 8 * j + 4 * hh);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int r = 4 * j + i;
+          pr[r] = __expf(s[r] * p.scale - l4[i]);
+          ds[r] = pr[r] * (dp[r] - d4[i]);
+        }
+      }
+#pragma unroll
+      for (int mm = 0; mm < 2; ++mm) {
+        dv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_operand(otr, qb * 32 + 16 * mm),
+                                                     bpack8(pr + 8 * mm), dv, 0, 0, 0);
+        dk = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_operand(qtr, qb * 32 + 16 * mm),
+                                                     bpack8(ds + 8 * mm), dk, 0, 0, 0);
+      }
     }
   }
-  if (kj < p.Skv) {
+  if (active && kj < p.Skv) {
     store_col((bf16_t*)p.dk + ((long long)b * p.Skv + kj) * p.ldk + h * 32 + 4 * hh, dk, p.scale);
     store_col((bf16_t*)p.dv + ((long long)b * p.Skv + kj) * p.ldv + h * 32 + 4 * hh, dv, 1.f);
   }
@@ -434,7 +452,9 @@ int launch_attn_bwd_mfma(const SdmiAttnBwdArgs& a, hipStream_t st) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     done = true;
   }
-  const int skv_pad = (a.Skv + 31) / 32 * 32, sq_pad = (a.Sq + 31) / 32 * 32;
+  int skv_pad = (a.Skv + 31) / 32 * 32, sq_pad = (a.Sq + 31) / 32 * 32;
+  if (skv_pad > ATB_CHUNK) skv_pad = ATB_CHUNK;
+  if (sq_pad > ATB_CHUNK) sq_pad = ATB_CHUNK;
   const int smem_q = skv_pad * (2 * P80 + P64), smem_k = sq_pad * (2 * P80 + 2 * P64 + 8);
   const int nqx = (a.Sq + 127) / 128, nkx = (a.Skv + 127) / 128;
   hipLaunchKernelGGL(attn_bwd_mfma_kernel, dim3(nqx + nkx, a.heads, a.B), dim3(256),
@@ -450,12 +470,15 @@ extern "C" int sdmi_attention_bwd(const SdmiAttnBwdArgs* a, void* stream) {
   const int vec = a->dtype == SDMI_BF16 ? 8 : 4;
   SDMI_REQUIRE(a->ldq % vec == 0 && a->ldk % vec == 0 && a->ldv % vec == 0 && a->ldo % vec == 0,
                "row pitches must keep 16-byte alignment");
-  SDMI_REQUIRE(a->Skv >= 1 && a->Skv <= 400, "Skv must be in [1, 400]");
   const int hd = a->head_dim > 0 ? a->head_dim : 32;
   SDMI_REQUIRE(hd == 32 || hd == 48, "head_dim must be 32 or 48");
   hipStream_t st = (hipStream_t)stream;
-  if (a->dtype == SDMI_BF16 && hd == 32 && (a->Sq + 31) / 32 * 32 * (2 * P80 + 2 * P64 + 8) <= 160 * 1024)
+  // chunked staging: any sequence length (few keys x many queries keeps the thread-per-(key, channel)
+  // dK/dV kernel below: one workgroup walking every query chunk would serialise it)
+  if (a->dtype == SDMI_BF16 && hd == 32 &&
+      ((a->Sq + 31) / 32 * 32 * (2 * P80 + 2 * P64 + 8) <= 160 * 1024 || a->Skv > 16))
     return launch_attn_bwd_mfma(*a, st);
+  SDMI_REQUIRE(a->Skv >= 1 && a->Skv <= 400, "Skv must be in [1, 400] (fp32 / head_dim 48: K/V staged whole in LDS)");
   if (a->dtype == SDMI_BF16)
     return hd == 32 ? launch_attn_bwd<bf16_t, 32>(*a, st) : launch_attn_bwd<bf16_t, 48>(*a, st);
   return hd == 32 ? launch_attn_bwd<float, 32>(*a, st) : launch_attn_bwd<float, 48>(*a, st);

@@ -52,8 +52,9 @@ def position_embedding(K, name='encoder_pos_embedding'):
 # ------------------------------------------------------------------------------------------
 def dino_encoder(K, img_nhwc, meta, prefix='encoder.dino'):
     """img [B,H,W,Cpad] compute dtype -> patch features [B, (H/p)*(W/p), hidden] (CLS dropped).
-    No autograd: the ViT is frozen (dino.py:39-41).  Attention over the 785 tokens runs as batched
-    MFMA GEMMs per head (S = q k^T, row softmax, O = P v) -- head dim 64."""
+    No autograd: the ViT is frozen (dino.py:39-41).  Attention over the 785 tokens (head dim 64): bf16 ->
+    the matrix-core kernel with K/V chunked through LDS (one launch per layer); fp32 -> batched GEMMs
+    per head (S = q k^T, row softmax, O = P v)."""
     wb = K.wb
     hid, heads, p_ = meta['hidden'], meta['heads'], meta['patch']
     hd = hid // heads
@@ -79,7 +80,8 @@ def dino_encoder(K, img_nhwc, meta, prefix='encoder.dino'):
             h = Kf.ln(x, l + '.layernorm_before', eps=1e-12)
             qkv = Kf.linear(h, (a + '.query.weight', a + '.key.weight', a + '.value.weight'),
                             (a + '.query.bias', a + '.key.bias', a + '.value.bias'))
-            ctx = ops.attention_long(qkv[..., :hid], qkv[..., hid:2 * hid], qkv[..., 2 * hid:], heads, hd)
+            att = ops.attention if (dt == torch.bfloat16 and hd == 64) else ops.attention_long
+            ctx = att(qkv[..., :hid], qkv[..., hid:2 * hid], qkv[..., 2 * hid:], heads, head_dim=hd)
             x = Kf.linear(ctx, l + '.attention.output.dense.weight', l + '.attention.output.dense.bias',
                           residual=x)
             h = Kf.ln(x, l + '.layernorm_after', eps=1e-12)

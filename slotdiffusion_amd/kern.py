@@ -680,7 +680,8 @@ class Kern:
 
     def attn_self(self, qkv, heads, head_dim=32):
         C = heads * head_dim
-        if qkv.shape[1] > ops.ATTN_LDS_MAX_KV:          # e.g. 28 x 28 tokens of the 224^2 configs
+        fits = ops.ATTN_MFMA_MAX_KV if (qkv.dtype == torch.bfloat16 and head_dim == 32) else ops.ATTN_LDS_MAX_KV
+        if qkv.shape[1] > fits:          # e.g. the 785 tokens x head_dim 64 of the DINO ViT
             return ops.attention_long(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], heads, head_dim)
         return ops.attention(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], heads,
                              head_dim=head_dim)
@@ -1869,7 +1870,8 @@ class KernGrad(Kern):
         return LayerNormFn.apply(x, self.wb.anchor_for(name), self.wb, name)
 
     def attn_self(self, qkv, heads, head_dim=32):
-        if qkv.shape[1] > ops.ATTN_LDS_MAX_KV:
+        fits = ops.ATTN_MFMA_MAX_KV if (qkv.dtype == torch.bfloat16 and head_dim == 32) else ops.ATTN_LDS_MAX_KV
+        if qkv.shape[1] > fits:
             return LongAttnFn.apply(qkv, heads, head_dim)
         return AttnFn.apply(qkv, None, heads, head_dim)
 

@@ -434,6 +434,7 @@ def softmax_rows_bwd_(p, dp, scale=1.0):
 
 
 ATTN_LDS_MAX_KV = 400       # longer key sequences do not fit the LDS-resident attention kernels
+ATTN_MFMA_MAX_KV = 1024     # ... except the bf16 / head_dim 32 forward kernel (144 B of LDS per key)
 
 
 def attention_long(q, k, v, heads, head_dim, keep_p=False):

@@ -299,10 +299,12 @@ def test_layernorm(C, dtype):
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize('cfg', [(2, 8, 256, 256), (2, 12, 64, 64), (3, 16, 16, 16), (2, 8, 256, 7),
-                                 (2, 16, 16, 15)])
+                                 (2, 16, 16, 15), (2, 5, 784, 784), (1, 3, 200, 1000)])
 def test_attention(cfg, dtype):
     ops = _ops()
     B, heads, Sq, Skv = cfg
+    if Skv > ops.ATTN_LDS_MAX_KV and dtype != torch.bfloat16:
+        pytest.skip('beyond 400 keys only the bf16 matrix-core kernel keeps K/V in LDS')
     C = heads * 32
     g = torch.Generator().manual_seed(Sq * 7 + Skv)
     qq = q(torch.randn(B, Sq, C, generator=g), dtype)
@@ -316,6 +318,28 @@ def test_attention(cfg, dtype):
     kvd = kv.to(dtype).to(DEV)
     out = ops.attention(qq.to(dtype).to(DEV), kvd[..., :C], kvd[..., C:], heads)
     check(out, ref, dtype, f'attention {cfg}')
+
+
+@pytest.mark.parametrize('cfg', [(2, 6, 785, 785), (1, 3, 100, 300), (2, 2, 40, 17)])
+def test_attention_head_dim_64(cfg):
+    """bf16 matrix-core attention at the DINO ViT's head size (keys chunked through LDS, 256 at a time)
+    against fp32 torch on the bf16-rounded inputs."""
+    ops = _ops()
+    B, heads, Sq, Skv = cfg
+    hd, dtype = 64, torch.bfloat16
+    C = heads * hd
+    g = torch.Generator().manual_seed(Sq + Skv)
+    qq = q(torch.randn(B, Sq, C, generator=g), dtype)
+    kv = q(torch.randn(B, Skv, 2 * C, generator=g), dtype)
+    sp = lambda t, S: t.view(B, S, heads, hd).permute(0, 2, 1, 3)
+    sim = torch.einsum('bhid,bhjd->bhij', sp(qq, Sq), sp(kv[..., :C].contiguous(), Skv)) * hd ** -0.5
+    ref = torch.einsum('bhij,bhjd->bhid', sim.softmax(-1), sp(kv[..., C:].contiguous(), Skv))
+    ref = ref.permute(0, 2, 1, 3).reshape(B, Sq, C)
+    kvd = kv.to(dtype).to(DEV)
+    lse = torch.empty(B, heads, Sq, device=DEV)
+    out = ops.attention(qq.to(dtype).to(DEV), kvd[..., :C], kvd[..., C:], heads, head_dim=hd, lse=lse)
+    check(out, ref, dtype, f'attention hd64 {cfg}')
+    assert float((lse.cpu() - torch.logsumexp(sim, -1)).abs().max()) < 2e-2
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])

@@ -607,13 +607,17 @@ def test_layernorm_and_gemm_fanout(dtype):
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize('cfg', [(2, 8, 256, 256), (2, 12, 64, 64), (3, 16, 16, 16), (2, 8, 256, 7),
-                                 (2, 4, 50, 15), (1, 2, 130, 100)])
+                                 (2, 4, 50, 15), (1, 2, 130, 100), (2, 5, 784, 784), (1, 2, 1000, 600),
+                                 (1, 3, 520, 1024)])
 def test_attention_bwd_kernel(cfg, dtype):
     """dq/dk/dv of the attention backward (matrix-core kernels for bf16, VALU kernels for fp32)
-    against torch autograd; inputs are quantised to the compute dtype first."""
+    against torch autograd; inputs are quantised to the compute dtype first.  The cases beyond 400
+    keys (bf16 only) cross the 512-row LDS chunks of the matrix-core kernels on both sides."""
     from slotdiffusion_amd import _lib, ops
     from slotdiffusion_amd.kern import _DT
     B, heads, Sq, Skv = cfg
+    if Skv > ops.ATTN_LDS_MAX_KV and dtype != torch.bfloat16:
+        pytest.skip('fp32 keeps K/V whole in LDS: at most 400 keys')
     C = heads * 32
     g = torch.Generator().manual_seed(Sq * 3 + Skv)
     qz = lambda t: t.to(dtype).float()
