@@ -130,7 +130,7 @@ __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
 }
 
 // HD = 32 (UNet) or 64 (DINO ViT).  Keys pass through LDS in chunks of CHUNK rows (one chunk covers the
-// UNet's sequences; the ViT's 785 keys x 64 channels take four), the online-softmax state and the
+// UNet's sequences at 128^2; the ViT's 785 keys x 64 channels take four), the online-softmax state and the
 // output accumulators stay in registers across chunks.  V is kept as HD/32 separate 32-channel images
 // so the transposing read sees the same 64-byte pitch for either head size.
 template <int HD, int CHUNK>
@@ -262,25 +262,24 @@ extern "C" int sdmi_attention(const SdmiAttnArgs* a, void* stream) {
                "head_dim must be 32 (UNet), 48 (SAVi predictor) or 64 (DINO ViT, bf16 only)");
   hipStream_t st = (hipStream_t)stream;
   if (a->dtype == SDMI_BF16 && (hd == 32 || hd == 64)) {
-    // matrix-core kernel.  head_dim 32: K and V of one (image, head) in one LDS image of 144 B per key
-    // (1024 keys = 147 KB of the CU's 160 KB: the 28 x 28 self-attention of the 224^2 configs fits);
-    // head_dim 64: 272 B per key, staged in chunks of 256 keys (two workgroups per CU), any length.
+    // matrix-core kernel, any key count: K and V of one (image, head) pass through LDS in chunks of 512
+    // keys x 144 B (head_dim 32; one chunk covers every 128^2 configuration, the 28 x 28 self-attention
+    // of the 224^2 configs takes two) or 256 keys x 272 B (head_dim 64): two workgroups per CU either way.
     static bool big = false;
     if (!big) {
-      (void)hipFuncSetAttribute((const void*)attn_fwd_mfma_kernel<32, 1024>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 1024 * (32 * 2 + 16 + ATT_VP));
+      (void)hipFuncSetAttribute((const void*)attn_fwd_mfma_kernel<32, 512>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 512 * (32 * 2 + 16 + ATT_VP));
       (void)hipFuncSetAttribute((const void*)attn_fwd_mfma_kernel<64, 256>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 256 * (64 * 2 + 16 + 2 * ATT_VP));
       big = true;
     }
+    SDMI_REQUIRE(a->Skv >= 1, "Skv must be positive");
     const int skv_pad = (a->Skv + 31) / 32 * 32;
     dim3 g2((a->Sq + 127) / 128, a->heads, a->B);
     if (hd == 32) {
-      SDMI_REQUIRE(a->Skv >= 1 && a->Skv <= 1024, "Skv must be in [1, 1024] for bf16 / head_dim 32");
-      hipLaunchKernelGGL((attn_fwd_mfma_kernel<32, 1024>), g2, dim3(256), skv_pad * (32 * 2 + 16 + ATT_VP),
-                         st, *a);
+      const int cap = skv_pad < 512 ? skv_pad : 512;
+      hipLaunchKernelGGL((attn_fwd_mfma_kernel<32, 512>), g2, dim3(256), cap * (32 * 2 + 16 + ATT_VP), st, *a);
     } else {
-      SDMI_REQUIRE(a->Skv >= 1, "Skv must be positive");
       const int cap = skv_pad < 256 ? skv_pad : 256;
       hipLaunchKernelGGL((attn_fwd_mfma_kernel<64, 256>), g2, dim3(256), cap * (64 * 2 + 16 + 2 * ATT_VP),
                          st, *a);

@@ -244,14 +244,16 @@ __device__ __forceinline__ void store_col(bf16_t* rp, const f32x16& acc, float s
   }
 }
 
-// Keys (dQ body) / queries (dKV body) pass through LDS in chunks of ATB_CHUNK rows, so sequences beyond
-// one LDS image (the 784 tokens of the 224^2 configs) take the same kernel: the accumulators stay in
-// registers across chunks, only the staged images are replaced between two barriers.
+// Keys (dQ body) / queries (dKV body) pass through LDS in chunks of `chunk` rows (a multiple of 32, at
+// most ATB_CHUNK), so sequences beyond one LDS image (the 784 tokens of the 224^2 configs) take the same
+// kernel: the accumulators stay in registers across chunks, only the staged images are replaced
+// between two barriers.  Slot cross-attention (a handful of keys) uses short query chunks: the launch
+// allocates the larger of the two bodies' images for every workgroup, and occupancy follows it.
 constexpr int ATB_CHUNK = 512;
 
-__device__ __forceinline__ void attn_bwd_dq_mfma_body(const SdmiAttnBwdArgs& p, char* smem, int bx) {
+__device__ __forceinline__ void attn_bwd_dq_mfma_body(const SdmiAttnBwdArgs& p, char* smem, int bx, int chunk) {
   const int skv_pad = (p.Skv + 31) / 32 * 32;
-  const int cap = skv_pad < ATB_CHUNK ? skv_pad : ATB_CHUNK;
+  const int cap = skv_pad < chunk ? skv_pad : chunk;
   char* K80 = smem;
   char* K64 = K80 + cap * P80;
   char* V80 = K64 + cap * P64;
@@ -286,8 +288,8 @@ __device__ __forceinline__ void attn_bwd_dq_mfma_body(const SdmiAttnBwdArgs& p, 
   const char* ktr = K64 + (4 * hh + (t >> 2)) * P64 + ((g & 1) * 16 + (t & 3) * 4) * 2;
   const bf16_t* kbase = (const bf16_t*)p.k + (long long)b * p.Skv * p.ldk + h * 32;
   const bf16_t* vbase = (const bf16_t*)p.v + (long long)b * p.Skv * p.ldv + h * 32;
-  for (int c0 = 0; c0 < skv_pad; c0 += ATB_CHUNK) {
-    const int rows = skv_pad - c0 < ATB_CHUNK ? skv_pad - c0 : ATB_CHUNK;
+  for (int c0 = 0; c0 < skv_pad; c0 += chunk) {
+    const int rows = skv_pad - c0 < chunk ? skv_pad - c0 : chunk;
     if (c0) __syncthreads();              // everyone is done with the previous chunk's images
     {
       const u32x4 zero4 = {0u, 0u, 0u, 0u};
@@ -331,9 +333,9 @@ __device__ __forceinline__ void attn_bwd_dq_mfma_body(const SdmiAttnBwdArgs& p, 
     store_col((bf16_t*)p.dq + ((long long)b * p.Sq + qi) * p.ldq + h * 32 + 4 * hh, dq, p.scale);
 }
 
-__device__ __forceinline__ void attn_bwd_dkv_mfma_body(const SdmiAttnBwdArgs& p, char* smem, int bx) {
+__device__ __forceinline__ void attn_bwd_dkv_mfma_body(const SdmiAttnBwdArgs& p, char* smem, int bx, int chunk) {
   const int sq_pad = (p.Sq + 31) / 32 * 32;
-  const int cap = sq_pad < ATB_CHUNK ? sq_pad : ATB_CHUNK;
+  const int cap = sq_pad < chunk ? sq_pad : chunk;
   char* Q80 = smem;
   char* Q64 = Q80 + cap * P80;
   char* O80 = Q64 + cap * P64;
@@ -367,8 +369,8 @@ __device__ __forceinline__ void attn_bwd_dkv_mfma_body(const SdmiAttnBwdArgs& p,
   const bf16_t* qb_ = (const bf16_t*)p.q + (long long)b * p.Sq * p.ldq + h * 32;
   const bf16_t* db = (const bf16_t*)p.dout + (long long)b * p.Sq * p.ldo + h * 32;
   const bf16_t* ob = (const bf16_t*)p.out + (long long)b * p.Sq * p.ldo + h * 32;
-  for (int c0 = 0; c0 < sq_pad; c0 += ATB_CHUNK) {
-    const int rows = sq_pad - c0 < ATB_CHUNK ? sq_pad - c0 : ATB_CHUNK;
+  for (int c0 = 0; c0 < sq_pad; c0 += chunk) {
+    const int rows = sq_pad - c0 < chunk ? sq_pad - c0 : chunk;
     if (c0) __syncthreads();
     {
       const u32x4 zero4 = {0u, 0u, 0u, 0u};
@@ -439,10 +441,10 @@ __device__ __forceinline__ void attn_bwd_dkv_mfma_body(const SdmiAttnBwdArgs& p,
 
 // dq and dk / dv of one attention in ONE launch: workgroups [0, nqx) take query blocks, the rest key
 // blocks (two dependent-free halves of the same backward: one launch instead of two)
-__global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(SdmiAttnBwdArgs p, int nqx) {
+__global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(SdmiAttnBwdArgs p, int nqx, int chunk_k, int chunk_q) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  if ((int)blockIdx.x < nqx) attn_bwd_dq_mfma_body(p, smem, blockIdx.x);
-  else attn_bwd_dkv_mfma_body(p, smem, (int)blockIdx.x - nqx);
+  if ((int)blockIdx.x < nqx) attn_bwd_dq_mfma_body(p, smem, blockIdx.x, chunk_k);
+  else attn_bwd_dkv_mfma_body(p, smem, (int)blockIdx.x - nqx, chunk_q);
 }
 
 int launch_attn_bwd_mfma(const SdmiAttnBwdArgs& a, hipStream_t st) {
@@ -454,11 +456,12 @@ int launch_attn_bwd_mfma(const SdmiAttnBwdArgs& a, hipStream_t st) {
   }
   int skv_pad = (a.Skv + 31) / 32 * 32, sq_pad = (a.Sq + 31) / 32 * 32;
   if (skv_pad > ATB_CHUNK) skv_pad = ATB_CHUNK;
-  if (sq_pad > ATB_CHUNK) sq_pad = ATB_CHUNK;
+  const int qmax = a.Skv <= 32 ? 128 : ATB_CHUNK;
+  if (sq_pad > qmax) sq_pad = qmax;
   const int smem_q = skv_pad * (2 * P80 + P64), smem_k = sq_pad * (2 * P80 + 2 * P64 + 8);
   const int nqx = (a.Sq + 127) / 128, nkx = (a.Skv + 127) / 128;
   hipLaunchKernelGGL(attn_bwd_mfma_kernel, dim3(nqx + nkx, a.heads, a.B), dim3(256),
-                     smem_q > smem_k ? smem_q : smem_k, st, a, nqx);
+                     smem_q > smem_k ? smem_q : smem_k, st, a, nqx, skv_pad, sq_pad);
   return sdmi_check_launch("attention_bwd (mfma)");
 }
 
@@ -473,10 +476,10 @@ extern "C" int sdmi_attention_bwd(const SdmiAttnBwdArgs* a, void* stream) {
   const int hd = a->head_dim > 0 ? a->head_dim : 32;
   SDMI_REQUIRE(hd == 32 || hd == 48, "head_dim must be 32 or 48");
   hipStream_t st = (hipStream_t)stream;
-  // chunked staging: any sequence length (few keys x many queries keeps the thread-per-(key, channel)
-  // dK/dV kernel below: one workgroup walking every query chunk would serialise it)
-  if (a->dtype == SDMI_BF16 && hd == 32 &&
-      ((a->Sq + 31) / 32 * 32 * (2 * P80 + 2 * P64 + 8) <= 160 * 1024 || a->Skv > 16))
+  // chunked staging: any sequence length on either side (slot cross-attention under 28 x 28 queries
+  // included: one wave walking the query chunks with MFMAs beats the thread-per-(key, channel) kernel
+  // below by an order of magnitude there)
+  if (a->dtype == SDMI_BF16 && hd == 32)
     return launch_attn_bwd_mfma(*a, st);
   SDMI_REQUIRE(a->Skv >= 1 && a->Skv <= 400, "Skv must be in [1, 400] (fp32 / head_dim 48: K/V staged whole in LDS)");
   if (a->dtype == SDMI_BF16)

@@ -101,6 +101,55 @@ __global__ __launch_bounds__(256) void rowgroup_sum_kernel(SdmiRowGroupSumArgs p
   p.out[(long long)g * (p.ldo ? p.ldo : p.N) + n] = (s0 + s1) + (s2 + s3);
 }
 
+// the same sums for long groups (e.g. 784 rows of a 28 x 28 map per image, few images): the column-per-thread
+// walk above is one latency-bound chain per thread; here a workgroup owns 64 columns (32 lanes x 2) and
+// its 8 row lanes stride the rows 8 loads deep, partial sums meet in LDS.  N and ldx even.
+template <typename T>
+__global__ __launch_bounds__(256) void rowgroup_sum_tall_kernel(SdmiRowGroupSumArgs p) {
+  __shared__ float part[8][64];
+  const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int n = blockIdx.x * 64 + 2 * cl;
+  const int g = blockIdx.y;
+  float s0 = 0.f, s1 = 0.f;
+  if (n < p.N) {
+    const T* x = (const T*)p.x + (long long)g * p.rows_per * p.ldx + n;
+    int r = rl;
+    for (; r + 56 < p.rows_per; r += 64) {
+      float a[8][2];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const T* q = x + (long long)(r + 8 * u) * p.ldx;
+        if constexpr (sizeof(T) == 2) {
+          const unsigned w = *reinterpret_cast<const unsigned*>(q);
+          a[u][0] = bf16_to_f32((bf16_t)(w & 0xffffu));
+          a[u][1] = bf16_to_f32((bf16_t)(w >> 16));
+        } else {
+          const float2 w = *reinterpret_cast<const float2*>(q);
+          a[u][0] = w.x; a[u][1] = w.y;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { s0 += a[u][0]; s1 += a[u][1]; }
+    }
+    for (; r < p.rows_per; r += 8) {
+      s0 += Elem<T>::ld(x + (long long)r * p.ldx);
+      s1 += Elem<T>::ld(x + (long long)r * p.ldx + 1);
+    }
+  }
+  part[rl][2 * cl] = s0;
+  part[rl][2 * cl + 1] = s1;
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c < p.N) {
+      float t = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) t += part[i][threadIdx.x];
+      p.out[(long long)g * (p.ldo ? p.ldo : p.N) + c] = t;
+    }
+  }
+}
+
 template <typename T>
 __global__ void pool2x2_kernel(SdmiPool2x2Args p) {      // x [B,2H,2W,C] -> y [B,H,W,C]
   constexpr int VEC = Elem<T>::VEC;
@@ -310,7 +359,11 @@ extern "C" int sdmi_ema_update(const SdmiEmaArgs* a, void* stream) {
 }
 extern "C" int sdmi_rowgroup_sum(const SdmiRowGroupSumArgs* a, void* stream) {
   SDMI_REQUIRE(a && a->x && a->out && a->groups >= 1 && a->rows_per >= 1, "bad args");
-  DISPATCH_T(rowgroup_sum_kernel, dim3((a->N + 255) / 256, a->groups), a);
+  const int es = a->dtype == SDMI_BF16 ? 2 : 4;
+  const bool tall = a->rows_per >= 128 && a->N % 2 == 0 && a->ldx % 2 == 0 &&
+                    ((uintptr_t)a->x % (2 * es)) == 0 && (long long)a->groups * ((a->N + 255) / 256) < 1024;
+  if (tall) DISPATCH_T(rowgroup_sum_tall_kernel, dim3((a->N + 63) / 64, a->groups), a);
+  else DISPATCH_T(rowgroup_sum_kernel, dim3((a->N + 255) / 256, a->groups), a);
   return sdmi_check_launch("rowgroup_sum");
 }
 extern "C" int sdmi_pool2x2_sum(const SdmiPool2x2Args* a, void* stream) {

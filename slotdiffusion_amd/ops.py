@@ -434,7 +434,7 @@ def softmax_rows_bwd_(p, dp, scale=1.0):
 
 
 ATTN_LDS_MAX_KV = 400       # longer key sequences do not fit the LDS-resident attention kernels
-ATTN_MFMA_MAX_KV = 1024     # ... except the bf16 / head_dim 32 forward kernel (144 B of LDS per key)
+ATTN_MFMA_MAX_KV = 1 << 20  # ... except the bf16 matrix-core kernels (head_dim 32 / 64), which chunk the keys through LDS
 
 
 def attention_long(q, k, v, heads, head_dim, keep_p=False):

@@ -299,7 +299,7 @@ def test_layernorm(C, dtype):
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize('cfg', [(2, 8, 256, 256), (2, 12, 64, 64), (3, 16, 16, 16), (2, 8, 256, 7),
-                                 (2, 16, 16, 15), (2, 5, 784, 784), (1, 3, 200, 1000)])
+                                 (2, 16, 16, 15), (2, 5, 784, 784), (1, 3, 200, 1000), (1, 2, 300, 1300)])
 def test_attention(cfg, dtype):
     ops = _ops()
     B, heads, Sq, Skv = cfg

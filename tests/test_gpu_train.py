@@ -608,7 +608,7 @@ def test_layernorm_and_gemm_fanout(dtype):
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize('cfg', [(2, 8, 256, 256), (2, 12, 64, 64), (3, 16, 16, 16), (2, 8, 256, 7),
                                  (2, 4, 50, 15), (1, 2, 130, 100), (2, 5, 784, 784), (1, 2, 1000, 600),
-                                 (1, 3, 520, 1024)])
+                                 (1, 3, 520, 1024), (2, 6, 784, 7), (1, 2, 1030, 11)])
 def test_attention_bwd_kernel(cfg, dtype):
     """dq/dk/dv of the attention backward (matrix-core kernels for bf16, VALU kernels for fp32)
     against torch autograd; inputs are quantised to the compute dtype first.  The cases beyond 400
@@ -644,6 +644,25 @@ def test_attention_bwd_kernel(cfg, dtype):
     assert rel(dq, qq.grad) <= tol, ('dq', rel(dq, qq.grad))
     assert rel(dk, kk.grad) <= tol, ('dk', rel(dk, kk.grad))
     assert rel(dv, vv.grad) <= tol, ('dv', rel(dv, vv.grad))
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('groups,rows,N,pitch', [(16, 784, 384, 384), (3, 130, 70, 96), (2, 50, 40, 40),
+                                                  (1, 16, 3000, 3000), (4, 256, 62, 64)])
+def test_rowgroup_sum(groups, rows, N, pitch, dtype):
+    """Per-group column sums (time-embedding / position gradients): the column-per-thread kernel and the
+    row-parallel one for tall groups against an fp64 sum of the same (dtype-rounded) values."""
+    from slotdiffusion_amd import _lib
+    from slotdiffusion_amd.kern import _DT
+    g = torch.Generator().manual_seed(rows + N)
+    x = torch.randn(groups * rows, pitch, generator=g).to(dtype)
+    ref = x[:, :N].double().view(groups, rows, N).sum(1)
+    xd = x.cuda()
+    out = torch.full((groups, N + 3), -7.0, device=DEV)
+    _lib.call('sdmi_rowgroup_sum', torch.cuda.current_stream().cuda_stream, x=xd.data_ptr(),
+              out=out.data_ptr(), dtype=_DT[dtype], groups=groups, rows_per=rows, N=N, ldx=pitch, ldo=N + 3)
+    assert float((out[:, :N].cpu().double() - ref).abs().max()) <= 2e-5 * math.sqrt(rows) * 4
+    assert bool((out[:, N:] == -7.0).all())
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
