@@ -297,17 +297,30 @@ __global__ __launch_bounds__(256) void ema_kernel(SdmiEmaArgs p) {
   }
 }
 
+// VEC4: four parameters per lane and iteration (16-byte loads of p / g / m / v, 16-byte stores, one
+// 8-byte store of the bf16 shadow); the launch picks it when every pointer is 16-byte aligned, the
+// tail n % 4 is finished by the first lanes in scalar form.
+template <bool VEC4>
 __global__ __launch_bounds__(256) void adam_kernel(SdmiAdamArgs p) {
   // global grad norm from the block partials (every block recomputes the same scalar)
+  __shared__ double s_part[256];
   __shared__ float s_coef;
-  if (threadIdx.x == 0) {
+  {
     double s = 0.0;
-    for (int i = 0; i < p.nblk; ++i) s += (double)p.sq_partial[i];
-    const float total = (float)sqrt(s);
-    float c = p.clip > 0.f ? p.clip / (total + 1e-6f) : 1.f;
-    s_coef = c < 1.f ? c : 1.f;
+    for (int i = threadIdx.x; i < p.nblk; i += 256) s += (double)p.sq_partial[i];
+    s_part[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+      if ((int)threadIdx.x < w) s_part[threadIdx.x] += s_part[threadIdx.x + w];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+      const float total = (float)sqrt(s_part[0]);
+      float c = p.clip > 0.f ? p.clip / (total + 1e-6f) : 1.f;
+      s_coef = c < 1.f ? c : 1.f;
+    }
+    __syncthreads();
   }
-  __syncthreads();
   const float coef = s_coef;
   const int step = p.step_dev ? *p.step_dev : p.step;
   const float lr = p.lr_dev ? *p.lr_dev : p.lr;
@@ -315,14 +328,45 @@ __global__ __launch_bounds__(256) void adam_kernel(SdmiAdamArgs p) {
   const float bc2 = 1.f - powf(p.beta2, (float)step);
   const float step_size = lr / bc1;
   const float inv_sqrt_bc2 = 1.f / sqrtf(bc2);
-  GRID_STRIDE(i, p.n) {
-    const float g = p.g[i] * coef;
-    const float m = p.beta1 * p.m[i] + (1.f - p.beta1) * g;
-    const float v = p.beta2 * p.v[i] + (1.f - p.beta2) * g * g;
+  auto update = [&](float g, float& m, float& v, float& w) {
+    g *= coef;
+    m = p.beta1 * m + (1.f - p.beta1) * g;
+    v = p.beta2 * v + (1.f - p.beta2) * g * g;
+    const float denom = sqrtf(v) * inv_sqrt_bc2 + p.eps;
+    w = w - step_size * (m / denom);
+  };
+  long long done = 0;
+  if constexpr (VEC4) {
+    const long long n4 = p.n / 4;
+    GRID_STRIDE(i, n4) {
+      const f32x4 g4 = reinterpret_cast<const f32x4*>(p.g)[i];
+      f32x4 m4 = reinterpret_cast<f32x4*>(p.m)[i];
+      f32x4 v4 = reinterpret_cast<f32x4*>(p.v)[i];
+      f32x4 w4 = reinterpret_cast<f32x4*>(p.p)[i];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float m = m4[j], v = v4[j], w = w4[j];
+        update(g4[j], m, v, w);
+        m4[j] = m; v4[j] = v; w4[j] = w;
+      }
+      reinterpret_cast<f32x4*>(p.m)[i] = m4;
+      reinterpret_cast<f32x4*>(p.v)[i] = v4;
+      reinterpret_cast<f32x4*>(p.p)[i] = w4;
+      if (p.shadow_bf16) {
+        uint2 sh;
+        sh.x = (unsigned)f32_to_bf16(w4[0]) | ((unsigned)f32_to_bf16(w4[1]) << 16);
+        sh.y = (unsigned)f32_to_bf16(w4[2]) | ((unsigned)f32_to_bf16(w4[3]) << 16);
+        reinterpret_cast<uint2*>(p.shadow_bf16)[i] = sh;
+      }
+    }
+    done = n4 * 4;
+  }
+  for (long long i = done + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < p.n;
+       i += (long long)gridDim.x * blockDim.x) {
+    float m = p.m[i], v = p.v[i], w = p.p[i];
+    update(p.g[i], m, v, w);
     p.m[i] = m;
     p.v[i] = v;
-    const float denom = sqrtf(v) * inv_sqrt_bc2 + p.eps;
-    const float w = p.p[i] - step_size * (m / denom);
     p.p[i] = w;
     if (p.shadow_bf16) ((bf16_t*)p.shadow_bf16)[i] = f32_to_bf16(w);
   }
@@ -435,6 +479,11 @@ extern "C" int sdmi_sqsum_partial(const SdmiSqSumArgs* a, void* stream) {
 extern "C" int sdmi_adam_clip(const SdmiAdamArgs* a, void* stream) {
   SDMI_REQUIRE(a && a->p && a->g && a->m && a->v && a->sq_partial && a->nblk >= 1 &&
                    (a->step >= 1 || a->step_dev), "bad args");
-  hipLaunchKernelGGL(adam_kernel, dim3(nblocks(a->n)), dim3(256), 0, ST, *a);
+  const uintptr_t al = (uintptr_t)a->p | (uintptr_t)a->g | (uintptr_t)a->m | (uintptr_t)a->v |
+                       ((uintptr_t)a->shadow_bf16 << 1);        // the bf16 shadow needs 8-byte alignment
+  if (al % 16 == 0 && a->n >= 4)
+    hipLaunchKernelGGL(adam_kernel<true>, dim3(nblocks(a->n / 4)), dim3(256), 0, ST, *a);
+  else
+    hipLaunchKernelGGL(adam_kernel<false>, dim3(nblocks(a->n)), dim3(256), 0, ST, *a);
   return sdmi_check_launch("adam_clip");
 }

@@ -117,6 +117,34 @@ def test_adam_clip_step_matches_oracle():
     assert worst <= 2e-6
 
 
+@pytest.mark.parametrize('n,off', [(4099, 0), (1003, 1), (8, 4), (3, 0)])
+def test_adam_kernel_tails_and_alignment(n, off):
+    """sdmi_adam_clip on ranges whose length is not a multiple of four and whose start is not 16-byte
+    aligned (the vector kernel's scalar tail / the scalar kernel) against the oracle's Adam."""
+    from oracle import slotdiff_oracle as O
+    from slotdiffusion_amd import _lib
+    g = torch.Generator().manual_seed(n)
+    P, Gd = torch.randn(n, generator=g), torch.randn(n, generator=g) * 3
+    M, V = torch.randn(n, generator=g) * 0.1, torch.rand(n, generator=g) * 0.1
+    buf = lambda t: torch.cat([torch.zeros(off), t]).cuda()
+    p, gr, m, v = buf(P), buf(Gd), buf(M), buf(V)
+    shadow = torch.zeros(n + off, dtype=torch.bfloat16, device=DEV)
+    partial = torch.zeros(1024, device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.call('sdmi_sqsum_partial', st, g=gr[off:].data_ptr(), partial=partial.data_ptr(), n=n, nblk=1024)
+    _lib.call('sdmi_adam_clip', st, p=p[off:].data_ptr(), g=gr[off:].data_ptr(), m=m[off:].data_ptr(),
+              v=v[off:].data_ptr(), shadow_bf16=shadow[off:].data_ptr(), sq_partial=partial.data_ptr(),
+              nblk=1024, n=n, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, clip=1.0, step=3, lr_dev=0,
+              step_dev=0)
+    Pl, Ml, Vl = [P.clone()], [M.clone()], [V.clone()]
+    O.clip_and_adam(Pl, [Gd.clone()], Ml, Vl, 3, [1e-3], clip=1.0)
+    assert float((p[off:].cpu() - Pl[0]).abs().max()) <= 1e-6
+    assert float((m[off:].cpu() - Ml[0]).abs().max()) <= 1e-6
+    assert float((v[off:].cpu() - Vl[0]).abs().max()) <= 1e-6
+    assert torch.equal(shadow[off:].cpu(), p[off:].cpu().to(torch.bfloat16))
+    assert float(p[:off].abs().sum()) == 0.0 and float(shadow[:off].float().abs().sum()) == 0.0
+
+
 def test_graphed_train_step_matches_eager():
     """The HIP-graph replay of zero-grad + fwd + bwd + clip + Adam must walk exactly the same
     trajectory as the eager step (same kernels, same order): 4 steps, fixed t / noise, dropout

@@ -21,7 +21,9 @@ done
 # 3. the fp8 sampling configuration and the COCO-224 / DINO configuration (kernel stats only)
 timeout 600 rocprofv3 --kernel-trace --stats -d $O/sample_fp8 -o sample_fp8 --output-format csv -- python $R/bench.py --mode sample --dtype fp8 --big-batch 0 --no-cpu-baseline --no-roofline --steps 3 --warmup 1 > $O/sample_fp8_trace.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats -d $O/coco -o coco --output-format csv -- python $R/bench.py --config coco224 --mode sample --dtype fp8 --no-cpu-baseline --no-roofline --steps 2 --warmup 1 > $O/coco_trace.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -d $O/coco_train -o coco_train --output-format csv -- python $R/bench.py --config coco224 --mode train --only-train --no-cpu-baseline --no-roofline --steps 4 --warmup 2 > $O/coco_train_trace.log 2>&1
 cd $R
+cp $O/coco_train/coco_train_kernel_stats.csv $O/${TAG}_coco224_train_b16_bf16_kernel_stats.csv 2>/dev/null
 cp $O/sample_fp8/sample_fp8_kernel_stats.csv $O/${TAG}_sample_b64_fp8_kernel_stats.csv 2>/dev/null
 cp $O/coco/coco_kernel_stats.csv $O/${TAG}_coco224_sample_b16_fp8_kernel_stats.csv 2>/dev/null
 cp $O/train/train_kernel_stats.csv $O/${TAG}_train_b64_bf16_kernel_stats.csv 2>/dev/null
@@ -30,5 +32,5 @@ python tools/trace_step.py $O/train/train_kernel_trace.csv 60 > $O/${TAG}_train_
 for mode in train sample; do
   python tools/pmc_summary.py "$O/pmc_${mode}_*/**/*counter_collection.csv" > $O/${TAG}_${mode}_pmc_by_kernel.csv 2>&1
 done
-rm -rf $O/train/*trace.csv $O/sample/*trace.csv $O/sample_fp8/*trace.csv $O/coco/*trace.csv $O/pmc_*/*counter_collection.csv $O/pmc_*/*kernel_trace.csv
+rm -rf $O/train/*trace.csv $O/sample/*trace.csv $O/sample_fp8/*trace.csv $O/coco/*trace.csv $O/coco_train/*trace.csv $O/pmc_*/*counter_collection.csv $O/pmc_*/*kernel_trace.csv
 ls -la $O | head -40
