@@ -107,6 +107,12 @@ typedef struct {
    * query weights, the values into the output projection; see engine.UNetRunner.cross_fold). */
   int softmax8;
   long long s_colsum, s_bias;
+  /* geglu only: if non-NULL, the pre-activation h [M][2N] (value columns, then gate columns; bias
+   * included; out_dtype, row pitch ldc2) is stored as well and out is computed from the ROUNDED h, i.e.
+   * exactly what nn.Linear followed by GEGLU's chunk / gelu / multiply gives -- the training forward
+   * keeps h for the backward (attention.py:44-48) without a separate GEGLU launch. */
+  void* out2;
+  int ldc2;
 } SdmiGemmArgs;
 int sdmi_igemm(const SdmiGemmArgs* a, void* stream);
 

@@ -228,7 +228,23 @@ __device__ __forceinline__ void fused_epilogue(const SdmiGemmArgs& p, f32x16 (&a
       for (int j = 0; j < NOUT; ++j) {
         float v = rs * (acc[i][j][r] * p.alpha - mu * s0[j]) + c0[j];
         if constexpr (GEGLU) {
-          const float g = rs * (acc[i][j + TN / 2][r] * p.alpha - mu * s1[j]) + c1[j];
+          float g = rs * (acc[i][j + TN / 2][r] * p.alpha - mu * s1[j]) + c1[j];
+          if (p.out2) {          // keep the pre-activation (training) and continue from its rounding
+            if (out_bf16) {
+              const bf16_t vb = f32_to_bf16(v), gb = f32_to_bf16(g);
+              v = bf16_to_f32(vb);
+              g = bf16_to_f32(gb);
+              if (ncol[j] < p.N && m < p.M) {
+                bf16_t* h = (bf16_t*)p.out2 + (long long)m * p.ldc2 + ncol[j];
+                h[0] = vb;
+                h[p.N] = gb;
+              }
+            } else if (ncol[j] < p.N && m < p.M) {
+              float* h = (float*)p.out2 + (long long)m * p.ldc2 + ncol[j];
+              h[0] = v;
+              h[p.N] = g;
+            }
+          }
           v *= act_apply(g, SDMI_ACT_GELU);
         } else if constexpr (SM8) {
           // softmax over the aligned 8-column group (softmax8 slot scores + pad columns): the group's lanes
@@ -1290,6 +1306,10 @@ int dispatch(const SdmiGemmArgs& p, hipStream_t st) {
   // fused LayerNorm-fold / GEGLU epilogues (sdmi.h: ln_colsum, geglu): 1x1 / linear problems only
   {
     const int epi = (p.ln_colsum ? 1 : 0) | (p.geglu ? 2 : 0) | (p.softmax8 ? 4 : 0);
+    if (p.out2 && (!p.geglu || p.ldc2 < 2 * p.N)) {
+      sdmi_set_error("igemm: out2 (pre-activation copy) goes with geglu and needs ldc2 >= 2N");
+      return SDMI_EUNSUPPORTED;
+    }
     if (epi == 5) {            // LayerNorm fold + softmax over 8-column groups (per-image batches allowed)
       if (sizeof(T) == 1 || !is1x1 || !fits31 || p.osy != 0 || p.split_k > 1 || p.bias_m || p.residual ||
           p.rowvec || (p.N & 7)) {

@@ -79,8 +79,8 @@ extern "C" int sdmi_vq_nearest(const SdmiVqArgs* a, void* stream) {
   SDMI_REQUIRE(a->ldz >= 3 && a->n_codes >= 1 && a->n_codes * 16 <= 160 * 1024, "bad shape");
   static bool done = false;
   if (!done) {
-    hipFuncSetAttribute((const void*)vq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                        160 * 1024);
+    (void)hipFuncSetAttribute((const void*)vq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024);
     done = true;
   }
   hipLaunchKernelGGL(vq_kernel, dim3((a->R + 127) / 128), dim3(256), a->n_codes * 16,

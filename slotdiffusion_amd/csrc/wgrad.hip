@@ -25,7 +25,7 @@
 namespace {
 
 template <typename T> struct WCfg;
-template <> struct WCfg<bf16_t> { static constexpr int MTB = 256; };  // 128 m per iteration
+template <> struct WCfg<bf16_t> { [[maybe_unused]] static constexpr int MTB = 256; };  // 128 m per iteration
 template <> struct WCfg<float> { static constexpr int MTB = 128; };   // 32 m per iteration
 
 // in-register VEC x VEC transpose of 16-byte vectors

@@ -44,6 +44,7 @@ def _dbg(tag, **tensors):
 FP8_ACT_SCALE = 8.0        # activations -> e4m3fn: +-56 representable, 2^-9 resolution near zero
 _WG_MAIN_BELOW = float(os.environ.get('SDMI_WGRAD_MAIN_BELOW_GF', '0')) * 1e9
 _LAZY_CAT = os.environ.get('SDMI_LAZY_CAT', '1') != '0'
+_GEGLU_FUSE = os.environ.get('SDMI_GEGLU_FUSE', '1') != '0'     # training: GEGLU in the FF GEMM's epilogue
 
 
 class CatPair:
@@ -1358,6 +1359,32 @@ class GegluFn(torch.autograd.Function):
         return dh
 
 
+class GegluLinearFn(torch.autograd.Function):
+    """y = GEGLU(x W^T + b) as ONE GEMM launch whose epilogue stores the pre-activation h as well
+    (sdmi.h: geglu + out2); backward = geglu_bwd on the kept h, then the linear layer's gradients."""
+
+    @staticmethod
+    def forward(ctx, x, anchor, wb, wname, bname):
+        w = wb.w(wname, x.dtype)
+        h = torch.empty(x.shape[:-1] + (w.shape[0],), dtype=x.dtype, device=x.device)
+        y = ops.linear(x, w, wb.b(bname), geglu=True, out2=h)
+        ctx.save_for_backward(x, h)
+        ctx.cfg = (wb, wname, bname)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, h = ctx.saved_tensors
+        wb, wname, bname = ctx.cfg
+        dy = dy.contiguous()
+        dh = torch.empty_like(h)
+        C = h.shape[-1] // 2
+        call('sdmi_geglu_bwd', _st(), h=_p(h), dy=_p(dy), dh=_p(dh), dtype=_DT[h.dtype],
+             rows=h.numel() // (2 * C), C=C)
+        dx = GemmFn.core(wb, x, dh, wname, bname, (0, 0, 1, (0, 0, 0, 0), False), ctx.needs_input_grad[0])[0]
+        return dx, None, None, None, None
+
+
 class ActFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, kind):
@@ -1849,6 +1876,9 @@ class KernGrad(Kern):
 
     def ln_linear_fan(self, x, ln_name, wnames, bnames=None, *, act=None, geglu=False, eps=1e-5):
         n, xres = self.ln_fan(x, ln_name)          # (training keeps the normalised rows for wgrad)
+        if geglu and _GEGLU_FUSE and act is None and isinstance(wnames, str) and n.dtype == torch.bfloat16 \
+                and n.shape[-1] % 64 == 0:
+            return GegluLinearFn.apply(n, self.wb.anchor_for(wnames), self.wb, wnames, bnames), xres
         h = self.linear(n, wnames, bnames, act=act)
         return (self.geglu(h) if geglu else h), xres
 

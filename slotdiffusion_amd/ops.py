@@ -121,10 +121,11 @@ def conv2d(x, w, bias=None, *, kh=3, kw=3, stride=1, pad=(1, 1, 1, 1), ups=False
 
 
 def linear(x, w, bias=None, *, act=None, residual=None, out=None, out_dtype=None, n=None,
-           alpha=1.0, lda=None, k=None, ln_colsum=None, ln_eps=0.0, geglu=False):
+           alpha=1.0, lda=None, k=None, ln_colsum=None, ln_eps=0.0, geglu=False, out2=None):
     """x [..., K] (last dim contiguous; row pitch lda) ; w [N, K] -> [..., N].
     ln_colsum: fused LayerNorm prologue (w pre-scaled by gamma, bias = W beta + b; see sdmi.h);
-    geglu: w [2N, K] (value rows, gate rows) -> value * gelu(gate), N columns."""
+    geglu: w [2N, K] (value rows, gate rows) -> value * gelu(gate), N columns; out2 [..., 2N]: also keep
+    the pre-activation (training)."""
     _need_gpu(x, w)
     K = k or x.shape[-1]
     lda = lda or x.stride(-2) if x.dim() > 1 else K
@@ -145,7 +146,8 @@ def linear(x, w, bias=None, *, act=None, residual=None, out=None, out_dtype=None
          ldr=(residual.stride(-2) if residual is not None else 0), B=M, H=1, W=1, Cin=K, Ho=1,
          Wo=1, KH=1, KW=1, stride=1, pad_t=0, pad_l=0, ups=0, act=ACT[act], alpha=alpha,
          bias_m=0, split_k=(0 if ws is not None else 1), batch=1, ln_colsum=_p(ln_colsum),
-         ln_eps=float(ln_eps), geglu=int(geglu))
+         ln_eps=float(ln_eps), geglu=int(geglu), out2=_p(out2),
+         ldc2=(out2.stride(-2) if out2 is not None else 0))
     return out
 
 

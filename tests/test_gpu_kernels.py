@@ -168,6 +168,15 @@ def test_igemm_layernorm_fold_and_geglu(mnk, geglu, dtype):
         h = F.linear(x, w2, b2)
         out2 = ops.linear(x.to(dtype).to(DEV), w2.to(dtype).to(DEV), b2.to(DEV), geglu=True)
         check(out2, h[:, :N] * F.gelu(h[:, N:]), dtype, f'geglu {mnk}')
+        # ... keeping the pre-activation (training): h as the plain linear gives it, y from the ROUNDED h
+        hk = torch.full((M, 2 * N + 8), 3.0, dtype=dtype, device=DEV)
+        y2 = ops.linear(x.to(dtype).to(DEV), w2.to(dtype).to(DEV), b2.to(DEV), geglu=True, out2=hk[:, :2 * N])
+        plain = ops.linear(x.to(dtype).to(DEV), w2.to(dtype).to(DEV), b2.to(DEV))
+        assert float((hk[:, :2 * N].float() - plain.float()).abs().max()) <= (0 if dtype == torch.float32 else 2e-2)
+        assert bool((hk[:, 2 * N:] == 3.0).all())
+        hr = hk[:, :2 * N].float().cpu()
+        assert float((y2.float().cpu() - hr[:, :N] * F.gelu(hr[:, N:])).abs().max()) <= \
+            (1e-5 if dtype == torch.float32 else 2e-2 * float(y2.float().abs().max()))
         out3 = ops.linear(x.to(dtype).to(DEV), wp.to(dtype).to(DEV), (w @ beta + b).to(DEV),
                           ln_colsum=wp.sum(1).to(DEV), ln_eps=eps, act='relu', out_dtype=torch.float32)
         check(out3, F.relu(ref), dtype, f'ln-fold relu {mnk}')

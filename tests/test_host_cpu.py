@@ -16,6 +16,20 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, name), name
 
 
+def test_integration_doc_struct_mirror_matches_header():
+    """The hand-written ctypes mirror of SdmiGemmArgs in INTEGRATION.md lists the header's fields in order."""
+    import ctypes
+    import os
+    from slotdiffusion_amd import _lib
+    src = open(os.path.join(os.path.dirname(__file__), '..', 'INTEGRATION.md')).read()
+    i = src.index('class SdmiGemmArgs(ctypes.Structure)')
+    ns = {}
+    exec('import ctypes\n' + src[i:src.index('# (a hand-written mirror', i)], ns)
+    gen, doc = _lib.CSTRUCT['SdmiGemmArgs'], ns['SdmiGemmArgs']
+    assert [f[0] for f in doc._fields_] == [f[0] for f in gen._fields_]
+    assert ctypes.sizeof(doc) == ctypes.sizeof(gen)
+
+
 def test_ops_refuse_cpu_tensors():
     from slotdiffusion_amd import ops
     x = torch.zeros(1, 4, 4, 8)

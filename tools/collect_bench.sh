@@ -1,0 +1,19 @@
+#!/bin/bash
+# Round bench lines on the GPU box (outputs under gpurun_out/bench_<tag>/, copy into profiles/).
+# usage: bash tools/collect_bench.sh r02
+TAG=${1:-r02}
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/bench_$TAG
+mkdir -p $O
+cd $R
+last() { grep '^{' | tail -1; }
+# the two headline lines: full contract (roofline from the replayed trace, CPU baseline)
+timeout 900 python bench.py 2> $O/train.err | last > $O/${TAG}_bench_train.json
+timeout 900 python bench.py --mode sample 2> $O/sample.err | last > $O/${TAG}_bench_sample.json
+# secondary configurations (no CPU baseline leg)
+timeout 600 python bench.py --mode sample --dtype fp8 --no-cpu-baseline 2> $O/sample_fp8.err | last > $O/${TAG}_bench_sample_fp8.json
+timeout 600 python bench.py --config coco224 --mode sample --dtype bf16 --no-cpu-baseline 2> $O/coco_bf16.err | last > $O/${TAG}_bench_coco_bf16.json
+timeout 600 python bench.py --config coco224 --mode sample --dtype fp8 --no-cpu-baseline 2> $O/coco_fp8.err | last > $O/${TAG}_bench_coco_fp8.json
+timeout 600 python bench.py --config coco224 --mode train --no-cpu-baseline 2> $O/coco_train.err | last > $O/${TAG}_bench_coco_train.json
+timeout 600 python tools/bench_video.py 2> $O/video.err | last > $O/${TAG}_bench_video_1gpu.json
+wc -c $O/*.json
