@@ -257,14 +257,18 @@ int sdmi_colsum_group(const SdmiColsumGroupArgs* a, void* stream);
 /* ------------------------------------------------------------------------------------------
  * Multi-head attention, head_dim 32 (UNet self- and slot cross-attention).
  *   out[b][i][h*32+d] = sum_j softmax_j(scale * q_i . k_j) v_j[d]
- * Replaces CrossAttention.forward, unet/attention.py:182-206.
- * q/k/v are [B][S][ld*] with head h at channel offset h*32.  lse (optional): [B][heads][Sq]
+ * Replaces CrossAttention.forward, unet/attention.py:182-206 (and the frozen DINO ViT's
+ * ViTSelfAttention at head_dim 64, dino.py:30-41 through transformers).
+ * q/k/v are [B][S][ld*] with head h at channel offset h*head_dim.  lse (optional): [B][heads][Sq]
  * log-sum-exp saved for the backward kernel.
+ * Sequence lengths: bf16 with head_dim 32 / 64 -- any Skv (keys pass through LDS in chunks; forward,
+ * and for head_dim 32 the backward too); fp32 and head_dim 48 -- Skv <= 400 (K/V whole in LDS), longer
+ * sequences are composed on the host from sdmi_igemm + sdmi_softmax_rows (ops.attention_long).
  * ------------------------------------------------------------------------------------------ */
 typedef struct {
   const void* q; const void* k; const void* v; void* out; float* lse;
   int dtype; int B, heads, Sq, Skv; int ldq, ldk, ldv, ldo; float scale;
-  int head_dim;        /* 0 or 32: UNet; 48: SAVi transformer predictor (predictor.py:20-44) */
+  int head_dim;        /* 0 or 32: UNet; 48: SAVi transformer predictor (predictor.py:20-44); 64: DINO ViT (bf16, forward) */
 } SdmiAttnArgs;
 int sdmi_attention(const SdmiAttnArgs* a, void* stream);
 

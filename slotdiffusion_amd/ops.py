@@ -440,11 +440,10 @@ ATTN_MFMA_MAX_KV = 1 << 20  # ... except the bf16 matrix-core kernels (head_dim 
 
 
 def attention_long(q, k, v, heads, head_dim, keep_p=False):
-    """Multi-head attention for key sequences beyond the LDS-resident kernels (DINO ViT: 785 tokens of
-    head dim 64; the UNet's 28 x 28 self-attention of the 224^2 configs: 784 tokens): per head,
-    batched MFMA GEMMs S = q k^T -> row softmax -> O = P v, with the score matrix in HBM (288 GB make
-    that affordable; a flash-style kernel is the known next step).  q [B,Sq,*], k / v [B,Skv,*] views
-    with head h at channel h * head_dim.  -> out [B,Sq,heads*hd] (, P [heads][B,Sq,Sp] if keep_p)."""
+    """Multi-head attention composed from GEMMs for what the attention kernels do not cover (fp32 parity
+    runs beyond 400 keys; head sizes other than 32 / 64): per head, batched MFMA GEMMs S = q k^T -> row
+    softmax -> O = P v, with the score matrix in HBM.  q [B,Sq,*], k / v [B,Skv,*] views with head h at
+    channel h * head_dim.  -> out [B,Sq,heads*hd] (, P [heads][B,Sq,Sp] if keep_p)."""
     _need_gpu(q, k, v)
     B, Sq, Skv, hd = q.shape[0], q.shape[1], k.shape[1], head_dim
     vec = vec_of(q.dtype)
