@@ -308,7 +308,8 @@ def test_layernorm(C, dtype):
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize('cfg', [(2, 8, 256, 256), (2, 12, 64, 64), (3, 16, 16, 16), (2, 8, 256, 7),
-                                 (2, 16, 16, 15), (2, 5, 784, 784), (1, 3, 200, 1000), (1, 2, 300, 1300)])
+                                 (2, 16, 16, 15), (2, 5, 784, 784), (1, 3, 200, 1000), (1, 2, 300, 1300),
+                                 (1, 2, 33, 512), (1, 2, 65, 513), (1, 1, 5, 1)])
 def test_attention(cfg, dtype):
     ops = _ops()
     B, heads, Sq, Skv = cfg
@@ -329,7 +330,7 @@ def test_attention(cfg, dtype):
     check(out, ref, dtype, f'attention {cfg}')
 
 
-@pytest.mark.parametrize('cfg', [(2, 6, 785, 785), (1, 3, 100, 300), (2, 2, 40, 17)])
+@pytest.mark.parametrize('cfg', [(2, 6, 785, 785), (1, 3, 100, 300), (2, 2, 40, 17), (1, 2, 70, 256), (1, 1, 31, 257)])
 def test_attention_head_dim_64(cfg):
     """bf16 matrix-core attention at the DINO ViT's head size (keys chunked through LDS, 256 at a time)
     against fp32 torch on the bf16-rounded inputs."""

@@ -636,7 +636,8 @@ def test_layernorm_and_gemm_fanout(dtype):
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize('cfg', [(2, 8, 256, 256), (2, 12, 64, 64), (3, 16, 16, 16), (2, 8, 256, 7),
                                  (2, 4, 50, 15), (1, 2, 130, 100), (2, 5, 784, 784), (1, 2, 1000, 600),
-                                 (1, 3, 520, 1024), (2, 6, 784, 7), (1, 2, 1030, 11)])
+                                 (1, 3, 520, 1024), (2, 6, 784, 7), (1, 2, 1030, 11),
+                                 (1, 2, 513, 512), (1, 2, 512, 513), (1, 1, 129, 33)])
 def test_attention_bwd_kernel(cfg, dtype):
     """dq/dk/dv of the attention backward (matrix-core kernels for bf16, VALU kernels for fp32)
     against torch autograd; inputs are quantised to the compute dtype first.  The cases beyond 400
