@@ -265,14 +265,9 @@ extern "C" int sdmi_attention(const SdmiAttnArgs* a, void* stream) {
     // matrix-core kernel, any key count: K and V of one (image, head) pass through LDS in chunks of 512
     // keys x 144 B (head_dim 32; one chunk covers every 128^2 configuration, the 28 x 28 self-attention
     // of the 224^2 configs takes two) or 256 keys x 272 B (head_dim 64): two workgroups per CU either way.
-    static bool big = false;
-    if (!big) {
-      (void)hipFuncSetAttribute((const void*)attn_fwd_mfma_kernel<32, 512>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 512 * (32 * 2 + 16 + ATT_VP));
-      (void)hipFuncSetAttribute((const void*)attn_fwd_mfma_kernel<64, 256>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 256 * (64 * 2 + 16 + 2 * ATT_VP));
-      big = true;
-    }
+    // (per device, return code checked: sdmi_optin_lds)
+    SDMI_OPTIN_LDS((attn_fwd_mfma_kernel<32, 512>), 512 * (32 * 2 + 16 + ATT_VP), "attention (mfma, head dim 32)");
+    SDMI_OPTIN_LDS((attn_fwd_mfma_kernel<64, 256>), 256 * (64 * 2 + 16 + 2 * ATT_VP), "attention (mfma, head dim 64)");
     SDMI_REQUIRE(a->Skv >= 1, "Skv must be positive");
     const int skv_pad = (a->Skv + 31) / 32 * 32;
     dim3 g2((a->Sq + 127) / 128, a->heads, a->B);
@@ -294,13 +289,8 @@ extern "C" int sdmi_attention(const SdmiAttnArgs* a, void* stream) {
   const int smem = 2 * a->Skv * hd * 4;
 #define ATTN_GO(T, HDV)                                                                      \
   do {                                                                                       \
-    static bool done = false;                                                                \
-    if (!done) {                                                                             \
-      (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<T, HDV>,                        \
-                                hipFuncAttributeMaxDynamicSharedMemorySize,                   \
-                                (2 * 512 * HDV * 4 < 160 * 1024 ? 2 * 512 * HDV * 4 : 160 * 1024)); \
-      done = true;                                                                           \
-    }                                                                                        \
+    SDMI_OPTIN_LDS((attn_fwd_kernel<T, HDV>),                                                \
+                   (2 * 512 * HDV * 4 < 160 * 1024 ? 2 * 512 * HDV * 4 : 160 * 1024), "attention"); \
     hipLaunchKernelGGL((attn_fwd_kernel<T, HDV>), grid, dim3(threads), smem, st, *a);        \
   } while (0)
   if (a->dtype == SDMI_BF16) { if (hd == 32) ATTN_GO(bf16_t, 32); else ATTN_GO(bf16_t, 48); }

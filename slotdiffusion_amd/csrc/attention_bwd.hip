@@ -170,13 +170,8 @@ int launch_attn_bwd(const SdmiAttnBwdArgs& a, hipStream_t st) {
   if (threads > 256) threads = 256;
   dim3 grid((a.Sq + threads - 1) / threads, a.heads, a.B);
   const int smem = 2 * a.Skv * HD * 4;
-  static bool done = false;
-  if (!done) {
-    (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<T, HD>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (2 * 512 * HD * 4 < 160 * 1024 ? 2 * 512 * HD * 4 : 160 * 1024));
-    done = true;
-  }
+  SDMI_OPTIN_LDS((attn_bwd_dq_kernel<T, HD>), (2 * 512 * HD * 4 < 160 * 1024 ? 2 * 512 * HD * 4 : 160 * 1024),
+                 "attention_bwd");
   hipLaunchKernelGGL((attn_bwd_dq_kernel<T, HD>), grid, dim3(threads), smem, st, a);
   if (a.Skv <= 16 && HD == 32) {
     hipLaunchKernelGGL((attn_bwd_dkv_small_kernel<T, HD>), dim3(a.heads, a.B), dim3(a.Skv * HD), 0,
@@ -448,12 +443,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(SdmiAttnBwdArgs p, i
 }
 
 int launch_attn_bwd_mfma(const SdmiAttnBwdArgs& a, hipStream_t st) {
-  static bool done = false;
-  if (!done) {
-    (void)hipFuncSetAttribute((const void*)attn_bwd_mfma_kernel,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    done = true;
-  }
+  SDMI_OPTIN_LDS(attn_bwd_mfma_kernel, 160 * 1024, "attention_bwd (mfma)");
   int skv_pad = (a.Skv + 31) / 32 * 32, sq_pad = (a.Sq + 31) / 32 * 32;
   if (skv_pad > ATB_CHUNK) skv_pad = ATB_CHUNK;
   const int qmax = a.Skv <= 32 ? 128 : ATB_CHUNK;

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include "../../include/sdmi.h"
 
 typedef unsigned short bf16_t;  // raw bf16 bits
@@ -13,6 +14,14 @@ typedef __attribute__((address_space(3))) void lds_void;   // LDS destination of
 
 void sdmi_set_error(const char* fmt, ...);
 int sdmi_check_launch(const char* what);
+// dynamic-LDS opt-in, once per (call site, device): `static std::atomic<unsigned long long> done{0};`
+int sdmi_optin_lds(std::atomic<unsigned long long>& done, const void* fn, int bytes, const char* what);
+#define SDMI_OPTIN_LDS(fn, bytes, what)                                                  \
+  do {                                                                                   \
+    static std::atomic<unsigned long long> sdmi_lds_done_{0};                            \
+    const int sdmi_lds_rc_ = sdmi_optin_lds(sdmi_lds_done_, (const void*)(fn), (bytes), (what)); \
+    if (sdmi_lds_rc_) return sdmi_lds_rc_;                                               \
+  } while (0)
 
 #define SDMI_REQUIRE(cond, msg)                       \
   do {                                                \

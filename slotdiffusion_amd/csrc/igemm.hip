@@ -1108,18 +1108,10 @@ int launch_cfg(const SdmiGemmArgs& p, int split_k, int hw_shift, hipStream_t st)
   constexpr int BK = BKB / sizeof(T);
   constexpr int smem = 2 * (BM + BN) * (BKB + 16);
   constexpr int BN_OUT = (EPI & 2) ? BN / 2 : BN;          // GEGLU: value + gate rows per output column
-  static bool attr_done = false;
   void (*kern)(SdmiGemmArgs, int, int, int, int);
   if constexpr (BM > 128) kern = igemm_kernel_tall<T, BM, BN, BKB, MODE>;
   else kern = igemm_kernel<T, BM, BN, BKB, MODE, EPI, XS>;
-  if (!attr_done) {
-    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem) !=
-        hipSuccess) {
-      sdmi_set_error("igemm: hipFuncSetAttribute failed");
-      return SDMI_ELAUNCH;
-    }
-    attr_done = true;
-  }
+  SDMI_OPTIN_LDS(kern, smem, "igemm");
   SdmiGemmArgs q = p;
   q.split_k = split_k;
   const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN_OUT - 1) / BN_OUT;
@@ -1164,16 +1156,8 @@ int launch_dma(const SdmiGemmArgs& p, int hw_shift, hipStream_t st) {
   constexpr int BK = 128 / sizeof(T);
   constexpr int smem = NSTAGE * (BM + BN) * 128;
   constexpr int threads = 512;
-  static bool attr_done = false;
   auto kern = igemm_dma_kernel<T, BM, BN, NSTAGE, MODE>;
-  if (!attr_done) {
-    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem) !=
-        hipSuccess) {
-      sdmi_set_error("igemm: hipFuncSetAttribute failed");
-      return SDMI_ELAUNCH;
-    }
-    attr_done = true;
-  }
+  SDMI_OPTIN_LDS(kern, smem, "igemm (lds-dma)");
   SdmiGemmArgs q = p;
   q.split_k = 1;
   const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
@@ -1251,15 +1235,7 @@ int dispatch(const SdmiGemmArgs& p, hipStream_t st) {
       p.out_dtype == SDMI_BF16 && p.ldc % 8 == 0 && p.N % 8 == 0 && !p.bias_m &&
       (!p.residual || p.ldr % 8 == 0) &&
       (long long)p.B * (p.H / 4) * (p.W / 64) >= 2 * device_cus()) {
-    static bool attr_done = false;
-    if (!attr_done) {
-      if (hipFuncSetAttribute((const void*)conv3x3_c64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              D33_SMEM) != hipSuccess) {
-        sdmi_set_error("igemm: hipFuncSetAttribute failed");
-        return SDMI_ELAUNCH;
-      }
-      attr_done = true;
-    }
+    SDMI_OPTIN_LDS(conv3x3_c64_kernel, D33_SMEM, "igemm (direct 3x3 c64)");
     SdmiGemmArgs q = p;
     q.split_k = 1;
     int grid = device_cus();

@@ -457,12 +457,7 @@ extern "C" int sdmi_groupnorm(const SdmiGroupNormArgs* a, void* stream) {
       const size_t smem = ((size_t)RR * cvp * vec * 2 + 2 * 128) * sizeof(float);
 #define GN_GO3(T_, TH, NV_, F8_)                                                                   \
   do {                                                                                             \
-    static bool attr = false;                                                                      \
-    if (!attr) {                                                                                   \
-      (void)hipFuncSetAttribute((const void*)gn_fused_kernel<T_, TH, NV_, F8_>,                    \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);            \
-      attr = true;                                                                                 \
-    }                                                                                              \
+    SDMI_OPTIN_LDS((gn_fused_kernel<T_, TH, NV_, F8_>), 80 * 1024, "groupnorm");                   \
     hipLaunchKernelGGL((gn_fused_kernel<T_, TH, NV_, F8_>), grid, dim3(TH), smem, st, *a);         \
   } while (0)
 #define GN_GO2(T_, TH, NV_) GN_GO3(T_, TH, NV_, false)

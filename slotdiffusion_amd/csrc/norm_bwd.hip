@@ -582,12 +582,7 @@ extern "C" int sdmi_groupnorm_bwd(const SdmiGroupNormBwdArgs* a, void* stream) {
       const size_t smem = ((size_t)RR * cvp * vec * 2 + 2 * 256) * sizeof(float);
 #define GNB_GO(T_, TH, NV_)                                                                        \
   do {                                                                                             \
-    static bool attr = false;                                                                      \
-    if (!attr) {                                                                                   \
-      (void)hipFuncSetAttribute((const void*)gn_bwd_fused_kernel<T_, TH, NV_>,                     \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);            \
-      attr = true;                                                                                 \
-    }                                                                                              \
+    SDMI_OPTIN_LDS((gn_bwd_fused_kernel<T_, TH, NV_>), 80 * 1024, "groupnorm_bwd");                \
     hipLaunchKernelGGL((gn_bwd_fused_kernel<T_, TH, NV_>), gf, dim3(TH), smem, st, *a);            \
   } while (0)
 #define GNB_PICK(T_, TH)                                                                           \

@@ -208,15 +208,7 @@ template <typename T, int NMAX, int DPL>
 int launch_sa(const SdmiSlotAttnArgs& a, hipStream_t st) {
   const int smem = (4 * NMAX * a.D + 16 + 2 * NMAX * 3 * a.D + NMAX * a.Hid) * 4;
   auto kern = slot_attn_kernel<T, NMAX, DPL>;
-  static bool done = false;
-  if (!done) {
-    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            160 * 1024) != hipSuccess) {
-      sdmi_set_error("slot_attention: hipFuncSetAttribute failed");
-      return SDMI_ELAUNCH;
-    }
-    done = true;
-  }
+  SDMI_OPTIN_LDS(kern, 160 * 1024, "slot_attention");
   if (smem > 160 * 1024) {
     sdmi_set_error("slot_attention: LDS budget exceeded (%d B)", smem);
     return SDMI_EUNSUPPORTED;

@@ -522,12 +522,7 @@ int sat_launch_fwd(const SdmiSaAttendArgs& a, hipStream_t st) {
   constexpr int TM = SatCfg<T>::TM;
   const int tiles = (a.M + TM - 1) / TM;
   const int smem = 2 * TM * (a.D * (int)sizeof(T) + 16) + (NP * a.D + TM * NP) * 4;
-  static bool done = false;
-  if (!done) {
-    (void)hipFuncSetAttribute((const void*)sat_fwd_kernel<T, NP>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    done = true;
-  }
+  SDMI_OPTIN_LDS((sat_fwd_kernel<T, NP>), 160 * 1024, "sa_attend_fwd");
   hipLaunchKernelGGL((sat_fwd_kernel<T, NP>), dim3(tiles, a.B), dim3(256), smem, st, a, tiles);
   hipLaunchKernelGGL(sat_fwd_finalize_kernel, dim3(a.B), dim3(256), 0, st, a, tiles);
   return sdmi_check_launch("sa_attend_fwd (tiled)");
@@ -541,12 +536,7 @@ int sat_launch_bwd(const SdmiSaAttendBwdArgs& a, hipStream_t st) {
   const int cw = (NP == 16 && VEC == 8) ? 4 : VEC;
   const int red = (256 / (a.D / cw)) * NP * a.D * 4;
   if (red > smem) smem = red;
-  static bool done = false;
-  if (!done) {
-    (void)hipFuncSetAttribute((const void*)sat_bwd_kernel<T, NP>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    done = true;
-  }
+  SDMI_OPTIN_LDS((sat_bwd_kernel<T, NP>), 160 * 1024, "sa_attend_bwd");
   hipLaunchKernelGGL((sat_bwd_kernel<T, NP>), dim3(tiles, a.B), dim3(256), smem, st, a, tiles);
   hipLaunchKernelGGL(sat_bwd_finalize_kernel, dim3(a.B), dim3(256), 0, st, a, tiles);
   return sdmi_check_launch("sa_attend_bwd (tiled)");

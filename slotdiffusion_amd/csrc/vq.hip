@@ -77,12 +77,7 @@ extern "C" int sdmi_vq_nearest(const SdmiVqArgs* a, void* stream) {
   SDMI_REQUIRE(a && a->z && a->codebook && (a->idx || a->zq), "null pointer");
   SDMI_REQUIRE(a->dim == 3, "embed_dim must be 3 (every LDM config)");
   SDMI_REQUIRE(a->ldz >= 3 && a->n_codes >= 1 && a->n_codes * 16 <= 160 * 1024, "bad shape");
-  static bool done = false;
-  if (!done) {
-    (void)hipFuncSetAttribute((const void*)vq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              160 * 1024);
-    done = true;
-  }
+  SDMI_OPTIN_LDS(vq_kernel, 160 * 1024, "vq_nearest");
   hipLaunchKernelGGL(vq_kernel, dim3((a->R + 127) / 128), dim3(256), a->n_codes * 16,
                      (hipStream_t)stream, *a);
   return sdmi_check_launch("vq_nearest");

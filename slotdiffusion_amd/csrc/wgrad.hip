@@ -722,15 +722,7 @@ int launch_wgrad(const SdmiWgradArgs& a, hipStream_t st) {
   constexpr int MTB = WCfg<T>::MTB;
   constexpr int smem = 2 * (TN + TK) * (MTB + 16);
   auto kern = wgrad_kernel<T, TN, TK, IS1X1>;
-  static bool done = false;
-  if (!done) {
-    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem) !=
-        hipSuccess) {
-      sdmi_set_error("wgrad: hipFuncSetAttribute failed");
-      return SDMI_ELAUNCH;
-    }
-    done = true;
-  }
+  SDMI_OPTIN_LDS(kern, smem, "wgrad");
   const int tiles_n = (a.N + TN - 1) / TN, tiles_k = (a.K + TK - 1) / TK;
   const int MT = MTB / (int)sizeof(T);
   int mps = (a.M + a.splits - 1) / a.splits;
@@ -745,15 +737,7 @@ int launch_wgrad_tr(const SdmiWgradArgs& a, hipStream_t st) {
   constexpr int MT = 64;
   constexpr int smem = 2 * MT * (TN * 2 + 64 + TK * 2 + 64);
   auto kern = wgrad_tr_kernel<TN, TK, MODE>;
-  static bool done = false;
-  if (!done) {
-    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem) !=
-        hipSuccess) {
-      sdmi_set_error("wgrad: hipFuncSetAttribute failed");
-      return SDMI_ELAUNCH;
-    }
-    done = true;
-  }
+  SDMI_OPTIN_LDS(kern, smem, "wgrad");
   const int tiles_n = (a.N + TN - 1) / TN, tiles_k = (a.K + TK - 1) / TK;
   int mps = (a.M + a.splits - 1) / a.splits;
   mps = (mps + MT - 1) / MT * MT;
@@ -831,15 +815,7 @@ extern "C" int sdmi_wgrad_group(const SdmiWgradGroupArgs* ga, void* stream) {
   }
   for (int i = ga->n; i <= WG_MAX; ++i) { g.item_begin[i] = items; g.red_begin[i] = red; }
   constexpr int smem = 2 * 64 * (128 * 2 + 64 + 128 * 2 + 64);
-  static bool done = false;
-  if (!done) {
-    if (hipFuncSetAttribute((const void*)wgrad_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            smem) != hipSuccess) {
-      sdmi_set_error("wgrad group: hipFuncSetAttribute failed");
-      return SDMI_ELAUNCH;
-    }
-    done = true;
-  }
+  SDMI_OPTIN_LDS(wgrad_group_kernel, smem, "wgrad group");
   hipLaunchKernelGGL(wgrad_group_kernel, dim3(items), dim3(512), smem, st, g);
   int rc = sdmi_check_launch("wgrad group");
   if (rc || red == 0) return rc;

@@ -49,6 +49,8 @@ class Method:
                  use_fp16=False):
         self.model, self.datamodule, self.params = model, datamodule, params
         self.ckp_path, self.local_rank, self.use_ddp = ckp_path, local_rank, use_ddp
+        from . import configure_runtime
+        configure_runtime(warn=False)     # effective when the method is built before the first device call
         if use_fp16:                      # the reference's --fp16 switch = our bf16 compute path
             model.set_compute_dtype('bf16')
         self.world = torch.distributed.get_world_size() if use_ddp else 1
@@ -69,8 +71,14 @@ class Method:
         total = p.max_epochs * len(self.datamodule)
         clip = self._get('clip_grad', 0) or 0
         clip = clip if clip > 0 else 0.0
+        # schedule floor: the diffusion methods anneal to 0 (img_based/method.py:277-283,
+        # video_based/method.py:186-194 / 331-339); SA / SAVi / VQ-VAE stage 1 run on the base
+        # method's schedule, min_lr = lr / 100 (img_based/method.py:69-85, video_based/method.py:86-96)
+        from .models import SADiffusion, SAViDiffusion
+        diffusion = isinstance(self.model, (SADiffusion, SAViDiffusion))
         return FusedAdam(self.model, lr=p.lr, dec_lr=self._get('dec_lr', p.lr), clip_grad=clip,
-                         total_steps=total, warmup_pct=p.warmup_steps_pct)
+                         total_steps=total, warmup_pct=p.warmup_steps_pct,
+                         min_lr_ratio=(0.0 if diffusion else 0.01))
 
     def _loss(self, batch):
         out = self.model(batch)
@@ -103,8 +111,14 @@ class Method:
             self._restore_training_state(ckp)
         graphed = None
         steps_per_epoch = len(self.datamodule)
-        for epoch in range(self.it // max(1, steps_per_epoch), self.params.max_epochs):
-            for batch in self.datamodule.train_loader(epoch):
+        first_epoch = self.it // max(1, steps_per_epoch)
+        # a mid-epoch checkpoint resumes BEHIND the batches it already consumed: the run then sees the
+        # same batch sequence, and executes exactly max_epochs * steps_per_epoch steps in total
+        skip = self.it - first_epoch * steps_per_epoch
+        for epoch in range(first_epoch, self.params.max_epochs):
+            for bi, batch in enumerate(self.datamodule.train_loader(epoch)):
+                if epoch == first_epoch and bi < skip:
+                    continue
                 if max_steps is not None and self.it >= max_steps:
                     return self
                 if self.use_graph and graphed is None and len(self._loss_names()) == 1:

@@ -177,12 +177,25 @@ class LDM(_Owned):
         t = torch.empty((B,), dtype=torch.int64, device=device)
         tf, ca, cb = (torch.empty((B,), dtype=torch.float32, device=device) for _ in range(3))
         nz = torch.empty((B, hw, 4), dtype=torch.float32, device=device)
-        seed_dev = getattr(r, 'step_seed', None)
-        kern.call('sdmi_draw_tn', torch.cuda.current_stream().cuda_stream, t=t.data_ptr(),
+        st = torch.cuda.current_stream().cuda_stream
+        salt = 17
+        if r.training and torch.is_grad_enabled():
+            # training forward: `_begin_train_forward` advanced the step's seed word already
+            seed_dev = getattr(r, 'step_seed', None)
+        else:
+            # validation / no_grad calls (calc_eval_loss): the reference draws fresh randint / randn for
+            # every batch (ldm.py:65-69), so these calls advance a seed word of their own -- every call
+            # sees new timesteps and noise, and the training stream is left untouched
+            seed_dev = getattr(r, 'eval_seed', None)
+            if seed_dev is None or seed_dev.device != device:
+                seed_dev = r.eval_seed = torch.zeros(1, dtype=torch.int64, device=device)
+            kern.call('sdmi_counters_inc', st, seed=seed_dev.data_ptr())
+            salt = 6151
+        kern.call('sdmi_draw_tn', st, t=t.data_ptr(),
                   tf=tf.data_ptr(), ca=ca.data_ptr(), cb=cb.data_ptr(), noise=nz.data_ptr(),
                   tab_a=self.sqrt_alphas_bar.data_ptr(), tab_b=self.sqrt_one_minus_alphas_bar.data_ptr(),
                   B=B, T=self.num_timesteps, per=hw * 4,
-                  seed=(int(getattr(r, 'seed', 0)) * 7919 + int(os.environ.get('RANK', 0)) * 104729 + 17),
+                  seed=(int(getattr(r, 'seed', 0)) * 7919 + int(os.environ.get('RANK', 0)) * 104729 + salt),
                   seed_dev=(seed_dev.data_ptr() if seed_dev is not None else 0))
         return t, tf, ca, cb, nz.view(B, h, w, 4)
 
@@ -349,6 +362,7 @@ class SADiffusion(SlotModelBase):
         self._plan = None
         self._Kinf = self._Kgrad = None
         self.step_seed = None      # device word mixed into dropout seeds (see optim.GraphedTrainStep)
+        self.eval_seed = None      # its no_grad / validation counterpart (LDM._draw_tn)
         self.use_graph = os.environ.get('SDMI_GRAPH', '1') != '0'
         self._graph_cache = {}
 
@@ -694,6 +708,7 @@ class SA(SlotModelBase):
         self.testing = False
         self.compute_dtype = compute_dtype or default_compute_dtype()
         self.step_seed = None
+        self.eval_seed = None
         self._graph_cache = {}
 
     def _make_spec(self, resolution, slot_dict, enc_dict, dec_dict):

@@ -20,10 +20,14 @@ def _p(t):
 
 class FusedAdam:
     def __init__(self, model, lr=1e-4, dec_lr=None, clip_grad=1.0, betas=(0.9, 0.999), eps=1e-8,
-                 total_steps=None, warmup_pct=0.05):
+                 total_steps=None, warmup_pct=0.05, min_lr_ratio=0.0):
         self.model = model
         self.lr, self.dec_lr = lr, (dec_lr if dec_lr is not None else lr)
         self.clip = clip_grad
+        # floor of the schedule as a fraction of each group's max lr: 0 for the diffusion models
+        # (img_based/method.py:277-283, video_based/method.py:186-194, 331-339), 1/100 for the base
+        # method SA / SAVi / VQ-VAE stage 1 train with (img_based/method.py:69-85, video_based/method.py:86-96)
+        self.min_lr_ratio = float(min_lr_ratio)
         self.b1, self.b2, self.eps = betas[0], betas[1], eps
         self.split, self.n_train, _ = model.arena_ranges()
         dev = model.arena().device
@@ -44,17 +48,20 @@ class FusedAdam:
                                                        if total_steps else 0.0)
 
     def lr_scale(self, done):
-        """CosineAnnealingWarmupRestarts(first_cycle_steps=total, min_lr=0, single cycle) factor for
-        the optimiser step that follows `done` completed steps -- the scheduler is stepped after the
-        optimiser, so the first update runs at min_lr = 0 and update k at (k-1)/warmup (nerv's
-        scheduler, recalled: not under /root/reference)."""
+        """CosineAnnealingWarmupRestarts(first_cycle_steps=total, min_lr = min_lr_ratio * max_lr, single
+        cycle) factor for the optimiser step that follows `done` completed steps -- the scheduler is
+        stepped after the optimiser, so the first update runs at min_lr and update k at
+        min + (max - min) (k-1)/warmup (nerv's scheduler, recalled: not under /root/reference, see
+        DESIGN section 2)."""
         if not self.total_steps:
             return 1.0
         if done < self.warmup:
-            return done / self.warmup
-        span = self.total_steps - self.warmup
-        prog = (done - self.warmup) / span if span > 0 else 1.0
-        return 0.5 * (1. + math.cos(math.pi * min(1.0, prog)))
+            f = done / self.warmup
+        else:
+            span = self.total_steps - self.warmup
+            prog = (done - self.warmup) / span if span > 0 else 1.0
+            f = 0.5 * (1. + math.cos(math.pi * min(1.0, prog)))
+        return self.min_lr_ratio + (1.0 - self.min_lr_ratio) * f
 
     def zero_grad(self):
         g = self.model.grad_arena()
@@ -66,9 +73,15 @@ class FusedAdam:
     def state_dict(self):
         """Everything a resumed run needs: moments, step (bias correction + schedule position)."""
         return {'m': self.m.detach().cpu(), 'v': self.v.detach().cpu(), 'step_count': self.step_count,
-                'total_steps': self.total_steps, 'warmup': self.warmup}
+                'total_steps': self.total_steps, 'warmup': self.warmup, 'min_lr_ratio': self.min_lr_ratio}
 
     def load_state_dict(self, sd):
+        # a resumed run continues the SAME schedule: a different length / warm-up / floor is a
+        # configuration error, not something to paper over
+        for k, mine in (('total_steps', self.total_steps), ('warmup', self.warmup),
+                        ('min_lr_ratio', self.min_lr_ratio)):
+            if k in sd and sd[k] is not None and mine is not None and abs(float(sd[k]) - float(mine)) > 1e-9:
+                raise ValueError(f'optimizer checkpoint was written with {k}={sd[k]}, this run has {mine}')
         self.m.copy_(sd['m'])
         self.v.copy_(sd['v'])
         self.step_count = int(sd['step_count'])
@@ -128,9 +141,10 @@ CAPTURE_MODE = 'thread_local'
 
 class GraphedTrainStep:
     """zero-grad -> forward -> loss -> backward -> clip+Adam captured once into HIP graphs and
-    replayed per step (about 2.2k kernel launches per replay instead of 2.2k host launches).
-    RNG (t, noise) comes from torch's graph-safe Philox generator, dropout masks from the device
-    word `model.step_seed`, Adam's step / lr from device scalars -- nothing host-side is baked in.
+    replayed per step (about 1.5k kernel launches per replay instead of as many host launches).
+    The draws of a step -- t, noise (`sdmi_draw_tn`) and the dropout masks -- come from the library's
+    counter-based generator keyed on the device word `model.step_seed`, which the captured forward
+    advances itself; Adam's step / lr are device scalars -- nothing host-side is baked in.
 
     world == 1: one graph for forward + backward, one for the update.
     world  > 1 (`allreduce` given): the backward is split at the slots -- graph A = forward + loss +
@@ -143,6 +157,8 @@ class GraphedTrainStep:
                  loss_weight=1.0, world=None):
         self.model, self.opt, self.allreduce = model, opt, allreduce
         self.loss_key, self.loss_weight = loss_key, loss_weight
+        from . import configure_runtime
+        configure_runtime(warn=False)      # (normally too late here: the entry points call it first)
         self.static = {k: v.clone() for k, v in example_batch.items()}
         dev = model.arena().device
         if getattr(model, 'step_seed', None) is None or model.step_seed.device != dev:

@@ -221,6 +221,28 @@ def test_eager_steps_draw_new_dropout_masks():
         del os.environ['RANK']
 
 
+def test_eval_loss_draws_fresh_timesteps_and_noise():
+    """calc_eval_loss (no_grad / eval mode) draws t and noise like the reference does for every batch
+    (ldm.py:65-69): consecutive validation calls see different timesteps / noise, before and after
+    training steps, and they do not advance the training stream's seed word."""
+    img = C.make_inputs(2)[0].cuda()
+    m = _model(torch.float32)
+    m.eval()
+    ldm = m.dm_decoder
+    with torch.no_grad():
+        d1 = ldm._draw_tn(64, 32, 32, img.device)
+        d2 = ldm._draw_tn(64, 32, 32, img.device)
+        assert not torch.equal(d1[0], d2[0]) and not torch.equal(d1[4], d2[4])
+        assert int(d1[0].min()) >= 0 and int(d1[0].max()) < 1000
+        assert torch.equal(d1[2], ldm.sqrt_alphas_bar[d1[0]])
+        out = m(dict(img=img))
+        l1 = float(m.calc_eval_loss(dict(img=img), out)['denoise_loss'])
+        l2 = float(m.calc_eval_loss(dict(img=img), out)['denoise_loss'])
+    assert l1 != l2
+    assert m.step_seed is None or int(m.step_seed) == 0
+    assert int(m.eval_seed) == 4
+
+
 def test_checkpoint_resume_continues_the_trajectory(tmp_path):
     """Method.save / fit(resume_from): weights, Adam moments, step (bias correction + schedule
     position), iteration and the dropout seed word are restored -- 3 steps + save + 2 steps equals
@@ -261,6 +283,39 @@ def test_checkpoint_resume_continues_the_trajectory(tmp_path):
                 meth._eager_step(batch)
         assert torch.equal(b.model.arena(), a.model.arena())
         assert a.optimizer.lr_scale(a.optimizer.step_count) == b.optimizer.lr_scale(b.optimizer.step_count)
+    finally:
+        del os.environ['SDMI_GRAPH']
+
+
+def test_mid_epoch_resume_skips_consumed_batches(tmp_path):
+    """A checkpoint written in the middle of an epoch resumes behind the batches it consumed: 3 steps +
+    save + resume for 2 steps equals 5 uninterrupted steps bit for bit, and the run executes exactly
+    max_epochs * steps_per_epoch steps (eager steps)."""
+    from slotdiffusion_amd import img_based as task
+    os.environ['SDMI_GRAPH'] = '0'
+    try:
+        def make():
+            P = C.make_params('SADiffusion')
+            P.max_epochs = 1
+            model = task.build_model(P)
+            det_fill_(model.state_dict().items(), skip=is_buffer_name)
+            model = model.cuda()
+            model.set_compute_dtype('fp32')
+            dm = task.build_dataset(P)
+            dm.steps_per_epoch = 5
+            return task.build_method(model=model, datamodule=dm, params=P, ckp_path=None,
+                                     local_rank=0, use_ddp=False, use_fp16=False)
+        a = make()
+        a.fit(max_steps=3)
+        path = str(tmp_path / 'mid.pth')
+        a.save(path)
+        b = make()
+        b.fit(resume_from=path)                    # runs to the end of the (only) epoch
+        c = make()
+        c.fit()
+        assert b.it == 5 and c.it == 5 and b.optimizer.step_count == 5
+        assert [float(x) for x in b.history] == [float(x) for x in c.history[3:]]
+        assert torch.equal(b.model.arena(), c.model.arena())
     finally:
         del os.environ['SDMI_GRAPH']
 

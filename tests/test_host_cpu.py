@@ -185,3 +185,62 @@ def test_lr_schedule_closed_form():
     assert abs(opt.lr_dev[0].item() - 1e-4) < 1e-10 and abs(opt.lr_dev[1].item() - 2e-4) < 1e-10
     # no schedule configured: constant factor
     assert FusedAdam(Fake(), lr=1.0).lr_scale(123) == 1.0
+    # base-method floor (img_based/method.py:69-85: min_lr = lr / 100 for SA / SAVi / VQ-VAE stage 1):
+    # update 1 runs at lr/100, the warm-up rises linearly from it, the cosine decays back to it
+    opt3 = FusedAdam(Fake(), lr=4e-4, total_steps=total, warmup_pct=pct, min_lr_ratio=0.01)
+    assert abs(opt3.lr_scale(0) - 0.01) < 1e-15
+    assert abs(opt3.lr_scale(int(w) - 1) - (0.01 + 0.99 * (w - 1) / w)) < 1e-12
+    assert abs(opt3.lr_scale(int(w)) - 1.0) < 1e-12
+    assert abs(opt3.lr_scale(mid) - (0.01 + 0.99 * ref)) < 1e-12
+    assert abs(opt3.lr_scale(total) - 0.01) < 1e-12
+    opt3.set_lr_for_next_step()
+    assert abs(opt3.lr_dev[0].item() - 4e-6) < 1e-12
+    # a resumed optimiser must continue the same schedule
+    sd = opt3.state_dict()
+    assert sd['min_lr_ratio'] == 0.01
+    with pytest.raises(ValueError):
+        FusedAdam(Fake(), lr=4e-4, total_steps=total + 1, warmup_pct=pct, min_lr_ratio=0.01).load_state_dict(sd)
+    with pytest.raises(ValueError):
+        opt.load_state_dict(sd)             # floor 0 vs 0.01
+
+
+def test_method_schedule_floor_follows_the_reference_method():
+    """Method._configure_optimizers: SADiffusion anneals to 0 (img_based/method.py:277-283), SA / VQ-VAE
+    stage 1 run on the base method's schedule with min_lr = lr / 100 (img_based/method.py:69-85)."""
+    from tests import common as C
+    from slotdiffusion_amd import method as M
+
+    class FakeModel:
+        def arena_ranges(self):
+            return 8, 16, 16
+
+        def arena(self):
+            return torch.zeros(16)
+
+    class DM:
+        def __len__(self):
+            return 10
+    import slotdiffusion_amd.models as models
+    for name, floor in (('SADiffusion', 0.0), ('SA', 0.01), ('VQVAE', 0.01)):
+        P = C.make_params(name)
+        fm = FakeModel()
+        fm.__class__ = type('Fake' + name, (FakeModel, getattr(models, name)), {})   # isinstance dispatch only
+        meth = M.Method.__new__(M.Method)
+        meth.model, meth.datamodule, meth.params = fm, DM(), P
+        opt = meth._configure_optimizers()
+        assert opt.min_lr_ratio == floor, name
+        assert abs(opt.lr_scale(0) - floor) < 1e-15
+
+
+def test_runtime_knob_is_set_by_entry_points_not_by_import(monkeypatch):
+    """Importing the package leaves the process environment alone; configure_runtime() (bench.py,
+    Method, GraphedTrainStep) applies the HIP-graph queue pool setting unless the user exported one."""
+    import importlib
+    import os
+    import slotdiffusion_amd
+    monkeypatch.delenv('DEBUG_HIP_FORCE_GRAPH_QUEUES', raising=False)
+    importlib.reload(slotdiffusion_amd)
+    assert 'DEBUG_HIP_FORCE_GRAPH_QUEUES' not in os.environ
+    assert slotdiffusion_amd.configure_runtime() == '2'
+    monkeypatch.setenv('DEBUG_HIP_FORCE_GRAPH_QUEUES', '4')
+    assert slotdiffusion_amd.configure_runtime() == '4'
