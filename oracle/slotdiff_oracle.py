@@ -717,11 +717,15 @@ def clip_and_adam(params, grads, m, v, step, lrs, clip, b1=0.9, b2=0.999, eps=1e
 # metrics used by the acceptance checks
 # ---------------------------------------------------------------------------
 def ema_update(shadow, params, num_updates, decay=0.9999):
-    """LitEma.forward (ddpm/ema.py:29-52): returns the new num_updates; shadows updated in place."""
+    """LitEma.forward (ddpm/ema.py:29-52): returns the new num_updates; shadows updated in place.
+    The reference keeps `decay` as a float32 buffer and `num_updates` as an int tensor, so the warm-up
+    ratio and 1 - decay are float32 values; restated the same way (pinned by tests/golden/ema_lit.npz)."""
+    d = torch.tensor(decay, dtype=torch.float32)
     if num_updates >= 0:
         num_updates += 1
-        decay = min(decay, (1 + num_updates) / (10 + num_updates))
-    omd = 1.0 - decay
+        n = torch.tensor(num_updates, dtype=torch.int32)
+        d = torch.minimum(d, (1 + n) / (10 + n))
+    omd = 1.0 - d
     for s, p in zip(shadow, params):
         s.sub_(omd * (s - p))
     return num_updates

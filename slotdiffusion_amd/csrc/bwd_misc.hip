@@ -290,10 +290,14 @@ __global__ __launch_bounds__(256) void sqsum_kernel(SdmiSqSumArgs p) {
 }
 
 __global__ __launch_bounds__(256) void ema_kernel(SdmiEmaArgs p) {
+  // the reference's three roundings (ema.py:48-50: sub, mul, sub_): no fused multiply-add here
+#pragma clang fp contract(off)
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < p.n;
        i += (long long)gridDim.x * 256) {
     const float s = p.shadow[i];
-    p.shadow[i] = s - p.one_minus_decay * (s - p.p[i]);
+    const float d = s - p.p[i];
+    const float u = p.one_minus_decay * d;
+    p.shadow[i] = s - u;
   }
 }
 

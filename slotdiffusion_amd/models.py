@@ -121,14 +121,17 @@ class LDM(_Owned):
     def _training_step_end(self, *a, **k):
         if not self.use_ema:
             return
-        decay = self.ema_decay
+        # float32 arithmetic like the reference's buffers (ema.py:29-38: `decay` is a float32 tensor,
+        # `num_updates` an int tensor), so 1 - decay is the same float32 value
+        import numpy as np
+        decay = np.float32(self.ema_decay)
         if self.ema_num_updates >= 0:
             self.ema_num_updates += 1
-            decay = min(decay, (1 + self.ema_num_updates) / (10 + self.ema_num_updates))
+            decay = min(decay, np.float32(1 + self.ema_num_updates) / np.float32(10 + self.ema_num_updates))
         lo, hi = self._ema_range()
         kern.call('sdmi_ema_update', torch.cuda.current_stream().cuda_stream,
                   shadow=self._ema_shadow.data_ptr(), p=self.root.arena()[lo:hi].data_ptr(),
-                  n=hi - lo, one_minus_decay=1.0 - decay)
+                  n=hi - lo, one_minus_decay=float(np.float32(1.0) - decay))
 
     # -- a7/a8 ---------------------------------------------------------------------------
     def loss_function(self, data_dict, t=None, noise=None):

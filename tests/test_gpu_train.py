@@ -889,6 +889,36 @@ def test_ema_hook_matches_reference_formula():
     assert torch.equal(m.arena(), before)
 
 
+def test_ema_kernel_matches_reference_litema_fixture():
+    """Row a18 against the reference itself: sdmi_ema_update with the host-side decay arithmetic of
+    LDM._training_step_end on the parameter sequence of tests/golden/ema_lit.npz (the reference's
+    LitEma run, tools/gen_golden.py ema): shadows after each of 4 updates, with the num_updates
+    warm-up and with a fixed decay."""
+    import numpy as np
+    from slotdiffusion_amd import _lib
+    G = C.load_golden('ema_lit.npz')
+    st = torch.cuda.current_stream().cuda_stream
+    worst, exact = 0.0, True
+    for tag, decay, n in (('warm', 0.9999, 0), ('flat', 0.95, -1)):
+        shadow = torch.cat([G['init_a'].flatten(), G['init_w'].flatten()]).cuda()
+        for it in range(4):
+            p = torch.cat([G[f'{tag}_p_a_{it}'].flatten(), G[f'{tag}_p_w_{it}'].flatten()]).cuda()
+            d = np.float32(decay)
+            if n >= 0:
+                n += 1
+                d = min(d, np.float32(1 + n) / np.float32(10 + n))
+            _lib.call('sdmi_ema_update', st, shadow=shadow.data_ptr(), p=p.data_ptr(), n=shadow.numel(),
+                      one_minus_decay=float(np.float32(1.0) - d))
+            ref = torch.cat([G[f'{tag}_s_a_{it}'].flatten(), G[f'{tag}_s_w_{it}'].flatten()])
+            worst = max(worst, float((shadow.cpu() - ref).abs().max()))
+            exact = exact and torch.equal(shadow.cpu(), ref)
+        assert n == int(G[f'{tag}_num_updates'])
+    REPORT['ema_vs_litema_maxerr'] = worst
+    REPORT['ema_vs_litema_bit_exact'] = bool(exact)
+    _dump()
+    assert worst <= 2.4e-7, worst
+
+
 @pytest.mark.parametrize('name', ['SADiffusion', 'SA', 'VQVAE'])
 def test_method_fit_through_the_registry(name):
     """build_model -> build_dataset -> build_method -> fit(): the plugin path of scripts/train.py,

@@ -576,6 +576,51 @@ def main_video(cfg_name='savi_ldm_movie_params-res128', num_slots=None, T=3, out
         print(k, v.shape, v.dtype)
 
 
+def main_ema():
+    """tests/golden/ema_lit.npz: the reference's LitEma (video_based/models/ddpm/ema.py:7-52) run for
+    4 updates on a small module (two trainable tensors + one frozen) whose parameters move between
+    updates by a fixed recipe -- with the num_updates warm-up of the decay (use_num_upates=True, decay
+    0.9999: effective decays 2/11, 3/12, 4/13, 5/14) and without it (decay 0.95).  Stored: the
+    parameter values before every update and the shadows after it."""
+    import importlib
+    rh.install()
+    ema_mod = importlib.import_module('slotdiffusion.video_based.models.ddpm.ema')
+
+    class Tiny(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            g = torch.Generator().manual_seed(5)
+            self.a = torch.nn.Parameter(torch.randn(7, 33, generator=g))
+            self.sub = torch.nn.Linear(5, 3)
+            with torch.no_grad():
+                self.sub.weight.copy_(torch.randn(3, 5, generator=g))
+                self.sub.bias.copy_(torch.randn(3, generator=g))
+            self.sub.bias.requires_grad_(False)        # frozen: no shadow (ema.py:48-49)
+
+    G = {}
+    for tag, decay, use_n in (('warm', 0.9999, True), ('flat', 0.95, False)):
+        m = Tiny()
+        ema = ema_mod.LitEma(m, decay=decay, use_num_upates=use_n)
+        g = torch.Generator().manual_seed(9)
+        for it in range(4):
+            with torch.no_grad():
+                m.a.add_(0.1 * torch.randn(m.a.shape, generator=g))
+                m.sub.weight.mul_(1.0 + 0.05 * (it + 1))
+            G[f'{tag}_p_a_{it}'] = m.a.detach().clone()
+            G[f'{tag}_p_w_{it}'] = m.sub.weight.detach().clone()
+            ema(m)
+            sh = dict(ema.named_buffers())
+            G[f'{tag}_s_a_{it}'] = sh[ema.m_name2s_name['a']].detach().clone()
+            G[f'{tag}_s_w_{it}'] = sh[ema.m_name2s_name['sub.weight']].detach().clone()
+        G[f'{tag}_num_updates'] = torch.tensor(int(ema.num_updates))
+        assert 'sub.bias' not in ema.m_name2s_name
+    m0 = Tiny()
+    G['init_a'], G['init_w'] = m0.a.detach().clone(), m0.sub.weight.detach().clone()
+    np.savez_compressed(os.path.join(OUT, 'ema_lit.npz'), **{k: v.numpy() for k, v in G.items()})
+    for k, v in G.items():
+        print(k, tuple(v.shape))
+
+
 def main_savi():
     """tests/golden/savi_b1t3.npz: video_based SAVi baseline (registry 'SAVi', MOVi-E config: 15
     slots, 2 iterations, transformer predictor, spatial-broadcast transposed-conv decoder), B=1 clip
@@ -700,6 +745,14 @@ if __name__ == '__main__':
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'vpred':
         main_vpred()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'ema':
+        main_ema()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'video15x6':
+        # BASELINE config 3's shape: MOVi-E config (15 slots) on 6-frame clips
+        main_video('savi_ldm_movie_params-res128', num_slots=15, T=6, out_name='savidiff_b1t6_n15.npz',
+                   seed=17)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'video11x6':
         main_video('savi_ldm_movid_params-res128', num_slots=11, T=6, out_name='savidiff_b1t6_n11.npz',
