@@ -1,31 +1,40 @@
 #!/usr/bin/env python
 """Hot-path benchmark (see DESIGN.md "Measurement").
 
-    python bench.py --gpus N --steps K --warmup W [--batch B] [--dtype bf16|fp32] [--mode sample|train]
+    python bench.py --gpus N --steps K --warmup W [--config C] [--batch B] [--dtype bf16|fp32|fp8]
+                    [--mode train|sample]
 
-Workload = BASELINE.json configs[1]: img_based SlotDiffusion (Slot Attention + LDM UNet),
-CLEVRTex 128x128, 7 slots, bf16 storage / fp32 accumulate, synthetic data, seeded random weights
-(zero-initialised layers replaced by small random values so no work is optimised away).
+Workloads (`--config`, values restated in slotdiffusion_amd/configs.py), bf16 storage / fp32 accumulate,
+synthetic data, seeded random weights (zero-initialised layers replaced by small random values so no
+work is optimised away):
+  clevrtex128 (default) BASELINE.json configs[1], the configuration the metric is quoted on: img_based
+               SlotDiffusion (Slot Attention + LDM UNet), CLEVRTex 128x128, 7 slots, 64 images per GPU
+  movid11x6    configs[2]: video_based SAVi+LDM, MOVi-D 128x128 x 6-frame clips, 11 slots, 16 clips per GPU
+  movie15x6    configs[3]: video_based SlotDiffusion, MOVi-E 128x128 x 6 frames, 15 slots, 16 clips per GPU
+               (the configuration north_star states its 2- / 8-GPU targets on)
+  coco224      configs[4]: DINO ViT-S/8 encoder, COCO 224x224, 7 slots, 16 images per GPU
 
-A "step" (mode=train, the default) is one optimiser step on a batch of B images: zero-grad, slot
-encoder forward, frozen VQ-VAE encode, q-sample, UNet forward, MSE, full backward, gradient
-all-reduce (N > 1), global-norm clip, Adam.  value = N * B * K / seconds [images/s], whole job.
-mode=sample: one 20-NFE DPM-Solver++ sampling pass over B images' slots (20 x (UNet eps + x0
-conversion + VQ quantise) + solver updates); value = N * B * 20 * K / seconds.  Inputs are resident
-in HBM; for N > 1 every rank works on its own B images (weak scaling), time is the max over ranks
-between barriers.
-Extra JSON objects: roofline (MFMA, dominant kernel family sdmi_igemm) and roofline_hbm (GroupNorm
-family): algorithmic flops / bytes per launch counted from the launch arguments, durations from a
-rocprofv3 --kernel-trace of THIS command's graph-replayed timed region (a child run on the same box,
-see replayed_trace(); falls back to a live eager HIP-event pass, labelled, if rocprofv3 is not
-usable); cpu_baseline (the CPU oracle on this box's host cores, bounded sample).
+A "step" (mode=train, the default) is one optimiser step on a batch: zero-grad, slot encoder forward
+(per-frame recurrence + predictor on clips), frozen VQ-VAE encode, q-sample, UNet forward, MSE, full
+backward, gradient all-reduce (N > 1), global-norm clip, Adam.  value = N * images * K / seconds
+[images/s; a clip counts its frames], whole job.  mode=sample: one 20-NFE DPM-Solver++ sampling pass over
+the batch's slots (20 x (UNet eps + x0 conversion + VQ quantise) + solver updates); value = N * images *
+20 * K / seconds.  Inputs are resident in HBM; for N > 1 every rank works on its own batch (weak
+scaling), time is the max over ranks between barriers.
+Extra JSON objects: `roofline` (MFMA, dominant kernel family sdmi_igemm) and `roofline_hbm` (GroupNorm
+family) for the timed step, `denoise.roofline` for the sampling leg: algorithmic flops / bytes per
+launch counted from the launch arguments, durations from a rocprofv3 --kernel-trace of THIS command's
+graph-replayed timed region (child runs on the same box, see replayed_trace(); falls back to a live eager
+HIP-event pass, labelled, if rocprofv3 is not usable); `traffic` / `mfma_util_pmc` from rocprofv3 --pmc
+passes of this command taken by this run (pmc_pass()); `cpu_baseline` (the CPU oracle on this box's host
+cores, bounded sample, pinned thread count and affinity).
 """
 import argparse
 import json
 import os
 
 os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')   # dmabuf IPC (RCCL across processes)
-os.environ.setdefault('DEBUG_HIP_FORCE_GRAPH_QUEUES', '2')  # see slotdiffusion_amd/__init__.py
+os.environ.setdefault('DEBUG_HIP_FORCE_GRAPH_QUEUES', '2')  # = slotdiffusion_amd.configure_runtime(), before HIP starts
 import sys
 import time
 
@@ -35,92 +44,110 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_TFLOPS = {'bf16': 2500.0, 'fp32': 157.3, 'fp8': 5000.0}      # MI355X dense MFMA peaks (MI355X_MICROARCH.md)
+CPU_THREADS = 64       # cpu_baseline: fixed thread count, pinned to the first cores (repeatable across boxes)
 
 
 def build_model(dtype, seed=1234, config='clevrtex128'):
-    from slotdiffusion_amd.models import SADiffusion
-    from tests.common import clevrtex_cfg, dino_coco_cfg
-    # clevrtex128 = BASELINE configs[1] (the metric's configuration); coco224 = configs[4]: DINO ViT-S/8
-    # encoder, 224 x 224 images, latent 56 x 56 (reference config values: tests/golden/configs)
-    cfg = dino_coco_cfg() if config == 'coco224' else clevrtex_cfg(num_slots=7)
-    m = SADiffusion(cfg['resolution'], cfg['slot_dict'], cfg['enc_dict'], cfg['dec_dict'],
-                    cfg['loss_dict'], compute_dtype=dtype, seed=seed)
+    """-> (model, cfg dict, frames per clip or None)."""
+    from slotdiffusion_amd import configs
+    from slotdiffusion_amd.models import SADiffusion, SAViDiffusion
+    bc = configs.BENCH_CONFIGS[config]
+    cfg = bc['cfg']()
+    if bc['frames']:
+        m = SAViDiffusion(cfg['resolution'], bc['frames'], cfg['slot_dict'], cfg['enc_dict'], cfg['dec_dict'],
+                          cfg['pred_dict'], cfg['loss_dict'], compute_dtype=dtype, seed=seed)
+    else:
+        m = SADiffusion(cfg['resolution'], cfg['slot_dict'], cfg['enc_dict'], cfg['dec_dict'],
+                        cfg['loss_dict'], compute_dtype=dtype, seed=seed)
     g = torch.Generator().manual_seed(seed)
     with torch.no_grad():
         init = {s.name: s.init for s in m._spec}
         for n, p in m.named_parameters():
             if init[n] == 'zlin' and p.dim() > 1:         # zero-init convs -> N(0, 0.02)
                 p.copy_(torch.randn(p.shape, generator=g) * 0.02)
-    return m, cfg
+    return m, cfg, bc['frames']
 
 
-def synth_batch(B, rank, device, res=128):
+def synth_batch(B, rank, device, res=128, frames=None):
     g = torch.Generator().manual_seed(1234 + rank)
-    img = (torch.randn(B, 3, res, res, generator=g) * 0.5).clamp(-1, 1)
-    return img.to(device)
+    shape = (B, 3, res, res) if not frames else (B, frames, 3, res, res)
+    return (torch.randn(shape, generator=g) * 0.5).clamp(-1, 1).to(device)
 
 
-def cpu_baseline(cfg, mode, quick=False):
-    """Oracle (CPU port of the reference path) timed on this box's host cores, B=4 (bounded sample)."""
+def cpu_baseline(model, cfg, mode, quick=False):
+    """Oracle (CPU port of the reference path) timed on this box's host cores, B=4 (bounded sample).
+    The weights are the bench model's own (a CPU copy of its state dict: checkpoint keys are the
+    reference's).  Threads: min(CPU_THREADS, cores), pinned to the first cores, so that the figure does
+    not depend on how many cores the box happens to have beyond that."""
     from oracle import slotdiff_oracle as O
     from slotdiffusion_amd import spec
-    from tests.common import load_keys, oracle_weights
     cores = os.cpu_count() or 1
-    threads = min(cores, 64)
+    threads = min(cores, CPU_THREADS)
+    pinned = False
+    old_aff = None
+    try:
+        old_aff = os.sched_getaffinity(0)
+        os.sched_setaffinity(0, set(sorted(old_aff)[:threads]))
+        pinned = True
+    except (AttributeError, OSError):
+        pass
     torch.set_num_threads(threads)
-    W = oracle_weights(cfg)
+    W = {k: v.detach().float().cpu().clone() for k, v in model.state_dict().items()}
+    trainable = [n for n, p in model.named_parameters() if p.requires_grad]
     B = 4
     g = torch.Generator().manual_seed(0)
     img = (torch.randn(B, 3, 128, 128, generator=g) * 0.5).clamp(-1, 1)
     rplan = spec.resnet18_plan(False)
     uplan = spec.unet_plan(cfg['dec_dict']['unet_dict'])
     ed = cfg['dec_dict']['vae_dict']['enc_dec_dict']
-    if mode == 'train':
-        keys = load_keys()['img_based/SADiffusion/clevrtex-7slot']
-        frozen = set(keys['frozen'])
-        names = [k for k, _ in keys['params'] if k not in frozen]
-        P = [W[k].requires_grad_(True) for k in names]
-        M = [torch.zeros_like(p) for p in P]
-        V = [torch.zeros_like(p) for p in P]
-        lrs = [2e-4 if 'dm_decoder' in n else 1e-4 for n in names]
-        t = torch.randint(0, 1000, (B,), generator=g)
-        noise = torch.randn(B, 3, 32, 32, generator=g)
-        nsteps = 1 if quick else 3
-        times = []
-        for it in range(nsteps + 1):
+    aff = f'pinned to {threads} cores' if pinned else 'no affinity control'
+    try:
+        if mode == 'train':
+            P = [W[k].requires_grad_(True) for k in trainable]
+            M = [torch.zeros_like(p) for p in P]
+            V = [torch.zeros_like(p) for p in P]
+            lrs = [2e-4 if 'dm_decoder' in n else 1e-4 for n in trainable]
+            t = torch.randint(0, 1000, (B,), generator=g)
+            noise = torch.randn(B, 3, 32, 32, generator=g)
+            nsteps = 1 if quick else 3
+            times = []
+            for it in range(nsteps + 1):
+                t0 = time.perf_counter()
+                for p in P:
+                    p.grad = None
+                slots, _ = O.sa_encode(W, img, rplan, 3, training=True)
+                loss, _, _ = O.ldm_loss(W, uplan, ed, img, slots, t, noise)
+                loss.backward()
+                with torch.no_grad():
+                    O.clip_and_adam(P, [p.grad for p in P], M, V, it + 1, lrs, clip=1.0)
+                times.append(time.perf_counter() - t0)
+            dt = sorted(times[1:])[len(times[1:]) // 2]
+            return dict(value=B / dt, unit='images/s', cores=threads, kind='port',
+                        sample=f'oracle train step (fwd+bwd+clip+Adam, no dropout), B={B}, fp32, torch-CPU '
+                               f'{threads} threads of {cores} cores ({aff}), median of {nsteps} steps, '
+                               f'{dt:.2f}s/step')
+        with torch.no_grad():
+            slots, _ = O.sa_encode(W, img, rplan, 3, training=False)
+            x_T = torch.randn(B, 3, 32, 32, generator=g)
+            nfe = 5 if quick else 20
+            betas = W['dm_decoder.betas']
+            eps_fn = lambda xc, t_in: O.unet_forward(W, uplan, xc, t_in, slots)
+            q_fn = lambda x0: O.vq_quantize(W, x0)[0]
             t0 = time.perf_counter()
-            for p in P:
-                p.grad = None
-            slots, _ = O.sa_encode(W, img, rplan, 3, training=True)
-            loss, _, _ = O.ldm_loss(W, uplan, ed, img, slots, t, noise)
-            loss.backward()
-            with torch.no_grad():
-                O.clip_and_adam(P, [p.grad for p in P], M, V, it + 1, lrs, clip=1.0)
-            times.append(time.perf_counter() - t0)
-        dt = sorted(times[1:])[len(times[1:]) // 2]
-        return dict(value=B / dt, unit='images/s', cores=threads, kind='port',
-                    sample=f'oracle train step (fwd+bwd+clip+Adam, no dropout), B={B}, fp32, torch-CPU '
-                           f'{threads} threads of {cores} cores, median of {nsteps} steps, '
-                           f'{dt:.2f}s/step')
-    with torch.no_grad():
-        slots, _ = O.sa_encode(W, img, rplan, 3, training=False)
-        x_T = torch.randn(B, 3, 32, 32, generator=g)
-        nfe = 5 if quick else 20
-        betas = W['dm_decoder.betas']
-        eps_fn = lambda xc, t_in: O.unet_forward(W, uplan, xc, t_in, slots)
-        q_fn = lambda x0: O.vq_quantize(W, x0)[0]
-        t0 = time.perf_counter()
-        O.dpm_solver_sample(eps_fn, q_fn, betas, x_T, steps=nfe, order=3)
-        dt = time.perf_counter() - t0
-    return dict(value=B * nfe / dt, unit='image-denoise-steps/s', cores=threads, kind='port',
-                sample=f'oracle DPM-Solver++ {nfe} NFE, B={B}, fp32, torch-CPU {threads} threads '
-                       f'of {cores} cores, {dt:.1f}s')
+            O.dpm_solver_sample(eps_fn, q_fn, betas, x_T, steps=nfe, order=3)
+            dt = time.perf_counter() - t0
+        return dict(value=B * nfe / dt, unit='image-denoise-steps/s', cores=threads, kind='port',
+                    sample=f'oracle DPM-Solver++ {nfe} NFE, B={B}, fp32, torch-CPU {threads} threads '
+                           f'of {cores} cores ({aff}), {dt:.1f}s')
+    finally:
+        if pinned:
+            os.sched_setaffinity(0, old_aff)
 
 
-# kernels behind the C-ABI entry points the roofline legs price (csrc/igemm.hip, norm.hip, norm_bwd.hip)
+# kernels behind the C-ABI entry points the roofline legs price (csrc/igemm.hip, wgrad.hip, norm.hip, norm_bwd.hip)
 FAMILIES = {
     'sdmi_igemm': ('igemm_kernel', 'igemm_kernel_tall', 'igemm_dma_kernel', 'conv3x3_c64_kernel',
-                   'splitk_epilogue_kernel'),
+                   'splitk_epilogue_kernel', 'bwd_pair_kernel'),
     'sdmi_wgrad': ('wgrad_kernel', 'wgrad_tr_kernel', 'wgrad_group_kernel', 'wgrad_group_reduce_kernel',
                    'wgrad_reduce_kernel'),
     'sdmi_groupnorm': ('gn_fused_kernel', 'gn_stats_kernel', 'gn_apply_kernel'),
@@ -136,13 +163,8 @@ def kernel_base_name(k):
     return re.sub(r'[<(].*', '', k).strip()
 
 
-def replayed_trace(argv, steps):
-    """Per-kernel durations of the graph-replayed timed region: runs this same command (same box,
-    same flags, --mark) under `rocprofv3 --kernel-trace` and keeps the kernels between the two
-    marker launches = exactly the K timed steps.  -> ({kernel base name: [calls/step, ms/step]},
-    note) or (None, reason)."""
-    import csv
-    import glob
+def _rocprof_child(extra_prof_args, argv, child_flags, timeout=900):
+    """Run this same command under rocprofv3 (same box) -> (output dir, note) or (None, reason)."""
     import shutil
     import subprocess
     import tempfile
@@ -151,23 +173,52 @@ def replayed_trace(argv, steps):
         return None, 'rocprofv3 not found'
     d = tempfile.mkdtemp(prefix='sdmi_trace_', dir='/tmp')
     env = dict(os.environ, TMPDIR='/tmp')
-    cmd = [exe, '--kernel-trace', '--output-format', 'csv', '-d', d, '-o', 't', '--', sys.executable,
-           os.path.abspath(__file__)] + argv + ['--mark', '--no-roofline', '--no-cpu-baseline',
-                                                '--big-batch', '0', '--only-train']
+    cmd = [exe, '--kernel-trace'] + extra_prof_args + ['--output-format', 'csv', '-d', d, '-o', 't', '--',
+                                                     sys.executable, os.path.abspath(__file__)] + argv + child_flags
     try:
-        r = subprocess.run(cmd, cwd='/tmp', env=env, capture_output=True, text=True, timeout=900)
+        r = subprocess.run(cmd, cwd='/tmp', env=env, capture_output=True, text=True, timeout=timeout)
+    except Exception as e:              # noqa: BLE001 -- instrumentation must not take the bench down
+        shutil.rmtree(d, ignore_errors=True)
+        return None, f'{type(e).__name__}: {e}'
+    if r.returncode != 0:
+        shutil.rmtree(d, ignore_errors=True)
+        return None, f'rocprofv3 child failed (rc {r.returncode}): {(r.stderr or "")[-300:]}'
+    return d, 'ok'
+
+
+def _marked_segment(rows):
+    marks = [i for i, q in enumerate(rows) if kernel_base_name(q[2]) == MARK]
+    if len(marks) < 2:
+        return None
+    return rows[marks[-2] + 1:marks[-1]]
+
+
+def replayed_trace(argv, steps, mode):
+    """Per-kernel durations of the graph-replayed timed region of `mode`'s leg: runs this same command
+    (same box, same flags, --mark) under `rocprofv3 --kernel-trace` and keeps the kernels between the
+    two marker launches = exactly the K timed steps.  -> ({kernel base name: [calls/step, ms/step]},
+    note) or (None, reason)."""
+    import csv
+    import glob
+    import shutil
+    flags = ['--mark', '--no-roofline', '--no-cpu-baseline', '--big-batch', '0', '--mode', mode]
+    if mode == 'train':
+        flags.append('--only-train')
+    d, note = _rocprof_child([], argv, flags)
+    if d is None:
+        return None, note
+    try:
         files = glob.glob(os.path.join(d, '**', '*kernel_trace.csv'), recursive=True)
-        if r.returncode != 0 or not files:
-            return None, f'rocprofv3 child failed (rc {r.returncode}): {(r.stderr or "")[-300:]}'
+        if not files:
+            return None, 'no kernel trace written'
         rows = []
         with open(files[0]) as f:
             for q in csv.DictReader(f):
                 rows.append((int(q['Start_Timestamp']), int(q['End_Timestamp']), q['Kernel_Name']))
         rows.sort()
-        marks = [i for i, q in enumerate(rows) if kernel_base_name(q[2]) == MARK]
-        if len(marks) < 2:
+        seg = _marked_segment(rows)
+        if seg is None:
             return None, 'markers not found in the trace'
-        seg = rows[marks[-2] + 1:marks[-1]]
         agg = {}
         for a, b, k in seg:
             v = agg.setdefault(kernel_base_name(k), [0.0, 0.0])
@@ -176,42 +227,66 @@ def replayed_trace(argv, steps):
         span = (seg[-1][1] - seg[0][0]) / 1e6 / steps if seg else 0.0
         agg['__span_ms_per_step__'] = [len(seg) / steps, span]
         return agg, 'rocprofv3 --kernel-trace of the graph-replayed timed region (child run of this command, same box)'
-    except Exception as e:              # noqa: BLE001 -- instrumentation must not take the bench down
+    except Exception as e:              # noqa: BLE001
         return None, f'{type(e).__name__}: {e}'
     finally:
         shutil.rmtree(d, ignore_errors=True)
 
 
-def pmc_traffic(which):
-    """HBM traffic / MFMA utilisation of the igemm kernels from the COMMITTED rocprofv3 PMC passes
-    (profiles/r0N_<which>_pmc_by_kernel.csv; separate --pmc runs of this same command on an earlier
-    box) -- replayed numbers, labelled as such in the JSON, never observed by
-    the run that prints them.  FETCH_SIZE is doubled (gfx950 counts 128-byte requests as 64 bytes)."""
+def pmc_pass(argv, mode):
+    """HBM traffic and MFMA busy fraction of the igemm family OBSERVED BY THIS RUN: two `rocprofv3
+    --kernel-trace --pmc` child passes of this command (eager launches so that every dispatch is
+    attributable, one timed step between the markers; counters in their own runs, MI355X_MICROARCH.md
+    "rocprofv3 PMC slots": FETCH_SIZE and WRITE_SIZE cannot share a pass).
+    Calibration, as the guide prescribes ("calibrate on a known byte count in your own access pattern"):
+    the same passes see two kernels of known traffic in the step -- the gradient arena's zero fill
+    (`fillBufferAligned`: n * 4 bytes written, nothing read) and `sqsum_kernel` (n * 4 bytes read) -- and
+    the byte counters are scaled by known / counted for each of them (the guide's gfx950 note: FETCH_SIZE
+    reads exactly 1/2 of a wide coalesced stream; WRITE_SIZE uncalibrated)."""
     import csv
-    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles')
-    path = next((q for q in (os.path.join(root, f'r02_{which}_pmc_by_kernel.csv'),
-                             os.path.join(root, f'r01_{which}_pmc_by_kernel.csv')) if os.path.exists(q)), None)
-    if path is None:
-        return {}
-    f = w = n = act = busy = 0.0
-    have_tcc = True
-    with open(path) as fh:
-        for r in csv.DictReader(fh):
-            if kernel_base_name(r['kernel']) in FAMILIES['sdmi_igemm']:
-                n += float(r['dispatches'])
-                have_tcc = have_tcc and 'FETCH_SIZE' in r and 'WRITE_SIZE' in r
-                if have_tcc:
-                    f += float(r['FETCH_SIZE'])
-                    w += float(r['WRITE_SIZE'])
-                act += float(r['GRBM_GUI_ACTIVE'])
-                busy += float(r['SQ_VALU_MFMA_BUSY_CYCLES'])
-    if not n:
-        return {}
-    # GRBM_GUI_ACTIVE is summed over the 8 XCDs; 1024 SIMDs.  (The TCC passes of the sampling
-    # command abort inside rocprofv3 on this image: traffic is then reported as null.)
-    return {'bytes_per_launch': (2.0 * f + w) * 1024.0 / n if have_tcc else None,
-            'mfma_util': busy / (act / 8.0 * 1024.0),
-            'source': os.path.relpath(path, os.path.dirname(os.path.abspath(__file__)))}
+    import glob
+    import shutil
+    flags = ['--mark', '--no-roofline', '--no-cpu-baseline', '--big-batch', '0', '--mode', mode, '--no-graph',
+             '--steps', '1', '--warmup', '1']
+    if mode == 'train':
+        flags.append('--only-train')
+    argv = [a for i, a in enumerate(argv) if a not in ('--steps', '--warmup') and
+            (i == 0 or argv[i - 1] not in ('--steps', '--warmup'))]
+    out = {'source': 'rocprofv3 --pmc child passes of this command on this box (this run; eager launches, 1 step)'}
+    per_kernel = {}
+    notes = []
+    for counters in (['SQ_VALU_MFMA_BUSY_CYCLES', 'GRBM_GUI_ACTIVE', 'FETCH_SIZE'], ['WRITE_SIZE']):
+        d, note = _rocprof_child(['--pmc'] + counters, argv, flags)
+        if d is None:
+            notes.append(f'{"+".join(counters)}: {note}')
+            continue
+        try:
+            files = glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True)
+            rows = []
+            for path in files:
+                with open(path) as f:
+                    for q in csv.DictReader(f):
+                        rows.append((int(q['Dispatch_Id']), q['Kernel_Name'], q['Counter_Name'],
+                                     float(q['Counter_Value'])))
+            rows.sort()
+            ids = sorted({r[0] for r in rows if kernel_base_name(r[1]) == MARK})
+            if len(ids) < 2:
+                notes.append(f'{"+".join(counters)}: markers not found')
+                continue
+            lo, hi = ids[-2], ids[-1]
+            for did, k, c, v in rows:
+                if lo < did < hi:
+                    e = per_kernel.setdefault(kernel_base_name(k), {})
+                    e[c] = e.get(c, 0.0) + v
+                    e.setdefault('_ids_' + c, set()).add(did)
+        except Exception as e:          # noqa: BLE001
+            notes.append(f'{"+".join(counters)}: {type(e).__name__}: {e}')
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    if notes:
+        out['notes'] = notes
+    out['per_kernel'] = per_kernel
+    return out
 
 
 def main():
@@ -219,16 +294,20 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--batch', type=int, default=0, help='images per GPU (default 64; coco224: 16)')
+    ap.add_argument('--batch', type=int, default=0,
+                    help='images (clips for the video configs) per GPU; default 64 / 16 clips / coco224: 16')
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32', 'fp8'],
                     help="fp8 = bf16 storage + e4m3fn operands on the denoiser's 3x3 convolutions "
                          '(sampling path only this round)')
-    ap.add_argument('--config', default='clevrtex128', choices=['clevrtex128', 'coco224'],
-                    help='clevrtex128 = BASELINE configs[1] (the metric); coco224 = configs[4]')
+    ap.add_argument('--config', default='clevrtex128',
+                    choices=['clevrtex128', 'coco224', 'movid11x6', 'movie15x6'],
+                    help='clevrtex128 = BASELINE configs[1] (the metric); movid11x6 / movie15x6 = configs[2] / '
+                         '[3] (video, 6-frame clips); coco224 = configs[4]')
     ap.add_argument('--mode', default='train', choices=['train', 'sample'])
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--no-pmc', action='store_true', help='skip the rocprofv3 --pmc child passes (traffic = null)')
     ap.add_argument('--big-batch', type=int, default=256,
                     help='extra sampling measurement at this batch (0 = off): the chip is far from '
                          'full at the configured B = 64')
@@ -274,16 +353,18 @@ def main():
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
     dtype = torch.float32 if args.dtype == 'fp32' else torch.bfloat16
 
-    model, cfg = build_model(dtype, config=args.config)
+    from slotdiffusion_amd import configs, ops, parallel
+    bc = configs.BENCH_CONFIGS[args.config]
+    model, cfg, frames = build_model(dtype, config=args.config)
     model = model.to(dev)
     if args.dtype == 'fp8':
         model.set_compute_dtype('fp8')
     model.use_graph = not args.no_graph
     res = cfg['resolution'][0]
     lat = res // 4
-    B = args.batch if args.batch > 0 else (64 if args.config == 'clevrtex128' else 16)
-    img = synth_batch(B, rank, dev, res)
-    from slotdiffusion_amd import ops, parallel
+    B = args.batch if args.batch > 0 else bc['batch']
+    n_img = B * (frames or 1)                 # images per step and GPU (a clip counts its frames)
+    img = synth_batch(B, rank, dev, res, frames)
     if dist is not None:                      # every rank starts from rank 0's parameters
         parallel.broadcast_parameters(model.arena())
         model.weights_updated()
@@ -320,24 +401,25 @@ def main():
             dt = float(tt)
         return dt
 
-    # ---- sampling leg: 20-NFE DPM-Solver++ over B images' slots --------------------------
+    # ---- sampling leg: 20-NFE DPM-Solver++ over the batch's slots ------------------------
     model.eval()
     with torch.no_grad():
         slots, _ = model.encode(img)
+        if frames:
+            slots = slots.flatten(0, 1).contiguous()          # every frame's slots condition one latent
         g = torch.Generator(device='cpu').manual_seed(77 + rank)
-        x_T = ops.nchw_to_nhwc(torch.randn(B, 3, lat, lat, generator=g).to(dev), torch.float32, 4)
+        x_T = ops.nchw_to_nhwc(torch.randn(n_img, 3, lat, lat, generator=g).to(dev), torch.float32, 4)
 
         def sample_step():
             return model._dpm_sample(x_T, slots)[0]
-        if args.only_train and args.mode == 'train':
-            sample_step = lambda: None
-        dt_s = timed(sample_step, args.steps if args.mode == 'sample' else max(2, args.steps // 2),
-                     args.warmup if args.mode == 'sample' else 1, marked=args.mode == 'sample')
+        skip_sample = args.only_train and args.mode == 'train'
         n_s = args.steps if args.mode == 'sample' else max(2, args.steps // 2)
-        denoise_rate = world * B * nfe * n_s / dt_s
+        dt_s = timed((lambda: None) if skip_sample else sample_step, n_s,
+                     args.warmup if args.mode == 'sample' else 1, marked=args.mode == 'sample')
+        denoise_rate = world * n_img * nfe * n_s / dt_s
         big_rate = None
-        if args.big_batch and args.big_batch != B and world == 1 and not args.only_train and \
-                args.config == 'clevrtex128':
+        if args.big_batch and args.big_batch != n_img and world == 1 and not args.only_train and \
+                args.config == 'clevrtex128' and args.mode == 'train':
             # informational: the same sampler at a batch that fills the chip better
             Bb = args.big_batch
             slots_b = slots[:1].expand(Bb, -1, -1).contiguous() + 0.01 * torch.randn(
@@ -351,7 +433,7 @@ def main():
 
     # ---- training leg: forward + loss + backward (+ DDP all-reduce) + clip + Adam --------
     model.train()
-    opt = FusedAdam(model, lr=1e-4, dec_lr=2e-4, clip_grad=1.0, total_steps=100000)
+    opt = FusedAdam(model, lr=1e-4, dec_lr=2e-4, clip_grad=bc['clip_grad'], total_steps=100000)
     garena = model.grad_arena()
 
     def train_step(reduce=True):
@@ -377,7 +459,7 @@ def main():
                                        allreduce=(True if dist is not None else None), world=world)
             run_step = lambda: graphed(dict(img=img))
         dt_t = timed(run_step, args.steps, args.warmup, marked=True)
-        train_rate = world * B * args.steps / dt_t
+        train_rate = world * n_img * args.steps / dt_t
         if dist is not None:
             # the exchange by itself (all ranks idle otherwise) and what of it the step exposes:
             # the same graphed step without the collective, timed the same way
@@ -395,89 +477,94 @@ def main():
                     'all_reduce_ms': 1e3 * dt_ar / 3,
                     'exposed_comm_ms': (1e3 * (dt_t - dt_nored) / args.steps) if dt_nored else None}
 
-    if True:
-        if args.mode == 'train':
-            value, unit, ms = train_rate, 'images/s', 1e3 * dt_t / args.steps
-            metric = 'train-step images/sec, 128^2 7-slot (DPM-Solver denoise-steps/sec in `denoise`)'
-            work = ('img_based SlotDiffusion CLEVRTex 128x128 7 slots: train step = SA encoder + '
-                    'frozen VQ-VAE encode + q-sample + UNet eps + MSE, backward, clip, Adam '
-                    '(dropout 0.1)')
-        else:
-            value, unit, ms = denoise_rate, 'image-denoise-steps/s', 1e3 * dt_s / n_s
-            metric = 'DPM-Solver denoise-steps/sec, 128^2 7-slot'
-            work = ('img_based SlotDiffusion CLEVRTex 128x128 7 slots: 20-NFE DPM-Solver++ '
-                    'sampling (UNet eps + VQ per NFE)')
-        if args.config == 'coco224':
-            metric = metric.replace('128^2 7-slot', '224^2 7-slot (COCO / DINO config, BASELINE configs[4])')
-            work = work.replace('CLEVRTex 128x128', 'COCO 224x224 (DINO ViT-S/8 encoder, latent 56x56)')
-        if args.dtype == 'fp8':
-            work += "; e4m3fn operands on the UNet's 3x3 convolutions (fp8 MFMA), bf16 elsewhere"
-        out = {
-            'metric': metric, 'value': value, 'unit': unit, 'n_gpus': world, 'steps': args.steps,
-            'warmup': args.warmup, 'ms_per_step': ms, 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
-            'config': {'workload': work, 'batch_per_gpu': B, 'hip_graph': not args.no_graph,
-                       'parallelism': f'dp{world}'},
-            'denoise_big_batch': ({'value': big_rate, 'unit': 'image-denoise-steps/s',
-                                   'batch': args.big_batch} if big_rate else None),
-            'denoise': {'value': denoise_rate, 'unit': 'image-denoise-steps/s',
-                        'ms_per_20nfe_pass': 1e3 * dt_s / n_s, 'nfe': nfe},
-            'comm': comm,
-        }
-        # rank-0-only instrumentation pass: no collective inside
-        step = (lambda: train_step(reduce=False)) if args.mode == 'train' else sample_step
-        if rank == 0 and not args.no_roofline:
-            # live per-kernel timing of ONE sampling pass, eager (events around every launch)
-            from slotdiffusion_amd._lib import KernelTimer
-            model.use_graph = False
-            overlap, model.bank().overlap_wgrad = model.bank().overlap_wgrad, False  # clean timings
-            step()
-            with KernelTimer() as kt:
-                step()
-            summ = kt.summary()           # launch counts + algorithmic flops / bytes per entry point
-            model.bank().overlap_wgrad = overlap
-            model.use_graph = not args.no_graph
-            peak = PEAK_TFLOPS[args.dtype]
-            # durations: the graph-replayed timed region itself (rocprofv3 child run on this box);
-            # eager HIP events only as the labelled fallback
-            trace, tnote = (None, 'not taken (--no-graph or N > 1)') if (args.no_graph or world > 1) else \
-                replayed_trace([a for a in sys.argv[1:] if a != '--mark'], args.steps)
+    what = bc['baseline']
+    shape = f'{res}x{res}' + (f' x {frames}-frame clips' if frames else '')
+    slots_n = cfg['slot_dict']['num_slots']
+    if args.mode == 'train':
+        value, unit, ms = train_rate, 'images/s', 1e3 * dt_t / args.steps
+        metric = f'train-step images/sec, {shape} {slots_n}-slot (DPM-Solver denoise-steps/sec in `denoise`)'
+        work = (f'BASELINE {what}: train step = slot encoder + frozen VQ-VAE encode + q-sample + UNet eps + '
+                f'MSE, backward, clip, Adam (dropout 0.1)')
+    else:
+        value, unit, ms = denoise_rate, 'image-denoise-steps/s', 1e3 * dt_s / n_s
+        metric = f'DPM-Solver denoise-steps/sec, {shape} {slots_n}-slot'
+        work = f'BASELINE {what}: 20-NFE DPM-Solver++ sampling (UNet eps + VQ per NFE)'
+    if args.dtype == 'fp8':
+        work += "; e4m3fn operands on the UNet's 3x3 convolutions (fp8 MFMA), bf16 elsewhere"
+    out = {
+        'metric': metric, 'value': value, 'unit': unit, 'n_gpus': world, 'steps': args.steps,
+        'warmup': args.warmup, 'ms_per_step': ms, 'higher_is_better': True,
+        'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
+        'config': {'workload': work, 'name': args.config, 'batch_per_gpu': B,
+                   'images_per_step_per_gpu': n_img, 'frames_per_clip': frames,
+                   'hip_graph': not args.no_graph, 'parallelism': f'dp{world}'},
+        'denoise_big_batch': ({'value': big_rate, 'unit': 'image-denoise-steps/s',
+                               'batch': args.big_batch} if big_rate else None),
+        'denoise': {'value': denoise_rate, 'unit': 'image-denoise-steps/s',
+                    'ms_per_20nfe_pass': 1e3 * dt_s / n_s, 'nfe': nfe, 'images': n_img},
+        'comm': comm,
+    }
+    if skip_sample:
+        out['denoise'] = None
 
-            def fam_ms(entry):
-                if trace is None:
-                    return summ[entry]['ms'], summ[entry]['calls']
-                ms = sum(trace[k][1] for k in FAMILIES[entry] if k in trace)
-                n = sum(trace[k][0] for k in FAMILIES[entry] if k in trace)
-                return ms, n
-            ig = summ['sdmi_igemm']
-            ig_ms, ig_kernels = fam_ms('sdmi_igemm')
-            ach = ig['flops'] / (ig_ms * 1e-3) / 1e12
-            fam_flops = ig['flops'] + summ.get('sdmi_wgrad', {}).get('flops', 0.0)
-            fam_time = ig_ms + (fam_ms('sdmi_wgrad')[0] if 'sdmi_wgrad' in summ else 0.0)
-            pmc = pmc_traffic('train' if args.mode == 'train' else 'sample')
-            src = ('replayed from ' + pmc['source'] + ' (committed PMC pass of an earlier run of this command; '
-                   'NOT observed by this run)') if pmc else None
-            out['roofline'] = {
-                'bound': 'mfma', 'kernel': 'igemm family (sdmi_igemm: implicit-GEMM conv/linear fwd + dgrad): '
-                                           + ', '.join(FAMILIES['sdmi_igemm']),
-                'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak,
-                'timing_source': tnote if trace is not None else f'eager HIP-event pass (fallback: {tnote})',
-                'driver_observed': trace is not None,
-                'launches_per_step': ig['calls'], 'kernels_per_step': ig_kernels,
-                'family_ms_per_step': ig_ms, 'avg_launch_us': 1e3 * ig_ms / ig['calls'],
-                'algorithmic_gflop_per_launch': ig['flops'] / ig['calls'] / 1e9,
-                'algorithmic_gflop_per_step': ig['flops'] / 1e9,
-                'algorithmic_bytes_per_launch': ig['bytes'] / ig['calls'],
-                'traffic': pmc.get('bytes_per_launch'), 'traffic_unit': 'HBM bytes per launch',
-                'traffic_source': src, 'mfma_util_pmc': pmc.get('mfma_util'), 'mfma_util_pmc_source': src,
-                'gemm_family_tflops_incl_wgrad': fam_flops / (fam_time * 1e-3) / 1e12,
-                'gemm_family_gflop_per_step_incl_wgrad': fam_flops / 1e9,
-                'whole_step_tflops': fam_flops / (ms * 1e-3) / 1e12,
-                'eager_event_pass': {'igemm_ms': ig['ms'], 'tflops': ig['flops'] / (ig['ms'] * 1e-3) / 1e12,
-                                     'all_kernels_ms': sum(v['ms'] for v in summ.values())}}
-            if trace is not None:
-                out['roofline']['kernels_in_timed_region_per_step'] = trace['__span_ms_per_step__'][0]
-                out['roofline']['kernel_span_ms_per_step'] = trace['__span_ms_per_step__'][1]
+    # ---- rank-0-only instrumentation: no collective inside -------------------------------
+    argv0 = [a for a in sys.argv[1:] if a != '--mark']
+    argv0 = [a for i, a in enumerate(argv0) if a != '--mode' and (i == 0 or argv0[i - 1] != '--mode')]
+
+    def roofline_of(mode, step_fn, steps, ms_step, want_hbm):
+        """Roofline objects of one leg (see the module docstring)."""
+        from slotdiffusion_amd._lib import KernelTimer
+        model.use_graph = False
+        overlap, model.bank().overlap_wgrad = model.bank().overlap_wgrad, False  # clean timings
+        with torch.set_grad_enabled(mode == 'train'):
+            step_fn()
+            with KernelTimer() as kt:
+                step_fn()
+            summ = kt.summary()       # launch counts + algorithmic flops / bytes per entry point
+        model.bank().overlap_wgrad = overlap
+        model.use_graph = not args.no_graph
+        peak = PEAK_TFLOPS[args.dtype]
+        # durations: the graph-replayed timed region itself (rocprofv3 child run on this box);
+        # eager HIP events only as the labelled fallback
+        trace, tnote = (None, 'not taken (--no-graph or N > 1)') if (args.no_graph or world > 1) else \
+            replayed_trace(argv0, steps, mode)
+
+        def fam_ms(entry):
+            if trace is None:
+                return summ[entry]['ms'], summ[entry]['calls']
+            t_ms = sum(trace[k][1] for k in FAMILIES[entry] if k in trace)
+            n = sum(trace[k][0] for k in FAMILIES[entry] if k in trace)
+            return t_ms, n
+        ig = summ['sdmi_igemm']
+        ig_flops = ig['flops'] + summ.get('sdmi_bwd_pair', {}).get('flops_dgrad', 0.0)
+        ig_ms, ig_kernels = fam_ms('sdmi_igemm')
+        ach = ig_flops / (ig_ms * 1e-3) / 1e12
+        wg = summ.get('sdmi_wgrad', {})
+        fam_flops = ig_flops + wg.get('flops', 0.0)
+        fam_time = ig_ms + (fam_ms('sdmi_wgrad')[0] if wg else 0.0)
+        rf = {
+            'bound': 'mfma', 'kernel': 'igemm family (sdmi_igemm: implicit-GEMM conv/linear fwd + dgrad): '
+                                       + ', '.join(FAMILIES['sdmi_igemm']),
+            'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak,
+            'timing_source': tnote if trace is not None else f'eager HIP-event pass (fallback: {tnote})',
+            'driver_observed': trace is not None,
+            'launches_per_step': ig['calls'], 'kernels_per_step': ig_kernels,
+            'family_ms_per_step': ig_ms, 'avg_launch_us': 1e3 * ig_ms / ig['calls'],
+            'algorithmic_gflop_per_launch': ig_flops / ig['calls'] / 1e9,
+            'algorithmic_gflop_per_step': ig_flops / 1e9,
+            'algorithmic_bytes_per_launch': ig['bytes'] / ig['calls'],
+            'traffic': None, 'traffic_unit': 'HBM bytes per launch', 'traffic_source': None,
+            'mfma_util_pmc': None,
+            'gemm_family_tflops_incl_wgrad': fam_flops / (fam_time * 1e-3) / 1e12,
+            'gemm_family_gflop_per_step_incl_wgrad': fam_flops / 1e9,
+            'whole_step_tflops': fam_flops / (ms_step * 1e-3) / 1e12,
+            'eager_event_pass': {'igemm_ms': ig['ms'], 'tflops': ig_flops / (ig['ms'] * 1e-3) / 1e12,
+                                 'all_kernels_ms': sum(v['ms'] for v in summ.values())}}
+        if trace is not None:
+            rf['kernels_in_timed_region_per_step'] = trace['__span_ms_per_step__'][0]
+            rf['kernel_span_ms_per_step'] = trace['__span_ms_per_step__'][1]
+        hbm = None
+        if want_hbm:
             # the HBM-bound family that costs the most time: GroupNorm (+SiLU/residual/dropout) passes
             hb = {}
             for entry in ('sdmi_groupnorm', 'sdmi_groupnorm_bwd'):
@@ -490,14 +577,71 @@ def main():
                                  'avg_launch_us': 1e3 * t_ms / summ[entry]['calls']}
             if hb:
                 worst = min(hb, key=lambda k: hb[k]['frac'])
-                out['roofline_hbm'] = dict(hb[worst], bound='hbm', peak=8000.0, unit='GB/s',
-                                           kernel=f'{worst}: ' + ', '.join(FAMILIES[worst]),
-                                           timing_source=out['roofline']['timing_source'], traffic=None,
-                                           families=hb)
+                hbm = dict(hb[worst], bound='hbm', peak=8000.0, unit='GB/s',
+                           kernel=f'{worst}: ' + ', '.join(FAMILIES[worst]),
+                           timing_source=rf['timing_source'], traffic=None, families=hb)
+        return rf, hbm, summ
+
+    def apply_pmc(rf, mode, n_known):
+        """Fill traffic / mfma_util_pmc of a roofline object from this run's PMC child passes."""
+        pm = pmc_pass(argv0, mode)
+        pk = pm.get('per_kernel', {})
+        fam = [pk[k] for k in FAMILIES['sdmi_igemm'] if k in pk]
+        if not fam:
+            rf['traffic_source'] = 'PMC passes unusable on this box: ' + '; '.join(pm.get('notes', ['no igemm dispatches seen']))
+            return
+        tot = lambda c: sum(e.get(c, 0.0) for e in fam)
+        n_disp = max(sum(len(e.get('_ids_' + c, ())) for e in fam) for c in ('FETCH_SIZE', 'WRITE_SIZE', 'GRBM_GUI_ACTIVE'))
+        cal = {}
+        # known-bytes kernels of the same step (units of the counters: KiB)
+        fill = pk.get('__amd_rocclr_fillBufferAligned')
+        sq = pk.get('sqsum_kernel')
+        if fill and fill.get('WRITE_SIZE') and n_known:
+            cal['write_scale'] = (n_known * 4.0 / 1024.0) / (fill['WRITE_SIZE'] / max(1, len(fill['_ids_WRITE_SIZE']))
+                                                              ) if fill['WRITE_SIZE'] else None
+        if sq and sq.get('FETCH_SIZE') and n_known:
+            cal['fetch_scale'] = (n_known * 4.0 / 1024.0) / (sq['FETCH_SIZE'] / max(1, len(sq['_ids_FETCH_SIZE'])))
+        fs = cal.get('fetch_scale') or 2.0       # guide: FETCH_SIZE reads 1/2 of a wide coalesced stream
+        wsc = cal.get('write_scale') or 1.0
+        if tot('FETCH_SIZE') or tot('WRITE_SIZE'):
+            rf['traffic'] = (fs * tot('FETCH_SIZE') + wsc * tot('WRITE_SIZE')) * 1024.0 / max(1, n_disp)
+        if tot('GRBM_GUI_ACTIVE'):
+            # GRBM_GUI_ACTIVE is summed over the 8 XCDs; 1024 SIMDs
+            rf['mfma_util_pmc'] = tot('SQ_VALU_MFMA_BUSY_CYCLES') / (tot('GRBM_GUI_ACTIVE') / 8.0 * 1024.0)
+        rf['traffic_source'] = pm['source'] + (
+            f"; FETCH_SIZE x {fs:.3f} ({'calibrated on sqsum_kernel, ' + str(n_known * 4) + ' bytes read' if 'fetch_scale' in cal else 'guide default: 128-byte requests tallied at 64 B'})"
+            f", WRITE_SIZE x {wsc:.3f} ({'calibrated on the arena zero fill, ' + str(n_known * 4) + ' bytes written' if 'write_scale' in cal else 'uncalibrated'})"
+            + (' -- ' + '; '.join(pm['notes']) if pm.get('notes') else ''))
+        rf['traffic_dispatches'] = n_disp
+        rf['traffic_ratio_to_algorithmic'] = (rf['traffic'] / rf['algorithmic_bytes_per_launch']) if rf['traffic'] else None
+
+    if rank == 0 and not args.no_roofline:
+        if args.mode == 'train':
+            rf, hbm, summ = roofline_of('train', lambda: train_step(reduce=False), args.steps, ms, True)
+            if world == 1 and not args.no_graph and not args.no_pmc:
+                apply_pmc(rf, 'train', garena.numel())
+            out['roofline'] = rf
+            if hbm:
+                out['roofline_hbm'] = hbm
             out['kernel_breakdown_ms'] = {k: round(v['ms'], 3) for k, v in
                                           sorted(summ.items(), key=lambda kv: -kv[1]['ms'])}
-        if rank == 0 and world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(cfg, args.mode) if args.config == 'clevrtex128' else None
+            if not skip_sample:
+                model.eval()
+                rfs, _, _ = roofline_of('sample', sample_step, n_s, 1e3 * dt_s / n_s, False)
+                model.train()
+                out['denoise']['roofline'] = rfs
+        else:
+            model.eval()
+            rf, hbm, summ = roofline_of('sample', sample_step, n_s, ms, True)
+            if world == 1 and not args.no_graph and not args.no_pmc:
+                apply_pmc(rf, 'sample', 0)
+            out['roofline'] = rf
+            if hbm:
+                out['roofline_hbm'] = hbm
+            out['kernel_breakdown_ms'] = {k: round(v['ms'], 3) for k, v in
+                                          sorted(summ.items(), key=lambda kv: -kv[1]['ms'])}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out['cpu_baseline'] = cpu_baseline(model, cfg, args.mode) if args.config == 'clevrtex128' else None
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -140,6 +140,7 @@ class LDM(_Owned):
         r = self.root
         img, slots = data_dict['img'], data_dict[self.cond_stage_key]
         B = img.shape[0]
+        train_draw = bool(r.training and torch.is_grad_enabled())    # (read before the no_grad block below)
         with torch.no_grad():
             x0 = engine.vae_encode(r.K(), r._to_nhwc(img), r.ed, scale_factor=r.z_scale)
             tf = None
@@ -147,7 +148,7 @@ class LDM(_Owned):
                 # the reference's two draws (ldm.py:65-69) + the schedule gathers in ONE launch of
                 # the counter-based generator (keyed on the run seed and the per-step seed word, so a
                 # graph replay draws new values); explicit t / noise (fixtures) take the path below
-                t, tf, ca, cb, nz = self._draw_tn(B, x0.shape[1], x0.shape[2], img.device)
+                t, tf, ca, cb, nz = self._draw_tn(B, x0.shape[1], x0.shape[2], img.device, train=train_draw)
             else:
                 if t is None:
                     t = torch.randint(0, self.num_timesteps, (B,), device=img.device).long()
@@ -174,7 +175,7 @@ class LDM(_Owned):
                 loss = (ops.mse(pred, gt) * (4.0 / 3.0)).reshape(())
         return {'denoise_loss': loss}
 
-    def _draw_tn(self, B, h, w, device):
+    def _draw_tn(self, B, h, w, device, train=None):
         r = self.root
         hw = h * w
         t = torch.empty((B,), dtype=torch.int64, device=device)
@@ -182,7 +183,9 @@ class LDM(_Owned):
         nz = torch.empty((B, hw, 4), dtype=torch.float32, device=device)
         st = torch.cuda.current_stream().cuda_stream
         salt = 17
-        if r.training and torch.is_grad_enabled():
+        if train is None:
+            train = bool(r.training and torch.is_grad_enabled())
+        if train:
             # training forward: `_begin_train_forward` advanced the step's seed word already
             seed_dev = getattr(r, 'step_seed', None)
         else:

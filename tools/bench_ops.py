@@ -10,7 +10,7 @@ from slotdiffusion_amd import _lib
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 SKIP = ('sdmi_igemm', 'sdmi_wgrad', 'sdmi_pack_dgrad', 'sdmi_pack_dgrad_batch')
 REPS = 20
-model, cfg = bench.build_model(torch.bfloat16)
+model, cfg, _ = bench.build_model(torch.bfloat16)
 model = model.cuda()
 model.train()
 model.bank().overlap_wgrad = False

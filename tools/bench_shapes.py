@@ -11,7 +11,7 @@ mode = sys.argv[1] if len(sys.argv) > 1 else 'unet'
 dtype = torch.bfloat16
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 REPS = 20
-model, cfg = bench.build_model(dtype)
+model, cfg, _ = bench.build_model(dtype)
 model = model.cuda()
 model.use_graph = False
 recs = []

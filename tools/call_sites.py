@@ -25,7 +25,7 @@ def spy(fname, stream, **kw):
 
 
 _lib._call = spy
-model, cfg = bench.build_model(torch.bfloat16)
+model, cfg, _ = bench.build_model(torch.bfloat16)
 model = model.cuda().train()
 model.use_graph = False
 img = bench.synth_batch(64, 0, 'cuda')

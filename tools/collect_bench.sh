@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round bench lines on the GPU box (outputs under gpurun_out/bench_<tag>/, copy into profiles/).
-# usage: bash tools/collect_bench.sh r02
-TAG=${1:-r02}
+# usage: bash tools/collect_bench.sh r03
+TAG=${1:-r03}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/bench_$TAG
 mkdir -p $O
@@ -15,5 +15,7 @@ timeout 600 python bench.py --mode sample --dtype fp8 --no-cpu-baseline 2> $O/sa
 timeout 600 python bench.py --config coco224 --mode sample --dtype bf16 --no-cpu-baseline 2> $O/coco_bf16.err | last > $O/${TAG}_bench_coco_bf16.json
 timeout 600 python bench.py --config coco224 --mode sample --dtype fp8 --no-cpu-baseline 2> $O/coco_fp8.err | last > $O/${TAG}_bench_coco_fp8.json
 timeout 600 python bench.py --config coco224 --mode train --no-cpu-baseline 2> $O/coco_train.err | last > $O/${TAG}_bench_coco_train.json
-timeout 600 python tools/bench_video.py 2> $O/video.err | last > $O/${TAG}_bench_video_1gpu.json
+# the video configurations (BASELINE configs[2] / [3]) through the same contract
+timeout 900 python bench.py --config movid11x6 --no-cpu-baseline --no-pmc 2> $O/movid.err | last > $O/${TAG}_bench_movid11x6.json
+timeout 900 python bench.py --config movie15x6 --no-cpu-baseline --no-pmc 2> $O/movie.err | last > $O/${TAG}_bench_movie15x6.json
 wc -c $O/*.json

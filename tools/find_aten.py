@@ -49,7 +49,7 @@ for n in ('zero_', 'fill_', 'add_', 'mul_', 'copy_', 'clone', 'float', 'long', '
     wrap(T, n, c)
 wrap(T, 'contiguous', lambda self, *a, **k: self.is_cuda and not self.is_contiguous(), 'contiguous(copy)')
 
-model, cfg = bench.build_model(torch.bfloat16)
+model, cfg, _ = bench.build_model(torch.bfloat16)
 model = model.cuda().train()
 model.use_graph = False
 from slotdiffusion_amd.optim import FusedAdam

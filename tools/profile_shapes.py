@@ -8,7 +8,7 @@ from slotdiffusion_amd import _lib, ops
 
 dtype = torch.bfloat16 if (len(sys.argv) < 2 or sys.argv[1] == 'bf16') else torch.float32
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 64
-model, cfg = bench.build_model(dtype)
+model, cfg, _ = bench.build_model(dtype)
 model = model.cuda().eval()
 model.use_graph = False
 recs = []

@@ -16,7 +16,7 @@ B = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 TOP = int(sys.argv[3]) if len(sys.argv) > 3 else 90
 REPS = 20
 dtype = torch.bfloat16
-model, cfg = bench.build_model(dtype)
+model, cfg, _ = bench.build_model(dtype)
 model = model.cuda()
 model.use_graph = False
 model.bank().overlap_wgrad = False
