@@ -201,7 +201,8 @@ def replayed_trace(argv, steps, mode):
     import csv
     import glob
     import shutil
-    flags = ['--mark', '--no-roofline', '--no-cpu-baseline', '--big-batch', '0', '--mode', mode]
+    flags = ['--mark', '--no-roofline', '--no-cpu-baseline', '--big-batch', '0', '--mode', mode,
+             '--steps', str(steps)]          # (the last occurrence of a flag wins)
     if mode == 'train':
         flags.append('--only-train')
     d, note = _rocprof_child([], argv, flags)
@@ -278,6 +279,7 @@ def pmc_pass(argv, mode):
                 if lo < did < hi:
                     e = per_kernel.setdefault(kernel_base_name(k), {})
                     e[c] = e.get(c, 0.0) + v
+                    e['_max_' + c] = max(e.get('_max_' + c, 0.0), v)      # largest single dispatch
                     e.setdefault('_ids_' + c, set()).add(did)
         except Exception as e:          # noqa: BLE001
             notes.append(f'{"+".join(counters)}: {type(e).__name__}: {e}')
@@ -535,15 +537,21 @@ def main():
             t_ms = sum(trace[k][1] for k in FAMILIES[entry] if k in trace)
             n = sum(trace[k][0] for k in FAMILIES[entry] if k in trace)
             return t_ms, n
-        ig = summ['sdmi_igemm']
-        ig_flops = ig['flops'] + summ.get('sdmi_bwd_pair', {}).get('flops_dgrad', 0.0)
+        # the igemm family = sdmi_igemm launches + the fused data / weight gradient launches (sdmi_bwd_pair:
+        # igemm's tile body + the weight-gradient body in one kernel; its flops count both gradients)
+        pr = summ.get('sdmi_bwd_pair', {})
+        ig = {k: summ['sdmi_igemm'].get(k, 0.0) + pr.get(k, 0.0) for k in ('calls', 'ms', 'flops', 'bytes')}
+        ig_flops = ig['flops']
         ig_ms, ig_kernels = fam_ms('sdmi_igemm')
+        if trace is None:
+            ig_ms = ig['ms']
         ach = ig_flops / (ig_ms * 1e-3) / 1e12
         wg = summ.get('sdmi_wgrad', {})
         fam_flops = ig_flops + wg.get('flops', 0.0)
         fam_time = ig_ms + (fam_ms('sdmi_wgrad')[0] if wg else 0.0)
         rf = {
-            'bound': 'mfma', 'kernel': 'igemm family (sdmi_igemm: implicit-GEMM conv/linear fwd + dgrad): '
+            'bound': 'mfma', 'kernel': 'igemm family (sdmi_igemm: implicit-GEMM conv/linear fwd + dgrad; sdmi_bwd_pair: '
+                                       'dgrad + wgrad of a layer in one launch): '
                                        + ', '.join(FAMILIES['sdmi_igemm']),
             'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak,
             'timing_source': tnote if trace is not None else f'eager HIP-event pass (fallback: {tnote})',
@@ -596,11 +604,11 @@ def main():
         # known-bytes kernels of the same step (units of the counters: KiB)
         fill = pk.get('__amd_rocclr_fillBufferAligned')
         sq = pk.get('sqsum_kernel')
-        if fill and fill.get('WRITE_SIZE') and n_known:
-            cal['write_scale'] = (n_known * 4.0 / 1024.0) / (fill['WRITE_SIZE'] / max(1, len(fill['_ids_WRITE_SIZE']))
-                                                              ) if fill['WRITE_SIZE'] else None
-        if sq and sq.get('FETCH_SIZE') and n_known:
-            cal['fetch_scale'] = (n_known * 4.0 / 1024.0) / (sq['FETCH_SIZE'] / max(1, len(sq['_ids_FETCH_SIZE'])))
+        # (the step has several fills / one sqsum: the known-size one is the largest dispatch)
+        if fill and fill.get('_max_WRITE_SIZE') and n_known:
+            cal['write_scale'] = (n_known * 4.0 / 1024.0) / fill['_max_WRITE_SIZE']
+        if sq and sq.get('_max_FETCH_SIZE') and n_known:
+            cal['fetch_scale'] = (n_known * 4.0 / 1024.0) / sq['_max_FETCH_SIZE']
         fs = cal.get('fetch_scale') or 2.0       # guide: FETCH_SIZE reads 1/2 of a wide coalesced stream
         wsc = cal.get('write_scale') or 1.0
         if tot('FETCH_SIZE') or tot('WRITE_SIZE'):

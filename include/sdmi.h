@@ -149,6 +149,28 @@ typedef struct { const void* problems; int n; } SdmiWgradGroupArgs;
 int sdmi_wgrad_group(const SdmiWgradGroupArgs* a, void* stream);
 int sdmi_wgrad_fold_group(const SdmiWgradGroupArgs* a, void* stream);
 
+/* Data gradient AND weight gradient of one conv / linear layer in ONE launch (bf16) -- the backward of
+ * unet.py:271-285 (ResBlock convolutions), attention.py:182-206, 247-251 (Linear layers),
+ * slot_attention.py:57-106, as torch autograd runs it behind `loss.backward()` (ldm.py:59-83).
+ *   dgrad  HOST pointer to the SdmiGemmArgs of the data gradient exactly as sdmi_igemm would take it
+ *          (a = dY, w = the flipped operand, out = dX; alpha / bias / residual epilogue only; no split-K,
+ *          batch, sub-sampled output or fused epilogues; N > 64);
+ *   wgrad  HOST pointer to the SdmiWgradArgs of the weight gradient as sdmi_wgrad would take it (N > 64,
+ *          K > 64; 1x1 / linear, or a stride-1 same-size convolution on a power-of-two image; splits > 1
+ *          leaves the M-split partials in `workspace` -- see `fold`);
+ *   fold   optional HOST pointer to the SdmiWgradArgs of an EARLIER launch whose partials are complete
+ *          (dw, dbias, workspace, N, K, splits, accumulate are read): folded into its dw / dbias by extra
+ *          workgroups of this launch, in split order (bit-identical to sdmi_wgrad's own fold).  Must not
+ *          target this launch's dw / dbias.  The last layer's partials are folded with
+ *          sdmi_wgrad_fold_group.
+ *   dgrad_cap  workgroups that walk the data-gradient tiles (0: what is left of two per CU).
+ * Results equal sdmi_igemm + sdmi_wgrad bit for bit (same tile bodies, same split order). */
+typedef struct {
+  const void* dgrad; const void* wgrad; const void* fold;
+  int dgrad_cap;
+} SdmiBwdPairArgs;
+int sdmi_bwd_pair(const SdmiBwdPairArgs* a, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * GroupNorm (+ fused activation) on NHWC, statistics in fp32.
  * Replaces GroupNorm32/Normalize + SiLU/ReLU/swish: unet/utils.py:120-139, unet.py:219-222,

@@ -128,8 +128,9 @@ class KernelTimer:
             d = out.setdefault(name, dict(calls=0, ms=0.0, flops=0.0, bytes=0.0))
             d['calls'] += 1
             d['ms'] += e0.elapsed_time(e1)
-            d['flops'] += meta.get('flops', 0.0)
-            d['bytes'] += meta.get('bytes', 0.0)
+            for k, v in meta.items():               # flops / bytes (+ entry-specific splits of them)
+                if isinstance(v, (int, float)):
+                    d[k] = d.get(k, 0.0) + v
         return out
 
 

@@ -6,7 +6,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 OUT = os.path.join(HERE, '..', 'libsdmi.so')
-SOURCES = ['api.cpp', 'igemm.hip', 'wgrad.hip', 'norm.hip', 'norm_bwd.hip', 'attention.hip',
+SOURCES = ['api.cpp', 'igemm.hip', 'wgrad.hip', 'bwd_pair.hip', 'norm.hip', 'norm_bwd.hip', 'attention.hip',
            'attention_bwd.hip', 'slot_attn.hip', 'slot_attn_train.hip', 'bwd_misc.hip',
            'elementwise.hip', 'vq.hip', 'metrics.hip', 'vae_train.hip']
 EXTRA = {'vq.hip': ['-ffp-contract=off'], 'elementwise.hip': ['-ffp-contract=off']}
@@ -21,8 +21,8 @@ def _obj(src):
 def _stale(src, obj):
     if not os.path.exists(obj):
         return True
-    deps = [os.path.join(HERE, src), os.path.join(HERE, 'common.h'), os.path.join(HERE, 'gn_geom.h'),
-            os.path.join(HERE, '..', '..', 'include', 'sdmi.h')]
+    deps = [os.path.join(HERE, src), os.path.join(HERE, '..', '..', 'include', 'sdmi.h')] + \
+        [os.path.join(HERE, h) for h in os.listdir(HERE) if h.endswith('.h')]
     return any(os.path.getmtime(d) > os.path.getmtime(obj) for d in deps)
 
 

@@ -114,6 +114,14 @@ class WeightBank:
         self.group_wgrad = os.environ.get('SDMI_WGRAD_GROUP', '0') != '0'
         self._wq, self._wq_keep, self._wq_items, self._wq_bytes = [], [], 0, 0
         self.defer_colsum = os.environ.get('SDMI_DEFER_COLSUM', '1') != '0'
+        # data gradient + weight gradient of a layer in ONE launch on the main stream (sdmi_bwd_pair):
+        # no side-stream fork / join per layer, the M-split partials of a layer are folded by extra
+        # workgroups of the NEXT layer's launch (`_pfold`: the pending fold), the last one at the join
+        self.pair_bwd = os.environ.get('SDMI_BWD_PAIR', '1') != '0'
+        self.pair_slots = int(os.environ.get('SDMI_PAIR_SLOTS', '512'))       # resident workgroups (2 per CU)
+        self.pair_dgrad = int(os.environ.get('SDMI_PAIR_DGRAD', '256'))       # of which walk dX tiles
+        self.pair_min_steps = int(os.environ.get('SDMI_PAIR_MIN_STEPS', '8'))  # 64-row steps per wgrad workgroup
+        self._pfold = None
         # dgrad operands: key -> [buffer, epoch, (stable source view | None, geometry)]
         self._wd, self._wd_epoch, self._wd_stale, self._wd_table = {}, 0, False, None
 
@@ -270,7 +278,64 @@ class WeightBank:
             call('sdmi_colsum_group', _st(), items=ctypes.addressof(arr), n=len(chunk))
         # (the partial buffers die with q: the launches above are ordered before their reuse)
 
+    # ---- fused data + weight gradient launches --------------------------------------------------
+    def flush_pending_fold(self, dst_ptrs=None):
+        """Fold the pending M-split partials now (own launch).  dst_ptrs given: only when the pending
+        fold targets one of these gradient buffers (a parameter used again before its fold ran)."""
+        pf = self._pfold
+        if pf is None:
+            return
+        if dst_ptrs is not None and pf[0]['dw'] not in dst_ptrs and (not pf[0]['dbias'] or pf[0]['dbias'] not in dst_ptrs):
+            return
+        self._pfold = None
+        import ctypes
+        arr = (_lib.CSTRUCT['SdmiWgradArgs'] * 1)()
+        for k, v in pf[0].items():
+            setattr(arr[0], k, v)
+        call('sdmi_wgrad_fold_group', _st(), problems=ctypes.addressof(arr), n=1)
+
+    def pair_launch(self, dkw, wkw, keep):
+        """One sdmi_bwd_pair launch: dkw / wkw are the sdmi_igemm / sdmi_wgrad fields of the layer's data
+        and weight gradient; M-split chosen here (the weight-gradient workgroups take what the data
+        gradient leaves of `pair_slots` resident workgroups, >= pair_min_steps 64-row steps each)."""
+        import ctypes
+        M, N, K = wkw['M'], wkw['N'], wkw['K']
+        tiles_w = ((N + 127) // 128) * ((K + 127) // 128) + (((N + 127) // 128) if wkw['dbias'] else 0)
+        t128 = ((dkw['M'] + 127) // 128) * ((dkw['N'] + 127) // 128)
+        shallow = dkw['KH'] == 1 and dkw['KW'] == 1 and dkw['K'] * 2 <= 512
+        tiles_d = t128 if (t128 >= 192 and not shallow) else ((dkw['M'] + 63) // 64) * ((dkw['N'] + 63) // 64)
+        n_d = min(tiles_d, self.pair_dgrad)
+        steps = (M + 63) // 64
+        splits = max(1, min((self.pair_slots - n_d) // tiles_w, steps // self.pair_min_steps, 256))
+        self.flush_pending_fold((wkw['dw'], wkw['dbias']))      # this parameter again: fold first
+        ws = None
+        if splits > 1:
+            ws = torch.empty((splits * (N * K + N),), dtype=torch.float32, device=keep[0].device)
+        S = _lib.CSTRUCT
+        d, w, f = S['SdmiGemmArgs'](), S['SdmiWgradArgs'](), S['SdmiWgradArgs']()
+        for k, v in dkw.items():
+            setattr(d, k, v)
+        for k, v in wkw.items():
+            setattr(w, k, v)
+        w.splits, w.workspace, w.defer_fold = splits, _p(ws), 1
+        pf, self._pfold = self._pfold, None
+        if pf is not None:
+            for k, v in pf[0].items():
+                setattr(f, k, v)
+        call('sdmi_bwd_pair', _st(), dgrad=ctypes.addressof(d), wgrad=ctypes.addressof(w),
+             fold=(ctypes.addressof(f) if pf is not None else 0), dgrad_cap=((n_d + 7) // 8 * 8),
+             _meta=dict(flops=2.0 * dkw['M'] * dkw['N'] * dkw['K'] + 2.0 * M * N * K,
+                        flops_dgrad=2.0 * dkw['M'] * dkw['N'] * dkw['K'],
+                        bytes=float(2 * (dkw['M'] * dkw['K'] // (dkw['KH'] * dkw['KW']) + dkw['N'] * dkw['K']
+                                         + dkw['M'] * dkw['N'] * (2 if dkw.get('residual', 0) else 1)
+                                         + M * wkw['Cin']) + 4 * N * K)))
+        if splits > 1:            # folded by the next pair launch (or at the join)
+            self._pfold = (dict(dw=wkw['dw'], dbias=wkw['dbias'], workspace=_p(ws), N=N, K=K, splits=splits,
+                                accumulate=wkw['accumulate']), ws)
+            self.ensure_join()
+
     def join(self):
+        self.flush_pending_fold()
         self.flush_wgrad()
         self.flush_colsum()
         for side in self._sides:
@@ -965,6 +1030,33 @@ class GemmFn(torch.autograd.Function):
         elif os.environ.get('SDMI_EXP_SKIP_WGRAD') == '1':
             pass            # measurement only (wrong gradients): the step without weight gradients
         else:
+            # ---- data + weight gradient in ONE launch (sdmi_bwd_pair) when both are of the same loader
+            # class: 1x1 / linear, or a stride-1 same-size convolution on a power-of-two image
+            same = is_conv and stride == 1 and not ups and Ho == H and Wo == W_
+            pow2 = (H & (H - 1)) == 0 and (W_ & (W_ - 1)) == 0
+            one = kh == 1 and kw == 1 and stride == 1 and not ups and pad[0] == 0 and pad[2] == 0
+            kd = kh * kw * ldy                                   # contraction depth of the data gradient
+            bk = 64 if kd * 2 >= 512 else 32
+            pair = (wb.pair_bwd and need_dx and dt == torch.bfloat16 and direct and N > 64 and K > 64 and Cin > 64
+                    and (bnames is None or bdst is not None) and Cin % 8 == 0 and ldy % 8 == 0
+                    and (one or (same and pow2 and kh * kw <= 32 and ldy % bk == 0
+                                 and pad[0] == pad[1] == (kh - 1) // 2 and pad[2] == pad[3] == (kw - 1) // 2))
+                    and (dalias is None or dalias.shape[-1] == Cin)
+                    and (M + (kh + 1) * W_ + 128) * max(lda, ldy, Cin) * 2 < (1 << 31) and N * kd * 2 < (1 << 31))
+            if pair:
+                wd = wb.wd(wnames, dt, kh, kw, Cin)
+                dx = torch.empty(x.shape if not is_conv else (B, H, W_, Cin), dtype=dt, device=x.device)
+                wb.pair_launch(
+                    dict(a=_p(dy), w=_p(wd), out=_p(dx), dtype=_DT[dt], out_dtype=_DT[dt], M=M, N=Cin, K=kd,
+                         lda=ldy, ldw=kd, ldc=Cin, B=B, H=Ho, W=Wo, Cin=ldy, Ho=H, Wo=W_, KH=kh, KW=kw, stride=1,
+                         pad_t=kh - 1 - pad[0], pad_l=kw - 1 - pad[2], ups=0, act=0, alpha=1.0, split_k=1, batch=1,
+                         residual=_p(dalias), ldr=Cin),
+                    dict(a=_p(x), dy=_p(dy), dw=_p(dst), dbias=_p(bdst), dtype=_DT[dt], M=M, N=N, K=K, lda=lda,
+                         ldy=ldy, B=B, H=H, W=W_, Cin=Cin, Ho=Ho, Wo=Wo, KH=kh, KW=kw, stride=stride,
+                         pad_t=pad[0], pad_l=pad[2], ups=0, accumulate=1),
+                    (x, dy, dx))
+                return dx, dy, (N, ldy, B, Ho, Wo, dt)
+            wb.flush_pending_fold((_p(dst), _p(bdst)))     # (a pending fold into this parameter goes first)
             side = wb.side_stream(names[0])
             if side is not None and 2.0 * M * N * K < _WG_MAIN_BELOW:
                 side = None                  # small contraction: not worth a cross-stream edge

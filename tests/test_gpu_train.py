@@ -630,6 +630,155 @@ def test_wgrad_group_matches_single_launches():
         _lib.call('sdmi_wgrad_group', st, problems=ctypes.addressof(bad), n=1)
 
 
+@pytest.mark.parametrize('case', [
+    # (B, H, Cin, Cout, k, bias, residual, splits)   H = 0: linear with B rows
+    (1024, 0, 512, 512, 1, True, False, 1), (1000, 0, 384, 1536, 1, False, True, 3),
+    (16384, 0, 256, 256, 1, True, True, 16), (448, 0, 192, 576, 1, True, False, 1),
+    (4, 16, 128, 256, 3, True, True, 2), (2, 32, 128, 128, 3, True, False, 4),
+    (8, 8, 384, 384, 3, False, True, 1), (3, 16, 256, 192, 1, True, False, 2),
+    (64, 4, 512, 512, 3, True, False, 1)])
+def test_bwd_pair_matches_separate_launches(case):
+    """sdmi_bwd_pair: data gradient + weight gradient (+ the fold of an earlier layer's M-split partials)
+    in ONE launch equal sdmi_igemm + sdmi_wgrad (+ its fold) bit for bit, and torch's fp32 gradients
+    within bf16 tolerance.  Linear and 3x3 / 1x1 convolutions, ragged M, bias gradient, residual in the
+    data gradient's epilogue, splits 1 ... 16, chained folds, accumulation into existing gradients."""
+    import ctypes
+    from slotdiffusion_amd import _lib
+    B, H, Cin, Cout, k, bias, res, splits = case
+    g = torch.Generator().manual_seed(sum(case[:5]) + splits)
+    st = torch.cuda.current_stream().cuda_stream
+    conv = H > 0
+    M = B * H * H if conv else B
+    K = k * k * Cin
+    pad = (k - 1) // 2
+    xf = torch.randn(M, Cin, generator=g).bfloat16()
+    wf = (torch.randn(Cout, K, generator=g) / math.sqrt(K)).bfloat16()           # [Cout][kh][kw][Cin]
+    dyf = (torch.randn(M, Cout, generator=g) / 8).bfloat16()
+    rf = torch.randn(M, Cin, generator=g).bfloat16() if res else None
+    x, w, dy = xf.cuda(), wf.cuda(), dyf.cuda()
+    r = rf.cuda() if res else None
+    wd = torch.zeros(Cin * k * k, Cout, dtype=torch.bfloat16, device='cuda')
+    _lib.call('sdmi_pack_dgrad', st, src=w.data_ptr(), dst=wd.data_ptr(), dtype=_lib.BF16, Cout=Cout, KH=k, KW=k,
+              Cin=Cin, CoutPad=Cout)
+    Hh = H if conv else 1
+    Bb = B if conv else M
+    init = torch.randn(Cout, K, generator=g).cuda()
+    binit = torch.randn(Cout, generator=g).cuda()
+
+    def dkw(out):
+        return dict(a=dy.data_ptr(), w=wd.data_ptr(), out=out.data_ptr(), dtype=_lib.BF16, out_dtype=_lib.BF16,
+                    M=M, N=Cin, K=k * k * Cout, lda=Cout, ldw=k * k * Cout, ldc=Cin, B=Bb, H=Hh, W=Hh, Cin=Cout,
+                    Ho=Hh, Wo=Hh, KH=k, KW=k, stride=1, pad_t=k - 1 - pad, pad_l=k - 1 - pad, ups=0, act=0,
+                    alpha=1.0, split_k=1, batch=1, residual=(r.data_ptr() if res else 0), ldr=Cin)
+
+    def wkw(dw, db, ws, sp):
+        return dict(a=x.data_ptr(), dy=dy.data_ptr(), dw=dw.data_ptr(), dbias=(db.data_ptr() if bias else 0),
+                    workspace=ws.data_ptr(), dtype=_lib.BF16, M=M, N=Cout, K=K, lda=Cin, ldy=Cout, B=Bb, H=Hh,
+                    W=Hh, Cin=Cin, Ho=Hh, Wo=Hh, KH=k, KW=k, stride=1, pad_t=pad, pad_l=pad, ups=0, splits=sp,
+                    accumulate=1)
+    # ---- separate launches
+    dx0 = torch.empty(M, Cin, dtype=torch.bfloat16, device='cuda')
+    dw0, db0 = init.clone(), binit.clone()
+    ws0 = torch.empty(splits * (Cout * K + Cout), device='cuda')
+    _lib.call('sdmi_igemm', st, **dkw(dx0))
+    _lib.call('sdmi_wgrad', st, **wkw(dw0, db0, ws0, splits))
+    # ---- one launch (+ a second pair launch that folds the first one's partials, + the final fold)
+    S = _lib.CSTRUCT
+
+    def pair(dx, dw, db, ws, sp, fold):
+        d, wg = S['SdmiGemmArgs'](), S['SdmiWgradArgs']()
+        for kk, v in dkw(dx).items():
+            setattr(d, kk, v)
+        for kk, v in wkw(dw, db, ws, sp).items():
+            setattr(wg, kk, v)
+        wg.defer_fold = 1
+        f = None
+        if fold is not None:
+            f = S['SdmiWgradArgs']()
+            for kk, v in fold.items():
+                setattr(f, kk, v)
+        _lib.call('sdmi_bwd_pair', st, dgrad=ctypes.addressof(d), wgrad=ctypes.addressof(wg),
+                  fold=(ctypes.addressof(f) if f is not None else 0), dgrad_cap=0)
+    dx1 = torch.empty_like(dx0)
+    dw1, db1 = init.clone(), binit.clone()
+    ws1 = torch.empty_like(ws0)
+    pair(dx1, dw1, db1, ws1, splits, None)
+    fold1 = dict(dw=dw1.data_ptr(), dbias=(db1.data_ptr() if bias else 0), workspace=ws1.data_ptr(), N=Cout, K=K,
+                 splits=splits, accumulate=1) if splits > 1 else None
+    # second "layer" (same operands, other destinations) whose launch folds the first one's partials
+    dx2 = torch.empty_like(dx0)
+    dw2, db2 = init.clone(), binit.clone()
+    ws2 = torch.empty_like(ws0)
+    pair(dx2, dw2, db2, ws2, splits, fold1)
+    if splits > 1:
+        arr = (S['SdmiWgradArgs'] * 1)()
+        for kk, v in dict(dw=dw2.data_ptr(), dbias=(db2.data_ptr() if bias else 0), workspace=ws2.data_ptr(), N=Cout,
+                          K=K, splits=splits, accumulate=1).items():
+            setattr(arr[0], kk, v)
+        _lib.call('sdmi_wgrad_fold_group', st, problems=ctypes.addressof(arr), n=1)
+    torch.cuda.synchronize()
+    for dxp, dwp, dbp in ((dx1, dw1, db1), (dx2, dw2, db2)):
+        assert torch.equal(dxp, dx0), case
+        assert torch.equal(dwp, dw0), case
+        if bias:
+            assert torch.equal(dbp, db0), case
+    # ---- and the numbers themselves (torch fp32 on the bf16-rounded operands)
+    if conv:
+        x4 = xf.float().view(B, H, H, Cin).permute(0, 3, 1, 2).requires_grad_(True)
+        w4 = wf.float().view(Cout, k, k, Cin).permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+        y = F.conv2d(x4, w4, None, padding=pad)
+        y.backward(dyf.float().view(B, H, H, Cout).permute(0, 3, 1, 2))
+        ref_dx = x4.grad.permute(0, 2, 3, 1).reshape(M, Cin)
+        ref_dw = w4.grad.permute(0, 2, 3, 1).reshape(Cout, K)
+    else:
+        ref_dx = dyf.float() @ wf.float()
+        ref_dw = dyf.float().t() @ xf.float()
+    if res:
+        ref_dx = ref_dx + rf.float()
+    assert float((dx1.float().cpu() - ref_dx).norm() / ref_dx.norm()) < 1e-2, case
+    assert float((dw1.cpu() - init.cpu() - ref_dw).norm() / ref_dw.norm()) < 3e-3, case
+    if bias:
+        rb = dyf.float().sum(0)
+        assert float((db1.cpu() - binit.cpu() - rb).norm() / rb.norm()) < 3e-3, case
+    # argument validation: narrow outputs / mismatched loader classes are refused without a launch
+    d, wg = S['SdmiGemmArgs'](), S['SdmiWgradArgs']()
+    for kk, v in dict(dkw(dx1), N=32).items():
+        setattr(d, kk, v)
+    for kk, v in wkw(dw1, db1, ws1, 1).items():
+        setattr(wg, kk, v)
+    with pytest.raises(_lib.SdmiError):
+        _lib.call('sdmi_bwd_pair', st, dgrad=ctypes.addressof(d), wgrad=ctypes.addressof(wg), fold=0, dgrad_cap=0)
+
+
+def test_pair_backward_equals_side_stream_backward():
+    """The train step's backward with the fused data / weight gradient launches (sdmi_bwd_pair, the
+    default) against the same step with separate launches on side streams (pair_bwd = False): the
+    gradients of the bf16 model agree to fp32 summation-order noise (the tile bodies are the same, the
+    M-splits of the weight gradients differ), and the pair path replaces most igemm + wgrad launch pairs."""
+    from slotdiffusion_amd._lib import KernelTimer
+    G = C.load_golden()
+    img = C.make_inputs(2)[0].cuda()
+    arenas, launches = [], []
+    m = _model(torch.bfloat16)
+    for pair in (True, False):
+        m.bank().pair_bwd = pair
+        _train_backward(m, G, img)                 # warm-up (lazy operands)
+        with KernelTimer() as kt:
+            _train_backward(m, G, img)
+        summ = kt.summary()
+        torch.cuda.synchronize()
+        arenas.append(m.grad_arena().clone())
+        launches.append({k: v['calls'] for k, v in summ.items() if k in ('sdmi_igemm', 'sdmi_wgrad', 'sdmi_bwd_pair')})
+    m.bank().pair_bwd = True
+    REPORT['pair_bwd_launches'] = launches
+    a, b = arenas
+    rel = float((a - b).norm() / b.norm())
+    REPORT['pair_vs_side_grad_rel_l2'] = rel
+    _dump()
+    assert launches[0].get('sdmi_bwd_pair', 0) > 100 and launches[1].get('sdmi_bwd_pair', 0) == 0, launches
+    assert rel < 1e-5, rel
+
+
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 def test_layernorm_and_gemm_fanout(dtype):
     """LayerNormFn / GemmFn alias outputs: the residual branch's gradient is summed inside the
