@@ -164,10 +164,14 @@ int sdmi_wgrad_fold_group(const SdmiWgradGroupArgs* a, void* stream);
  *          target this launch's dw / dbias.  The last layer's partials are folded with
  *          sdmi_wgrad_fold_group.
  *   dgrad_cap  workgroups that walk the data-gradient tiles (0: what is left of two per CU).
- * Results equal sdmi_igemm + sdmi_wgrad bit for bit (same tile bodies, same split order). */
+ *   wgrad_tile 0 / 128: 128 x 128 output tiles of dW (sdmi_wgrad's choice); 64: 64 x 64 tiles for small
+ *              layers (only next to 64 x 64 data-gradient tiles) -- more, shorter workgroups.
+ * Results equal sdmi_igemm + sdmi_wgrad bit for bit with 128 x 128 tiles (same tile bodies, same split
+ * order); with 64 x 64 tiles every dW element is still one fp32 accumulation chain over its rows in m
+ * order, M-split partials folded in split order. */
 typedef struct {
   const void* dgrad; const void* wgrad; const void* fold;
-  int dgrad_cap;
+  int dgrad_cap, wgrad_tile;
 } SdmiBwdPairArgs;
 int sdmi_bwd_pair(const SdmiBwdPairArgs* a, void* stream);
 

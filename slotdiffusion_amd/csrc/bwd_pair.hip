@@ -32,9 +32,12 @@ struct PairGeom {
   int d_tiles_m, d_tiles_n, d_ktps, d_hw_shift;
 };
 
-constexpr int PAIR_WG_LDS = 2 * 64 * (128 * 2 + 64 + 128 * 2 + 64);     // wgrad_tr_body<128, 128>: 80 KB
+constexpr int pair_wg_lds(int wt) { return 2 * 64 * (wt * 2 + 64 + wt * 2 + 64); }   // wgrad_tr_body<WT, WT>: 80 / 48 KB
 
-template <int BM, int BN, int BKB, int MODE>
+// WT: output tile of the weight gradient, 128 (two workgroups per CU next to 128 x 128 data-gradient tiles)
+// or 64 for small layers: four times the workgroups per dW element, each a quarter of the MFMA work per
+// 64-row step, 48 KB of LDS (three workgroups per CU next to 64 x 64 data-gradient tiles).
+template <int BM, int BN, int BKB, int MODE, int WT>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void bwd_pair_kernel(
     SdmiGemmArgs d, SdmiWgradArgs w, SdmiWgradArgs f, PairGeom g) {
   const int b = (int)blockIdx.x;
@@ -45,7 +48,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   if (b < g.n_fold + g.n_wgrad) {
     const int idx = b - g.n_fold;
     const int split = idx / g.w_per_split;
-    wgrad_tr_body<128, 128, MODE>(w, g.w_tiles_n, g.w_tiles_k, g.w_mps, idx - split * g.w_per_split, split);
+    wgrad_tr_body<WT, WT, MODE>(w, g.w_tiles_n, g.w_tiles_k, g.w_mps, idx - split * g.w_per_split, split);
     return;
   }
   if (b < g.d_begin) return;          // padding up to a multiple of 8
@@ -53,13 +56,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                                         g.n_dgrad, 0);
 }
 
-template <int BM, int BN, int BKB, int MODE>
+template <int BM, int BN, int BKB, int MODE, int WT>
 int launch_pair(const SdmiGemmArgs& d, const SdmiWgradArgs& w, const SdmiWgradArgs* f, int dgrad_cap,
                 int hw_shift, hipStream_t st) {
   constexpr int BK = BKB / 2;
   constexpr int d_lds = 2 * (BM + BN) * (BKB + 16);
-  constexpr int smem = d_lds > PAIR_WG_LDS ? d_lds : PAIR_WG_LDS;
-  auto kern = bwd_pair_kernel<BM, BN, BKB, MODE>;
+  constexpr int smem = d_lds > pair_wg_lds(WT) ? d_lds : pair_wg_lds(WT);
+  auto kern = bwd_pair_kernel<BM, BN, BKB, MODE, WT>;
   SDMI_OPTIN_LDS(kern, smem, "bwd_pair");
   PairGeom g;
   SdmiWgradArgs fz = {};
@@ -71,8 +74,8 @@ int launch_pair(const SdmiGemmArgs& d, const SdmiWgradArgs& w, const SdmiWgradAr
   } else {
     g.n_fold = 0;
   }
-  g.w_tiles_n = (w.N + 127) / 128;
-  g.w_tiles_k = (w.K + 127) / 128;
+  g.w_tiles_n = (w.N + WT - 1) / WT;
+  g.w_tiles_k = (w.K + WT - 1) / WT;
   g.w_per_split = g.w_tiles_n * g.w_tiles_k + (w.dbias ? g.w_tiles_n : 0);
   int mps = (w.M + w.splits - 1) / w.splits;
   g.w_mps = (mps + 63) / 64 * 64;
@@ -83,8 +86,9 @@ int launch_pair(const SdmiGemmArgs& d, const SdmiWgradArgs& w, const SdmiWgradAr
   g.d_ktps = (d.K + BK - 1) / BK;
   g.d_hw_shift = hw_shift;
   const int tiles = g.d_tiles_m * g.d_tiles_n;
-  int cap = dgrad_cap > 0 ? dgrad_cap : 512 - g.d_begin;
-  cap = cap < 64 ? 64 : (cap > 512 ? 512 : cap);
+  constexpr int SLOTS = smem <= 49152 ? 768 : 512;       // resident workgroups (LDS: 3 or 2 per CU)
+  int cap = dgrad_cap > 0 ? dgrad_cap : SLOTS - g.d_begin;
+  cap = cap < 64 ? 64 : (cap > SLOTS ? SLOTS : cap);
   cap &= ~7;                             // a virtual block id keeps its XCD
   g.n_dgrad = tiles <= cap ? tiles : cap;
   SdmiGemmArgs q = d;
@@ -145,14 +149,20 @@ extern "C" int sdmi_bwd_pair(const SdmiBwdPairArgs* a, void* stream) {
   const int bk = (wide ? 128 : 64) / 2;
   if (!d1x1) SDMI_REQUIRE(d.KH * d.KW <= 32 && d.Cin % bk == 0, "convolution data gradient: K tiles must lie inside one filter tap");
   hipStream_t st = (hipStream_t)stream;
-#define PAIR_GO(BM, BN, BKB)                                                                           \
-  return d1x1 ? launch_pair<BM, BN, BKB, 1>(d, w, f, a->dgrad_cap, hw_shift, st)                        \
-              : launch_pair<BM, BN, BKB, 2>(d, w, f, a->dgrad_cap, hw_shift, st)
+  SDMI_REQUIRE(a->wgrad_tile == 0 || a->wgrad_tile == 128 || (a->wgrad_tile == 64 && !big),
+               "wgrad_tile: 128, or 64 next to 64 x 64 data-gradient tiles");
+#define PAIR_GO(BM, BN, BKB, WT)                                                                       \
+  return d1x1 ? launch_pair<BM, BN, BKB, 1, WT>(d, w, f, a->dgrad_cap, hw_shift, st)                    \
+              : launch_pair<BM, BN, BKB, 2, WT>(d, w, f, a->dgrad_cap, hw_shift, st)
   if (big) {
-    if (wide) PAIR_GO(128, 128, 128);
-    PAIR_GO(128, 128, 64);
+    if (wide) PAIR_GO(128, 128, 128, 128);
+    PAIR_GO(128, 128, 64, 128);
   }
-  if (wide) PAIR_GO(64, 64, 128);
-  PAIR_GO(64, 64, 64);
+  if (a->wgrad_tile == 64) {
+    if (wide) PAIR_GO(64, 64, 128, 64);
+    PAIR_GO(64, 64, 64, 64);
+  }
+  if (wide) PAIR_GO(64, 64, 128, 128);
+  PAIR_GO(64, 64, 64, 128);
 #undef PAIR_GO
 }

@@ -25,7 +25,7 @@
 #include <stdlib.h>
 
 #ifndef SDMI_IGEMM_DMA
-#define SDMI_IGEMM_DMA 0
+#define SDMI_IGEMM_DMA 3      // 0 off, 1 / 2 experiments (all eligible shapes), 3 the measured-faster shapes only
 #endif
 
 #include "igemm_body.h"
@@ -694,7 +694,14 @@ int dispatch(const SdmiGemmArgs& p, hipStream_t st) {
     }
     const bool dma_ok = sizeof(T) != 1 && !p.a2 && dma_env && wide && kbytes >= 8 * 128 && split_k == 1 && p.N > 64 && fits31 &&
                         (is1x1 || (plain && p.Cin % (128 / (int)sizeof(T)) == 0)) && p.KH * p.KW <= 32;
-    if (dma_ok) {
+    if (dma_ok && dma_env == 3) {
+      // default: the 4-stage 128 x 128 LDS-DMA kernel where it measured faster in dependent chains on MI355X
+      // (tools/exp/conv_chain.py, B = 64): about one tile per CU and a deep K -- the 16^2 level's 3x3
+      // convolutions, 30.0 -> 27.8 us (256 -> 256) and 50.4 -> 42.4 us (512 -> 256); neutral or slower elsewhere
+      const long long t256 = ((p.M + 255) / 256) * ((p.N + 127) / 128) * batch;
+      if (t128 >= 192 && t256 < 192 && kbytes >= 2048 * 2 && !is1x1)
+        return launch_dma<T, 128, 128, 4, 2>(p, hw_shift, st);
+    } else if (dma_ok) {
       const long long t256 = ((p.M + 255) / 256) * ((p.N + 127) / 128) * batch;
       if (t256 >= 192) {
         if (is1x1) return launch_dma<T, 256, 128, 3, 1>(p, hw_shift, st);

@@ -121,6 +121,7 @@ class WeightBank:
         self.pair_slots = int(os.environ.get('SDMI_PAIR_SLOTS', '512'))       # resident workgroups (2 per CU)
         self.pair_dgrad = int(os.environ.get('SDMI_PAIR_DGRAD', '256'))       # of which walk dX tiles
         self.pair_min_steps = int(os.environ.get('SDMI_PAIR_MIN_STEPS', '8'))  # 64-row steps per wgrad workgroup
+        self.pair_wt64 = int(os.environ.get('SDMI_PAIR_WT64_BELOW', '96'))     # 64 x 64 dW tiles below this many wgrad workgroups (0: never)
         self._pfold = None
         # dgrad operands: key -> [buffer, epoch, (stable source view | None, geometry)]
         self._wd, self._wd_epoch, self._wd_stale, self._wd_table = {}, 0, False, None
@@ -300,13 +301,23 @@ class WeightBank:
         gradient leaves of `pair_slots` resident workgroups, >= pair_min_steps 64-row steps each)."""
         import ctypes
         M, N, K = wkw['M'], wkw['N'], wkw['K']
-        tiles_w = ((N + 127) // 128) * ((K + 127) // 128) + (((N + 127) // 128) if wkw['dbias'] else 0)
         t128 = ((dkw['M'] + 127) // 128) * ((dkw['N'] + 127) // 128)
         shallow = dkw['KH'] == 1 and dkw['KW'] == 1 and dkw['K'] * 2 <= 512
-        tiles_d = t128 if (t128 >= 192 and not shallow) else ((dkw['M'] + 63) // 64) * ((dkw['N'] + 63) // 64)
-        n_d = min(tiles_d, self.pair_dgrad)
+        big = t128 >= 192 and not shallow
+        tiles_d = t128 if big else ((dkw['M'] + 63) // 64) * ((dkw['N'] + 63) // 64)
         steps = (M + 63) // 64
-        splits = max(1, min((self.pair_slots - n_d) // tiles_w, steps // self.pair_min_steps, 256))
+
+        def plan(wt, slots, min_steps):
+            tn = (N + wt - 1) // wt
+            tiles_w = tn * ((K + wt - 1) // wt) + (tn if wkw['dbias'] else 0)
+            n_d = min(tiles_d, self.pair_dgrad)
+            return tiles_w, n_d, max(1, min((slots - n_d) // tiles_w, steps // min_steps, 256))
+        wt = 128
+        tiles_w, n_d, splits = plan(128, self.pair_slots, self.pair_min_steps)
+        if not big and self.pair_wt64 and tiles_w * splits < self.pair_wt64:
+            # a small layer: 64 x 64 weight-gradient tiles -- four times the workgroups, three per CU
+            wt = 64
+            tiles_w, n_d, splits = plan(64, self.pair_slots * 3 // 2, max(2, self.pair_min_steps // 2))
         self.flush_pending_fold((wkw['dw'], wkw['dbias']))      # this parameter again: fold first
         ws = None
         if splits > 1:
@@ -323,7 +334,7 @@ class WeightBank:
             for k, v in pf[0].items():
                 setattr(f, k, v)
         call('sdmi_bwd_pair', _st(), dgrad=ctypes.addressof(d), wgrad=ctypes.addressof(w),
-             fold=(ctypes.addressof(f) if pf is not None else 0), dgrad_cap=((n_d + 7) // 8 * 8),
+             fold=(ctypes.addressof(f) if pf is not None else 0), dgrad_cap=((n_d + 7) // 8 * 8), wgrad_tile=wt,
              _meta=dict(flops=2.0 * dkw['M'] * dkw['N'] * dkw['K'] + 2.0 * M * N * K,
                         flops_dgrad=2.0 * dkw['M'] * dkw['N'] * dkw['K'],
                         bytes=float(2 * (dkw['M'] * dkw['K'] // (dkw['KH'] * dkw['KW']) + dkw['N'] * dkw['K']

@@ -685,7 +685,7 @@ def test_bwd_pair_matches_separate_launches(case):
     # ---- one launch (+ a second pair launch that folds the first one's partials, + the final fold)
     S = _lib.CSTRUCT
 
-    def pair(dx, dw, db, ws, sp, fold):
+    def pair(dx, dw, db, ws, sp, fold, wt=0):
         d, wg = S['SdmiGemmArgs'](), S['SdmiWgradArgs']()
         for kk, v in dkw(dx).items():
             setattr(d, kk, v)
@@ -698,18 +698,19 @@ def test_bwd_pair_matches_separate_launches(case):
             for kk, v in fold.items():
                 setattr(f, kk, v)
         _lib.call('sdmi_bwd_pair', st, dgrad=ctypes.addressof(d), wgrad=ctypes.addressof(wg),
-                  fold=(ctypes.addressof(f) if f is not None else 0), dgrad_cap=0)
+                  fold=(ctypes.addressof(f) if f is not None else 0), dgrad_cap=0, wgrad_tile=wt)
     dx1 = torch.empty_like(dx0)
     dw1, db1 = init.clone(), binit.clone()
     ws1 = torch.empty_like(ws0)
     pair(dx1, dw1, db1, ws1, splits, None)
     fold1 = dict(dw=dw1.data_ptr(), dbias=(db1.data_ptr() if bias else 0), workspace=ws1.data_ptr(), N=Cout, K=K,
                  splits=splits, accumulate=1) if splits > 1 else None
-    # second "layer" (same operands, other destinations) whose launch folds the first one's partials
+    # second "layer" (same operands, other destinations) whose launch folds the first one's partials; its
+    # own weight gradient on 64 x 64 tiles (every dW element is the same accumulation chain: still bit-exact)
     dx2 = torch.empty_like(dx0)
     dw2, db2 = init.clone(), binit.clone()
     ws2 = torch.empty_like(ws0)
-    pair(dx2, dw2, db2, ws2, splits, fold1)
+    pair(dx2, dw2, db2, ws2, splits, fold1, wt=64)
     if splits > 1:
         arr = (S['SdmiWgradArgs'] * 1)()
         for kk, v in dict(dw=dw2.data_ptr(), dbias=(db2.data_ptr() if bias else 0), workspace=ws2.data_ptr(), N=Cout,
@@ -717,11 +718,13 @@ def test_bwd_pair_matches_separate_launches(case):
             setattr(arr[0], kk, v)
         _lib.call('sdmi_wgrad_fold_group', st, problems=ctypes.addressof(arr), n=1)
     torch.cuda.synchronize()
-    for dxp, dwp, dbp in ((dx1, dw1, db1), (dx2, dw2, db2)):
+    for dxp, dwp, dbp, exact_bias in ((dx1, dw1, db1, True), (dx2, dw2, db2, False)):
         assert torch.equal(dxp, dx0), case
         assert torch.equal(dwp, dw0), case
-        if bias:
+        if bias and exact_bias:
             assert torch.equal(dbp, db0), case
+        elif bias:       # 64-wide bias tiles sum the rows in a different thread partition: fp32 reordering only
+            assert float((dbp - db0).abs().max()) <= 1e-5 * float(db0.abs().max()), case
     # ---- and the numbers themselves (torch fp32 on the bf16-rounded operands)
     if conv:
         x4 = xf.float().view(B, H, H, Cin).permute(0, 3, 1, 2).requires_grad_(True)
