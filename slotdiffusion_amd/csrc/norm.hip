@@ -190,6 +190,20 @@ __global__ __launch_bounds__(THREADS) void gn_fused_kernel(SdmiGroupNormArgs p) 
     const int row = r0 + i * R;
     if (act_c && row < p.HW) xr[i] = *reinterpret_cast<const uint4*>(xb + (long long)row * xp);
   }
+  // the affine parameters are fetched NOW, next to the slab: this kernel is one latency chain (load ->
+  // reduce -> combine -> apply -> store), and a second dependent global load behind the statistics
+  // costs about a microsecond of the ~10 a small image takes
+  // (not in the 16-vector variants: their slab fills the register budget)
+  constexpr bool PRE = NV <= 8;
+  float gam[VEC], bet[VEC];
+  if constexpr (PRE) {
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      const int c = c_lo + (act_c ? cv : 0) * VEC + j;
+      gam[j] = p.gamma[c];
+      bet[j] = p.beta[c];
+    }
+  }
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int row = r0 + i * R;
@@ -256,8 +270,8 @@ __global__ __launch_bounds__(THREADS) void gn_fused_kernel(SdmiGroupNormArgs p) 
 #pragma unroll
   for (int j = 0; j < VEC; ++j) {
     const int cl = cv * VEC + j, g = cl / cpg;            // chunk-local channel / group
-    sc[j] = s_stats[g][1] * p.gamma[c_lo + cl];
-    sh[j] = p.beta[c_lo + cl] - s_stats[g][0] * sc[j];
+    sc[j] = s_stats[g][1] * (PRE ? gam[j] : p.gamma[c_lo + cl]);
+    sh[j] = (PRE ? bet[j] : p.beta[c_lo + cl]) - s_stats[g][0] * sc[j];
   }
   T* yb = (T*)p.y + base;
   const T* rb = p.residual ? (const T*)p.residual + base : nullptr;

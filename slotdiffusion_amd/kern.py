@@ -43,6 +43,7 @@ def _dbg(tag, **tensors):
 
 FP8_ACT_SCALE = 8.0        # activations -> e4m3fn: +-56 representable, 2^-9 resolution near zero
 _WG_MAIN_BELOW = float(os.environ.get('SDMI_WGRAD_MAIN_BELOW_GF', '0')) * 1e9
+_LN_UNFOLD_ROWS = int(os.environ.get('SDMI_LN_UNFOLD_ROWS', '4096'))     # folded LayerNorm only below this many rows
 _LAZY_CAT = os.environ.get('SDMI_LAZY_CAT', '1') != '0'
 _GEGLU_FUSE = os.environ.get('SDMI_GEGLU_FUSE', '1') != '0'     # training: GEGLU in the FF GEMM's epilogue
 
@@ -726,7 +727,13 @@ class Kern:
         GEMM (sdmi.h: ln_colsum), the gated activation into its epilogue.  -> (out, x for the
         residual branch).  bf16 (throughput) path only: the fp32 path keeps the reference's kernel
         sequence for the parity tests.  SDMI_LN_FOLD=0: the unfused sequence everywhere."""
-        if not _LN_FOLD or x.dtype != torch.bfloat16:
+        rows = x.numel() // x.shape[-1]
+        # The fold's row sums are VALU work of the MFMA waves: with 128 x 128 tiles (many rows) the folded
+        # GEMM is 1.6x a plain one.  Measured in dependent chains on MI355X (tools/exp/short_k.py): q|k|v at
+        # 16384 rows 35 us folded vs 5.6 (LayerNorm) + 20.2 (plain GEMM); at 4096 rows 19.3 vs 5 + 9; at
+        # 1024 rows the fold wins.  The GEGLU form keeps the fold (53 vs 50 us at 16384 rows: a tie).
+        unfold = rows >= _LN_UNFOLD_ROWS and not geglu
+        if not _LN_FOLD or x.dtype != torch.bfloat16 or unfold:
             h = self.linear(self.ln(x, ln_name, eps), wnames, bnames, act=act)
             return (self.geglu(h) if geglu else h), x
         w, colsum, bias = self.wb.ln_folded(ln_name, wnames, bnames, x.dtype)
