@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round profile collection on the GPU box (outputs under gpurun_out/prof_<tag>/, copy the summaries
-# into profiles/).  usage: bash tools/collect_profiles.sh r01
-TAG=${1:-r01}
+# into profiles/).  usage: bash tools/collect_profiles.sh r03
+TAG=${1:-r03}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof_$TAG
 mkdir -p $O
