@@ -1,5 +1,7 @@
-"""EXPERIMENT: cost of the GEMM epilogue's 2-byte column stores (timing only; act bits 0x100 = one store per
-tile, 0x200 = fake 8-byte row stores, 0x400 = fake 16-byte row stores -- results are wrong on purpose)."""
+"""EXPERIMENT (apply tools/exp/igemm_ablation.patch to csrc/igemm_body.h and rebuild first): where an igemm
+launch spends its time.  Run-time switches ride in the `act` bits: 0x100 one store per tile, 0x800 no fragment
+reads / MFMAs, 0x1000 no global loads, 0x2000 no LDS writes, 0x4000 no epilogue.  Results are wrong on purpose;
+the numbers of round 3 are in profiles/r03_igemm_ablation.txt."""
 import os
 import sys
 import torch
