@@ -55,8 +55,12 @@ namespace {
 // 256 x 128 a wave computes 128 x 64 = 4 x 2 MFMA tiles and reads 6 fragments per 8 MFMAs -- 96 B/clk
 // of LDS reads per CU at full matrix rate, where 64 x 64 wave tiles (4 fragments per 4 MFMAs) need
 // the LDS's whole 256 B/clk (the limit the 128 x 128 kernels run into).
-template <typename T, int BM, int BN, int NSTAGE, int MODE>
-__global__ __launch_bounds__(512) void igemm_dma_kernel(
+// LW = loader waves (4 or 8).  PMC + issue-cost arithmetic (round 3): a wave issues one 1 KB LDS-DMA
+// piece per ~150 cycles next to MFMA traffic, so FOUR loader waves deliver ~27 B/clk per CU -- the 25 B/clk the
+// 128 x 128 kernel was observed at (a K tile every ~1300 cycles against 512 cycles of MFMA).  Eight loader
+// waves halve the issue time per K tile; the workgroup is then 12 waves (one per CU, three per SIMD).
+template <typename T, int BM, int BN, int NSTAGE, int MODE, int LW = 4>
+__global__ __launch_bounds__(256 + 64 * LW) void igemm_dma_kernel(
     SdmiGemmArgs p, int tiles_m, int tiles_n, int kt_per_split, int hw_shift) {
   constexpr int VEC = 16 / sizeof(T);
   constexpr int BK = 128 / sizeof(T);
@@ -64,7 +68,7 @@ __global__ __launch_bounds__(512) void igemm_dma_kernel(
   constexpr int TMf = WM / 32, TNf = WN / 32;
   constexpr int NMFMA = 256;                         // MFMA threads; 256 loader threads follow
   constexpr int STAGE = (BM + BN) * 128;
-  constexpr int A_PC = BM / 32, B_PC = BN / 32;      // 1 KB pieces per loader wave per K tile
+  constexpr int A_PC = BM / (8 * LW), B_PC = BN / (8 * LW);      // 1 KB pieces per loader wave per K tile
   constexpr int NLOAD = A_PC + B_PC;
   constexpr unsigned OOB = 0x80000000u;              // == num_records: always out of range
   static_assert((NSTAGE - 2) * NLOAD <= 63, "vmcnt field");
@@ -113,7 +117,7 @@ __global__ __launch_bounds__(512) void igemm_dma_kernel(
       }
 #pragma unroll
       for (int i = 0; i < A_PC; ++i) {
-        const int row = (lw + 4 * i) * 8 + (l >> 3);
+        const int row = (lw + LW * i) * 8 + (l >> 3);
         const int m = min(m0 + row, p.M - 1);
         if (MODE == 1) {
           a_vo[i] = ((unsigned)m * (unsigned)p.lda + kc * VEC) * (unsigned)sizeof(T);
@@ -137,7 +141,7 @@ __global__ __launch_bounds__(512) void igemm_dma_kernel(
       }
 #pragma unroll
       for (int i = 0; i < B_PC; ++i) {
-        const int row = (lw + 4 * i) * 8 + (l >> 3);
+        const int row = (lw + LW * i) * 8 + (l >> 3);
         const int n = min(n0 + row, p.N - 1);
         b_vo[i] = ((unsigned)n * (unsigned)p.ldw + kc * VEC) * (unsigned)sizeof(T);
         b_cur[i] = b_vo[i];
@@ -168,11 +172,11 @@ __global__ __launch_bounds__(512) void igemm_dma_kernel(
       char* st = smem + ld_stage * STAGE + lw * 1024;
 #pragma unroll
       for (int i = 0; i < A_PC; ++i)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void*)(st + i * 4096), 16, (int)a_cur[i],
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void*)(st + i * (LW * 1024)), 16, (int)a_cur[i],
                                                  (int)so_a, 0, 0);
 #pragma unroll
       for (int i = 0; i < B_PC; ++i)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_void*)(st + BM * 128 + i * 4096), 16,
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_void*)(st + BM * 128 + i * (LW * 1024)), 16,
                                                  (int)b_cur[i], (int)so_b, 0, 0);
       if (MODE == 2) {
         ci += BK;
@@ -514,12 +518,12 @@ static int device_cus() {
   return n_cu;
 }
 
-template <typename T, int BM, int BN, int NSTAGE, int MODE>
+template <typename T, int BM, int BN, int NSTAGE, int MODE, int LW = 4>
 int launch_dma(const SdmiGemmArgs& p, int hw_shift, hipStream_t st) {
   constexpr int BK = 128 / sizeof(T);
   constexpr int smem = NSTAGE * (BM + BN) * 128;
-  constexpr int threads = 512;
-  auto kern = igemm_dma_kernel<T, BM, BN, NSTAGE, MODE>;
+  constexpr int threads = 256 + 64 * LW;
+  auto kern = igemm_dma_kernel<T, BM, BN, NSTAGE, MODE, LW>;
   SDMI_OPTIN_LDS(kern, smem, "igemm (lds-dma)");
   SdmiGemmArgs q = p;
   q.split_k = 1;
@@ -699,8 +703,21 @@ int dispatch(const SdmiGemmArgs& p, hipStream_t st) {
       // (tools/exp/conv_chain.py, B = 64): about one tile per CU and a deep K -- the 16^2 level's 3x3
       // convolutions, 30.0 -> 27.8 us (256 -> 256) and 50.4 -> 42.4 us (512 -> 256); neutral or slower elsewhere
       const long long t256 = ((p.M + 255) / 256) * ((p.N + 127) / 128) * batch;
-      if (t128 >= 192 && t256 < 192 && kbytes >= 2048 * 2 && !is1x1)
-        return launch_dma<T, 128, 128, 4, 2>(p, hw_shift, st);
+      static int dma_lw = -1;
+      if (dma_lw < 0) {
+        const char* e = getenv("SDMI_IGEMM_DMA_LW");
+        dma_lw = e ? atoi(e) : 8;
+      }
+      static int dma_all = -1;              // experiment: every 128 x 128 deep-K plain convolution
+      if (dma_all < 0) {
+        const char* e = getenv("SDMI_IGEMM_DMA_ALL");
+        dma_all = e ? atoi(e) : 0;
+      }
+      const bool pick = dma_all ? (t128 >= 192 && kbytes >= 1024 * 2) : (t128 >= 192 && t256 < 192 && kbytes >= 2048 * 2);
+      if (pick && !is1x1)
+        return dma_lw == 85 ? launch_dma<T, 128, 128, 5, 2, 8>(p, hw_shift, st)
+               : dma_lw == 8 ? launch_dma<T, 128, 128, 4, 2, 8>(p, hw_shift, st)
+                             : launch_dma<T, 128, 128, 4, 2>(p, hw_shift, st);
     } else if (dma_ok) {
       const long long t256 = ((p.M + 255) / 256) * ((p.N + 127) / 128) * batch;
       if (t256 >= 192) {

@@ -42,9 +42,9 @@ def conv(x, w, y, B, H, C, N, k=3):
               split_k=(0 if auto else 1), batch=1)
 
 
-tag = os.environ.get('SDMI_IGEMM_DMA', '0') + ' T128_MIN=' + os.environ.get('SDMI_IGEMM_T128_MIN', '192')
+tag = os.environ.get('SDMI_IGEMM_DMA', '3') + ' LW=' + os.environ.get('SDMI_IGEMM_DMA_LW', '8') + ' ALL=' + os.environ.get('SDMI_IGEMM_DMA_ALL', '0')
 for B, H, C, N in [(64, 32, 128, 128), (64, 32, 256, 128), (64, 32, 256, 256), (64, 16, 256, 256), (64, 16, 512, 256),
-                   (64, 8, 384, 384), (64, 8, 768, 384), (64, 4, 512, 512), (64, 4, 1024, 512)]:
+                   (64, 8, 384, 384), (64, 64, 128, 128), (256, 16, 256, 256)]:
     w = (torch.randn(N, 9 * C, device=dev) / (9 * C) ** 0.5).bfloat16()
     xs = [torch.randn(B, H, H, C, device=dev).bfloat16(), torch.empty(B, H, H, N, device=dev, dtype=torch.bfloat16)]
     if C == N:
@@ -60,3 +60,15 @@ for B, H, C, N in [(64, 32, 128, 128), (64, 32, 256, 128), (64, 32, 256, 256), (
     us = chain_time(fn)
     fl = 2.0 * B * H * H * N * 9 * C
     print(f'DMA={tag} conv3x3 B={B:3d} H={H:3d} C={C:4d} N={N:4d}: {us:7.2f} us  {fl / us / 1e6:7.1f} TF/s', flush=True)
+
+# correctness of whatever kernel the dispatch picked: against torch's fp32 convolution on the bf16-rounded operands
+import torch.nn.functional as F
+for B, H, C, N in [(64, 16, 256, 256), (64, 32, 128, 128)]:
+    g = torch.Generator(device=dev).manual_seed(B + H + C)
+    w = (torch.randn(N, 3, 3, C, device=dev, generator=g) / (9 * C) ** 0.5).bfloat16()
+    x = torch.randn(B, H, H, C, device=dev, generator=g).bfloat16()
+    y = torch.empty(B, H, H, N, device=dev, dtype=torch.bfloat16)
+    conv(x, w, y, B, H, C, N)
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2), padding=1).permute(0, 2, 3, 1)
+    err = float((y.float() - ref).norm() / ref.norm())
+    print(f'check B={B} H={H} C={C} N={N}: rel-L2 {err:.2e}', 'OK' if err < 5e-3 else 'WRONG', flush=True)
