@@ -255,6 +255,13 @@ __device__ __forceinline__ void fused_epilogue(const SdmiGemmArgs& p, f32x16 (&a
   // C layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
   const int col_l = lane & 31, row_l = (lane >> 5) * 4;
   const bool out_bf16 = p.out_dtype == SDMI_BF16;
+  // streamlined stores for interior blocks (see wave_epilogue_fast)
+  const int mwu = __builtin_amdgcn_readfirstlane(mw0);
+  const unsigned ldc2 = (unsigned)p.ldc * 2u;
+  const bool fast = out_bf16 && mw0 + TM * 32 <= p.M && nw0 + NOUT * 32 <= p.N &&
+                    (long long)p.M * p.ldc < (1ll << 30);
+  const __amdgpu_buffer_rsrc_t rsO =
+      __builtin_amdgcn_make_buffer_rsrc((void*)((bf16_t*)p.out + zc), 0, 0x7fffffff, 0x00020000);
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     float mean = 0.f, rstd = 1.f;
@@ -323,7 +330,13 @@ __device__ __forceinline__ void fused_epilogue(const SdmiGemmArgs& p, f32x16 (&a
         } else {
           v = act_apply(v, p.act);
         }
-        if (ncol[j] < p.N && m < p.M) {
+        if (fast) {
+          // interior block, bf16 out: the row's byte offset is wave-uniform (SGPR offset of the buffer store),
+          // the lane part is fixed per column tile -- no 64-bit address, bounds test or branch per element
+          __builtin_amdgcn_raw_buffer_store_b16(
+              f32_to_bf16(v), rsO, (int)((unsigned)row_l * ldc2 + (unsigned)ncol[j] * 2u),
+              (int)((unsigned)(mwu + i * 32 + (r & 3) + 8 * (r >> 2)) * ldc2), 0);
+        } else if (ncol[j] < p.N && m < p.M) {
           const long long o = zc + (long long)m * p.ldc + ncol[j];
           if (out_bf16) ((bf16_t*)p.out)[o] = f32_to_bf16(v);
           else ((float*)p.out)[o] = v;

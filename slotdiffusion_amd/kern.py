@@ -43,7 +43,7 @@ def _dbg(tag, **tensors):
 
 FP8_ACT_SCALE = 8.0        # activations -> e4m3fn: +-56 representable, 2^-9 resolution near zero
 _WG_MAIN_BELOW = float(os.environ.get('SDMI_WGRAD_MAIN_BELOW_GF', '0')) * 1e9
-_LN_UNFOLD_ROWS = int(os.environ.get('SDMI_LN_UNFOLD_ROWS', '4096'))     # folded LayerNorm only below this many rows
+_LN_UNFOLD_ROWS = int(os.environ.get('SDMI_LN_UNFOLD_ROWS', str(1 << 30)))     # folded LayerNorm only below this many rows (default: always folded)
 _LAZY_CAT = os.environ.get('SDMI_LAZY_CAT', '1') != '0'
 _GEGLU_FUSE = os.environ.get('SDMI_GEGLU_FUSE', '1') != '0'     # training: GEGLU in the FF GEMM's epilogue
 
@@ -728,11 +728,12 @@ class Kern:
         residual branch).  bf16 (throughput) path only: the fp32 path keeps the reference's kernel
         sequence for the parity tests.  SDMI_LN_FOLD=0: the unfused sequence everywhere."""
         rows = x.numel() // x.shape[-1]
-        # The fold's row sums are VALU work of the MFMA waves: with 128 x 128 tiles (many rows) the folded
-        # GEMM is 1.6x a plain one.  Measured in dependent chains on MI355X (tools/exp/short_k.py): q|k|v at
-        # 16384 rows 35 us folded vs 5.6 (LayerNorm) + 20.2 (plain GEMM); at 4096 rows 19.3 vs 5 + 9; at
-        # 1024 rows the fold wins.  The GEGLU form keeps the fold (53 vs 50 us at 16384 rows: a tie).
-        unfold = rows >= _LN_UNFOLD_ROWS and not geglu
+        # The fold's row sums are VALU work of the MFMA waves, so a folded GEMM on 128 x 128 tiles costs ~1.45x a
+        # plain one (tools/exp/short_k.py).  With the round-2 epilogue the unfolded sequence (LayerNorm kernel +
+        # plain GEMM) won above 4096 rows (sampling 95.97 -> 94.6 ms); with the streamlined epilogue stores the
+        # fold wins again end to end (94.75 vs 95.6 / 95.8 ms, same box): one dependent launch less per site is
+        # worth more than the slower GEMM.  SDMI_LN_UNFOLD_ROWS=4096 restores the unfolded form above that size.
+        unfold = rows >= (_LN_UNFOLD_ROWS if not geglu else 4 * _LN_UNFOLD_ROWS)
         if not _LN_FOLD or x.dtype != torch.bfloat16 or unfold:
             h = self.linear(self.ln(x, ln_name, eps), wnames, bnames, act=act)
             return (self.geglu(h) if geglu else h), x
