@@ -383,7 +383,12 @@ static bool wgrad_is1x1(const SdmiWgradArgs& a) {
 }
 
 int dispatch_wgrad_f32(const SdmiWgradArgs& a, hipStream_t st) {
-  const bool small = a.N <= 64 || a.K <= 64;
+  // exact-fp32 MFMA runs at 1/16 of the bf16 rate (0.6 TFLOP/s per CU), so a launch with few workgroups is
+  // COMPUTE bound on the handful of CUs it occupies: the Slot Attention / predictor layers (M = clips x slots
+  // = 240 ... 448 rows, N, K <= 768) gave 4 - 36 workgroups of 128 x 128 and took 34 - 50 us each.  Below 96
+  // workgroups the 64 x 64 tiles (four times the workgroups, a quarter of the work each) are used.
+  const long long wg128 = (long long)((a.N + 127) / 128) * ((a.K + 127) / 128) * a.splits;
+  const bool small = a.N <= 64 || a.K <= 64 || wg128 < 96;
   const bool is1x1 = wgrad_is1x1(a);
   if (small)
     return is1x1 ? launch_wgrad<float, 64, 64, true>(a, st)
