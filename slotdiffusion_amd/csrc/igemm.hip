@@ -60,7 +60,7 @@ namespace {
 // 128 x 128 kernel was observed at (a K tile every ~1300 cycles against 512 cycles of MFMA).  Eight loader
 // waves halve the issue time per K tile; the workgroup is then 12 waves (one per CU, three per SIMD).
 template <typename T, int BM, int BN, int NSTAGE, int MODE, int LW = 4>
-__global__ __launch_bounds__(256 + 64 * LW) void igemm_dma_kernel(
+__global__ __launch_bounds__(256 + 64 * LW, (BM * BN <= 64 * 64 ? 4 : 0)) void igemm_dma_kernel(
     SdmiGemmArgs p, int tiles_m, int tiles_n, int kt_per_split, int hw_shift) {
   constexpr int VEC = 16 / sizeof(T);
   constexpr int BK = 128 / sizeof(T);
@@ -519,23 +519,35 @@ static int device_cus() {
 }
 
 template <typename T, int BM, int BN, int NSTAGE, int MODE, int LW = 4>
-int launch_dma(const SdmiGemmArgs& p, int hw_shift, hipStream_t st) {
+int launch_dma(const SdmiGemmArgs& p, int hw_shift, hipStream_t st, int split_k = 1) {
   constexpr int BK = 128 / sizeof(T);
   constexpr int smem = NSTAGE * (BM + BN) * 128;
   constexpr int threads = 256 + 64 * LW;
   auto kern = igemm_dma_kernel<T, BM, BN, NSTAGE, MODE, LW>;
   SDMI_OPTIN_LDS(kern, smem, "igemm (lds-dma)");
   SdmiGemmArgs q = p;
-  q.split_k = 1;
+  q.split_k = split_k;
   const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
   const int nk = (p.K + BK - 1) / BK;
-  const int ny = p.batch > 0 ? p.batch : 1;
-  int cap = device_cus() / ny;               // one workgroup per CU (its LDS stages fill the CU)
+  const int ktps = (nk + split_k - 1) / split_k;
+  const int ny = split_k * (p.batch > 0 ? p.batch : 1);
+  // workgroups the chip holds at once: one per CU for the large tiles (their LDS stages fill the CU),
+  // two for the 64 x 64 tile
+  int cap = device_cus() * (smem <= 72 * 1024 ? 2 : 1) / ny;
   cap = cap < 8 ? 8 : (cap & ~7);
   const int nwg = tiles_m * tiles_n;
   dim3 grid(nwg <= cap ? nwg : cap, ny);
-  hipLaunchKernelGGL(kern, grid, dim3(threads), smem, st, q, tiles_m, tiles_n, nk, hw_shift);
-  return sdmi_check_launch("igemm (lds-dma)");
+  hipLaunchKernelGGL(kern, grid, dim3(threads), smem, st, q, tiles_m, tiles_n, ktps, hw_shift);
+  int rc = sdmi_check_launch("igemm (lds-dma)");
+  if (rc) return rc;
+  if (split_k > 1) {
+    const long long total = (long long)p.M * p.N;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(blocks), dim3(256), 0, st, q, hw_shift);
+    rc = sdmi_check_launch("igemm splitk epilogue");
+  }
+  return rc;
 }
 
 template <typename T>
@@ -591,7 +603,12 @@ int dispatch(const SdmiGemmArgs& p, hipStream_t st) {
   else if (!big && batch == 1 && p.workspace && p.osy == 0) {
     const long long t64 = (long long)((p.M + 63) / 64) * ((p.N + 63) / 64);
     const int nk = (kbytes + (wide ? 127 : 63)) / (wide ? 128 : 64);
-    while (t64 * split_k < 384 && split_k * 2 <= nk / 4 && split_k < 16) split_k *= 2;
+    static int sk_target = -1;           // workgroups a split-K launch aims for (experiment knob)
+    if (sk_target < 0) {
+      const char* e = getenv("SDMI_IGEMM_SPLIT_TARGET");
+      sk_target = e ? atoi(e) : 384;
+    }
+    while (t64 * split_k < sk_target && split_k * 2 <= nk / 4 && split_k < 16) split_k *= 2;
   }
   if (split_k > 1 && !p.workspace) split_k = 1;
   const bool plain = !is1x1 && !p.ups && p.zins <= 1;
@@ -728,6 +745,21 @@ int dispatch(const SdmiGemmArgs& p, hipStream_t st) {
         if (is1x1) return launch_dma<T, 128, 128, 4, 1>(p, hw_shift, st);
         return launch_dma<T, 128, 128, 4, 2>(p, hw_shift, st);
       }
+    }
+  }
+  if constexpr (sizeof(T) == 2) {
+    // LDS-DMA kernel on 64 x 64 tiles (4 stages of 16 KB: two workgroups per CU), split-K as below: the 8^2 /
+    // 4^2 levels' convolutions 12 - 17 % faster in dependent chains (29.0 -> 24.3 us 384 -> 384 @8^2, 50.6 -> 41.9
+    // 768 -> 384), sampling pass 94.7 -> 92.9 ms, train step 29.58 -> 29.33 ms (same-box A/B, twice each).
+    // SDMI_IGEMM_DMA64 = smallest K (bytes per row) that takes it, 0 = off.
+    static int dma64 = -1;
+    if (dma64 < 0) {
+      const char* e = getenv("SDMI_IGEMM_DMA64");
+      dma64 = e ? atoi(e) : 256;
+    }
+    if (dma64 && shape == T64x64 && !p.a2 && kbytes >= dma64 && fits31 && p.osy == 0 && batch == 1) {
+      if (is1x1) return launch_dma<T, 64, 64, 4, 1, 4>(p, hw_shift, st, split_k);
+      if (plain && p.KH * p.KW <= 32 && p.Cin % 64 == 0) return launch_dma<T, 64, 64, 4, 2, 4>(p, hw_shift, st, split_k);
     }
   }
 #define SDMI_GO(BM, BN, BKB)                                                                    \

@@ -43,8 +43,13 @@ def conv(x, w, y, B, H, C, N, k=3):
 
 
 tag = os.environ.get('SDMI_IGEMM_DMA', '3') + ' LW=' + os.environ.get('SDMI_IGEMM_DMA_LW', '8') + ' ALL=' + os.environ.get('SDMI_IGEMM_DMA_ALL', '0')
-for B, H, C, N in [(64, 32, 128, 128), (64, 32, 256, 128), (64, 32, 256, 256), (64, 16, 256, 256), (64, 16, 512, 256),
-                   (64, 8, 384, 384), (64, 64, 128, 128), (256, 16, 256, 256)]:
+SHAPES = [(64, 32, 128, 128), (64, 32, 256, 128), (64, 32, 256, 256), (64, 16, 256, 256), (64, 16, 512, 256),
+          (64, 8, 384, 384), (64, 64, 128, 128), (256, 16, 256, 256)]
+if os.environ.get('SHAPES') == 'low':      # the 8^2 / 4^2 levels (64 x 64 tiles, split-K)
+    SHAPES = [(64, 8, 384, 384), (64, 8, 768, 384), (64, 8, 640, 384), (64, 4, 512, 512), (64, 4, 1024, 512),
+              (64, 4, 896, 512), (64, 8, 256, 384), (16, 16, 256, 256)]
+    tag += ' BK256=' + os.environ.get('SDMI_IGEMM_BK256', '0') + ' SPLIT=' + os.environ.get('SDMI_IGEMM_SPLIT_TARGET', '384')
+for B, H, C, N in SHAPES:
     w = (torch.randn(N, 9 * C, device=dev) / (9 * C) ** 0.5).bfloat16()
     xs = [torch.randn(B, H, H, C, device=dev).bfloat16(), torch.empty(B, H, H, N, device=dev, dtype=torch.bfloat16)]
     if C == N:
@@ -63,7 +68,7 @@ for B, H, C, N in [(64, 32, 128, 128), (64, 32, 256, 128), (64, 32, 256, 256), (
 
 # correctness of whatever kernel the dispatch picked: against torch's fp32 convolution on the bf16-rounded operands
 import torch.nn.functional as F
-for B, H, C, N in [(64, 16, 256, 256), (64, 32, 128, 128)]:
+for B, H, C, N in [(64, 16, 256, 256), (64, 32, 128, 128), (64, 8, 384, 384), (64, 4, 1024, 512)]:
     g = torch.Generator(device=dev).manual_seed(B + H + C)
     w = (torch.randn(N, 3, 3, C, device=dev, generator=g) / (9 * C) ** 0.5).bfloat16()
     x = torch.randn(B, H, H, C, device=dev, generator=g).bfloat16()
