@@ -59,7 +59,7 @@ namespace {
 // piece per ~150 cycles next to MFMA traffic, so FOUR loader waves deliver ~27 B/clk per CU -- the 25 B/clk the
 // 128 x 128 kernel was observed at (a K tile every ~1300 cycles against 512 cycles of MFMA).  Eight loader
 // waves halve the issue time per K tile; the workgroup is then 12 waves (one per CU, three per SIMD).
-template <typename T, int BM, int BN, int NSTAGE, int MODE, int LW = 4>
+template <typename T, int BM, int BN, int NSTAGE, int MODE, int LW = 4, bool XS = false>
 __global__ __launch_bounds__(256 + 64 * LW, (BM * BN <= 64 * 64 ? 4 : 0)) void igemm_dma_kernel(
     SdmiGemmArgs p, int tiles_m, int tiles_n, int kt_per_split, int hw_shift) {
   constexpr int VEC = 16 / sizeof(T);
@@ -104,6 +104,8 @@ __global__ __launch_bounds__(256 + 64 * LW, (BM * BN <= 64 * 64 ? 4 : 0)) void i
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)Ag, 0, (int)OOB, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)Wg, 0, (int)OOB, 0x00020000);
     unsigned a_vo[A_PC], a_cur[A_PC], a_inv[A_PC], b_vo[B_PC], b_cur[B_PC];
+    // extra A sources appended along K (sdmi.h: a2 / a3): 1x1 taps at the output pixel
+    unsigned a_vo2[XS ? A_PC : 1], a_vo3[XS ? A_PC : 1];
     int ld_tile = 0, ld_kt = 0, k0 = 0, ci = 0, kh = 0, kw = 0;   // wave-uniform
     auto begin_tile = [&]() __attribute__((always_inline)) {
       int m0, n0;
@@ -119,6 +121,10 @@ __global__ __launch_bounds__(256 + 64 * LW, (BM * BN <= 64 * 64 ? 4 : 0)) void i
       for (int i = 0; i < A_PC; ++i) {
         const int row = (lw + LW * i) * 8 + (l >> 3);
         const int m = min(m0 + row, p.M - 1);
+        if constexpr (XS) {        // (stride-1 "same" convolutions: output pixel m = input pixel m)
+          a_vo2[i] = ((unsigned)m * (unsigned)p.lda2 + kc * VEC) * (unsigned)sizeof(T);
+          a_vo3[i] = ((unsigned)m * (unsigned)p.lda3 + kc * VEC) * (unsigned)sizeof(T);
+        }
         if (MODE == 1) {
           a_vo[i] = ((unsigned)m * (unsigned)p.lda + kc * VEC) * (unsigned)sizeof(T);
           a_inv[i] = 0;
@@ -170,10 +176,25 @@ __global__ __launch_bounds__(256 + 64 * LW, (BM * BN <= 64 * 64 ? 4 : 0)) void i
       }
       const unsigned so_b = (unsigned)k0 * (unsigned)sizeof(T);
       char* st = smem + ld_stage * STAGE + lw * 1024;
+      if constexpr (XS) {
+        // which source this K tile reads (wave-uniform selects; the descriptor is rebuilt per K tile)
+        const bool s1 = p.a2 != nullptr && k0 >= p.K1;
+        const bool s2 = s1 && p.a3 != nullptr && k0 >= p.K2;
+        const unsigned so_x = s2 ? (unsigned)(k0 - p.K2) * (unsigned)sizeof(T)
+                                 : (s1 ? (unsigned)(k0 - p.K1) * (unsigned)sizeof(T) : so_a);
+        const void* base_x = s2 ? p.a3 : (s1 ? p.a2 : (const void*)Ag);
+        const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)base_x, 0, (int)OOB, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < A_PC; ++i) {
+          const unsigned vo = s2 ? a_vo3[i] : (s1 ? a_vo2[i] : a_cur[i]);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void*)(st + i * (LW * 1024)), 16, (int)vo, (int)so_x, 0, 0);
+        }
+      } else {
 #pragma unroll
       for (int i = 0; i < A_PC; ++i)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void*)(st + i * (LW * 1024)), 16, (int)a_cur[i],
                                                  (int)so_a, 0, 0);
+      }
 #pragma unroll
       for (int i = 0; i < B_PC; ++i)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_void*)(st + BM * 128 + i * (LW * 1024)), 16,
@@ -518,12 +539,12 @@ static int device_cus() {
   return n_cu;
 }
 
-template <typename T, int BM, int BN, int NSTAGE, int MODE, int LW = 4>
+template <typename T, int BM, int BN, int NSTAGE, int MODE, int LW = 4, bool XS = false>
 int launch_dma(const SdmiGemmArgs& p, int hw_shift, hipStream_t st, int split_k = 1) {
   constexpr int BK = 128 / sizeof(T);
   constexpr int smem = NSTAGE * (BM + BN) * 128;
   constexpr int threads = 256 + 64 * LW;
-  auto kern = igemm_dma_kernel<T, BM, BN, NSTAGE, MODE, LW>;
+  auto kern = igemm_dma_kernel<T, BM, BN, NSTAGE, MODE, LW, XS>;
   SDMI_OPTIN_LDS(kern, smem, "igemm (lds-dma)");
   SdmiGemmArgs q = p;
   q.split_k = split_k;
@@ -656,6 +677,14 @@ int dispatch(const SdmiGemmArgs& p, hipStream_t st) {
       if (shape == T128x128)
         return is1x1 ? launch_cfg<T, 128, 128, 128, 1, 0, true>(p, split_k, hw_shift, st)
                      : launch_cfg<T, 128, 128, 128, 2, 0, true>(p, split_k, hw_shift, st);
+      static int dma64x = -1;
+      if (dma64x < 0) {
+        const char* e = getenv("SDMI_IGEMM_DMA64");
+        dma64x = e ? atoi(e) : 256;
+      }
+      if (sizeof(T) == 2 && dma64x)
+        return is1x1 ? launch_dma<T, 64, 64, 4, 1, 4, true>(p, hw_shift, st, split_k)
+                     : launch_dma<T, 64, 64, 4, 2, 4, true>(p, hw_shift, st, split_k);
       return is1x1 ? launch_cfg<T, 64, 64, 128, 1, 0, true>(p, split_k, hw_shift, st)
                    : launch_cfg<T, 64, 64, 128, 2, 0, true>(p, split_k, hw_shift, st);
     } else {
