@@ -59,7 +59,7 @@ namespace {
 // piece per ~150 cycles next to MFMA traffic, so FOUR loader waves deliver ~27 B/clk per CU -- the 25 B/clk the
 // 128 x 128 kernel was observed at (a K tile every ~1300 cycles against 512 cycles of MFMA).  Eight loader
 // waves halve the issue time per K tile; the workgroup is then 12 waves (one per CU, three per SIMD).
-template <typename T, int BM, int BN, int NSTAGE, int MODE, int LW = 4, bool XS = false>
+template <typename T, int BM, int BN, int NSTAGE, int MODE, int LW = 4, bool XS = false, int EPI = 0>
 __global__ __launch_bounds__(256 + 64 * LW, (BM * BN <= 64 * 64 ? 4 : 0)) void igemm_dma_kernel(
     SdmiGemmArgs p, int tiles_m, int tiles_n, int kt_per_split, int hw_shift) {
   constexpr int VEC = 16 / sizeof(T);
@@ -254,6 +254,9 @@ __global__ __launch_bounds__(256 + 64 * LW, (BM * BN <= 64 * 64 ? 4 : 0)) void i
       for (int j = 0; j < TNf; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    float sx[TMf], sxx[TMf];                      // LayerNorm fold (EPI bit 0): row sums from the A fragments
+#pragma unroll
+    for (int i = 0; i < TMf; ++i) sx[i] = sxx[i] = 0.f;
     for (int t = 0; t < n_kt; ++t) {
       __builtin_amdgcn_s_barrier();               // K tile landed; previous stage may be refilled
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -265,6 +268,22 @@ __global__ __launch_bounds__(256 + 64 * LW, (BM * BN <= 64 * 64 ? 4 : 0)) void i
       for (int ks = 0; ks < 4; ++ks) {
         if (ks + 1 < 4) read_frags(base, ks + 1, fa[(ks + 1) & 1], fb[(ks + 1) & 1]);
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr ((EPI & 1) != 0 && sizeof(T) == 2) {
+#pragma unroll
+          for (int i = 0; i < TMf; ++i) {
+            const sdmi_bf16x2 ones = __builtin_bit_cast(sdmi_bf16x2, 0x3F803F80u);
+            const bf16x8 a8 = __builtin_bit_cast(bf16x8, fa[ks & 1][i]);
+            const sdmi_bf16x2 v0 = {a8[0], a8[1]}, v1 = {a8[2], a8[3]}, v2 = {a8[4], a8[5]}, v3 = {a8[6], a8[7]};
+            sx[i] = __builtin_amdgcn_fdot2_f32_bf16(v0, ones, sx[i], false);
+            sxx[i] = __builtin_amdgcn_fdot2_f32_bf16(v0, v0, sxx[i], false);
+            sx[i] = __builtin_amdgcn_fdot2_f32_bf16(v1, ones, sx[i], false);
+            sxx[i] = __builtin_amdgcn_fdot2_f32_bf16(v1, v1, sxx[i], false);
+            sx[i] = __builtin_amdgcn_fdot2_f32_bf16(v2, ones, sx[i], false);
+            sxx[i] = __builtin_amdgcn_fdot2_f32_bf16(v2, v2, sxx[i], false);
+            sx[i] = __builtin_amdgcn_fdot2_f32_bf16(v3, ones, sx[i], false);
+            sxx[i] = __builtin_amdgcn_fdot2_f32_bf16(v3, v3, sxx[i], false);
+          }
+        }
 #pragma unroll
         for (int i = 0; i < TMf; ++i)
 #pragma unroll
@@ -282,7 +301,10 @@ __global__ __launch_bounds__(256 + 64 * LW, (BM * BN <= 64 * 64 ? 4 : 0)) void i
           }
       }
     }
-    wave_epilogue<TMf, TNf>(p, acc, m0 + wm * WM, n0 + wn * WN, zb, hw_shift, lane, (int)blockIdx.y);
+    if constexpr (EPI == 0)
+      wave_epilogue<TMf, TNf>(p, acc, m0 + wm * WM, n0 + wn * WN, zb, hw_shift, lane, (int)blockIdx.y);
+    else
+      fused_epilogue<TMf, TNf, EPI>(p, acc, sx, sxx, m0 + wm * WM, n0 + wn * WN, lane, zb);
   }
 }
 
@@ -539,12 +561,12 @@ static int device_cus() {
   return n_cu;
 }
 
-template <typename T, int BM, int BN, int NSTAGE, int MODE, int LW = 4, bool XS = false>
+template <typename T, int BM, int BN, int NSTAGE, int MODE, int LW = 4, bool XS = false, int EPI = 0>
 int launch_dma(const SdmiGemmArgs& p, int hw_shift, hipStream_t st, int split_k = 1) {
   constexpr int BK = 128 / sizeof(T);
   constexpr int smem = NSTAGE * (BM + BN) * 128;
   constexpr int threads = 256 + 64 * LW;
-  auto kern = igemm_dma_kernel<T, BM, BN, NSTAGE, MODE, LW, XS>;
+  auto kern = igemm_dma_kernel<T, BM, BN, NSTAGE, MODE, LW, XS, EPI>;
   SDMI_OPTIN_LDS(kern, smem, "igemm (lds-dma)");
   SdmiGemmArgs q = p;
   q.split_k = split_k;
@@ -569,6 +591,16 @@ int launch_dma(const SdmiGemmArgs& p, int hw_shift, hipStream_t st, int split_k 
     rc = sdmi_check_launch("igemm splitk epilogue");
   }
   return rc;
+}
+
+// SDMI_IGEMM_DMA64: smallest K (bytes per row) that takes the 64 x 64 LDS-DMA kernel, 0 = off
+static int dma64_min() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("SDMI_IGEMM_DMA64");
+    v = e ? atoi(e) : 256;
+  }
+  return v;
 }
 
 template <typename T>
@@ -677,12 +709,7 @@ int dispatch(const SdmiGemmArgs& p, hipStream_t st) {
       if (shape == T128x128)
         return is1x1 ? launch_cfg<T, 128, 128, 128, 1, 0, true>(p, split_k, hw_shift, st)
                      : launch_cfg<T, 128, 128, 128, 2, 0, true>(p, split_k, hw_shift, st);
-      static int dma64x = -1;
-      if (dma64x < 0) {
-        const char* e = getenv("SDMI_IGEMM_DMA64");
-        dma64x = e ? atoi(e) : 256;
-      }
-      if (sizeof(T) == 2 && dma64x)
+      if (sizeof(T) == 2 && dma64_min())
         return is1x1 ? launch_dma<T, 64, 64, 4, 1, 4, true>(p, hw_shift, st, split_k)
                      : launch_dma<T, 64, 64, 4, 2, 4, true>(p, hw_shift, st, split_k);
       return is1x1 ? launch_cfg<T, 64, 64, 128, 1, 0, true>(p, split_k, hw_shift, st)
@@ -705,6 +732,8 @@ int dispatch(const SdmiGemmArgs& p, hipStream_t st) {
         sdmi_set_error("igemm: softmax8 epilogue needs a plain 1x1 problem with N a multiple of 8");
         return SDMI_EUNSUPPORTED;
       }
+      if constexpr (sizeof(T) == 2)
+        if (dma64_min() && kbytes >= dma64_min()) return launch_dma<T, 64, 64, 4, 1, 4, false, 5>(p, hw_shift, st, 1);
       if constexpr (sizeof(T) != 1)
         return wide ? launch_cfg<T, 64, 64, 128, 1, 5>(p, 1, hw_shift, st)
                     : launch_cfg<T, 64, 64, 64, 1, 5>(p, 1, hw_shift, st);
@@ -720,6 +749,9 @@ int dispatch(const SdmiGemmArgs& p, hipStream_t st) {
       }
       // GEGLU pairs tiles inside a 64-column wave block: 128 x 128 only
       const bool t128 = (epi & 2) || (shape == T128x128 && lnf_tile != 64);
+      if constexpr (sizeof(T) == 2)
+        if (epi == 1 && !t128 && dma64_min() && kbytes >= dma64_min())
+          return launch_dma<T, 64, 64, 4, 1, 4, false, 1>(p, hw_shift, st, 1);
 #define SDMI_EPI(E)                                                                              \
   do {                                                                                           \
     if (t128) return wide ? launch_cfg<T, 128, 128, 128, 1, E>(p, 1, hw_shift, st)               \
@@ -780,12 +812,7 @@ int dispatch(const SdmiGemmArgs& p, hipStream_t st) {
     // LDS-DMA kernel on 64 x 64 tiles (4 stages of 16 KB: two workgroups per CU), split-K as below: the 8^2 /
     // 4^2 levels' convolutions 12 - 17 % faster in dependent chains (29.0 -> 24.3 us 384 -> 384 @8^2, 50.6 -> 41.9
     // 768 -> 384), sampling pass 94.7 -> 92.9 ms, train step 29.58 -> 29.33 ms (same-box A/B, twice each).
-    // SDMI_IGEMM_DMA64 = smallest K (bytes per row) that takes it, 0 = off.
-    static int dma64 = -1;
-    if (dma64 < 0) {
-      const char* e = getenv("SDMI_IGEMM_DMA64");
-      dma64 = e ? atoi(e) : 256;
-    }
+    const int dma64 = dma64_min();
     if (dma64 && shape == T64x64 && !p.a2 && kbytes >= dma64 && fits31 && p.osy == 0 && batch == 1) {
       if (is1x1) return launch_dma<T, 64, 64, 4, 1, 4>(p, hw_shift, st, split_k);
       if (plain && p.KH * p.KW <= 32 && p.Cin % 64 == 0) return launch_dma<T, 64, 64, 4, 2, 4>(p, hw_shift, st, split_k);
