@@ -68,7 +68,7 @@ int launch_pair(const SdmiGemmArgs& d, const SdmiWgradArgs& w, const SdmiWgradAr
   SdmiWgradArgs fz = {};
   if (f) {
     fz = *f;
-    const long long v4 = (long long)f->N * f->K / 4;
+    const long long v4 = (long long)f->N * f->K / 4 * wgrad_fold_lanes(f->splits);
     long long nf = (v4 + 512 * 4 - 1) / (512 * 4);           // ~4 output vectors per thread
     g.n_fold = (int)(nf < 1 ? 1 : (nf > 128 ? 128 : nf));
   } else {

@@ -91,10 +91,12 @@ __global__ __launch_bounds__(256 + 64 * LW, (BM * BN <= 64 * 64 ? 4 : 0)) void i
   if (kt_end > nk_total) kt_end = nk_total;
   const int n_kt = kt_end > kt_begin ? kt_end - kt_begin : 0;
   const int total = my_tiles * n_kt;
-  if (total == 0) return;
 
   if (threadIdx.x >= NMFMA) {
     // =============================== loader waves ===============================
+    // (a split-K slice without K tiles -- 16 splits of 129 K tiles leave the last one empty -- still writes its
+    // zero partial: only the loaders leave)
+    if (total == 0) return;
     const int lt = threadIdx.x - NMFMA, l = lt & 63;
     const int lw = __builtin_amdgcn_readfirstlane(lt >> 6);      // scalar: LDS piece addresses stay in SGPRs
     const int kc = (l & 7) ^ ((4 * (lw & 1) + (l >> 4)) & 7);   // logical chunk fetched by this lane

@@ -377,6 +377,186 @@ int launch_wgrad_tr(const SdmiWgradArgs& a, hipStream_t st) {
   return sdmi_check_launch("wgrad");
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Direct weight gradient of the 64 -> 64 channel 3x3 convolutions at full resolution (slot encoder /
+// VQ-VAE at 128^2: M = 1M pixels, N = 64, K = 576).  As an implicit GEMM (wgrad_tr_kernel<64, 128, 2>) this
+// shape re-fetches every activation row for each of the 9 taps and dY for each of the 5 column blocks --
+// 1.9 GB of L2 -> LDS traffic per launch, 211 us.  Here (the weight-gradient twin of conv3x3_c64_kernel):
+//   * persistent workgroup s of `splits` (256 threads = 4 waves, one per CU) walks output tiles of 4 image
+//     rows x 64 pixels; the tile's dY (256 px x 64 ch) and its 6 x 66 pixel input halo (zeros outside the
+//     image) are staged ONCE and serve all 9 taps: a tap only shifts the fragment address;
+//   * the contraction runs over pixels, both operands are pixel-major: fragments come from the transposing
+//     LDS read (ds_read_b64_tr_b16, pixel pitch 192 B = 64 mod 256: conflict free), 16 pixels of an image
+//     row per MFMA k-step;
+//   * wave w owns output channels [32 (w & 1), +32) x taps {w >> 1, + 2, ...} (5 / 5 / 4 / 4 of the 18
+//     (tap, half) units): 160 accumulator registers, kept across ALL tiles of the workgroup;
+//   * the next tile's operands are prefetched into registers under the MFMAs;
+//   * the workgroup's partial dW [64][576] (and column sums of dY) go to slot s of the M-split workspace,
+//     folded by the usual deterministic reduce.
+constexpr int W33_PIX = 192;
+constexpr int W33_HALO = 6 * 66, W33_DY = 4 * 64;
+constexpr int W33_HV = (W33_HALO * 8 + 255) / 256, W33_DV = W33_DY * 8 / 256;     // uint4 per thread
+constexpr int W33_SMEM = (W33_HALO + W33_DY) * W33_PIX;
+
+__global__ __launch_bounds__(256) void wgrad3x3_c64_kernel(SdmiWgradArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const Xs = smem;
+  char* const Ys = smem + W33_HALO * W33_PIX;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bf16_t* __restrict__ Ag = (const bf16_t*)p.a;
+  const bf16_t* __restrict__ Yg = (const bf16_t*)p.dy;
+  const int tiles_x = p.W / 64, tiles_y = p.H / 4;
+  const int n_tiles = p.B * tiles_y * tiles_x;
+  const int split = blockIdx.x, nsplit = gridDim.x;
+
+  u32x4 prex[W33_HV], prey[W33_DV];
+  float bsum[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) bsum[j] = 0.f;
+  auto fetch = [&](int t) __attribute__((always_inline)) {
+    const int b = t / (tiles_y * tiles_x), r = t - b * tiles_y * tiles_x;
+    const int ty = r / tiles_x, tx = r - ty * tiles_x;
+    const int iy0 = ty * 4 - 1, ix0 = tx * 64 - 1;
+#pragma unroll
+    for (int i = 0; i < W33_HV; ++i) {
+      const int v = tid + i * 256, px = v >> 3, ch = v & 7;
+      const int hy = px / 66, hx = px - hy * 66;
+      const int iy = iy0 + hy, ix = ix0 + hx;
+      const bool ok = px < W33_HALO && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+      prex[i] = ok ? *reinterpret_cast<const u32x4*>(Ag + ((long long)(b * p.H + iy) * p.W + ix) * p.lda + ch * 8)
+                   : u32x4{0u, 0u, 0u, 0u};
+    }
+#pragma unroll
+    for (int i = 0; i < W33_DV; ++i) {
+      const int v = tid + i * 256, px = v >> 3, ch = v & 7;
+      const long long m = (long long)(b * p.H + ty * 4 + (px >> 6)) * p.W + tx * 64 + (px & 63);
+      prey[i] = *reinterpret_cast<const u32x4*>(Yg + m * p.ldy + ch * 8);
+    }
+  };
+  auto stash = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < W33_HV; ++i) {
+      const int v = tid + i * 256, px = v >> 3, ch = v & 7;
+      if (px < W33_HALO) *reinterpret_cast<u32x4*>(Xs + px * W33_PIX + ch * 16) = prex[i];
+    }
+#pragma unroll
+    for (int i = 0; i < W33_DV; ++i) {
+      const int v = tid + i * 256, px = v >> 3, ch = v & 7;
+      *reinterpret_cast<u32x4*>(Ys + px * W33_PIX + ch * 16) = prey[i];
+      float f[8];
+      unpack16<bf16_t>(__builtin_bit_cast(uint4, prey[i]), f);     // column sums of dY: channels (tid & 7) * 8 ...
+#pragma unroll
+      for (int j = 0; j < 8; ++j) bsum[j] += f[j];
+    }
+  };
+
+  // fragment addressing of the transposing read (wgrad_body.h): lane (g, t) -> pixel (g >> 1) * 8 + t / 4
+  // (+4 for the second read), channels (g & 1) * 16 + (t % 4) * 4 of a 32-channel fragment
+  const int g = lane >> 4, tt = lane & 15;
+  const int lrow = (g >> 1) * 8 + (tt >> 2), lcol = (g & 1) * 16 + (tt & 3) * 4;
+  const int chh = wave & 1, tp0 = wave >> 1;
+  const char* const yb = Ys + lrow * W33_PIX + (chh * 32 + lcol) * 2;
+  const char* const xb = Xs + lrow * W33_PIX + lcol * 2;
+  int tapoff[5];
+#pragma unroll
+  for (int u = 0; u < 5; ++u) {
+    const int tap = tp0 + 2 * u, kh = tap / 3, kw = tap - kh * 3;
+    tapoff[u] = (kh * 66 + kw) * W33_PIX;
+  }
+  const int n_units = tp0 == 0 ? 5 : 4;
+  f32x16 acc[5][2];
+#pragma unroll
+  for (int u = 0; u < 5; ++u)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[u][j][r] = 0.f;
+
+  auto read_y = [&](int ks) __attribute__((always_inline)) {
+    const char* q = yb + ((ks >> 2) * 64 + (ks & 3) * 16) * W33_PIX;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(SDMI_LDS_V4(q));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(SDMI_LDS_V4(q + 4 * W33_PIX));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  };
+  auto read_x = [&](int ks, int toff, s16x8 (&fx)[2]) __attribute__((always_inline)) {
+    const char* q = xb + ((ks >> 2) * 66 + (ks & 3) * 16) * W33_PIX + toff;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(SDMI_LDS_V4(q + j * 64));
+      const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(SDMI_LDS_V4(q + j * 64 + 4 * W33_PIX));
+      fx[j] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+  };
+
+  int t = split;
+  if (t < n_tiles) fetch(t);
+  for (; t < n_tiles; t += nsplit) {
+    __syncthreads();                       // previous tile's fragment reads are done
+    stash();
+    __syncthreads();
+    if (t + nsplit < n_tiles) fetch(t + nsplit);     // in flight under the MFMAs below
+    s16x8 fy = read_y(0), fx[3][2];            // unit u uses buffer u % 3 (five units: two would collide)
+    read_x(0, tapoff[0], fx[0]);
+    for (int ks = 0; ks < 16; ++ks) {
+      s16x8 fy_n = fy;
+#pragma unroll
+      for (int u = 0; u < 5; ++u) {
+        // fragments of the next unit (or of the next k-step's first unit) are fetched under this unit's MFMAs
+        if (u + 1 < 5) {
+          if (u + 1 < n_units) read_x(ks, tapoff[u + 1], fx[(u + 1) % 3]);
+        } else if (ks + 1 < 16) {
+          fy_n = read_y(ks + 1);
+          read_x(ks + 1, tapoff[0], fx[0]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (u < n_units) {
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[u][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                __builtin_bit_cast(bf16x8, fy), __builtin_bit_cast(bf16x8, fx[u % 3][j]), acc[u][j], 0, 0, 0);
+        }
+      }
+      fy = fy_n;
+    }
+  }
+
+  // ---- this workgroup's partials: dW [64][576] and the column sums of dY
+  float* const ws = p.workspace + (long long)split * p.N * p.K;
+  const int col = lane & 31, row_l = (lane >> 5) * 4;
+#pragma unroll
+  for (int u = 0; u < 5; ++u) {
+    if (u < n_units) {
+      const int tap = tp0 + 2 * u;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int n = chh * 32 + (r & 3) + 8 * (r >> 2) + row_l;
+          ws[(long long)n * p.K + tap * 64 + j * 32 + col] = acc[u][j][r];
+        }
+    }
+  }
+  __syncthreads();
+  float* red = reinterpret_cast<float*>(smem);       // [256][8]
+#pragma unroll
+  for (int j = 0; j < 8; ++j) red[tid * 8 + j] = bsum[j];
+  __syncthreads();
+  if (tid < 64) {
+    const int c = tid >> 3, j = tid & 7;              // channel tid = chunk c, element j
+    float sacc = 0.f;
+    for (int r = 0; r < 32; ++r) sacc += red[(r * 8 + c) * 8 + j];
+    p.workspace[(long long)nsplit * p.N * p.K + (long long)split * p.N + tid] = sacc;
+  }
+}
+
+static int launch_wgrad3x3_c64(const SdmiWgradArgs& a, hipStream_t st) {
+  SDMI_OPTIN_LDS(wgrad3x3_c64_kernel, W33_SMEM, "wgrad (direct 3x3 c64)");
+  hipLaunchKernelGGL(wgrad3x3_c64_kernel, dim3(a.splits), dim3(256), W33_SMEM, st, a);
+  return sdmi_check_launch("wgrad (direct 3x3 c64)");
+}
+
 static bool wgrad_is1x1(const SdmiWgradArgs& a) {
   return a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad_t == 0 && a.pad_l == 0 && !a.ups &&
          a.H == a.Ho && a.W == a.Wo;
@@ -407,6 +587,18 @@ int dispatch_wgrad_bf16(const SdmiWgradArgs& a, hipStream_t st) {
   const long long mps = ((long long)a.M + a.splits - 1) / a.splits + 64;
   const long long ld = a.lda > a.ldy ? a.lda : a.ldy;
   const bool fits = (mps + (long long)(a.KH + 1) * a.W + 64) * ld * 2 < (1ll << 31);
+  // direct kernel for the 64 -> 64 channel 3x3 layers at full resolution (one workgroup per M-split slot)
+  {
+    static int d33 = -1;
+    if (d33 < 0) {
+      const char* e = getenv("SDMI_WGRAD_D33");
+      d33 = e ? atoi(e) : 1;
+    }
+    if (d33 && a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad_t == 1 && a.pad_l == 1 && !a.ups && a.Cin == 64 &&
+        a.N == 64 && a.K == 576 && a.H == a.Ho && a.W == a.Wo && a.W % 64 == 0 && a.H % 4 == 0 && a.splits >= 2 &&
+        (long long)a.B * (a.H / 4) * (a.W / 64) >= a.splits && (long long)a.B * a.H * a.W * (a.lda > a.ldy ? a.lda : a.ldy) < (1ll << 40))
+      return launch_wgrad3x3_c64(a, st);
+  }
 #define WG_TR(TN, TK)                                                              \
   (is1x1 && fits ? launch_wgrad_tr<TN, TK, 1>(a, st)                               \
    : lin && fits ? launch_wgrad_tr<TN, TK, 2>(a, st) : launch_wgrad_tr<TN, TK, 0>(a, st))
@@ -445,7 +637,7 @@ extern "C" int sdmi_wgrad_group(const SdmiWgradGroupArgs* ga, void* stream) {
     items += g.per_split[i] * a.splits;
     g.red_begin[i] = red;
     if (a.splits > 1) {
-      long long blocks = ((long long)a.N * a.K / 4 + 255) / 256;
+      long long blocks = wgrad_fold_blocks(a);
       red += (int)(blocks > 512 ? 512 : blocks);
     }
   }
@@ -471,7 +663,7 @@ extern "C" int sdmi_wgrad_fold_group(const SdmiWgradGroupArgs* ga, void* stream)
     g.p[i] = ps[i];
     g.item_begin[i] = 0;
     g.red_begin[i] = red;
-    long long blocks = ((long long)ps[i].N * ps[i].K / 4 + 255) / 256;
+    long long blocks = wgrad_fold_blocks(ps[i]);
     red += (int)(blocks > 512 ? 512 : blocks);
   }
   for (int i = ga->n; i <= WG_MAX; ++i) { g.item_begin[i] = 0; g.red_begin[i] = red; }
@@ -493,7 +685,7 @@ extern "C" int sdmi_wgrad(const SdmiWgradArgs* a, void* stream) {
   rc = a->dtype == SDMI_BF16 ? dispatch_wgrad_bf16(*a, st) : dispatch_wgrad_f32(*a, st);
   if (rc || a->splits == 1 || a->defer_fold) return rc;
   const long long total = (long long)a->N * a->K;     // K % 4 == 0 (Cin % vec == 0)
-  int blocks = (int)((total / 4 + 255) / 256);
+  int blocks = (int)wgrad_fold_blocks(*a);
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, *a);
   return sdmi_check_launch("wgrad reduce");

@@ -349,32 +349,65 @@ __device__ __forceinline__ void wgrad_tr_body(const SdmiWgradArgs& p, int tiles_
 }
 
 
+// Fold of the M-split partials, deterministic: output vector i is owned by G adjacent lanes (G = 1 below 64
+// splits, else 8); lane g sums the contiguous split range [g * ceil(S / G), ...) in split order, the G range sums are
+// added in range order behind the destination's previous value.  With one lane per output a 256-split fold
+// (the direct 3x3 kernel's one slot per CU) was a chain of 32 dependent load batches on 36 workgroups: 72 us.
+__host__ __device__ inline int wgrad_fold_lanes(int splits) { return splits >= 64 ? 8 : 1; }
+// workgroups of THREADS threads that cover the fold of one problem (callers cap it)
+static inline long long wgrad_fold_blocks(const SdmiWgradArgs& a, int threads = 256) {
+  return ((long long)a.N * a.K / 4 * wgrad_fold_lanes(a.splits) + threads - 1) / threads;
+}
+
 template <int THREADS = 256>
 __device__ __forceinline__ void wgrad_reduce_body(const SdmiWgradArgs& p, int blk, int nblk) {
   const long long total = (long long)p.N * p.K;
   const long long total4 = total >> 2;
-  for (long long i = (long long)blk * THREADS + threadIdx.x; i < total4; i += (long long)nblk * THREADS) {
+  const int G = wgrad_fold_lanes(p.splits);
+  const int per = (p.splits + G - 1) / G;
+  const int gl = threadIdx.x & (G - 1);
+  const int k0 = gl * per, k1 = min(p.splits, k0 + per);
+  for (long long i = ((long long)blk * THREADS + threadIdx.x) / G;; i += (long long)nblk * THREADS / G) {
+    // (the G lanes of an output leave the loop together: i is the same for all of them)
+    if (i >= total4) break;
     const f32x4* src = reinterpret_cast<const f32x4*>(p.workspace) + i;
     f32x4* dst = reinterpret_cast<f32x4*>(p.dw) + i;
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    if (p.accumulate) s = *dst;
-    int k = 0;
-    for (; k + 8 <= p.splits; k += 8) {
+    if (G == 1 && p.accumulate) s = *dst;
+    int k = k0;
+    for (; k + 8 <= k1; k += 8) {
       f32x4 v[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) v[u] = src[(long long)(k + u) * total4];
 #pragma unroll
       for (int u = 0; u < 8; ++u) s += v[u];
     }
-    for (; k < p.splits; ++k) s += src[(long long)k * total4];
-    *dst = s;
+    for (; k < k1; ++k) s += src[(long long)k * total4];
+    if (G > 1) {
+      f32x4 t = {0.f, 0.f, 0.f, 0.f};
+      if (p.accumulate && gl == 0) t = *dst;
+      const int base = (threadIdx.x & 63) & ~(G - 1);
+      for (int g = 0; g < G; ++g) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) t[c] += __shfl(s[c], base + g, 64);
+      }
+      s = t;
+    }
+    if (gl == 0) *dst = s;
   }
   if (p.dbias)
-    for (long long n = (long long)blk * THREADS + threadIdx.x; n < p.N; n += (long long)nblk * THREADS) {
-      float s = p.accumulate ? p.dbias[n] : 0.f;
-      for (int k = 0; k < p.splits; ++k)
-        s += p.workspace[(long long)p.splits * total + (long long)k * p.N + n];
-      p.dbias[n] = s;
+    for (long long n = ((long long)blk * THREADS + threadIdx.x) / G;; n += (long long)nblk * THREADS / G) {
+      if (n >= p.N) break;
+      const float* src = p.workspace + (long long)p.splits * total + n;
+      float s = (G == 1 && p.accumulate) ? p.dbias[n] : 0.f;
+      for (int k = k0; k < k1; ++k) s += src[(long long)k * p.N];
+      if (G > 1) {
+        float t = (p.accumulate && gl == 0) ? p.dbias[n] : 0.f;
+        const int base = (threadIdx.x & 63) & ~(G - 1);
+        for (int g = 0; g < G; ++g) t += __shfl(s, base + g, 64);
+        s = t;
+      }
+      if (gl == 0) p.dbias[n] = s;
     }
 }
 

@@ -941,6 +941,17 @@ class RowvecSplitFn(torch.autograd.Function):
         return buf, None
 
 
+_CUS = {}
+
+
+def _n_cus(device):
+    """Compute units of `device` (cached)."""
+    key = str(device)
+    if key not in _CUS:
+        _CUS[key] = int(torch.cuda.get_device_properties(device).multi_processor_count)
+    return _CUS[key]
+
+
 class GemmFn(torch.autograd.Function):
     """out = conv/linear(x, W) + bias (+ rowvec[b]) (+ residual).  Activation-free."""
 
@@ -1035,6 +1046,11 @@ class GemmFn(torch.autograd.Function):
         splits = max(1, min((192 + tiles - 1) // tiles, M // (8 * mt), 512))
         if M <= 16 * mt:
             splits = 1
+        if (dt == torch.bfloat16 and is_conv and kh == 3 and kw == 3 and stride == 1 and not ups and Cin == 64
+                and N == 64 and tuple(pad) == (1, 1, 1, 1) and W_ % 64 == 0 and H % 4 == 0
+                and B * (H // 4) * (W_ // 64) >= 2 * _n_cus(x.device)):
+            # the direct 3x3 kernel (wgrad.hip: wgrad3x3_c64_kernel): one persistent workgroup per CU and slot
+            splits = _n_cus(x.device)
         bdst = _grads_of(wb, bnames) if bnames is not None else None
         lda = Cin if is_conv else x.stride(-2)
         if (wb.group_wgrad and dt == torch.bfloat16 and kh == 1 and kw == 1 and stride == 1 and not ups

@@ -69,6 +69,7 @@ CONV_CASES = [
     (2, 64, 128, 16, 1, 2, (0, 0, 0, 0), False, ''),                 # ResNet downsample 1x1 s2
     (4, 512, 512, 4, 3, 1, (1, 1, 1, 1), False, 'bias,rowvec'),      # skinny: split-K path
     (1, 896, 384, 8, 3, 1, (1, 1, 1, 1), False, 'bias'),             # non power-of-two Cin
+    (1, 960, 64, 4, 3, 1, (1, 1, 1, 1), False, 'bias'),              # 16 K-splits of 135 K tiles: the last one is empty
     # LDS-DMA kernels (>= 192 tiles of 256x128, or of 128x128 when M is too small for that)
     (48, 64, 128, 32, 3, 1, (1, 1, 1, 1), False, 'bias,rowvec,res,silu'),   # 256x128, 3 stages
     (25, 128, 192, 30, 3, 1, (1, 1, 1, 1), False, 'bias'),           # 128x128 x4 stages, ragged M / N

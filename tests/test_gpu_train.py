@@ -354,6 +354,8 @@ def test_train_step_bf16_gradients_close():
                                   (3, 128, 3, 16, 3, 1, (1, 1, 1, 1), False),
                                   (2, 96, 192, 8, 1, 1, (0, 0, 0, 0), False),
                                   (2, 64, 64, 32, 5, 1, (2, 2, 2, 2), False),     # 5x5 "same"
+                                  (3, 64, 64, 64, 3, 1, (1, 1, 1, 1), False),     # direct 3x3 c64 kernel (splits > 1)
+                                  (1, 64, 64, 128, 3, 1, (1, 1, 1, 1), False),    # ... two tiles per image row
                                   (1, 16, 32, 128, 3, 1, (1, 1, 1, 1), False),    # W > m step
                                   (2, 32, 64, 12, 3, 1, (1, 1, 1, 1), False),     # not 2^n
                                   (5, 72, 200, 8, 1, 1, (0, 0, 0, 0), False)])    # 1x1 tails
