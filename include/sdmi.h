@@ -156,7 +156,7 @@ int sdmi_wgrad_fold_group(const SdmiWgradGroupArgs* a, void* stream);
  *          (a = dY, w = the flipped operand, out = dX; alpha / bias / residual epilogue only; no split-K,
  *          batch, sub-sampled output or fused epilogues; N > 64);
  *   wgrad  HOST pointer to the SdmiWgradArgs of the weight gradient as sdmi_wgrad would take it (N > 64,
- *          K > 64; 1x1 / linear, or a stride-1 same-size convolution on a power-of-two image; splits > 1
+ *          K > 64; 1x1 / linear, or a stride-1 same-size convolution; splits > 1
  *          leaves the M-split partials in `workspace` -- see `fold`);
  *   fold   optional HOST pointer to the SdmiWgradArgs of an EARLIER launch whose partials are complete
  *          (dw, dbias, workspace, N, K, splits, accumulate are read): folded into its dw / dbias by extra

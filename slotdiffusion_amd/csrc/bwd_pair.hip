@@ -120,8 +120,7 @@ extern "C" int sdmi_bwd_pair(const SdmiBwdPairArgs* a, void* stream) {
   // ---- the weight gradient: 128 x 128 output tiles, same loader class as the data gradient
   const bool w1x1 = w.KH == 1 && w.KW == 1 && w.stride == 1 && w.pad_t == 0 && w.pad_l == 0 && !w.ups && w.H == w.Ho &&
                     w.W == w.Wo;
-  const bool wlin = !w1x1 && !w.ups && w.stride == 1 && w.H == w.Ho && w.W == w.Wo && (w.H & (w.H - 1)) == 0 &&
-                    (w.W & (w.W - 1)) == 0;
+  const bool wlin = !w1x1 && !w.ups && w.stride == 1 && w.H == w.Ho && w.W == w.Wo;
   SDMI_REQUIRE((d1x1 && w1x1) || (dplain && wlin), "both gradients must be 1x1, or both a stride-1 same-size convolution");
   SDMI_REQUIRE(w.N > 64 && w.K > 64 && w.K == w.KH * w.KW * w.Cin && w.M == w.B * w.Ho * w.Wo && w.Cin % 8 == 0 &&
                w.lda % 8 == 0 && w.ldy % 8 == 0, "bad wgrad geometry");

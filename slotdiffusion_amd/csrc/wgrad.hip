@@ -581,8 +581,13 @@ int dispatch_wgrad_bf16(const SdmiWgradArgs& a, hipStream_t st) {
   const bool is1x1 = wgrad_is1x1(a);
   const bool n64 = a.N <= 64, k64 = a.K <= 64;
   // "same" stride-1 convolution on a power-of-two image: the input pixel is linear in m
+  static int lin_any = -1;              // SDMI_WGRAD_LIN_ANY=0: the fast loaders only for power-of-two images
+  if (lin_any < 0) {
+    const char* e = getenv("SDMI_WGRAD_LIN_ANY");
+    lin_any = e ? atoi(e) : 1;
+  }
   const bool lin = !is1x1 && !a.ups && a.stride == 1 && a.H == a.Ho && a.W == a.Wo &&
-                   (a.H & (a.H - 1)) == 0 && (a.W & (a.W - 1)) == 0;
+                   (lin_any || ((a.H & (a.H - 1)) == 0 && (a.W & (a.W - 1)) == 0));
   // the scalar-only loaders address a split's rows with 31-bit byte offsets
   const long long mps = ((long long)a.M + a.splits - 1) / a.splits + 64;
   const long long ld = a.lda > a.ldy ? a.lda : a.ldy;

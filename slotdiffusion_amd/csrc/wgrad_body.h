@@ -164,6 +164,7 @@ __device__ __forceinline__ void wgrad_tr_body(const SdmiWgradArgs& p, int tiles_
       }
       while ((1 << lw_sh) < p.W) ++lw_sh;
     }
+    const bool pow2 = (p.H & (p.H - 1)) == 0 && (p.W & (p.W - 1)) == 0;
 
     auto issue = [&](int mt, u32x4 (&ry)[Y_PER], u32x4 (&ra)[A_PER], unsigned& mask)
                      __attribute__((always_inline)) {
@@ -184,7 +185,20 @@ __device__ __forceinline__ void wgrad_tr_body(const SdmiWgradArgs& p, int tiles_
           unsigned vo = a_vo[i];
           const int m = mt + ar0 + i * RSA;
           if constexpr (MODE == 2) {
-            const int ox = m & (p.W - 1), oy = (m >> lw_sh) & (p.H - 1);
+            int ox, oy;
+            if (pow2) {
+              ox = m & (p.W - 1);
+              oy = (m >> lw_sh) & (p.H - 1);
+            } else {
+              // any image size (28^2 latents of the 224^2 configurations): the row's pixel is carried along,
+              // advanced by the MT rows of a step (steps are issued in order)
+              ox = pox[i];
+              oy = poy[i];
+              pox[i] += adv_x;
+              poy[i] += adv_y;
+              if (pox[i] >= p.Wo) { pox[i] -= p.Wo; ++poy[i]; }
+              if (poy[i] >= p.Ho) poy[i] -= p.Ho;
+            }
             const bool bad = (unsigned)(oy + a_kh - p.pad_t) >= (unsigned)p.H ||
                              (unsigned)(ox + a_kw - p.pad_l) >= (unsigned)p.W;
             vo = bad ? OOB : vo;

@@ -119,6 +119,8 @@ class WeightBank:
         # no side-stream fork / join per layer, the M-split partials of a layer are folded by extra
         # workgroups of the NEXT layer's launch (`_pfold`: the pending fold), the last one at the join
         self.pair_bwd = os.environ.get('SDMI_BWD_PAIR', '1') != '0'
+        # same-size convolutions on images that are not powers of two (28^2 latents) take the pair launch as well
+        self.pair_any_size = os.environ.get('SDMI_PAIR_ANY', '1') != '0'
         self.pair_slots = int(os.environ.get('SDMI_PAIR_SLOTS', '512'))       # resident workgroups (2 per CU)
         self.pair_dgrad = int(os.environ.get('SDMI_PAIR_DGRAD', '256'))       # of which walk dX tiles
         self.pair_min_steps = int(os.environ.get('SDMI_PAIR_MIN_STEPS', '8'))  # 64-row steps per wgrad workgroup
@@ -1066,9 +1068,9 @@ class GemmFn(torch.autograd.Function):
             pass            # measurement only (wrong gradients): the step without weight gradients
         else:
             # ---- data + weight gradient in ONE launch (sdmi_bwd_pair) when both are of the same loader
-            # class: 1x1 / linear, or a stride-1 same-size convolution on a power-of-two image
+            # class: 1x1 / linear, or a stride-1 same-size convolution
             same = is_conv and stride == 1 and not ups and Ho == H and Wo == W_
-            pow2 = (H & (H - 1)) == 0 and (W_ & (W_ - 1)) == 0
+            pow2 = ((H & (H - 1)) == 0 and (W_ & (W_ - 1)) == 0) or wb.pair_any_size
             one = kh == 1 and kw == 1 and stride == 1 and not ups and pad[0] == 0 and pad[2] == 0
             kd = kh * kw * ldy                                   # contraction depth of the data gradient
             bk = 64 if kd * 2 >= 512 else 32

@@ -638,7 +638,8 @@ def test_wgrad_group_matches_single_launches():
     (16384, 0, 256, 256, 1, True, True, 16), (448, 0, 192, 576, 1, True, False, 1),
     (4, 16, 128, 256, 3, True, True, 2), (2, 32, 128, 128, 3, True, False, 4),
     (8, 8, 384, 384, 3, False, True, 1), (3, 16, 256, 192, 1, True, False, 2),
-    (64, 4, 512, 512, 3, True, False, 1)])
+    (64, 4, 512, 512, 3, True, False, 1),
+    (3, 28, 128, 192, 3, True, True, 3), (5, 14, 256, 256, 3, False, False, 2)])     # 28^2 / 14^2: not powers of two
 def test_bwd_pair_matches_separate_launches(case):
     """sdmi_bwd_pair: data gradient + weight gradient (+ the fold of an earlier layer's M-split partials)
     in ONE launch equal sdmi_igemm + sdmi_wgrad (+ its fold) bit for bit, and torch's fp32 gradients
