@@ -652,3 +652,20 @@ def test_conv3x3_with_extra_1x1_sources(case, dtype):
     out = ops.conv2d(nhwc(h), wk, bias.to(DEV), kh=3, kw=3, pad=(1, 1, 1, 1), x2=nhwc(xa),
                      x3=(nhwc(xb) if xb is not None else None))
     check(out.permute(0, 3, 1, 2), ref, dtype, f'conv3x3 + 1x1 sources {case}')
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('shape', [(37, 64), (130, 1024), (9, 3136), (6, 520), (5, 4100), (7, 36)])
+def test_softmax_rows(shape, dtype):
+    """sdmi_softmax_rows (in place, scaled) against torch: register-resident rows up to 64 lanes x 8 vectors,
+    the sweeping kernel beyond that / for unaligned widths."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(shape[0] * shape[1])
+    x = (torch.randn(shape, generator=g) * 3).to(dtype)
+    ref = torch.softmax(x.float() * 0.37, -1)
+    y = x.to(DEV).clone()
+    ops.softmax_rows_(y, scale=0.37)
+    tol = 1e-6 if dtype == torch.float32 else 4e-3
+    assert float((y.float().cpu() - ref).abs().max()) <= tol
+    assert float((y.float().cpu().sum(-1) - 1).abs().max()) <= (1e-5 if dtype == torch.float32 else 2e-2)
