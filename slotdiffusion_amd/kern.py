@@ -121,6 +121,8 @@ class WeightBank:
         self.pair_bwd = os.environ.get('SDMI_BWD_PAIR', '1') != '0'
         # same-size convolutions on images that are not powers of two (28^2 latents) take the pair launch as well
         self.pair_any_size = os.environ.get('SDMI_PAIR_ANY', '1') != '0'
+        # experiment knob: layers whose data gradient has fewer 128 x 128 tiles than this keep separate launches
+        self.pair_min_t128 = int(os.environ.get('SDMI_PAIR_MIN_T128', '0'))
         self.pair_slots = int(os.environ.get('SDMI_PAIR_SLOTS', '512'))       # resident workgroups (2 per CU)
         self.pair_dgrad = int(os.environ.get('SDMI_PAIR_DGRAD', '256'))       # of which walk dX tiles
         self.pair_min_steps = int(os.environ.get('SDMI_PAIR_MIN_STEPS', '8'))  # 64-row steps per wgrad workgroup
@@ -1079,6 +1081,7 @@ class GemmFn(torch.autograd.Function):
                     and (one or (same and pow2 and kh * kw <= 32 and ldy % bk == 0
                                  and pad[0] == pad[1] == (kh - 1) // 2 and pad[2] == pad[3] == (kw - 1) // 2))
                     and (dalias is None or dalias.shape[-1] == Cin)
+                    and ((M + 127) // 128) * ((Cin + 127) // 128) >= wb.pair_min_t128
                     and (M + (kh + 1) * W_ + 128) * max(lda, ldy, Cin) * 2 < (1 << 31) and N * kd * 2 < (1 << 31))
             if pair:
                 wd = wb.wd(wnames, dt, kh, kw, Cin)
