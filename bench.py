@@ -148,7 +148,7 @@ def cpu_baseline(model, cfg, mode, quick=False):
 FAMILIES = {
     'sdmi_igemm': ('igemm_kernel', 'igemm_kernel_tall', 'igemm_dma_kernel', 'conv3x3_c64_kernel',
                    'splitk_epilogue_kernel', 'bwd_pair_kernel'),
-    'sdmi_wgrad': ('wgrad_kernel', 'wgrad_tr_kernel', 'wgrad_group_kernel', 'wgrad_group_reduce_kernel',
+    'sdmi_wgrad': ('wgrad_kernel', 'wgrad_tr_kernel', 'wgrad3x3_c64_kernel', 'wgrad_group_kernel', 'wgrad_group_reduce_kernel',
                    'wgrad_reduce_kernel'),
     'sdmi_groupnorm': ('gn_fused_kernel', 'gn_stats_kernel', 'gn_apply_kernel'),
     'sdmi_groupnorm_bwd': ('gn_bwd_fused_kernel', 'gn_bwd_stats_kernel', 'gn_bwd_apply_kernel'),
