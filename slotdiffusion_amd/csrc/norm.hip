@@ -7,6 +7,7 @@
 // strided runs, combined across threads and splits in fp64, deterministically (no atomics).
 #include "common.h"
 #include "gn_geom.h"
+#include <type_traits>
 
 namespace {
 
@@ -305,6 +306,202 @@ __global__ __launch_bounds__(THREADS) void gn_fused_kernel(SdmiGroupNormArgs p) 
 }
 
 // ------------------------------------------------------------------------------------------
+// Single-pass GroupNorm, second form (round 3).  Same geometry and data movement as gn_fused_kernel, but the
+// part between the loads and the stores is cut down: in a dependent chain the first form took 2 - 3.5x the
+// time of a copy of the same tensor (tools/exp/gn_chain.py: 10.9 vs 4.8 us at [64][16^2][256]), the
+// difference being VALU work and the three-barrier fp64 fold, not memory.
+//   * a 16-byte vector spans at most TWO groups whenever C/groups >= VEC/2: each lane folds its VEC channel
+//     sums into two (sum, sum of squares) slots BEFORE any cross-lane step, so the butterflies move 4 values
+//     instead of 2 * VEC, the in-row steps as DPP row rotations (no LDS crossbar), and an LDS entry is one float4;
+//   * fold: one thread per vector column sums the wave entries in fp64; after the second (last) barrier every
+//     thread gathers its own two groups' columns (<= 5 reads each) and derives mean / rstd itself -- no third
+//     barrier, no single-thread fp64 division + sqrt on the critical path (v_rsq_f64 + one Newton step);
+//   * lane coordinates by shifts (CVp is a power of two), gamma / beta as 16-byte loads, the activation
+//     hoisted out of the element loop, SiLU through v_rcp_f32 (common.h).
+__device__ __forceinline__ float dpp_ror_add(float v, int ctrl_sel) {
+  // v + (v rotated right by 1 / 2 / 4 / 8 lanes inside each row of 16 lanes)
+  int r;
+  const int iv = __float_as_int(v);
+  switch (ctrl_sel) {
+    case 1: r = __builtin_amdgcn_update_dpp(0, iv, 0x121, 0xf, 0xf, false); break;
+    case 2: r = __builtin_amdgcn_update_dpp(0, iv, 0x122, 0xf, 0xf, false); break;
+    case 4: r = __builtin_amdgcn_update_dpp(0, iv, 0x124, 0xf, 0xf, false); break;
+    default: r = __builtin_amdgcn_update_dpp(0, iv, 0x128, 0xf, 0xf, false); break;
+  }
+  return v + __int_as_float(r);
+}
+// all-reduce over the lanes of a wave that share (lane mod CVp); CVp a power of two < 64 (wave-uniform)
+__device__ __forceinline__ float col_allreduce(float v, int CVp) {
+  if (CVp <= 1) v = dpp_ror_add(v, 1);
+  if (CVp <= 2) v = dpp_ror_add(v, 2);
+  if (CVp <= 4) v = dpp_ror_add(v, 4);
+  if (CVp <= 8) v = dpp_ror_add(v, 8);
+  if (CVp <= 16) v += __shfl_xor(v, 16, 64);
+  if (CVp <= 32) v += __shfl_xor(v, 32, 64);
+  return v;
+}
+template <int VEC>
+__device__ __forceinline__ void load_fvec(const float* q, float* out) {
+  if ((reinterpret_cast<uintptr_t>(q) & 15) == 0) {
+#pragma unroll
+    for (int h = 0; h < VEC / 4; ++h) {
+      const float4 v = *reinterpret_cast<const float4*>(q + 4 * h);
+      out[4 * h] = v.x; out[4 * h + 1] = v.y; out[4 * h + 2] = v.z; out[4 * h + 3] = v.w;
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) out[j] = q[j];
+  }
+}
+
+template <typename T, int THREADS, int NV, bool F8 = false>
+__global__ __launch_bounds__(THREADS) void gn_fused2_kernel(SdmiGroupNormArgs p) {
+  constexpr int VEC = Elem<T>::VEC;
+  constexpr int VSH = VEC == 8 ? 3 : 2;
+  extern __shared__ __attribute__((aligned(16))) float gn_smem[];
+  const int b = blockIdx.x;
+  const int S = gridDim.y, sidx = blockIdx.y;
+  const int CV = p.C / VEC / S;
+  const int csh = CV <= 1 ? 0 : 32 - __builtin_clz(CV - 1);
+  const int CVp = 1 << csh;
+  const int c_lo = sidx * CV * VEC;
+  const int R = THREADS >> csh;
+  const int RR = CVp < 64 ? THREADS / 64 : R;             // LDS entries per vector column
+  float4* part = reinterpret_cast<float4*>(gn_smem);                         // [RR][CVp]
+  double* colsum = reinterpret_cast<double*>(gn_smem + RR * CVp * 4);        // [CVp][4]
+  const int tid = threadIdx.x;
+  const int cv = tid & (CVp - 1), r0 = tid >> csh;
+  const bool act_c = cv < CV;
+  const int cvc = act_c ? cv : 0;
+  const int cpg = p.C / p.groups;
+  const int cl0 = cvc * VEC;                              // chunk-local first channel of this lane
+  const int g0 = cl0 / cpg;                               // its (chunk-local) group = slot 0
+  const int bnd = (g0 + 1) * cpg - cl0;                   // channels j >= bnd belong to group g0 + 1 = slot 1
+  const long long base = (long long)b * p.HW * p.C + c_lo + cl0;
+  int xp;
+  const T* xb = gn_src<T>(p, b, c_lo + cl0, xp);
+  uint4 xr[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int row = r0 + i * R;
+    if (act_c && row < p.HW) xr[i] = *reinterpret_cast<const uint4*>(xb + (long long)row * xp);
+  }
+  float gam[VEC], bet[VEC];                               // fetched next to the slab (one latency chain)
+  load_fvec<VEC>(p.gamma + c_lo + cl0, gam);
+  load_fvec<VEC>(p.beta + c_lo + cl0, bet);
+  float s[VEC], ss[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) s[j] = ss[j] = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int row = r0 + i * R;
+    if (act_c && row < p.HW) {
+      float f[VEC];
+      unpack16<T>(xr[i], f);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) { s[j] += f[j]; ss[j] = fmaf(f[j], f[j], ss[j]); }
+    }
+  }
+  float a0 = 0.f, q0 = 0.f, a1 = 0.f, q1 = 0.f;
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    const bool lo = j < bnd;
+    a0 += lo ? s[j] : 0.f;
+    q0 += lo ? ss[j] : 0.f;
+    a1 += lo ? 0.f : s[j];
+    q1 += lo ? 0.f : ss[j];
+  }
+  if (CVp < 64) {
+    a0 = col_allreduce(a0, CVp);
+    q0 = col_allreduce(q0, CVp);
+    a1 = col_allreduce(a1, CVp);
+    q1 = col_allreduce(q1, CVp);
+    if ((tid & 63) < CVp) part[(tid >> 6) * CVp + cv] = make_float4(a0, q0, a1, q1);
+  } else {
+    part[tid] = make_float4(a0, q0, a1, q1);
+  }
+  __syncthreads();
+  if (tid < CVp) {
+    double d0 = 0.0, d1 = 0.0, d2 = 0.0, d3 = 0.0;
+    for (int r = 0; r < RR; ++r) {
+      const float4 v = part[r * CVp + tid];
+      d0 += (double)v.x; d1 += (double)v.y; d2 += (double)v.z; d3 += (double)v.w;
+    }
+    colsum[tid * 4 + 0] = d0; colsum[tid * 4 + 1] = d1; colsum[tid * 4 + 2] = d2; colsum[tid * 4 + 3] = d3;
+  }
+  __syncthreads();
+  if (!act_c) return;
+  const double inv_n = 1.0 / ((double)p.HW * (double)cpg);
+  float mean_[2], rstd_[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    if (k == 1 && bnd >= VEC) { mean_[1] = mean_[0]; rstd_[1] = rstd_[0]; break; }
+    const int f = (g0 + k) * cpg, l = f + cpg - 1;        // chunk-local channel range of the group
+    const int ca = f >> VSH, cb = l >> VSH;
+    double sm = 0.0, sq = 0.0;
+    for (int c = ca; c <= cb; ++c) {
+      const int o = c * 4 + (((c << VSH) >= f) ? 0 : 2);  // the column starts inside the group: its slot 0
+      sm += colsum[o];
+      sq += colsum[o + 1];
+    }
+    const double mean = sm * inv_n;
+    double var = sq * inv_n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const double v = var + (double)p.eps;
+    double y = __builtin_amdgcn_rsq(v);
+    y = y * (1.5 - 0.5 * v * y * y);
+    mean_[k] = (float)mean;
+    rstd_[k] = (float)y;
+  }
+  if (r0 == 0) {                                          // each group's statistics leave through one lane
+    const int gg = b * p.groups + sidx * (p.groups / S) + g0;
+    if (cl0 == g0 * cpg) { p.stats[gg * 2] = mean_[0]; p.stats[gg * 2 + 1] = rstd_[0]; }
+    if (bnd < VEC) { p.stats[gg * 2 + 2] = mean_[1]; p.stats[gg * 2 + 3] = rstd_[1]; }
+  }
+  float sc[VEC], sh[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    const bool lo = j < bnd;
+    sc[j] = (lo ? rstd_[0] : rstd_[1]) * gam[j];
+    sh[j] = bet[j] - (lo ? mean_[0] : mean_[1]) * sc[j];
+  }
+  T* yb = (T*)p.y + base;
+  const T* rb = p.residual ? (const T*)p.residual + base : nullptr;
+  const bool drop = p.drop_p > 0.f;
+  const unsigned long long dseed = drop ? sdmi_drop_seed(p.drop_seed, p.drop_seed_dev) : 0ULL;
+  const unsigned thr16 = (unsigned)(p.drop_p * 65536.f);
+  const float dinv = 1.f / (1.f - p.drop_p);
+  auto finish = [&](auto actc) __attribute__((always_inline)) {
+    constexpr int ACT = decltype(actc)::value;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int row = r0 + i * R;
+      if (row < p.HW) {
+        const long long o = (long long)row * p.C;
+        float f[VEC];
+        unpack16<T>(xr[i], f);
+        if (rb) {
+          float rr[VEC];
+          unpack16<T>(*reinterpret_cast<const uint4*>(rb + o), rr);
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) f[j] = act_apply(fmaf(f[j], sc[j], sh[j]) + rr[j], ACT);
+        } else {
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) f[j] = act_apply(fmaf(f[j], sc[j], sh[j]), ACT);
+        }
+        if (drop) sdmi_drop_apply<VEC>(f, dseed, (base + o) / VEC, thr16, dinv);
+        if constexpr (F8) gn_store_fp8(p, base + o, f);
+        else *reinterpret_cast<uint4*>(yb + o) = pack16<T>(f);
+      }
+    }
+  };
+  if (p.act == SDMI_ACT_SILU) finish(std::integral_constant<int, SDMI_ACT_SILU>{});
+  else if (p.act == SDMI_ACT_RELU) finish(std::integral_constant<int, SDMI_ACT_RELU>{});
+  else if (p.act == SDMI_ACT_GELU) finish(std::integral_constant<int, SDMI_ACT_GELU>{});
+  else finish(std::integral_constant<int, SDMI_ACT_NONE>{});
+}
+
+// ------------------------------------------------------------------------------------------
 // LayerNorm: a row is covered by LPR = pow2 >= C/VEC lanes holding one 16-byte vector each (two
 // when C/VEC > 64), so a wave handles 64/LPR rows per pass and every access is a whole 16-byte
 // vector; mean and variance (two-pass, in registers) are xor-butterflies inside the LPR lanes.
@@ -518,10 +715,23 @@ extern "C" int sdmi_groupnorm(const SdmiGroupNormArgs* a, void* stream) {
       while (cvp < cv) cvp <<= 1;
       const int RR = cvp < 64 ? gg.T / 64 : gg.T / cvp;
       const size_t smem = ((size_t)RR * cvp * vec * 2 + 2 * 128) * sizeof(float);
+      // second form (two group slots per lane): a 16-byte vector must span at most two groups
+      static int v2 = -1;
+      if (v2 < 0) {
+        const char* e = getenv("SDMI_GN_V2");
+        v2 = e ? atoi(e) : 1;
+      }
+      const int cpg = a->C / a->groups;
+      const bool two = v2 && (cpg * 2 == vec || cpg >= vec - 1);
+      const size_t smem2 = (size_t)RR * cvp * 16 + (size_t)cvp * 32;
 #define GN_GO3(T_, TH, NV_, F8_)                                                                   \
   do {                                                                                             \
-    SDMI_OPTIN_LDS((gn_fused_kernel<T_, TH, NV_, F8_>), 80 * 1024, "groupnorm");                   \
-    hipLaunchKernelGGL((gn_fused_kernel<T_, TH, NV_, F8_>), grid, dim3(TH), smem, st, *a);         \
+    if (two) {                                                                                     \
+      hipLaunchKernelGGL((gn_fused2_kernel<T_, TH, NV_, F8_>), grid, dim3(TH), smem2, st, *a);     \
+    } else {                                                                                       \
+      SDMI_OPTIN_LDS((gn_fused_kernel<T_, TH, NV_, F8_>), 80 * 1024, "groupnorm");                 \
+      hipLaunchKernelGGL((gn_fused_kernel<T_, TH, NV_, F8_>), grid, dim3(TH), smem, st, *a);       \
+    }                                                                                              \
   } while (0)
 #define GN_GO2(T_, TH, NV_) GN_GO3(T_, TH, NV_, false)
       // fewest registers that hold the slab: more workgroups per CU

@@ -277,7 +277,12 @@ def test_bmm_nt_and_softmax(dtype):
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize('shape', [(2, 64, 16, 'silu', 1e-5), (3, 128, 32, 'silu', 1e-5),
                                    (2, 896, 8, 'silu', 1e-5), (2, 384, 8, None, 1e-6),
-                                   (2, 64, 64, 'relu', 1e-5), (1, 1024, 4, 'silu', 1e-5)])
+                                   (2, 64, 64, 'relu', 1e-5), (1, 1024, 4, 'silu', 1e-5),
+                                   # group sizes 8 / 16 / 20 / 24 channels (a 16-byte vector inside one group,
+                                   # across two groups at odd offsets) on the two-slot single-pass kernel
+                                   (3, 256, 16, 'silu', 1e-5), (2, 512, 8, 'silu', 1e-5),
+                                   (2, 640, 16, 'silu', 1e-5), (2, 768, 8, 'silu', 1e-5),
+                                   (2, 224, 16, 'silu', 1e-5), (2, 160, 8, 'silu', 1e-5)])
 def test_groupnorm(shape, dtype):
     ops = _ops()
     B, C, H, act, eps = shape
@@ -288,6 +293,12 @@ def test_groupnorm(shape, dtype):
     ref = {'silu': F.silu, 'relu': F.relu, None: lambda v: v}[act](ref)
     out = ops.group_norm(nhwc(x, dtype), gam.to(DEV), bet.to(DEV), eps=eps, act=act)
     check(out.permute(0, 3, 1, 2), ref, dtype, f'groupnorm {shape}')
+    # the saved statistics (what the backward reads): every group written exactly once
+    _, st = ops.group_norm(nhwc(x, dtype), gam.to(DEV), bet.to(DEV), eps=eps, act=act, return_stats=True)
+    xg = x.view(B, 32, -1).double()
+    mean, var = xg.mean(-1), xg.var(-1, unbiased=False)
+    assert torch.allclose(st[..., 0].cpu().double(), mean, atol=1e-5, rtol=1e-5)
+    assert torch.allclose(st[..., 1].cpu().double(), (var + eps).rsqrt(), atol=1e-5, rtol=1e-5)
     # fused residual + relu (ResNet BasicBlock tail)
     r = q(torch.randn(B, C, H, H, generator=g), dtype)
     out = ops.group_norm(nhwc(x, dtype), gam.to(DEV), bet.to(DEV), eps=eps, act='relu',
