@@ -18,13 +18,25 @@ def _obj(src):
     return os.path.join(HERE, '_build', os.path.splitext(src)[0] + '.o')
 
 
+def _headers(src):
+    """csrc headers a source includes, transitively (`#include "x.h"` lines), sorted."""
+    import re
+    seen, todo = set(), [src]
+    while todo:
+        f = todo.pop()
+        for h in re.findall(r'^\s*#\s*include\s+"([^"/]+\.h)"', open(os.path.join(HERE, f)).read(), flags=re.M):
+            if h not in seen and os.path.exists(os.path.join(HERE, h)):
+                seen.add(h)
+                todo.append(h)
+    return sorted(os.path.join(HERE, h) for h in seen)
+
+
 def _digest(src):
-    """sha256 over the source, every header it may include, the C ABI header and the compile flags: an
+    """sha256 over the source, the csrc headers it includes (transitively), the C ABI header and the compile flags: an
     object file is reused only for byte-identical inputs (mtimes do not survive a snapshot copy)."""
     import hashlib
     h = hashlib.sha256()
-    deps = [os.path.join(HERE, src), os.path.join(HERE, '..', '..', 'include', 'sdmi.h')] + \
-        sorted(os.path.join(HERE, f) for f in os.listdir(HERE) if f.endswith('.h'))
+    deps = [os.path.join(HERE, src), os.path.join(HERE, '..', '..', 'include', 'sdmi.h')] + _headers(src)
     for d in deps:
         h.update(d.encode())
         h.update(open(d, 'rb').read())

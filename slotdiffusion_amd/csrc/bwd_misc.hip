@@ -241,7 +241,7 @@ template <typename T>
 __global__ void act_bwd_kernel(SdmiActBwdArgs p) {
   GRID_STRIDE(i, p.n) {
     Elem<T>::st((T*)p.dx + i,
-                Elem<T>::ld((const T*)p.dy + i) * act_grad(Elem<T>::ld((const T*)p.x + i), p.act));
+                Elem<T>::ld((const T*)p.dy + i) * act_grad<sizeof(T) == 2>(Elem<T>::ld((const T*)p.x + i), p.act));
   }
 }
 

@@ -96,26 +96,63 @@ template <> __device__ __forceinline__ uint4 pack16<bf16_t>(const float* f) {
   return v;
 }
 
+// erf without branches (both ranges evaluated, one select): minimax polynomials, the tail through v_exp_f32;
+// < 1.5 ulp (N. Juffa's single-precision erff, max error 0.995 ulp with a correctly rounded exp).  The library
+// erff is two divergent paths with a full-precision expf -- ~36 VALU instructions per element in the GEGLU
+// epilogue of a GEMM whose K loop is four tiles long.
+__device__ __forceinline__ float sdmi_erff(float a) {
+  const float t = fabsf(a), s = a * a;
+  float r = fmaf(-1.72853470e-5f, t, 3.83197126e-4f);
+  const float u = fmaf(-3.88396438e-3f, t, 2.42546219e-2f);
+  r = fmaf(r, s, u);
+  r = fmaf(r, t, -1.06777877e-1f);
+  r = fmaf(r, t, -6.34846687e-1f);
+  r = fmaf(r, t, -1.28717512e-1f);
+  r = fmaf(r, t, -t);
+  r = copysignf(1.0f - __expf(r), a);
+  float q = -5.96761703e-4f;
+  q = fmaf(q, s, 4.99119423e-3f);
+  q = fmaf(q, s, -2.67681349e-2f);
+  q = fmaf(q, s, 1.12819925e-1f);
+  q = fmaf(q, s, -3.76125336e-1f);
+  q = fmaf(q, s, 1.28379166e-1f);
+  q = fmaf(q, a, a);
+  return t > 0.927734375f ? r : q;
+}
+
+// FAST = the value is rounded to bf16 afterwards (bf16 storage): SiLU through v_rcp_f32 (1 ulp) instead of the
+// correctly rounded division (~11 VALU instructions per element: the single-pass GroupNorm + SiLU kernels were
+// VALU bound at 2x the time of a copy of the same tensor) and the branch-free erf.  fp32 storage (the parity
+// configuration) keeps the correctly rounded forms: the 20-step v-prediction sampler amplifies 1-ulp differences
+// of every activation into its 1e-3 latent bound.
+template <bool FAST = false>
 __device__ __forceinline__ float act_apply(float x, int act) {
   switch (act) {
     case SDMI_ACT_RELU: return x > 0.f ? x : 0.f;
-    // v_rcp_f32 (1 ulp) instead of the correctly rounded division (~11 VALU instructions per element: the
-    // single-pass GroupNorm + SiLU kernels were VALU bound at 2x the time of a copy of the same tensor)
-    case SDMI_ACT_SILU: return x * __builtin_amdgcn_rcpf(1.f + __expf(-x));
-    case SDMI_ACT_GELU: return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f));
+    case SDMI_ACT_SILU:
+      if constexpr (FAST) return x * __builtin_amdgcn_rcpf(1.f + __expf(-x));
+      else return x / (1.f + __expf(-x));
+    case SDMI_ACT_GELU:
+      if constexpr (FAST) return 0.5f * x * (1.f + sdmi_erff(x * 0.70710678118654752440f));
+      else return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f));
     default: return x;
   }
 }
 // derivative of act wrt its pre-activation input x
+template <bool FAST = false>
 __device__ __forceinline__ float act_grad(float x, int act) {
   switch (act) {
     case SDMI_ACT_RELU: return x > 0.f ? 1.f : 0.f;
     case SDMI_ACT_SILU: {
-      float s = __builtin_amdgcn_rcpf(1.f + __expf(-x));
+      float s;
+      if constexpr (FAST) s = __builtin_amdgcn_rcpf(1.f + __expf(-x));
+      else s = 1.f / (1.f + __expf(-x));
       return s * (1.f + x * (1.f - s));
     }
     case SDMI_ACT_GELU: {
-      float c = 0.5f * (1.f + erff(x * 0.70710678118654752440f));
+      float c;
+      if constexpr (FAST) c = 0.5f * (1.f + sdmi_erff(x * 0.70710678118654752440f));
+      else c = 0.5f * (1.f + erff(x * 0.70710678118654752440f));
       return c + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
     }
     default: return 1.f;

@@ -178,7 +178,7 @@ __global__ void time_emb_kernel(SdmiTimeEmbArgs p) {
 template <typename S, typename D>
 __global__ void act_kernel(SdmiActArgs p) {
   GRID_STRIDE(i, p.n) {
-    Elem<D>::st((D*)p.y + i, act_apply(Elem<S>::ld((const S*)p.x + i), p.act));
+    Elem<D>::st((D*)p.y + i, act_apply<sizeof(D) == 2>(Elem<S>::ld((const S*)p.x + i), p.act));
   }
 }
 
@@ -195,7 +195,7 @@ __global__ void geglu_kernel(SdmiGegluArgs p) {
     unpack16<T>(*reinterpret_cast<const uint4*>(h + c), x);
     unpack16<T>(*reinterpret_cast<const uint4*>(h + p.C + c), g);
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) x[j] *= act_apply(g[j], SDMI_ACT_GELU);
+    for (int j = 0; j < VEC; ++j) x[j] *= act_apply<sizeof(T) == 2>(g[j], SDMI_ACT_GELU);
     *reinterpret_cast<uint4*>((T*)p.y + r * p.C + c) = pack16<T>(x);
   }
 }
@@ -216,8 +216,8 @@ __global__ void geglu_bwd_kernel(SdmiGegluBwdArgs p) {
     unpack16<T>(*reinterpret_cast<const uint4*>((const T*)p.dy + r * p.C + c), dy);
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
-      dx[j] = dy[j] * act_apply(g[j], SDMI_ACT_GELU);
-      dg[j] = dy[j] * x[j] * act_grad(g[j], SDMI_ACT_GELU);
+      dx[j] = dy[j] * act_apply<sizeof(T) == 2>(g[j], SDMI_ACT_GELU);
+      dg[j] = dy[j] * x[j] * act_grad<sizeof(T) == 2>(g[j], SDMI_ACT_GELU);
     }
     *reinterpret_cast<uint4*>(dh + c) = pack16<T>(dx);
     *reinterpret_cast<uint4*>(dh + p.C + c) = pack16<T>(dg);

@@ -44,4 +44,3 @@ static inline GnGeom gn_pick(int B, int HW, int C, int groups, int vec, int nv_o
   }
   return best;
 }
-

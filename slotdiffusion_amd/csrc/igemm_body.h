@@ -70,13 +70,13 @@ __device__ __forceinline__ void wave_epilogue_fast(const SdmiGemmArgs& p, f32x16
       for (int r = 0; r < 16; ++r) v[r] = acc[i][j][r] * p.alpha + add[r];
       if (p.act == SDMI_ACT_SILU) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] = act_apply(v[r], SDMI_ACT_SILU);
+        for (int r = 0; r < 16; ++r) v[r] = act_apply<true>(v[r], SDMI_ACT_SILU);
       } else if (p.act == SDMI_ACT_RELU) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.f);
       } else if (p.act == SDMI_ACT_GELU) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] = act_apply(v[r], SDMI_ACT_GELU);
+        for (int r = 0; r < 16; ++r) v[r] = act_apply<true>(v[r], SDMI_ACT_GELU);
       }
 #pragma unroll
       for (int r = 0; r < 16; r += 2) {
@@ -207,14 +207,24 @@ __device__ __forceinline__ void wave_epilogue(const SdmiGemmArgs& p, f32x16 (&ac
 #pragma unroll
       for (int r = 0; r < 16; ++r) v[r] = acc[i][j][r] * p.alpha + add[r];
       if (p.act == SDMI_ACT_SILU) {
+        if (out_bf16) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] = act_apply(v[r], SDMI_ACT_SILU);
+          for (int r = 0; r < 16; ++r) v[r] = act_apply<true>(v[r], SDMI_ACT_SILU);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) v[r] = act_apply(v[r], SDMI_ACT_SILU);
+        }
       } else if (p.act == SDMI_ACT_RELU) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.f);
       } else if (p.act == SDMI_ACT_GELU) {
+        if (out_bf16) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] = act_apply(v[r], SDMI_ACT_GELU);
+          for (int r = 0; r < 16; ++r) v[r] = act_apply<true>(v[r], SDMI_ACT_GELU);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) v[r] = act_apply(v[r], SDMI_ACT_GELU);
+        }
       }
       if (out_bf16) {
         bf16_t* o = (bf16_t*)outp + zc + n;
@@ -312,7 +322,8 @@ __device__ __forceinline__ void fused_epilogue(const SdmiGemmArgs& p, f32x16 (&a
               h[p.N] = g;
             }
           }
-          v *= act_apply(g, SDMI_ACT_GELU);
+          if (out_bf16) v *= act_apply<true>(g, SDMI_ACT_GELU);
+          else v *= act_apply(g, SDMI_ACT_GELU);
         } else if constexpr (SM8) {
           // softmax over the aligned 8-column group (softmax8 slot scores + pad columns): the group's lanes
           // are 8 neighbours of this 32-lane half, every lane takes part

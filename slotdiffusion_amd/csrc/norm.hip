@@ -7,6 +7,7 @@
 // strided runs, combined across threads and splits in fp64, deterministically (no atomics).
 #include "common.h"
 #include "gn_geom.h"
+#include "gn_dev.h"
 #include <type_traits>
 
 namespace {
@@ -147,10 +148,10 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(SdmiGroupNormArgs p, int 
       float rr[VEC];
       unpack16<T>(*reinterpret_cast<const uint4*>(rb + o), rr);
 #pragma unroll
-      for (int j = 0; j < VEC; ++j) f[j] = act_apply(f[j] * sc[j] + sh[j] + rr[j], p.act);
+      for (int j = 0; j < VEC; ++j) f[j] = act_apply<sizeof(T) == 2>(f[j] * sc[j] + sh[j] + rr[j], p.act);
     } else {
 #pragma unroll
-      for (int j = 0; j < VEC; ++j) f[j] = act_apply(f[j] * sc[j] + sh[j], p.act);
+      for (int j = 0; j < VEC; ++j) f[j] = act_apply<sizeof(T) == 2>(f[j] * sc[j] + sh[j], p.act);
     }
     if (drop) sdmi_drop_apply<VEC>(f, dseed, (base + o) / VEC, thr16, dinv);
     if constexpr (F8) gn_store_fp8(p, base + o, f);
@@ -291,10 +292,10 @@ __global__ __launch_bounds__(THREADS) void gn_fused_kernel(SdmiGroupNormArgs p) 
         float rr[VEC];
         unpack16<T>(*reinterpret_cast<const uint4*>(rb + o), rr);
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) f[j] = act_apply(f[j] * sc[j] + sh[j] + rr[j], p.act);
+        for (int j = 0; j < VEC; ++j) f[j] = act_apply<sizeof(T) == 2>(f[j] * sc[j] + sh[j] + rr[j], p.act);
       } else {
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) f[j] = act_apply(f[j] * sc[j] + sh[j], p.act);
+        for (int j = 0; j < VEC; ++j) f[j] = act_apply<sizeof(T) == 2>(f[j] * sc[j] + sh[j], p.act);
       }
       if (drop) sdmi_drop_apply<VEC>(f, dseed, (base + o) / VEC, thr16, dinv);
       // (the e4m3fn output is its own instantiation: as a run-time branch it pushed the 16-vector
@@ -312,48 +313,12 @@ __global__ __launch_bounds__(THREADS) void gn_fused_kernel(SdmiGroupNormArgs p) 
 // difference being VALU work and the three-barrier fp64 fold, not memory.
 //   * a 16-byte vector spans at most TWO groups whenever C/groups >= VEC/2: each lane folds its VEC channel
 //     sums into two (sum, sum of squares) slots BEFORE any cross-lane step, so the butterflies move 4 values
-//     instead of 2 * VEC, the in-row steps as DPP row rotations (no LDS crossbar), and an LDS entry is one float4;
+//     instead of 2 * VEC (in fp64), the in-row steps as DPP row rotations (no LDS crossbar), an LDS entry is 32 bytes;
 //   * fold: one thread per vector column sums the wave entries in fp64; after the second (last) barrier every
 //     thread gathers its own two groups' columns (<= 5 reads each) and derives mean / rstd itself -- no third
 //     barrier, no single-thread fp64 division + sqrt on the critical path (v_rsq_f64 + one Newton step);
 //   * lane coordinates by shifts (CVp is a power of two), gamma / beta as 16-byte loads, the activation
 //     hoisted out of the element loop, SiLU through v_rcp_f32 (common.h).
-__device__ __forceinline__ float dpp_ror_add(float v, int ctrl_sel) {
-  // v + (v rotated right by 1 / 2 / 4 / 8 lanes inside each row of 16 lanes)
-  int r;
-  const int iv = __float_as_int(v);
-  switch (ctrl_sel) {
-    case 1: r = __builtin_amdgcn_update_dpp(0, iv, 0x121, 0xf, 0xf, false); break;
-    case 2: r = __builtin_amdgcn_update_dpp(0, iv, 0x122, 0xf, 0xf, false); break;
-    case 4: r = __builtin_amdgcn_update_dpp(0, iv, 0x124, 0xf, 0xf, false); break;
-    default: r = __builtin_amdgcn_update_dpp(0, iv, 0x128, 0xf, 0xf, false); break;
-  }
-  return v + __int_as_float(r);
-}
-// all-reduce over the lanes of a wave that share (lane mod CVp); CVp a power of two < 64 (wave-uniform)
-__device__ __forceinline__ float col_allreduce(float v, int CVp) {
-  if (CVp <= 1) v = dpp_ror_add(v, 1);
-  if (CVp <= 2) v = dpp_ror_add(v, 2);
-  if (CVp <= 4) v = dpp_ror_add(v, 4);
-  if (CVp <= 8) v = dpp_ror_add(v, 8);
-  if (CVp <= 16) v += __shfl_xor(v, 16, 64);
-  if (CVp <= 32) v += __shfl_xor(v, 32, 64);
-  return v;
-}
-template <int VEC>
-__device__ __forceinline__ void load_fvec(const float* q, float* out) {
-  if ((reinterpret_cast<uintptr_t>(q) & 15) == 0) {
-#pragma unroll
-    for (int h = 0; h < VEC / 4; ++h) {
-      const float4 v = *reinterpret_cast<const float4*>(q + 4 * h);
-      out[4 * h] = v.x; out[4 * h + 1] = v.y; out[4 * h + 2] = v.z; out[4 * h + 3] = v.w;
-    }
-  } else {
-#pragma unroll
-    for (int j = 0; j < VEC; ++j) out[j] = q[j];
-  }
-}
-
 template <typename T, int THREADS, int NV, bool F8 = false>
 __global__ __launch_bounds__(THREADS) void gn_fused2_kernel(SdmiGroupNormArgs p) {
   constexpr int VEC = Elem<T>::VEC;
@@ -367,8 +332,11 @@ __global__ __launch_bounds__(THREADS) void gn_fused2_kernel(SdmiGroupNormArgs p)
   const int c_lo = sidx * CV * VEC;
   const int R = THREADS >> csh;
   const int RR = CVp < 64 ? THREADS / 64 : R;             // LDS entries per vector column
-  float4* part = reinterpret_cast<float4*>(gn_smem);                         // [RR][CVp]
-  double* colsum = reinterpret_cast<double*>(gn_smem + RR * CVp * 4);        // [CVp][4]
+  // sums: fp32 for bf16 storage, fp64 for fp32 storage (the parity configuration: a near-tie of the evaluation
+  // argmax of the 15-slot video fixture depends on the order of an fp32 fold)
+  using acc_t = std::conditional_t<sizeof(T) == 4, double, float>;
+  acc_t* part = reinterpret_cast<acc_t*>(gn_smem);                           // [RR][CVp][4]
+  double* colsum = reinterpret_cast<double*>(part + RR * CVp * 4);           // [CVp][4]
   const int tid = threadIdx.x;
   const int cv = tid & (CVp - 1), r0 = tid >> csh;
   const bool act_c = cv < CV;
@@ -389,9 +357,9 @@ __global__ __launch_bounds__(THREADS) void gn_fused2_kernel(SdmiGroupNormArgs p)
   float gam[VEC], bet[VEC];                               // fetched next to the slab (one latency chain)
   load_fvec<VEC>(p.gamma + c_lo + cl0, gam);
   load_fvec<VEC>(p.beta + c_lo + cl0, bet);
-  float s[VEC], ss[VEC];
+  acc_t s[VEC], ss[VEC];
 #pragma unroll
-  for (int j = 0; j < VEC; ++j) s[j] = ss[j] = 0.f;
+  for (int j = 0; j < VEC; ++j) s[j] = ss[j] = (acc_t)0;
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int row = r0 + i * R;
@@ -399,33 +367,37 @@ __global__ __launch_bounds__(THREADS) void gn_fused2_kernel(SdmiGroupNormArgs p)
       float f[VEC];
       unpack16<T>(xr[i], f);
 #pragma unroll
-      for (int j = 0; j < VEC; ++j) { s[j] += f[j]; ss[j] = fmaf(f[j], f[j], ss[j]); }
+      for (int j = 0; j < VEC; ++j) { s[j] += (acc_t)f[j]; ss[j] += (acc_t)f[j] * (acc_t)f[j]; }
     }
   }
-  float a0 = 0.f, q0 = 0.f, a1 = 0.f, q1 = 0.f;
+  acc_t a0 = 0, q0 = 0, a1 = 0, q1 = 0;
 #pragma unroll
   for (int j = 0; j < VEC; ++j) {
     const bool lo = j < bnd;
-    a0 += lo ? s[j] : 0.f;
-    q0 += lo ? ss[j] : 0.f;
-    a1 += lo ? 0.f : s[j];
-    q1 += lo ? 0.f : ss[j];
+    a0 += lo ? s[j] : (acc_t)0;
+    q0 += lo ? ss[j] : (acc_t)0;
+    a1 += lo ? (acc_t)0 : s[j];
+    q1 += lo ? (acc_t)0 : ss[j];
   }
   if (CVp < 64) {
     a0 = col_allreduce(a0, CVp);
     q0 = col_allreduce(q0, CVp);
     a1 = col_allreduce(a1, CVp);
     q1 = col_allreduce(q1, CVp);
-    if ((tid & 63) < CVp) part[(tid >> 6) * CVp + cv] = make_float4(a0, q0, a1, q1);
+    if ((tid & 63) < CVp) {
+      acc_t* e = part + ((tid >> 6) * CVp + cv) * 4;
+      e[0] = a0; e[1] = q0; e[2] = a1; e[3] = q1;
+    }
   } else {
-    part[tid] = make_float4(a0, q0, a1, q1);
+    acc_t* e = part + tid * 4;
+    e[0] = a0; e[1] = q0; e[2] = a1; e[3] = q1;
   }
   __syncthreads();
   if (tid < CVp) {
     double d0 = 0.0, d1 = 0.0, d2 = 0.0, d3 = 0.0;
     for (int r = 0; r < RR; ++r) {
-      const float4 v = part[r * CVp + tid];
-      d0 += (double)v.x; d1 += (double)v.y; d2 += (double)v.z; d3 += (double)v.w;
+      const acc_t* e = part + (r * CVp + tid) * 4;
+      d0 += (double)e[0]; d1 += (double)e[1]; d2 += (double)e[2]; d3 += (double)e[3];
     }
     colsum[tid * 4 + 0] = d0; colsum[tid * 4 + 1] = d1; colsum[tid * 4 + 2] = d2; colsum[tid * 4 + 3] = d3;
   }
@@ -484,10 +456,10 @@ __global__ __launch_bounds__(THREADS) void gn_fused2_kernel(SdmiGroupNormArgs p)
           float rr[VEC];
           unpack16<T>(*reinterpret_cast<const uint4*>(rb + o), rr);
 #pragma unroll
-          for (int j = 0; j < VEC; ++j) f[j] = act_apply(fmaf(f[j], sc[j], sh[j]) + rr[j], ACT);
+          for (int j = 0; j < VEC; ++j) f[j] = act_apply<sizeof(T) == 2>(fmaf(f[j], sc[j], sh[j]) + rr[j], ACT);
         } else {
 #pragma unroll
-          for (int j = 0; j < VEC; ++j) f[j] = act_apply(fmaf(f[j], sc[j], sh[j]), ACT);
+          for (int j = 0; j < VEC; ++j) f[j] = act_apply<sizeof(T) == 2>(fmaf(f[j], sc[j], sh[j]), ACT);
         }
         if (drop) sdmi_drop_apply<VEC>(f, dseed, (base + o) / VEC, thr16, dinv);
         if constexpr (F8) gn_store_fp8(p, base + o, f);
@@ -723,7 +695,7 @@ extern "C" int sdmi_groupnorm(const SdmiGroupNormArgs* a, void* stream) {
       }
       const int cpg = a->C / a->groups;
       const bool two = v2 && (cpg * 2 == vec || cpg >= vec - 1);
-      const size_t smem2 = (size_t)RR * cvp * 16 + (size_t)cvp * 32;
+      const size_t smem2 = (size_t)RR * cvp * (vec == 4 ? 32 : 16) + (size_t)cvp * 32;
 #define GN_GO3(T_, TH, NV_, F8_)                                                                   \
   do {                                                                                             \
     if (two) {                                                                                     \

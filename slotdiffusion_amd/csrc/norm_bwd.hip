@@ -11,6 +11,8 @@
 // combines, no atomics.
 #include "common.h"
 #include "gn_geom.h"
+#include "gn_dev.h"
+#include <type_traits>
 
 namespace {
 
@@ -66,7 +68,7 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(SdmiGroupNormBwdArgs 
       for (int j = 0; j < VEC; ++j) {
         const float xh = (x[j] - mu[j]) * rs[j];
         const float z = xh * ga[j] + be[j] + (rb ? rr[j] : 0.f);
-        const float dz = dy[j] * act_grad(z, p.act);
+        const float dz = dy[j] * act_grad<sizeof(T) == 2>(z, p.act);
         A[j] += dz;
         Bv[j] += dz * xh;
       }
@@ -149,7 +151,7 @@ __global__ __launch_bounds__(THREADS) void gn_bwd_fused_kernel(SdmiGroupNormBwdA
       for (int j = 0; j < VEC; ++j) {
         const float xh = (x[j] - mu[j]) * rs[j];
         const float z = xh * ga[j] + be[j] + (rb ? rr[j] : 0.f);
-        const float dz = dy[j] * act_grad(z, p.act);
+        const float dz = dy[j] * act_grad<sizeof(T) == 2>(z, p.act);
         dy[j] = dz;                        // keep dz for the second half
         A[j] += dz;
         Bv[j] += dz * xh;
@@ -259,6 +261,230 @@ __global__ __launch_bounds__(THREADS) void gn_bwd_fused_kernel(SdmiGroupNormBwdA
         float t = 0.f;
         for (int r = 0; r < RR; ++r) t += part[r * CVp + cv][j][0];
         p.dxsum[(long long)b * p.ld_dxsum + c_lo + cv * VEC + j] = t;
+      }
+    }
+  }
+}
+
+// Single-pass backward, second form (the twin of gn_fused2_kernel, norm.hip): the group sums
+// (sum gamma dz, sum gamma dz xhat) are folded per lane into two group slots before any cross-lane step and
+// travel through two barriers; the per-channel totals (dgamma / dbeta partials) are reduced with DPP row
+// rotations, folded by all threads in parallel and stored OFF the path to the second pass (the first form
+// walked them with CV threads, then fetched gamma again behind a barrier); statistics and gamma / beta
+// arrive as 2 + 2 vector loads instead of 4 * VEC scalar ones; the activation derivative is hoisted.
+template <typename T, int THREADS, int NV>
+__global__ __launch_bounds__(THREADS) void gn_bwd_fused2_kernel(SdmiGroupNormBwdArgs p) {
+  constexpr int VEC = Elem<T>::VEC;
+  constexpr int VSH = VEC == 8 ? 3 : 2;
+  extern __shared__ __attribute__((aligned(16))) float gnb_smem[];
+  const int b = blockIdx.x;
+  const int S = gridDim.y, sidx = blockIdx.y;
+  const int CV = p.C / VEC / S;
+  const int csh = CV <= 1 ? 0 : 32 - __builtin_clz(CV - 1);
+  const int CVp = 1 << csh;
+  const int c_lo = sidx * CV * VEC;
+  const int R = THREADS >> csh;
+  const int RR = CVp < 64 ? THREADS / 64 : R;
+  float4* part = reinterpret_cast<float4*>(gnb_smem);                          // [RR][CVp] group slots
+  double* colsum = reinterpret_cast<double*>(gnb_smem + RR * CVp * 4);         // [CVp][4]
+  float (*chpart)[VEC][2] = reinterpret_cast<float (*)[VEC][2]>(gnb_smem + RR * CVp * 4 + CVp * 8);   // [RR*CVp]
+  const int tid = threadIdx.x;
+  const int cv = tid & (CVp - 1), r0 = tid >> csh;
+  const bool act_c = cv < CV;
+  const int cvc = act_c ? cv : 0;
+  const int cpg = p.C / p.groups;
+  const int cl0 = cvc * VEC;
+  const int g0 = cl0 / cpg;
+  const int bnd = (g0 + 1) * cpg - cl0;                   // channels j >= bnd: group g0 + 1 (slot 1)
+  const long long base = (long long)b * p.HW * p.C + c_lo + cl0;
+  const T* xb = (const T*)p.x + base;
+  const T* db = (const T*)p.dy + base;
+  const T* rb = p.residual ? (const T*)p.residual + base : nullptr;
+  uint4 xr[NV], dr[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int row = r0 + i * R;
+    if (act_c && row < p.HW) {
+      xr[i] = *reinterpret_cast<const uint4*>(xb + (long long)row * p.C);
+      dr[i] = *reinterpret_cast<const uint4*>(db + (long long)row * p.C);
+    }
+  }
+  const int gg = b * p.groups + sidx * (p.groups / S) + g0;
+  const float2 st0 = *reinterpret_cast<const float2*>(p.stats + gg * 2);
+  const float2 st1 = bnd < VEC ? *reinterpret_cast<const float2*>(p.stats + gg * 2 + 2) : st0;
+  float ga[VEC], be[VEC];
+  load_fvec<VEC>(p.gamma + c_lo + cl0, ga);
+  load_fvec<VEC>(p.beta + c_lo + cl0, be);
+  float mu[VEC], rs[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    mu[j] = j < bnd ? st0.x : st1.x;
+    rs[j] = j < bnd ? st0.y : st1.y;
+  }
+  float A[VEC], Bv[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) A[j] = Bv[j] = 0.f;
+  const bool drop = p.drop_p > 0.f;
+  const unsigned long long dseed = drop ? sdmi_drop_seed(p.drop_seed, p.drop_seed_dev) : 0ULL;
+  const unsigned thr16 = (unsigned)(p.drop_p * 65536.f);
+  const float dinv = 1.f / (1.f - p.drop_p);
+  auto first = [&](auto actc) __attribute__((always_inline)) {
+    constexpr int ACT = decltype(actc)::value;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int row = r0 + i * R;
+      if (act_c && row < p.HW) {
+        float x[VEC], dy[VEC], rr[VEC];
+        unpack16<T>(xr[i], x);
+        unpack16<T>(dr[i], dy);
+        if (drop) sdmi_drop_apply<VEC>(dy, dseed, (base + (long long)row * p.C) / VEC, thr16, dinv);
+        if (rb) unpack16<T>(*reinterpret_cast<const uint4*>(rb + (long long)row * p.C), rr);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          const float xh = (x[j] - mu[j]) * rs[j];
+          const float z = xh * ga[j] + be[j] + (rb ? rr[j] : 0.f);
+          const float dz = dy[j] * act_grad<sizeof(T) == 2>(z, ACT);
+          dy[j] = dz;                        // keep dz for the second half
+          A[j] += dz;
+          Bv[j] += dz * xh;
+        }
+        dr[i] = pack16<T>(dy);               // (bf16: dz rounded once more, as dresidual stores it)
+      }
+    }
+  };
+  if (p.act == SDMI_ACT_SILU) first(std::integral_constant<int, SDMI_ACT_SILU>{});
+  else if (p.act == SDMI_ACT_RELU) first(std::integral_constant<int, SDMI_ACT_RELU>{});
+  else if (p.act == SDMI_ACT_GELU) first(std::integral_constant<int, SDMI_ACT_GELU>{});
+  else first(std::integral_constant<int, SDMI_ACT_NONE>{});
+  // group slots: sum over the lane's channels of gamma * (dz | dz xhat)
+  float a0 = 0.f, q0 = 0.f, a1 = 0.f, q1 = 0.f;
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    const bool lo = j < bnd;
+    const float ta = ga[j] * A[j], tb = ga[j] * Bv[j];
+    a0 += lo ? ta : 0.f;
+    q0 += lo ? tb : 0.f;
+    a1 += lo ? 0.f : ta;
+    q1 += lo ? 0.f : tb;
+  }
+  if (CVp < 64) {
+    a0 = col_allreduce(a0, CVp);
+    q0 = col_allreduce(q0, CVp);
+    a1 = col_allreduce(a1, CVp);
+    q1 = col_allreduce(q1, CVp);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { A[j] = col_allreduce(A[j], CVp); Bv[j] = col_allreduce(Bv[j], CVp); }
+    if ((tid & 63) < CVp) {
+      const int e = (tid >> 6) * CVp + cv;
+      part[e] = make_float4(a0, q0, a1, q1);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) { chpart[e][j][0] = A[j]; chpart[e][j][1] = Bv[j]; }
+    }
+  } else {
+    part[tid] = make_float4(a0, q0, a1, q1);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { chpart[tid][j][0] = A[j]; chpart[tid][j][1] = Bv[j]; }
+  }
+  __syncthreads();
+  if (tid < CVp) {
+    double d0 = 0.0, d1 = 0.0, d2 = 0.0, d3 = 0.0;
+    for (int r = 0; r < RR; ++r) {
+      const float4 v = part[r * CVp + tid];
+      d0 += (double)v.x; d1 += (double)v.y; d2 += (double)v.z; d3 += (double)v.w;
+    }
+    colsum[tid * 4 + 0] = d0; colsum[tid * 4 + 1] = d1; colsum[tid * 4 + 2] = d2; colsum[tid * 4 + 3] = d3;
+  }
+  // channel totals -> partial[b][c] (dgamma / dbeta): every thread takes (channel, which) pairs, starting from
+  // the last waves (the first one is folding the group columns)
+  for (int u = THREADS - 1 - tid; u < CVp * VEC * 2; u += THREADS) {
+    const int ccv = u / (VEC * 2), j = (u >> 1) & (VEC - 1), which = u & 1;
+    if (ccv < CV) {
+      double sa = 0.0;
+      for (int r = 0; r < RR; ++r) sa += (double)chpart[r * CVp + ccv][j][which];
+      p.partial[(((long long)b * p.C) + c_lo + ccv * VEC + j) * 2 + which] = (float)sa;
+    }
+  }
+  __syncthreads();
+  const float inv_n = 1.f / ((float)p.HW * (float)cpg);
+  float s1_[2], s2_[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    if (k == 1 && bnd >= VEC) { s1_[1] = s1_[0]; s2_[1] = s2_[0]; break; }
+    const int f = (g0 + k) * cpg, l = f + cpg - 1;
+    const int ca = f >> VSH, cb = l >> VSH;
+    double sm = 0.0, sq = 0.0;
+    for (int c = ca; c <= cb; ++c) {
+      const int o = c * 4 + (((c << VSH) >= f) ? 0 : 2);
+      sm += colsum[o];
+      sq += colsum[o + 1];
+    }
+    s1_[k] = (float)sm * inv_n;
+    s2_[k] = (float)sq * inv_n;
+  }
+  float sd[VEC];                        // per-channel sums of dx over this thread's rows (dxsum)
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) sd[j] = 0.f;
+  if (act_c) {
+    float s1[VEC], s2[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      s1[j] = j < bnd ? s1_[0] : s1_[1];
+      s2[j] = j < bnd ? s2_[0] : s2_[1];
+    }
+    T* dxb = (T*)p.dx + base;
+    T* drb = p.dresidual ? (T*)p.dresidual + base : nullptr;
+    const T* e0 = p.dextra0 ? (const T*)p.dextra0 + base : nullptr;
+    const T* e1 = p.dextra1 ? (const T*)p.dextra1 + base : nullptr;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int row = r0 + i * R;
+      if (row < p.HW) {
+        const long long o = (long long)row * p.C;
+        float x[VEC], dz[VEC], dx[VEC];
+        unpack16<T>(xr[i], x);
+        unpack16<T>(dr[i], dz);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          const float xh = (x[j] - mu[j]) * rs[j];
+          dx[j] = rs[j] * (ga[j] * dz[j] - (s1[j] + xh * s2[j]));
+        }
+        if (e0) {                           // gradients of x's other consumers, summed here
+          float ex[VEC];
+          unpack16<T>(*reinterpret_cast<const uint4*>(e0 + o), ex);
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) dx[j] += ex[j];
+        }
+        if (e1) {
+          float ex[VEC];
+          unpack16<T>(*reinterpret_cast<const uint4*>(e1 + o), ex);
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) dx[j] += ex[j];
+        }
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) sd[j] += dx[j];
+        *reinterpret_cast<uint4*>(dxb + o) = pack16<T>(dx);
+        if (drb) *reinterpret_cast<uint4*>(drb + o) = dr[i];
+      }
+    }
+  }
+  if (p.dxsum) {                         // (uniform: every thread of the workgroup takes this path)
+    if (CVp < 64) {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) sd[j] = col_allreduce(sd[j], CVp);
+    }
+    __syncthreads();                     // the channel totals above have been read
+    if (CVp >= 64 || (tid & 63) < CVp) {
+      const int e = CVp < 64 ? (tid >> 6) * CVp + cv : tid;
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) chpart[e][j][0] = sd[j];
+    }
+    __syncthreads();
+    for (int u = tid; u < CVp * VEC; u += THREADS) {
+      const int ccv = u / VEC, j = u & (VEC - 1);
+      if (ccv < CV) {
+        float t = 0.f;
+        for (int r = 0; r < RR; ++r) t += chpart[r * CVp + ccv][j][0];
+        p.dxsum[(long long)b * p.ld_dxsum + c_lo + ccv * VEC + j] = t;
       }
     }
   }
@@ -409,7 +635,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(SdmiGroupNormBwdArgs 
     for (int j = 0; j < VEC; ++j) {
       const float xh = (x[j] - mu[j]) * rs[j];
       const float z = xh * ga[j] + be[j] + (rb ? rr[j] : 0.f);
-      dz[j] = dy[j] * act_grad(z, p.act);
+      dz[j] = dy[j] * act_grad<sizeof(T) == 2>(z, p.act);
       dx[j] = rs[j] * (ga[j] * dz[j] - (s1[j] + xh * s2[j]));
     }
     if (e0) {
@@ -580,10 +806,25 @@ extern "C" int sdmi_groupnorm_bwd(const SdmiGroupNormBwdArgs* a, void* stream) {
       while (cvp < cv) cvp <<= 1;
       const int RR = cvp < 64 ? gg.T / 64 : gg.T / cvp;
       const size_t smem = ((size_t)RR * cvp * vec * 2 + 2 * 256) * sizeof(float);
+      static int v2 = -1;
+      if (v2 < 0) {
+        const char* e = getenv("SDMI_GN_V2");
+        v2 = e ? atoi(e) : 1;
+      }
+      const int cpg = a->C / a->groups;
+      // (the 1024-thread and the 16-vector instantiations of the second form spill at their register budgets and
+      // measured slower than the first form: 43 vs 36 us at [64][32^2][128])
+      const bool two = v2 && (cpg * 2 == vec || cpg >= vec - 1) && gg.T != 1024 && gg.need <= 8;
+      const size_t smem2 = (size_t)RR * cvp * (16 + vec * 8) + (size_t)cvp * 32;
 #define GNB_GO(T_, TH, NV_)                                                                        \
   do {                                                                                             \
-    SDMI_OPTIN_LDS((gn_bwd_fused_kernel<T_, TH, NV_>), 80 * 1024, "groupnorm_bwd");                \
-    hipLaunchKernelGGL((gn_bwd_fused_kernel<T_, TH, NV_>), gf, dim3(TH), smem, st, *a);            \
+    if (two) {                                                                                     \
+      SDMI_OPTIN_LDS((gn_bwd_fused2_kernel<T_, TH, NV_>), 96 * 1024, "groupnorm_bwd");             \
+      hipLaunchKernelGGL((gn_bwd_fused2_kernel<T_, TH, NV_>), gf, dim3(TH), smem2, st, *a);        \
+    } else {                                                                                       \
+      SDMI_OPTIN_LDS((gn_bwd_fused_kernel<T_, TH, NV_>), 80 * 1024, "groupnorm_bwd");              \
+      hipLaunchKernelGGL((gn_bwd_fused_kernel<T_, TH, NV_>), gf, dim3(TH), smem, st, *a);          \
+    }                                                                                              \
   } while (0)
 #define GNB_PICK(T_, TH)                                                                           \
   do {                                                                                             \

@@ -689,7 +689,6 @@ extern "C" int sdmi_wgrad(const SdmiWgradArgs* a, void* stream) {
   int rc;
   rc = a->dtype == SDMI_BF16 ? dispatch_wgrad_bf16(*a, st) : dispatch_wgrad_f32(*a, st);
   if (rc || a->splits == 1 || a->defer_fold) return rc;
-  const long long total = (long long)a->N * a->K;     // K % 4 == 0 (Cin % vec == 0)
   int blocks = (int)wgrad_fold_blocks(*a);
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, *a);
