@@ -150,8 +150,8 @@ FAMILIES = {
                    'splitk_epilogue_kernel', 'bwd_pair_kernel'),
     'sdmi_wgrad': ('wgrad_kernel', 'wgrad_tr_kernel', 'wgrad3x3_c64_kernel', 'wgrad_group_kernel', 'wgrad_group_reduce_kernel',
                    'wgrad_reduce_kernel'),
-    'sdmi_groupnorm': ('gn_fused_kernel', 'gn_stats_kernel', 'gn_apply_kernel'),
-    'sdmi_groupnorm_bwd': ('gn_bwd_fused_kernel', 'gn_bwd_stats_kernel', 'gn_bwd_apply_kernel'),
+    'sdmi_groupnorm': ('gn_fused_kernel', 'gn_fused2_kernel', 'gn_stats_kernel', 'gn_apply_kernel'),
+    'sdmi_groupnorm_bwd': ('gn_bwd_fused_kernel', 'gn_bwd_fused2_kernel', 'gn_bwd_stats_kernel', 'gn_bwd_apply_kernel'),
 }
 MARK = 'sqerr_rows_kernel'      # a kernel no train / sampling step launches: brackets the timed region
 
@@ -578,6 +578,8 @@ def main():
             for entry in ('sdmi_groupnorm', 'sdmi_groupnorm_bwd'):
                 if entry in summ and summ[entry]['bytes']:
                     t_ms, n_k = fam_ms(entry)
+                    if not t_ms:        # no kernel of the family matched the trace (renamed kernel): say nothing
+                        continue
                     gbs = summ[entry]['bytes'] / (t_ms * 1e-3) / 1e9
                     hb[entry] = {'achieved': gbs, 'frac': gbs / 8000.0, 'launches_per_step': summ[entry]['calls'],
                                  'family_ms_per_step': t_ms,

@@ -315,12 +315,10 @@ __global__ __launch_bounds__(THREADS) void gn_bwd_fused2_kernel(SdmiGroupNormBwd
   float ga[VEC], be[VEC];
   load_fvec<VEC>(p.gamma + c_lo + cl0, ga);
   load_fvec<VEC>(p.beta + c_lo + cl0, be);
-  float mu[VEC], rs[VEC];
-#pragma unroll
-  for (int j = 0; j < VEC; ++j) {
-    mu[j] = j < bnd ? st0.x : st1.x;
-    rs[j] = j < bnd ? st0.y : st1.y;
-  }
+  // per-channel statistics / group sums are selects between the two slots at their uses (no VEC-wide arrays:
+  // the 1024-thread instantiation has 128 VGPRs)
+#define GNB_MU(j) ((j) < bnd ? st0.x : st1.x)
+#define GNB_RS(j) ((j) < bnd ? st0.y : st1.y)
   float A[VEC], Bv[VEC];
 #pragma unroll
   for (int j = 0; j < VEC; ++j) A[j] = Bv[j] = 0.f;
@@ -341,7 +339,7 @@ __global__ __launch_bounds__(THREADS) void gn_bwd_fused2_kernel(SdmiGroupNormBwd
         if (rb) unpack16<T>(*reinterpret_cast<const uint4*>(rb + (long long)row * p.C), rr);
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
-          const float xh = (x[j] - mu[j]) * rs[j];
+          const float xh = (x[j] - GNB_MU(j)) * GNB_RS(j);
           const float z = xh * ga[j] + be[j] + (rb ? rr[j] : 0.f);
           const float dz = dy[j] * act_grad<sizeof(T) == 2>(z, ACT);
           dy[j] = dz;                        // keep dz for the second half
@@ -425,12 +423,6 @@ __global__ __launch_bounds__(THREADS) void gn_bwd_fused2_kernel(SdmiGroupNormBwd
 #pragma unroll
   for (int j = 0; j < VEC; ++j) sd[j] = 0.f;
   if (act_c) {
-    float s1[VEC], s2[VEC];
-#pragma unroll
-    for (int j = 0; j < VEC; ++j) {
-      s1[j] = j < bnd ? s1_[0] : s1_[1];
-      s2[j] = j < bnd ? s2_[0] : s2_[1];
-    }
     T* dxb = (T*)p.dx + base;
     T* drb = p.dresidual ? (T*)p.dresidual + base : nullptr;
     const T* e0 = p.dextra0 ? (const T*)p.dextra0 + base : nullptr;
@@ -445,8 +437,9 @@ __global__ __launch_bounds__(THREADS) void gn_bwd_fused2_kernel(SdmiGroupNormBwd
         unpack16<T>(dr[i], dz);
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
-          const float xh = (x[j] - mu[j]) * rs[j];
-          dx[j] = rs[j] * (ga[j] * dz[j] - (s1[j] + xh * s2[j]));
+          const float rsj = GNB_RS(j);
+          const float xh = (x[j] - GNB_MU(j)) * rsj;
+          dx[j] = rsj * (ga[j] * dz[j] - ((j < bnd ? s1_[0] : s1_[1]) + xh * (j < bnd ? s2_[0] : s2_[1])));
         }
         if (e0) {                           // gradients of x's other consumers, summed here
           float ex[VEC];
@@ -467,6 +460,8 @@ __global__ __launch_bounds__(THREADS) void gn_bwd_fused2_kernel(SdmiGroupNormBwd
       }
     }
   }
+#undef GNB_MU
+#undef GNB_RS
   if (p.dxsum) {                         // (uniform: every thread of the workgroup takes this path)
     if (CVp < 64) {
 #pragma unroll
@@ -838,7 +833,7 @@ extern "C" int sdmi_groupnorm_bwd(const SdmiGroupNormBwdArgs* a, void* stream) {
       const int cpg = a->C / a->groups;
       // (the 1024-thread and the 16-vector instantiations of the second form spill at their register budgets and
       // measured slower than the first form: 43 vs 36 us at [64][32^2][128])
-      const bool two = v2 && (cpg * 2 == vec || cpg >= vec - 1) && gg.T != 1024 && gg.need <= 8;
+      const bool two = v2 && (cpg * 2 == vec || cpg >= vec - 1) && (gg.T != 1024 || v2 >= 2) && gg.need <= 8;
       const size_t smem2 = (size_t)RR * cvp * (16 + vec * 8) + (size_t)cvp * 32;
 #define GNB_GO(T_, TH, NV_)                                                                        \
   do {                                                                                             \
