@@ -163,7 +163,8 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(SdmiAttnArgs p) {
   for (int j = 0; j < ND; ++j)
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[j][r] = 0.f;
-  float m = -INFINITY, lsum = 0.f;
+  float m = -INFINITY, lsum = 0.f;            // m: running maximum in the exp2 domain
+  const float sc2 = p.scale * 1.4426950408889634f;
   const int g = lane >> 4, t = lane & 15;
   const char* kfrag = Ks + ql * KP + hh * 16;
   // transposing read: lane addresses piece (row t>>2, 4 columns at (t&3)*4) of its group's block
@@ -195,29 +196,46 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(SdmiAttnArgs p) {
         const u32x4 a = *reinterpret_cast<const u32x4*>(kfrag + kb * 32 * KP + ks * 32);
         s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), bq[ks], s, 0, 0, 0);
       }
+      // The softmax is this kernel's VALU bill (head dim 32: 2 x 8 MFMA passes per 16 scores of a lane next to
+      // ~12 VALU issue slots per score, and MFMA and VALU of a SIMD do not overlap), so it is kept minimal:
+      // scores live in the exp2 domain (scale * log2(e) folded into one multiply, v_exp_f32 directly), the key
+      // mask is applied only in a block that crosses Skv, and the running output is rescaled only when some
+      // lane's maximum moved (alpha == 1 exactly otherwise).
       float bmax = -INFINITY;
+      if (c0 + kb * 32 + 32 > p.Skv) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = c0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-        s[r] = key < p.Skv ? s[r] * p.scale : -INFINITY;
-        bmax = fmaxf(bmax, s[r]);
+        for (int r = 0; r < 16; ++r) {
+          const int key = c0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+          s[r] = key < p.Skv ? s[r] * sc2 : -INFINITY;
+          bmax = fmaxf(bmax, s[r]);
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          s[r] *= sc2;
+          bmax = fmaxf(bmax, s[r]);
+        }
       }
       bmax = fmaxf(bmax, __shfl_xor(bmax, 32, 64));
       const float m_new = fmaxf(m, bmax);
-      const float alpha = __expf(m - m_new);
       float psum = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        s[r] = __expf(s[r] - m_new);
+        s[r] = __builtin_amdgcn_exp2f(s[r] - m_new);
         psum += s[r];
       }
       psum += __shfl_xor(psum, 32, 64);
-      lsum = lsum * alpha + psum;
+      if (__builtin_amdgcn_ballot_w64(m_new > m) != 0) {
+        const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+        lsum = lsum * alpha + psum;
+#pragma unroll
+        for (int j = 0; j < ND; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[j][r] *= alpha;
+      } else {
+        lsum += psum;
+      }
       m = m_new;
-#pragma unroll
-      for (int j = 0; j < ND; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[j][r] *= alpha;
 #pragma unroll
       for (int mm = 0; mm < 2; ++mm) {
         const u32x4 pb = {pack_bf16x2(s[8 * mm + 0], s[8 * mm + 1]), pack_bf16x2(s[8 * mm + 2], s[8 * mm + 3]),
@@ -246,7 +264,7 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(SdmiAttnArgs p) {
         w.y = pack_bf16x2(o[jd][4 * j + 2] * inv, o[jd][4 * j + 3] * inv);
         *reinterpret_cast<uint2*>(op + 32 * jd + 8 * j) = w;
       }
-    if (p.lse && hh == 0) p.lse[((long long)b * p.heads + h) * p.Sq + qi] = m + __logf(lsum);
+    if (p.lse && hh == 0) p.lse[((long long)b * p.heads + h) * p.Sq + qi] = m * 0.6931471805599453f + __logf(lsum);
   }
 }
 
