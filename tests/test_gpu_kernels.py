@@ -307,6 +307,30 @@ def test_groupnorm(shape, dtype):
           'groupnorm+res')
 
 
+@pytest.mark.parametrize('kind', ['silu', 'gelu'])
+def test_fast_activations_bf16_storage(kind):
+    """bf16 storage takes the fast activation forms (v_rcp SiLU, branch-free erf; common.h act_apply<true>): after
+    the rounding to bf16 the result must be the correctly rounded one almost everywhere and never more than one
+    bf16 ulp away; fp32 storage keeps the correctly rounded forms (2e-7 of the exact value)."""
+    ops = _ops()
+    x = torch.cat([torch.linspace(-12, 12, 200001), torch.tensor([0.0, -0.0, 100.0, -100.0, 1.3120, -1.3120])])
+    xb = x.to(torch.bfloat16)
+    f = {'silu': F.silu, 'gelu': F.gelu}[kind]
+    exact = f(xb.double())
+    out = ops.act(xb.to(DEV), kind).cpu()
+    ref = exact.to(torch.bfloat16)
+    # (GELU below x = -4 is 0.5 x (1 + erf) with 1 + erf cancelling: any fp32 evaluation -- torch's included -- is
+    # only good to ~1e-7 ABSOLUTE there, on values below 1e-5)
+    main = xb.float() > -4.0
+    same = (out == ref) | ((out == 0) & (ref == 0))
+    assert float(same[main].float().mean()) >= 0.995, float(same[main].float().mean())
+    ulp = (exact.abs() * 2.0 ** -7).clamp_min(2.0 ** -126)
+    assert bool(((out.double() - exact).abs()[main] <= ulp[main]).all())
+    assert bool(((out.double() - exact).abs()[~main] <= ulp[~main] + 2e-7).all())
+    out32 = ops.act(xb.float().to(DEV), kind).cpu().double()
+    assert bool(((out32 - exact).abs() <= 4e-7 * exact.abs() + 2e-7).all())
+
+
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize('C', [192, 256, 384, 512])
 def test_layernorm(C, dtype):
