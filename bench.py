@@ -146,7 +146,7 @@ def cpu_baseline(model, cfg, mode, quick=False):
 
 # kernels behind the C-ABI entry points the roofline legs price (csrc/igemm.hip, wgrad.hip, norm.hip, norm_bwd.hip)
 FAMILIES = {
-    'sdmi_igemm': ('igemm_kernel', 'igemm_kernel_tall', 'igemm_dma_kernel', 'conv3x3_c64_kernel',
+    'sdmi_igemm': ('igemm_kernel', 'igemm_kernel_tall', 'igemm_dma_kernel', 'igemm_sym_kernel', 'conv3x3_c64_kernel',
                    'splitk_epilogue_kernel', 'bwd_pair_kernel'),
     'sdmi_wgrad': ('wgrad_kernel', 'wgrad_tr_kernel', 'wgrad3x3_c64_kernel', 'wgrad_group_kernel', 'wgrad_group_reduce_kernel',
                    'wgrad_reduce_kernel'),
@@ -419,6 +419,12 @@ def main():
         dt_s = timed((lambda: None) if skip_sample else sample_step, n_s,
                      args.warmup if args.mode == 'sample' else 1, marked=args.mode == 'sample')
         denoise_rate = world * n_img * nfe * n_s / dt_s
+        # the timed configuration's result must at least be finite: final latents of one more pass
+        sample_finite = None
+        if not skip_sample:
+            z_fin = sample_step()
+            sample_finite = bool(torch.isfinite(z_fin.float()).all())
+            sample_absmax = float(z_fin.float().abs().max())
         big_rate = None
         if args.big_batch and args.big_batch != n_img and world == 1 and not args.only_train and \
                 args.config == 'clevrtex128' and args.mode == 'train':
@@ -450,6 +456,8 @@ def main():
 
     train_rate = None
     dt_t = None
+    train_loss = None
+    params_finite = None
     comm = None
     if args.mode == 'train':
         run_step = train_step
@@ -462,6 +470,11 @@ def main():
             run_step = lambda: graphed(dict(img=img))
         dt_t = timed(run_step, args.steps, args.warmup, marked=True)
         train_rate = world * n_img * args.steps / dt_t
+        # loss of the last timed step (the graphed step keeps it in a static tensor) + a finite check of the
+        # updated parameters: a fast step that produces NaN is not a measurement
+        last = run_step()
+        train_loss = float(graphed.loss if not args.no_graph else last)
+        params_finite = bool(torch.isfinite(model.arena()).all())
         if dist is not None:
             # the exchange by itself (all ranks idle otherwise) and what of it the step exposes:
             # the same graphed step without the collective, timed the same way
@@ -508,6 +521,14 @@ def main():
     }
     if skip_sample:
         out['denoise'] = None
+    else:
+        out['denoise']['finite'] = sample_finite
+        out['denoise']['latent_absmax'] = sample_absmax
+    if args.mode == 'train':
+        out['loss'] = train_loss
+        out['finite'] = bool(params_finite and train_loss == train_loss and abs(train_loss) != float('inf'))
+    else:
+        out['finite'] = sample_finite
 
     # ---- rank-0-only instrumentation: no collective inside -------------------------------
     argv0 = [a for a in sys.argv[1:] if a != '--mark']
@@ -638,6 +659,8 @@ def main():
             if not skip_sample:
                 model.eval()
                 rfs, _, _ = roofline_of('sample', sample_step, n_s, 1e3 * dt_s / n_s, False)
+                if world == 1 and not args.no_graph and not args.no_pmc:
+                    apply_pmc(rfs, 'sample', 0)         # (the sampling leg's counters, this run)
                 model.train()
                 out['denoise']['roofline'] = rfs
         else:
@@ -665,6 +688,9 @@ def main():
         except Exception:
             pass
         print(json.dumps(out), flush=True)       # (normal interpreter exit: profilers finalise at exit)
+        if out.get('finite') is False or (out.get('denoise') or {}).get('finite') is False:
+            sys.stderr.write('bench.py: non-finite loss / parameters / latents in the timed configuration\n')
+            sys.exit(3)
 
 
 if __name__ == '__main__':

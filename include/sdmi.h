@@ -380,6 +380,36 @@ typedef struct {
   const void* src; void* dst; int src_dtype; long long rows; int cols, lds, ldd; float scale;
 } SdmiQuantFp8Args;
 int sdmi_quant_fp8(const SdmiQuantFp8Args* a, void* stream);
+/* ------------------------------------------------------------------------------------------
+ * Fused SpatialTransformer block (bf16 inference): GroupNorm -> proj_in -> [LayerNorm -> self-attention ->
+ * + ; LayerNorm -> slot cross-attention -> + ; LayerNorm -> GEGLU feed-forward -> +] -> proj_out -> + x in TWO
+ * launches (phase A: GroupNorm, proj_in, q | k | v; phase B: everything behind them), activations of a
+ * workgroup's 64 token rows resident in LDS / registers.
+ * Replaces SpatialTransformer.forward / BasicTransformerBlock._forward / CrossAttention.forward / FeedForward:
+ * video_based/models/unet/attention.py:297-308, 247-251, 182-206, 44-65 (10-13 launches of sdmi_groupnorm,
+ * sdmi_igemm, sdmi_attention per block otherwise).
+ *   x, tok, out [B][S][C] bf16; qkv [B][S][3C] bf16 (tok / qkv: workspaces written by phase A, read by B).
+ *   C = 256 or 384 (heads = C / 32, head dim 32); S = tokens per image, a multiple of 64, <= 256.
+ *   wstream_a / wstream_b: weights pre-packed into per-wave unit streams (2 KB units = the LDS image of 16
+ *     weight rows x 64 k, in the order the kernel consumes them; python: kern.WeightBank.st_pack).
+ *   wstream_img [B][...]: the per-image operands of the folded slot cross-attention (kern.Kern.cross_prepare)
+ *     in the same unit format; vec_img [B][256] fp32 = LayerNorm-fold column sums | biases of the score GEMM.
+ *   vec_a fp32 [7C]: proj_in bias | LayerNorm-fold column sums of q, k, v | folded biases of q, k, v.
+ *   vec_b fp32 [19C]: to_out bias | cross to_out bias | fold column sums of the GEGLU projection (8C) | its
+ *     folded biases (8C) | bias of the merged (ff.net.2 ; proj_out) output.
+ *   phase: 0 = both launches, 1 = A only, 2 = B only.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  const void* x; void* tok; void* qkv; void* out;
+  const float* gn_gamma; const float* gn_beta;
+  const void* wstream_a; const float* vec_a;
+  const void* wstream_b; const float* vec_b;
+  const void* wstream_img; const float* vec_img;
+  int B, S, C, slots, phase;
+  float gn_eps, ln_eps, attn_scale;
+} SdmiStBlockArgs;
+int sdmi_st_block(const SdmiStBlockArgs* a, void* stream);
+
 /* Head-expanded slot keys / values for the folded cross-attention (engine.UNetRunner.cross_fold):
  * kv [B][S][ldkv] holds K in columns [0, C) and V in [C, 2C); row h * 8 + j (j < S <= 7) of
  * kexp / vexp [B][heads * 8][C] is slot j's key (times `scale`) / value restricted to the channels of

@@ -29,6 +29,7 @@
 #endif
 
 #include "igemm_body.h"
+#include "igemm_sym.h"
 
 namespace {
 
@@ -605,6 +606,17 @@ static int dma64_min() {
   return v;
 }
 
+// SDMI_IGEMM_SYM: LDS stages of the symmetric-wave kernel (2: two workgroups per CU, 3 / 4: one), 0 = off
+static int sym_stages() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("SDMI_IGEMM_SYM");
+    v = e ? atoi(e) : 0;
+    if (v != 0 && (v < 2 || v > 4)) v = 4;
+  }
+  return v;
+}
+
 template <typename T>
 int dispatch(const SdmiGemmArgs& p, hipStream_t st) {
   constexpr int VEC = 16 / sizeof(T);
@@ -688,6 +700,33 @@ int dispatch(const SdmiGemmArgs& p, hipStream_t st) {
       ((long long)p.B * p.H * p.W + (long long)(p.KH + 1) * p.W) * p.lda * (long long)sizeof(T);
   const long long w_bytes = (long long)p.N * (p.geglu ? 2 : 1) * p.ldw * (long long)sizeof(T);
   const bool fits31 = a_bytes < (1ll << 31) && w_bytes < (1ll << 31);
+  // symmetric-wave kernel (igemm_sym.h): 128 x 128 tiles, bf16, 1x1 / plain convolutions, plain epilogue
+  if constexpr (sizeof(T) == 2) {
+    const int sym = sym_stages();
+    const int bk = 64;
+    bool ok = sym && shape == T128x128 && wide && split_k == 1 && batch == 1 && p.osy == 0 && fits31 && !p.ln_colsum &&
+              !p.geglu && !p.softmax8 && !p.out2 && (is1x1 || (plain && p.KH * p.KW <= 32 && p.Cin % bk == 0));
+    if (ok && p.a2) {
+      const long long a2_bytes = (long long)p.M * p.lda2 * 2, a3_bytes = p.a3 ? (long long)p.M * p.lda3 * 2 : 0;
+      const int kend2 = p.a3 ? p.K2 : p.K;
+      const bool same = p.stride == 1 && p.H == p.Ho && p.W == p.Wo;
+      ok = (is1x1 || same) && p.K1 == p.KH * p.KW * p.Cin && kend2 > p.K1 && (!p.a3 || p.K > p.K2) && p.K1 % bk == 0 &&
+           (kend2 - p.K1) % bk == 0 && (p.K - kend2) % bk == 0 && p.lda2 % VEC == 0 && (!p.a3 || p.lda3 % VEC == 0) &&
+           a2_bytes < (1ll << 31) && a3_bytes < (1ll << 31);
+    }
+    if (ok) {
+      const int n_cu = device_cus();
+#define SDMI_SYM(NS)                                                                               \
+  do {                                                                                             \
+    if (p.a2) return is1x1 ? launch_sym<1, NS, true>(p, hw_shift, st, n_cu) : launch_sym<2, NS, true>(p, hw_shift, st, n_cu); \
+    return is1x1 ? launch_sym<1, NS>(p, hw_shift, st, n_cu) : launch_sym<2, NS>(p, hw_shift, st, n_cu); \
+  } while (0)
+      if (sym == 2) SDMI_SYM(2);
+      if (sym == 3) SDMI_SYM(3);
+      SDMI_SYM(4);
+#undef SDMI_SYM
+    }
+  }
   if (p.a2) {       // extra A sources (sdmi.h: a2 / a3): 1x1, or a stride-1 "same" convolution on the fast path
     const int bk = (wide ? 128 : 64) / (int)sizeof(T);
     const long long a2_bytes = (long long)p.M * p.lda2 * (long long)sizeof(T);

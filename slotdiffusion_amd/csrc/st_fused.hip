@@ -1,0 +1,817 @@
+// Image-resident fused SpatialTransformer block (bf16 inference; sdmi.h: sdmi_st_block).
+//
+// Reference: video_based/models/unet/attention.py:297-308 (SpatialTransformer: GroupNorm -> proj_in ->
+// BasicTransformerBlock -> proj_out + x) and 247-251 (BasicTransformerBlock: self-attention, slot
+// cross-attention, GEGLU feed-forward, each behind a LayerNorm and with a residual add).
+//
+// Everything in the block is local to a token row or to an image, so a workgroup that owns 64 token rows of
+// one image needs no other workgroup -- except for the keys / values of its image's self-attention.  The
+// block is therefore TWO launches instead of 10-13:
+//   phase A  GroupNorm (statistics of the whole image recomputed by each of its S/64 workgroups: the image
+//            is 32-128 KB and L2 resident) -> proj_in -> tok;  LayerNorm-fold -> q | k | v
+//   phase B  self-attention of the 64 rows over the image's S keys -> to_out + tok -> LayerNorm-fold ->
+//            folded slot cross-attention (per-image weights, softmax over each head's 7 slots) -> + ->
+//            LayerNorm-fold -> GEGLU feed-forward, hidden chunk by hidden chunk, accumulated straight into
+//            the merged (ff.net.2 ; proj_out) output -> + x
+// Activations of the 64 rows stay in LDS (bf16, as the next GEMM's operand) and registers (fp32 residual
+// stream); only tok, q|k|v and the block output touch HBM.
+//
+// GEMM core: out^T[n][m] = W[n][:] . act[m][:] on v_mfma_f32_16x16x32_bf16 with W as the A operand, so a lane's
+// four accumulator values are FOUR CONSECUTIVE OUTPUT COLUMNS of ONE token row (lane & 15): residual adds,
+// LayerNorm-fold terms, GEGLU and the 8-wide slot softmax are lane-local, and the result goes back to LDS as
+// one ds_write_b64 in the next GEMM's operand layout.  The eight waves of the workgroup are the same program
+// (no loader waves): wave w owns output columns [w*C/8, (w+1)*C/8) -- NSL = C/128 slices of 16 -- for ALL 64
+// rows, and streams exactly the weight rows it multiplies through a PRIVATE ring of 2 KB units
+// (`buffer_load_dwordx4 ... lds`, counted `s_waitcnt vmcnt`): no barrier orders weight traffic -- the waves run
+// free inside a GEMM phase --, barriers exist only where an LDS activation buffer changes hands (~2 per phase).  The weights are pre-packed
+// on the host (kern.WeightBank.st_stream_*) into per-wave streams of units in consumption order, each unit
+// the exact XOR-swizzled LDS image of 16 weight rows x 64 k, so the fetch side is `base + g * 2048`.
+#include "common.h"
+
+namespace {
+
+typedef __attribute__((address_space(3))) char lds_char;
+typedef short st_s16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef short st_s16x8 __attribute__((ext_vector_type(8)));
+#define ST_LDS_V4(p) ((__attribute__((address_space(3))) st_s16x4*)(p))
+
+constexpr int ST_UNIT = 2048;          // 16 weight rows x 64 k x 2 B
+constexpr int ST_KP = 80, ST_VP = 64;  // attention staging: K row pitch (64 B + pad), V row pitch
+
+__device__ __forceinline__ unsigned st_pack2(float lo, float hi) { return f32x2_to_bf16x2(lo, hi); }
+
+// Epilogue vectors (biases, LayerNorm-fold column sums): lane group lg's four of the 16 floats of a slice.
+__device__ __forceinline__ f32x4 st_vec4(const float* base16, int lg) {
+  return *reinterpret_cast<const f32x4*>(base16 + 4 * lg);
+}
+
+template <int C>
+struct StGeom {
+  static constexpr int NSL = C / 128;          // 16-column slices per wave of an N = C GEMM
+  static constexpr int KT = C / 64;            // 64-wide K tiles of a K = C GEMM
+  static constexpr int HEADS = C / 32;
+  static constexpr int R = HEADS * 8;          // head-expanded slot rows of the folded cross-attention
+  static constexpr int RP = 128;               // ... padded (N of the score GEMM, K of the output GEMM)
+  static constexpr int NHC = C / 32;           // hidden chunks of 128 (4C hidden units)
+#ifdef ST_D
+  static constexpr int D = ST_D;
+#else
+  static constexpr int D = NSL <= 3 ? 6 : 8;   // ring depth in units per wave
+#endif
+  static constexpr int PITCH = C * 2;          // row pitch of the activation operand buffer
+  static constexpr int Y_BYTES = 64 * PITCH;
+  static constexpr int G_BYTES = 64 * 256;     // one GEGLU chunk / the cross-attention probabilities
+  static constexpr int GBUF = (Y_BYTES + 2 * G_BYTES + 8 * D * ST_UNIT <= 160 * 1024) ? 2 : 1;
+#ifdef ST_RING_FIRST
+  static constexpr int RING_OFF = 0;
+  static constexpr int Y_OFF = 8 * D * ST_UNIT;
+#else
+  static constexpr int Y_OFF = 0;
+  static constexpr int RING_OFF = Y_BYTES + GBUF * G_BYTES;
+#endif
+  static constexpr int SMEM_GEMM = Y_BYTES + GBUF * G_BYTES + 8 * D * ST_UNIT;
+  // units per wave
+  static constexpr int UA = KT * NSL + 3 * KT * NSL;                       // phase A: proj_in, q, k, v
+  static constexpr int UB1 = KT * NSL;                                     // phase B shared, part 1: to_out
+  static constexpr int UIMG = KT * 1 + 2 * NSL;                            // per image: scores, cross output
+  static constexpr int UB2 = KT * NSL + NHC * (KT * 2 + 2 * NSL);          // part 2: x2 @ Wpo, FF chunks
+};
+
+// ---------------------------------------------------------------------------------------------------------
+// per-wave weight stream + ring (all state wave-uniform)
+// ---------------------------------------------------------------------------------------------------------
+template <int D>
+struct StRing {
+  __amdgpu_buffer_rsrc_t rs_sh, rs_img;
+  int g_iss;            // next unit to fetch
+  int n1, n_img, total; // shared part 1 | per-image | shared part 2 (unit counts)
+  int pos_iss;          // ring position of unit g_iss
+  int pos_con;          // ring position of the next unit to consume
+  lds_char* ring;       // this wave's ring
+  int voff;             // lane * 16
+#ifdef ST_VERIFY
+  const char* sh_ptr; const char* img_ptr; int g_con; unsigned* dbg; int tag;
+#endif
+
+  __device__ __forceinline__ void issue_one() {
+    int g = g_iss < total ? g_iss : total - 1;          // (steps past the end re-fetch the last unit: static vmcnt)
+    lds_char* dst = ring + pos_iss * ST_UNIT;
+    if (g >= n1 && g < n1 + n_img) {
+      const int so = (g - n1) * ST_UNIT;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_img, (lds_void*)dst, 16, voff, so, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_img, (lds_void*)(dst + 1024), 16, voff, so + 1024, 0, 0);
+    } else {
+      const int so = (g >= n1 ? g - n_img : g) * ST_UNIT;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_sh, (lds_void*)dst, 16, voff, so, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_sh, (lds_void*)(dst + 1024), 16, voff, so + 1024, 0, 0);
+    }
+    ++g_iss;
+    if (++pos_iss == D) pos_iss = 0;
+  }
+};
+
+// EXTRA != 0: the step follows an epilogue that issued global stores; its wait is a full vmcnt(0) instead of
+// counting the stores into the allowance (four times per phase A launch: not worth an assumption).
+#if defined(ST_DRAIN)
+#define ST_WAIT_UNITS(D_, n_, extra_) asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#else
+#define ST_WAIT_UNITS(D_, n_, extra_) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((extra_) ? 0 : 2 * ((D_) - (n_))) : "memory")
+#endif
+// Workgroup barrier that leaves the DMA queue alone: `__syncthreads()` carries a fence that waits vmcnt(0) while
+// LDS-DMA is in flight (it is a pending LDS write); LDS stores / reads of this wave are retired explicitly.
+#define ST_BARRIER()                                         \
+  do {                                                       \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       \
+    __builtin_amdgcn_s_barrier();                            \
+    asm volatile("" ::: "memory");                           \
+  } while (0)
+
+// One K tile (64 k = two MFMA k-steps) of a GEMM whose wave block is NU 16-column slices x 64 rows:
+// acc[s][tt] += W_unit(s) . act[rows 16 tt ..][k tile kt].  STATS: LayerNorm-fold row sums from the
+// activation fragments (lane: row lane & 15 of tile tt, its 8 k of each 32).
+template <int D, int NU, bool STATS, int EXTRA = 0>
+__device__ __forceinline__ void st_gemm_step(StRing<D>& rg, const lds_char* act, const int (&yaddr)[4], int kt,
+                                             int tt_stride, const int (&woff)[2], f32x4 (&acc)[NU][4],
+                                             float (&sx)[4], float (&sxx)[4]) {
+#ifdef ST_STEP_BARRIER       // experiment: the eight waves in lock step (the default lets them run free)
+  __builtin_amdgcn_s_barrier();
+#endif
+  ST_WAIT_UNITS(D, NU, EXTRA);
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const int kk = kt * 2 + ks;
+    bf16x8 b[4];
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt)
+      b[tt] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(
+                                             act + yaddr[kk & 3] + tt * tt_stride + (kk >> 2) * 256));
+    if constexpr (STATS) {
+      const sdmi_bf16x2 ones = __builtin_bit_cast(sdmi_bf16x2, 0x3F803F80u);
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) {
+        const sdmi_bf16x2 v0 = {b[tt][0], b[tt][1]}, v1 = {b[tt][2], b[tt][3]}, v2 = {b[tt][4], b[tt][5]},
+                          v3 = {b[tt][6], b[tt][7]};
+        sx[tt] = __builtin_amdgcn_fdot2_f32_bf16(v0, ones, sx[tt], false);
+        sxx[tt] = __builtin_amdgcn_fdot2_f32_bf16(v0, v0, sxx[tt], false);
+        sx[tt] = __builtin_amdgcn_fdot2_f32_bf16(v1, ones, sx[tt], false);
+        sxx[tt] = __builtin_amdgcn_fdot2_f32_bf16(v1, v1, sxx[tt], false);
+        sx[tt] = __builtin_amdgcn_fdot2_f32_bf16(v2, ones, sx[tt], false);
+        sxx[tt] = __builtin_amdgcn_fdot2_f32_bf16(v2, v2, sxx[tt], false);
+        sx[tt] = __builtin_amdgcn_fdot2_f32_bf16(v3, ones, sx[tt], false);
+        sxx[tt] = __builtin_amdgcn_fdot2_f32_bf16(v3, v3, sxx[tt], false);
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < NU; ++s) {
+      int pos = rg.pos_con + s;
+      if (pos >= D) pos -= D;
+      const bf16x8 a = __builtin_bit_cast(
+          bf16x8, *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(rg.ring + pos * ST_UNIT + woff[ks]));
+#ifdef ST_VERIFY
+      {   // the unit as it lies in memory (its image there IS the LDS image) against what the ring holds
+        const int g = rg.g_con + s;
+        const char* src = (g >= rg.n1 && g < rg.n1 + rg.n_img) ? rg.img_ptr + (long long)(g - rg.n1) * ST_UNIT
+                                                               : rg.sh_ptr + (long long)(g >= rg.n1 ? g - rg.n_img : g) * ST_UNIT;
+        const u32x4 ex = *reinterpret_cast<const u32x4*>(src + woff[ks]);
+        const u32x4 got = __builtin_bit_cast(u32x4, a);
+        if (ex.x != got.x || ex.y != got.y || ex.z != got.z || ex.w != got.w)
+          atomicAdd(rg.dbg + (rg.tag * 8 + (threadIdx.x >> 6)), 1u);
+      }
+#endif
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) acc[s][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[tt], acc[s][tt], 0, 0, 0);
+    }
+  }
+  // The units just multiplied are free: refill their ring positions -- but only once this step's fragment reads have
+  // RETURNED.  To the instruction scheduler a `buffer_load ... lds` is a load, not an LDS store: without the wait and
+  // the scheduling barrier it moves the refill in front of the ds_reads of the very slot it overwrites, and when the
+  // stream hits in L2 the DMA wins the race now and then: with free-running waves 2 - 6 % of the 16-column output
+  // slices were wrong (exactly one 1 KB piece of one K tile each; tools/exp/st_forensic.py, st_stress.py), in lock step
+  // still ~1e-3.  Neither vmcnt(0) per step, a barrier behind the wait, nor waiting a step ahead cured it; this does:
+  // 0 / 102400 slices over 40 runs, bitwise repeatable.
+#ifndef ST_UNSAFE_REFILL
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+#endif
+  rg.pos_con += NU;
+  if (rg.pos_con >= D) rg.pos_con -= D;
+#ifdef ST_VERIFY
+  rg.g_con += NU;
+#endif
+#pragma unroll
+  for (int s = 0; s < NU; ++s) rg.issue_one();
+}
+
+// row statistics of the LayerNorm fold: after all K tiles, fold the four 8-k lane groups of a row
+__device__ __forceinline__ void st_ln_stats(float (&sx)[4], float (&sxx)[4], float inv_k, float eps, float (&mean)[4],
+                                            float (&rstd)[4]) {
+#pragma unroll
+  for (int tt = 0; tt < 4; ++tt) {
+    float a = sx[tt], b = sxx[tt];
+    a += __shfl_xor(a, 16, 64);
+    b += __shfl_xor(b, 16, 64);
+    a += __shfl_xor(a, 32, 64);
+    b += __shfl_xor(b, 32, 64);
+    mean[tt] = a * inv_k;
+    rstd[tt] = rsqrtf(fmaxf(b * inv_k - mean[tt] * mean[tt], 0.f) + eps);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// phase A: GroupNorm -> proj_in -> tok ; LayerNorm-fold -> q | k | v
+// ---------------------------------------------------------------------------------------------------------
+template <int C>
+__global__ __launch_bounds__(512, 2) void st_block_a_kernel(SdmiStBlockArgs p) {
+  typedef StGeom<C> G;
+  constexpr int NSL = G::NSL, KT = G::KT, D = G::D, PITCH = G::PITCH;
+  extern __shared__ __attribute__((aligned(16))) char smem_[];
+  lds_char* const smem = (lds_char*)smem_;
+  lds_char* const Y = smem + G::Y_OFF;
+  float* const red = (float*)(smem_ + G::Y_OFF + G::Y_BYTES);          // GroupNorm partials (the chunk buffer's region)
+  const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, lg = lane >> 4;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wgs_per_img = p.S / 64;
+  const int b = blockIdx.x / wgs_per_img, rb = blockIdx.x - b * wgs_per_img;
+  const long long row0 = (long long)b * p.S + rb * 64;       // first token row of this workgroup
+
+  StRing<D> rg;
+  rg.rs_sh = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.wstream_a + (long long)w * G::UA * ST_UNIT), 0,
+                                               G::UA * ST_UNIT, 0x00020000);
+  rg.rs_img = rg.rs_sh;
+  rg.g_iss = 0; rg.n1 = G::UA; rg.n_img = 0; rg.total = G::UA; rg.pos_iss = 0; rg.pos_con = 0;
+  rg.ring = smem + G::RING_OFF + w * D * ST_UNIT;
+  rg.voff = lane * 16;
+#ifdef ST_VERIFY
+  rg.sh_ptr = (const char*)p.wstream_a + (long long)w * G::UA * ST_UNIT; rg.img_ptr = rg.sh_ptr; rg.g_con = 0;
+  rg.dbg = (unsigned*)p.vec_img; rg.tag = 0;          // (debug build: vec_img doubles as the mismatch counters)
+#endif
+#pragma unroll
+  for (int i = 0; i < D; ++i) rg.issue_one();               // weights in flight under the GroupNorm
+
+  // ---- GroupNorm statistics of the image (32 groups): thread -> (row slot, 16-byte vector column)
+  constexpr int VPR = C / 8;                    // vectors per row
+  constexpr int RPP = 512 / VPR;                // rows per pass
+  constexpr int GS4 = C / 32 / 4;               // half-vectors (4 channels) per group
+  {
+    const bf16_t* xi = (const bf16_t*)p.x + (long long)b * p.S * C;
+    float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;
+    const int vr = tid / VPR, vc = tid - vr * VPR;
+    if (vr < RPP) {
+      for (int r = vr; r < p.S; r += RPP) {
+        float f[8];
+        unpack16<bf16_t>(*reinterpret_cast<const uint4*>(xi + (long long)r * C + vc * 8), f);
+        s0 += (f[0] + f[1]) + (f[2] + f[3]);
+        s1 += (f[4] + f[5]) + (f[6] + f[7]);
+        q0 += f[0] * f[0] + f[1] * f[1] + f[2] * f[2] + f[3] * f[3];
+        q1 += f[4] * f[4] + f[5] * f[5] + f[6] * f[6] + f[7] * f[7];
+      }
+      f32x4 v = {s0, q0, s1, q1};
+      *reinterpret_cast<f32x4*>(red + (vr * VPR + vc) * 4) = v;      // [row slot][vector][{s, q} x 2 halves]
+    }
+    ST_BARRIER();
+    if (tid < 32) {
+      float s = 0.f, q = 0.f;
+      for (int r = 0; r < RPP; ++r)
+        for (int h = 0; h < GS4; ++h) {
+          const int hv = tid * GS4 + h;           // half-vector index along C
+          const float* e = red + ((r * VPR + (hv >> 1)) * 4 + (hv & 1) * 2);
+          s += e[0];
+          q += e[1];
+        }
+      const float n = (float)(p.S * (C / 32));
+      const float mean = s / n;
+      const float var = fmaxf(q / n - mean * mean, 0.f);
+      red[512 * 4 + tid * 2] = mean;
+      red[512 * 4 + tid * 2 + 1] = rsqrtf(var + p.gn_eps);
+    }
+    ST_BARRIER();
+  }
+  // ---- normalise this workgroup's 64 rows into the operand buffer
+  {
+    const float* st = red + 512 * 4;
+    const bf16_t* xr = (const bf16_t*)p.x + row0 * C;
+    for (int i = tid; i < 64 * VPR; i += 512) {
+      const int r = i / VPR, vc = i - r * VPR;
+      float f[8], gm[8], bt[8];
+      unpack16<bf16_t>(*reinterpret_cast<const uint4*>(xr + (long long)r * C + vc * 8), f);
+      *reinterpret_cast<f32x4*>(gm) = *reinterpret_cast<const f32x4*>(p.gn_gamma + vc * 8);
+      *reinterpret_cast<f32x4*>(gm + 4) = *reinterpret_cast<const f32x4*>(p.gn_gamma + vc * 8 + 4);
+      *reinterpret_cast<f32x4*>(bt) = *reinterpret_cast<const f32x4*>(p.gn_beta + vc * 8);
+      *reinterpret_cast<f32x4*>(bt + 4) = *reinterpret_cast<const f32x4*>(p.gn_beta + vc * 8 + 4);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int g = (vc * 8 + h * 4) / (C / 32);
+        const float mean = st[g * 2], rstd = st[g * 2 + 1];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) f[h * 4 + j] = (f[h * 4 + j] - mean) * rstd * gm[h * 4 + j] + bt[h * 4 + j];
+      }
+      const int phys = (vc & ~15) | ((vc ^ r) & 15);
+      { const uint4 pk = pack16<bf16_t>(f);
+        *reinterpret_cast<__attribute__((address_space(3))) u32x4*>(Y + r * PITCH + phys * 16) = u32x4{pk.x, pk.y, pk.z, pk.w}; }
+    }
+  }
+  ST_BARRIER();
+
+  // lane constants of the GEMM core
+  int yaddr[4], woff[2];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) yaddr[j] = l15 * PITCH + ((((4 * j + lg) ^ l15) & 15) * 16);
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) woff[ks] = l15 * 128 + (((4 * ks + lg) ^ ((l15 >> 1) & 7)) * 16);
+  float sx[4] = {0.f, 0.f, 0.f, 0.f}, sxx[4] = {0.f, 0.f, 0.f, 0.f};
+
+  // Epilogue operands are fetched BEFORE the GEMM they follow: a vector load issued behind the weight DMAs
+  // would make its consumer wait for every DMA in front of it (vmcnt retires in order) -- a ring drain.
+  // ---- proj_in: tok = gn(x) Win^T + bin
+  f32x4 acc[NSL][4], ev0[NSL], ev1[NSL];
+#pragma unroll
+  for (int s = 0; s < NSL; ++s) {
+    ev0[s] = st_vec4(p.vec_a + (w * NSL + s) * 16, lg);
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) acc[s][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt) st_gemm_step<D, NSL, false>(rg, Y, yaddr, kt, 16 * PITCH, woff, acc, sx, sxx);
+  ST_BARRIER();                                      // every wave is done reading gn(x)
+  {
+    bf16_t* tok = (bf16_t*)p.tok + row0 * C;
+#pragma unroll
+    for (int s = 0; s < NSL; ++s) {
+      const int n0 = (w * NSL + s) * 16 + 4 * lg;
+      const f32x4 bi = ev0[s];
+      const int c = n0 >> 3;
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) {
+        const int r = tt * 16 + l15;
+        uint2 o;
+        o.x = st_pack2(acc[s][tt][0] + bi[0], acc[s][tt][1] + bi[1]);
+        o.y = st_pack2(acc[s][tt][2] + bi[2], acc[s][tt][3] + bi[3]);
+        *reinterpret_cast<uint2*>(tok + (long long)r * C + n0) = o;
+        const int phys = (c & ~15) | ((c ^ r) & 15);
+        *reinterpret_cast<__attribute__((address_space(3))) u32x2*>(Y + r * PITCH + phys * 16 + (lg & 1) * 8) = u32x2{o.x, o.y};
+      }
+    }
+  }
+  ST_BARRIER();
+
+  // ---- q | k | v = LayerNorm(tok) W^T through the fold: three passes of N = C over the same operand
+  float mean[4], rstd[4];
+#pragma unroll 1
+  for (int pass = 0; pass < 3; ++pass) {
+#ifdef ST_VERIFY
+    rg.tag = 1 + pass;
+#endif
+    const float* colsum = p.vec_a + C + pass * C;
+    const float* bias = p.vec_a + 4 * C + pass * C;
+#pragma unroll
+    for (int s = 0; s < NSL; ++s) {
+      ev0[s] = st_vec4(colsum + (w * NSL + s) * 16, lg);
+      ev1[s] = st_vec4(bias + (w * NSL + s) * 16, lg);
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) acc[s][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    // (the NSL * 4 row stores of the epilogue before this pass are younger than every DMA in flight)
+    if (pass == 0) {
+      st_gemm_step<D, NSL, true, NSL * 4>(rg, Y, yaddr, 0, 16 * PITCH, woff, acc, sx, sxx);
+#pragma unroll
+      for (int kt = 1; kt < KT; ++kt) st_gemm_step<D, NSL, true>(rg, Y, yaddr, kt, 16 * PITCH, woff, acc, sx, sxx);
+      st_ln_stats(sx, sxx, 1.f / (float)C, p.ln_eps, mean, rstd);
+    } else {
+      st_gemm_step<D, NSL, false, NSL * 4>(rg, Y, yaddr, 0, 16 * PITCH, woff, acc, sx, sxx);
+#pragma unroll
+      for (int kt = 1; kt < KT; ++kt) st_gemm_step<D, NSL, false>(rg, Y, yaddr, kt, 16 * PITCH, woff, acc, sx, sxx);
+    }
+    bf16_t* qkv = (bf16_t*)p.qkv + row0 * 3 * C + pass * C;
+#pragma unroll
+    for (int s = 0; s < NSL; ++s) {
+      const int n0 = (w * NSL + s) * 16 + 4 * lg;
+      const f32x4 cs = ev0[s];
+      const f32x4 bi = ev1[s];
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) {
+        const int r = tt * 16 + l15;
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = rstd[tt] * (acc[s][tt][j] - mean[tt] * cs[j]) + bi[j];
+        uint2 o;
+        o.x = st_pack2(v[0], v[1]);
+        o.y = st_pack2(v[2], v[3]);
+        *reinterpret_cast<uint2*>(qkv + (long long)r * 3 * C + n0) = o;
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no DMA may outlive the workgroup's LDS
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// phase B
+// ---------------------------------------------------------------------------------------------------------
+template <int C>
+__global__ __launch_bounds__(512, 2) void st_block_b_kernel(SdmiStBlockArgs p) {
+  typedef StGeom<C> G;
+  constexpr int NSL = G::NSL, KT = G::KT, D = G::D, PITCH = G::PITCH, HEADS = G::HEADS, R = G::R;
+  extern __shared__ __attribute__((aligned(16))) char smem_[];
+  lds_char* const smem = (lds_char*)smem_;
+  lds_char* const Y = smem + G::Y_OFF;
+  lds_char* const Gb = smem + G::Y_OFF + G::Y_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, lg = lane >> 4;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wgs_per_img = p.S / 64;
+  const int b = blockIdx.x / wgs_per_img, rb = blockIdx.x - b * wgs_per_img;
+  const long long row0 = (long long)b * p.S + rb * 64;
+  const int S = p.S;
+
+  // =========================== self-attention: 64 queries x HEADS heads over S keys ===========================
+  // (attention.hip's transposed matrix-core formulation: a wave owns 32 queries of one head; four heads per round)
+  unsigned opack[HEADS / 4][8];
+  {
+    const int hs = w >> 1, qh = w & 1;
+    const int ql = lane & 31, hh = lane >> 5;
+    const bf16_t* qkv_img = (const bf16_t*)p.qkv + (long long)b * S * 3 * C;
+    const int head_bytes = S * (ST_KP + ST_VP);
+    const lds_char* Ks = smem + hs * head_bytes;
+    const lds_char* Vs = Ks + S * ST_KP;
+    const float sc2 = p.attn_scale * 1.4426950408889634f;
+    const int g4 = lane >> 4, t16 = lane & 15;
+    const lds_char* kfrag = Ks + ql * ST_KP + hh * 16;
+    const lds_char* vfrag = Vs + (4 * hh + (t16 >> 2)) * ST_VP + ((g4 & 1) * 16 + (t16 & 3) * 4) * 2;
+#pragma unroll
+    for (int rd = 0; rd < HEADS / 4; ++rd) {
+      if (rd) __syncthreads();
+      // stage K, V of heads 4 rd .. 4 rd + 3: 32 16-byte pieces per key row
+      for (int i = tid; i < S * 32; i += 512) {
+        const int row = i >> 5, rem = i & 31;
+        const int isv = rem >> 4, h4 = (rem >> 2) & 3, c = rem & 3;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(qkv_img + (long long)row * 3 * C + (1 + isv) * C +
+                                                        (rd * 4 + h4) * 32 + c * 8);
+        lds_char* dst = smem + h4 * head_bytes + (isv ? S * ST_KP + row * ST_VP : row * ST_KP) + c * 16;
+        *reinterpret_cast<__attribute__((address_space(3))) u32x4*>(dst) = v;
+      }
+      const int h = rd * 4 + hs;
+      bf16x8 bq[2];
+      {
+        const bf16_t* qp = (const bf16_t*)p.qkv + (row0 + qh * 32 + ql) * 3 * C + h * 32 + hh * 8;
+        bq[0] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(qp));
+        bq[1] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(qp + 16));
+      }
+      __syncthreads();
+      f32x16 o;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[r] = 0.f;
+      float m = -INFINITY, lsum = 0.f;
+      for (int kb = 0; kb < S / 32; ++kb) {
+        f32x16 s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const u32x4 a = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(kfrag + kb * 32 * ST_KP + ks * 32);
+          s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), bq[ks], s, 0, 0, 0);
+        }
+        float bmax = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          s[r] *= sc2;
+          bmax = fmaxf(bmax, s[r]);
+        }
+        bmax = fmaxf(bmax, __shfl_xor(bmax, 32, 64));
+        const float m_new = fmaxf(m, bmax);
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          s[r] = __builtin_amdgcn_exp2f(s[r] - m_new);
+          psum += s[r];
+        }
+        psum += __shfl_xor(psum, 32, 64);
+        if (__builtin_amdgcn_ballot_w64(m_new > m) != 0) {
+          const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+          lsum = lsum * alpha + psum;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[r] *= alpha;
+        } else {
+          lsum += psum;
+        }
+        m = m_new;
+#pragma unroll
+        for (int mm = 0; mm < 2; ++mm) {
+          const u32x4 pb = {st_pack2(s[8 * mm + 0], s[8 * mm + 1]), st_pack2(s[8 * mm + 2], s[8 * mm + 3]),
+                            st_pack2(s[8 * mm + 4], s[8 * mm + 5]), st_pack2(s[8 * mm + 6], s[8 * mm + 7])};
+          const lds_char* vp = vfrag + (kb * 32 + 16 * mm) * ST_VP;
+          const st_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(ST_LDS_V4(vp));
+          const st_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(ST_LDS_V4(vp + 8 * ST_VP));
+          const st_s16x8 av = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+          o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, pb), o, 0, 0, 0);
+        }
+      }
+      const float inv = 1.f / lsum;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {       // d = 8 j + 4 hh + (0..3)
+        opack[rd][2 * j] = st_pack2(o[4 * j] * inv, o[4 * j + 1] * inv);
+        opack[rd][2 * j + 1] = st_pack2(o[4 * j + 2] * inv, o[4 * j + 3] * inv);
+      }
+    }
+    __syncthreads();                      // the staging region becomes operand buffers + rings
+  }
+
+  // the token residual of the first epilogue: fetched and RETIRED before any weight DMA is issued (st_vec4's note)
+  uint2 rsd[NSL][4];
+  {
+    const bf16_t* tok = (const bf16_t*)p.tok + row0 * C;
+#pragma unroll
+    for (int s = 0; s < NSL; ++s)
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt)
+        rsd[s][tt] = *reinterpret_cast<const uint2*>(tok + (long long)(tt * 16 + l15) * C + (w * NSL + s) * 16 + 4 * lg);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  // ================================ weight stream + ring of this wave ================================
+  StRing<D> rg;
+  rg.rs_sh = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)((const char*)p.wstream_b + (long long)w * (G::UB1 + G::UB2) * ST_UNIT), 0, (G::UB1 + G::UB2) * ST_UNIT, 0x00020000);
+  rg.rs_img = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)((const char*)p.wstream_img + ((long long)b * 8 + w) * G::UIMG * ST_UNIT), 0, G::UIMG * ST_UNIT, 0x00020000);
+  rg.g_iss = 0; rg.n1 = G::UB1; rg.n_img = G::UIMG; rg.total = G::UB1 + G::UIMG + G::UB2;
+  rg.pos_iss = 0; rg.pos_con = 0;
+  rg.ring = smem + G::RING_OFF + w * D * ST_UNIT;
+  rg.voff = lane * 16;
+#ifdef ST_VERIFY
+  rg.sh_ptr = (const char*)p.wstream_b + (long long)w * (G::UB1 + G::UB2) * ST_UNIT;
+  rg.img_ptr = (const char*)p.wstream_img + ((long long)b * 8 + w) * G::UIMG * ST_UNIT;
+  rg.g_con = 0; rg.dbg = (unsigned*)p.gn_gamma; rg.tag = 0;   // (debug build: gn_gamma doubles as the counters in phase B)
+#endif
+#pragma unroll
+  for (int i = 0; i < D; ++i) rg.issue_one();
+  {
+    const int hs = w >> 1, qh = w & 1;
+    const int ql = lane & 31, hh = lane >> 5;
+    // attention output -> operand buffer: row qh * 32 + ql, channels h * 32 + 8 j + 4 hh .. + 4
+    const int r = qh * 32 + ql;
+#pragma unroll
+    for (int rd = 0; rd < HEADS / 4; ++rd) {
+      const int h = rd * 4 + hs;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int c = h * 4 + j;
+        const int phys = (c & ~15) | ((c ^ r) & 15);
+        uint2 v;
+        v.x = opack[rd][2 * j];
+        v.y = opack[rd][2 * j + 1];
+        *reinterpret_cast<__attribute__((address_space(3))) u32x2*>(Y + r * PITCH + phys * 16 + hh * 8) = u32x2{v.x, v.y};
+      }
+    }
+  }
+  ST_BARRIER();                           // attention output complete in Y
+
+  int yaddr[4], gaddr[4], woff[2];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int sw = (((4 * j + lg) ^ l15) & 15) * 16;
+    yaddr[j] = l15 * PITCH + sw;
+    gaddr[j] = l15 * 256 + sw;
+  }
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) woff[ks] = l15 * 128 + (((4 * ks + lg) ^ ((l15 >> 1) & 7)) * 16);
+  float sx[4], sxx[4], mean[4], rstd[4];
+  const float* vb = p.vec_b;              // [bo | bo2 | colsum_ff (8C) | bias_ff (8C) | bias_out]  fp32
+  const float* vi = p.vec_img + (long long)b * 256;   // per image: [colsum_q (128) | bias_q (128)]
+
+  // residual stream of this wave's columns, fp32: res[s][tt][j] = row 16 tt + l15, column (w NSL + s) 16 + 4 lg + j
+  f32x4 res[NSL][4], acc[NSL][4];
+  auto zero_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int s = 0; s < NSL; ++s)
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) acc[s][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+  auto res_to_y = [&]() __attribute__((always_inline)) {      // bf16 copy of the residual stream = next GEMM's operand
+#pragma unroll
+    for (int s = 0; s < NSL; ++s) {
+      const int c = ((w * NSL + s) * 16 + 4 * lg) >> 3;
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) {
+        const int r = tt * 16 + l15;
+        const int phys = (c & ~15) | ((c ^ r) & 15);
+        uint2 o;
+        o.x = st_pack2(res[s][tt][0], res[s][tt][1]);
+        o.y = st_pack2(res[s][tt][2], res[s][tt][3]);
+        *reinterpret_cast<__attribute__((address_space(3))) u32x2*>(Y + r * PITCH + phys * 16 + (lg & 1) * 8) = u32x2{o.x, o.y};
+      }
+    }
+  };
+
+  // (epilogue operands are fetched BEFORE the GEMM they follow -- see phase A)
+  // ---- attn1.to_out + tok  -> x1
+  f32x4 ev0[NSL];
+#pragma unroll
+  for (int s = 0; s < NSL; ++s) ev0[s] = st_vec4(vb + (w * NSL + s) * 16, lg);
+  zero_acc();
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt) st_gemm_step<D, NSL, false>(rg, Y, yaddr, kt, 16 * PITCH, woff, acc, sx, sxx);
+  {
+#pragma unroll
+    for (int s = 0; s < NSL; ++s) {
+      const f32x4 bi = ev0[s];
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) {
+        const uint2 t2 = rsd[s][tt];
+        res[s][tt][0] = acc[s][tt][0] + bi[0] + __uint_as_float(t2.x << 16);
+        res[s][tt][1] = acc[s][tt][1] + bi[1] + __uint_as_float(t2.x & 0xffff0000u);
+        res[s][tt][2] = acc[s][tt][2] + bi[2] + __uint_as_float(t2.y << 16);
+        res[s][tt][3] = acc[s][tt][3] + bi[3] + __uint_as_float(t2.y & 0xffff0000u);
+      }
+    }
+  }
+  ST_BARRIER();
+  res_to_y();
+  ST_BARRIER();
+
+  // ---- folded slot cross-attention: P = softmax8(LN-fold(x1) Wq[b]^T) ; x2 = P W2[b]^T + bo2 + x1
+  {
+    f32x4 sc[1][4];
+#ifdef ST_VERIFY
+    rg.tag = 1;
+#endif
+    const int n0 = w * 16 + 4 * lg;                   // column of the padded score matrix
+    const f32x4 cs = st_vec4(vi + w * 16, lg);
+    const f32x4 bi = st_vec4(vi + 128 + w * 16, lg);
+#pragma unroll
+    for (int s = 0; s < NSL; ++s) ev0[s] = st_vec4(vb + C + (w * NSL + s) * 16, lg);
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) {
+      sc[0][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      sx[tt] = sxx[tt] = 0.f;
+    }
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) st_gemm_step<D, 1, true>(rg, Y, yaddr, kt, 16 * PITCH, woff, sc, sx, sxx);
+    st_ln_stats(sx, sxx, 1.f / (float)C, p.ln_eps, mean, rstd);
+    const int c = n0 >> 3;
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) {
+      float v[4];
+      float mx = -INFINITY;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bool ok = n0 < R && (4 * (lg & 1) + j) < p.slots;
+        v[j] = ok ? rstd[tt] * (sc[0][tt][j] - mean[tt] * cs[j]) + bi[j] : -INFINITY;
+        mx = fmaxf(mx, v[j]);
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));          // the group's other four columns: lane ^ 16
+      float sm = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        v[j] = n0 < R ? __expf(v[j] - mx) : 0.f;
+        sm += v[j];
+      }
+      sm += __shfl_xor(sm, 16, 64);
+      const float inv = n0 < R ? 1.f / sm : 0.f;
+      const int r = tt * 16 + l15;
+      const int phys = (c & ~15) | ((c ^ r) & 15);
+      uint2 o;
+      o.x = st_pack2(v[0] * inv, v[1] * inv);
+      o.y = st_pack2(v[2] * inv, v[3] * inv);
+      *reinterpret_cast<__attribute__((address_space(3))) u32x2*>(Gb + r * 256 + phys * 16 + (lg & 1) * 8) = u32x2{o.x, o.y};
+    }
+  }
+  ST_BARRIER();
+#ifdef ST_VERIFY
+  rg.tag = 2;
+#endif
+  zero_acc();
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt) st_gemm_step<D, NSL, false>(rg, Gb, gaddr, kt, 16 * 256, woff, acc, sx, sxx);
+#pragma unroll
+  for (int s = 0; s < NSL; ++s) {
+    const f32x4 bi = ev0[s];
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) res[s][tt][j] += acc[s][tt][j] + bi[j];
+  }
+  ST_BARRIER();                                         // (Y readers of the score GEMM are long done; Gb readers too)
+  res_to_y();
+  ST_BARRIER();
+
+  // ---- merged (ff.net.2 ; proj_out): out = [g | x2] [Wpo Wff | Wpo]^T + b' + x.  First the x2 part (also
+  //      yields the LayerNorm-fold statistics of x2 for the feed-forward), then the hidden chunks.
+#ifdef ST_VERIFY
+  rg.tag = 3;
+#endif
+#pragma unroll
+  for (int tt = 0; tt < 4; ++tt) sx[tt] = sxx[tt] = 0.f;
+  zero_acc();
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt) st_gemm_step<D, NSL, true>(rg, Y, yaddr, kt, 16 * PITCH, woff, acc, sx, sxx);
+  st_ln_stats(sx, sxx, 1.f / (float)C, p.ln_eps, mean, rstd);
+  const float* cs_ff = vb + 2 * C;
+  const float* bi_ff = vb + 10 * C;
+#pragma unroll 1
+  for (int hc = 0; hc < G::NHC; ++hc) {
+    f32x4 vg[2][4];                                     // [value | gate] columns hc * 128 + w * 16 + 4 lg ..
+    const f32x4 csv = st_vec4(cs_ff + hc * 128 + w * 16, lg);
+    const f32x4 csg = st_vec4(cs_ff + 4 * C + hc * 128 + w * 16, lg);
+    const f32x4 biv = st_vec4(bi_ff + hc * 128 + w * 16, lg);
+    const f32x4 big = st_vec4(bi_ff + 4 * C + hc * 128 + w * 16, lg);
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) vg[0][tt] = vg[1][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#ifdef ST_VERIFY
+    rg.tag = 4;
+#endif
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) st_gemm_step<D, 2, false>(rg, Y, yaddr, kt, 16 * PITCH, woff, vg, sx, sxx);
+    lds_char* gb = Gb + (G::GBUF == 2 ? (hc & 1) * G::G_BYTES : 0);
+    if (G::GBUF == 1) ST_BARRIER();                     // the previous chunk's readers are done
+    {
+      const int c = (w * 16 + 4 * lg) >> 3;
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) {
+        float y[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float v = rstd[tt] * (vg[0][tt][j] - mean[tt] * csv[j]) + biv[j];
+          const float g = rstd[tt] * (vg[1][tt][j] - mean[tt] * csg[j]) + big[j];
+          y[j] = v * act_apply<true>(g, SDMI_ACT_GELU);
+        }
+        const int r = tt * 16 + l15;
+        const int phys = (c & ~15) | ((c ^ r) & 15);
+        uint2 o;
+        o.x = st_pack2(y[0], y[1]);
+        o.y = st_pack2(y[2], y[3]);
+        *reinterpret_cast<__attribute__((address_space(3))) u32x2*>(gb + r * 256 + phys * 16 + (lg & 1) * 8) = u32x2{o.x, o.y};
+      }
+    }
+    ST_BARRIER();
+#ifdef ST_VERIFY
+    rg.tag = 5;
+#endif
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) st_gemm_step<D, NSL, false>(rg, gb, gaddr, kt, 16 * 256, woff, acc, sx, sxx);
+  }
+  // ---- + b' + x  -> out   (only dummy re-fetches are in flight now: drain them, then ordinary loads are safe)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  {
+    const bf16_t* xr = (const bf16_t*)p.x + row0 * C;
+#pragma unroll
+    for (int s = 0; s < NSL; ++s) {
+      ev0[s] = st_vec4(vb + 18 * C + (w * NSL + s) * 16, lg);
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt)
+        rsd[s][tt] = *reinterpret_cast<const uint2*>(xr + (long long)(tt * 16 + l15) * C + (w * NSL + s) * 16 + 4 * lg);
+    }
+  }
+  {
+    bf16_t* outp = (bf16_t*)p.out + row0 * C;
+#pragma unroll
+    for (int s = 0; s < NSL; ++s) {
+      const int n0 = (w * NSL + s) * 16 + 4 * lg;
+      const f32x4 bi = ev0[s];
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) {
+        const long long o_ = (long long)(tt * 16 + l15) * C + n0;
+        const uint2 x2 = rsd[s][tt];
+        uint2 o;
+        o.x = st_pack2(acc[s][tt][0] + bi[0] + __uint_as_float(x2.x << 16),
+                       acc[s][tt][1] + bi[1] + __uint_as_float(x2.x & 0xffff0000u));
+        o.y = st_pack2(acc[s][tt][2] + bi[2] + __uint_as_float(x2.y << 16),
+                       acc[s][tt][3] + bi[3] + __uint_as_float(x2.y & 0xffff0000u));
+        *reinterpret_cast<uint2*>(outp + o_) = o;
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <int C>
+int st_launch(const SdmiStBlockArgs& a, hipStream_t st) {
+  typedef StGeom<C> G;
+  const int att = 4 * a.S * (ST_KP + ST_VP);
+  const int smem_b = att > G::SMEM_GEMM ? att : G::SMEM_GEMM;
+  const int grid = a.B * (a.S / 64);
+  if (a.phase == 0 || a.phase == 1) {
+    SDMI_OPTIN_LDS((st_block_a_kernel<C>), G::SMEM_GEMM, "st_block (phase A)");
+    hipLaunchKernelGGL((st_block_a_kernel<C>), dim3(grid), dim3(512), G::SMEM_GEMM, st, a);
+    const int rc = sdmi_check_launch("st_block (phase A)");
+    if (rc) return rc;
+  }
+  if (a.phase == 0 || a.phase == 2) {
+    SDMI_OPTIN_LDS((st_block_b_kernel<C>), 160 * 1024, "st_block (phase B)");
+    hipLaunchKernelGGL((st_block_b_kernel<C>), dim3(grid), dim3(512), smem_b, st, a);
+    return sdmi_check_launch("st_block (phase B)");
+  }
+  return SDMI_OK;
+}
+
+}  // namespace
+
+extern "C" int sdmi_st_block(const SdmiStBlockArgs* a, void* stream) {
+  SDMI_REQUIRE(a && a->x && a->tok && a->qkv && a->out, "null pointer");
+  SDMI_REQUIRE(a->wstream_a && a->vec_a && a->wstream_b && a->wstream_img && a->vec_b && a->vec_img, "null stream");
+  SDMI_REQUIRE(a->C == 256 || a->C == 384, "C must be 256 or 384");
+  SDMI_REQUIRE(a->S >= 64 && a->S % 64 == 0 && 4 * a->S * (ST_KP + ST_VP) <= 160 * 1024,
+               "S must be a multiple of 64 and at most 256 tokens per image");
+  SDMI_REQUIRE(a->slots >= 1 && a->slots <= 8, "1..8 slots");
+  SDMI_REQUIRE(a->phase >= 0 && a->phase <= 2, "phase: 0 = both, 1 = A, 2 = B");
+  hipStream_t st = (hipStream_t)stream;
+  if (a->C == 256) return st_launch<256>(*a, st);
+  return st_launch<384>(*a, st);
+}

@@ -200,6 +200,10 @@ class UNetRunner:
     def _st(self, K, name, x, heads, kv):
         n = self.P + name
         B, H, W, C = x.shape
+        if not K.training and hasattr(K, 'st_fused'):     # bf16 inference: the block as two launches
+            out = K.st_fused(x, n, heads, kv)
+            if out is not None:
+                return out
         # (every residual branch takes an alias of the normalised tensor: its gradient is summed
         # inside the norm's backward kernel)
         h, xres = K.gn_fan(x, n + '.norm', eps=1e-6)

@@ -67,6 +67,7 @@ _RES_MERGE = os.environ.get('SDMI_RES_MERGE', '1') != '0'
 _FF_MERGE = os.environ.get('SDMI_FF_MERGE', '1') != '0'
 _CROSS_FOLD = os.environ.get('SDMI_CROSS_FOLD', '1') != '0'
 _LN_FOLD = os.environ.get('SDMI_LN_FOLD', '1') != '0'
+_ST_FUSED = os.environ.get('SDMI_ST_FUSED', '1') != '0'     # fused SpatialTransformer block (sdmi_st_block)
 
 
 def _copy_group(items):
@@ -79,6 +80,85 @@ def _copy_group(items):
         for a, (sp, dp, nb) in zip(arr, chunk):
             a.src, a.dst, a.bytes = sp, dp, nb
         call('sdmi_copy_group', _st(), items=ctypes.addressof(arr), n=len(chunk))
+
+
+
+# ------------------------------------------------------------------------------------------
+# weight streams of the fused SpatialTransformer block (csrc/st_fused.hip): per-wave sequences of 2 KB
+# units = the XOR-swizzled LDS image of 16 weight rows x 64 k, in the order the kernel multiplies them
+# ------------------------------------------------------------------------------------------
+def _st_unit_index(entries):
+    """entries[w] = [(element offset of the matrix, row pitch, first row, first k), ...] per unit, 8 waves
+    -> int64 [8 * U * 1024] gather index into the flat source (unit byte b of wave w, unit u at
+    ((w * U + u) * 1024 + b / 2)): physical 16-byte chunk p of row r holds logical chunk p ^ ((r >> 1) & 7)."""
+    import numpy as np
+    r = np.arange(16, dtype=np.int64)[:, None, None]
+    p_ = np.arange(8, dtype=np.int64)[None, :, None]
+    e = np.arange(8, dtype=np.int64)[None, None, :]
+    col = (p_ ^ ((r >> 1) & 7)) * 8 + e                       # [16, 8, 8]
+    out = []
+    for ent in entries:
+        for off, ld, row0, k0 in ent:
+            out.append((off + (row0 + r) * ld + k0 + col).reshape(-1))
+    return torch.from_numpy(np.concatenate(out))
+
+
+def st_geometry(C):
+    NSL, KT = C // 128, C // 64
+    return dict(NSL=NSL, KT=KT, NHC=C // 32, R=C // 32 * 8, UA=4 * KT * NSL, UB1=KT * NSL,
+                UIMG=KT + 2 * NSL, UB2=KT * NSL + (C // 32) * (2 * KT + 2 * NSL))
+
+
+def st_index_a(C):
+    """Phase A source = [W_in (C x C) | W_q' | W_k' | W_v' (C x C each)] flat."""
+    g = st_geometry(C)
+    ent = []
+    for w in range(8):
+        e = []
+        for m in range(4):                                  # proj_in, q, k, v
+            for kt in range(g['KT']):
+                for s_ in range(g['NSL']):
+                    e.append((m * C * C, C, (w * g['NSL'] + s_) * 16, kt * 64))
+        ent.append(e)
+    return _st_unit_index(ent)
+
+
+def st_index_b(C):
+    """Phase B shared source = [W_o (C x C) | W_po (C x C) | W_1' (8C x C) | W_m = W_po W_ff (C x 4C)] flat."""
+    g = st_geometry(C)
+    NSL, KT = g['NSL'], g['KT']
+    o_po, o_1, o_m = C * C, 2 * C * C, 2 * C * C + 8 * C * C
+    ent = []
+    for w in range(8):
+        e = []
+        for kt in range(KT):                                # attn1.to_out
+            for s_ in range(NSL):
+                e.append((0, C, (w * NSL + s_) * 16, kt * 64))
+        for kt in range(KT):                                # x2 @ W_po^T
+            for s_ in range(NSL):
+                e.append((o_po, C, (w * NSL + s_) * 16, kt * 64))
+        for hc in range(g['NHC']):
+            for kt in range(KT):                            # value | gate rows of hidden chunk hc
+                e.append((o_1, C, hc * 128 + w * 16, kt * 64))
+                e.append((o_1, C, 4 * C + hc * 128 + w * 16, kt * 64))
+            for k2 in range(2):                             # the chunk's 128 k of the merged output weight
+                for s_ in range(NSL):
+                    e.append((o_m, 4 * C, (w * NSL + s_) * 16, hc * 128 + k2 * 64))
+        ent.append(e)
+    return _st_unit_index(ent)
+
+
+def st_index_img(C):
+    """Per-image source = [Wq[b] padded to 128 rows (128 x C) | W2[b] with K padded to 128 (C x 128)] flat."""
+    g = st_geometry(C)
+    ent = []
+    for w in range(8):
+        e = [(0, C, w * 16, kt * 64) for kt in range(g['KT'])]
+        for k2 in range(2):
+            for s_ in range(g['NSL']):
+                e.append((128 * C, 128, (w * g['NSL'] + s_) * 16, k2 * 64))
+        ent.append(e)
+    return _st_unit_index(ent)
 
 
 class WeightBank:
@@ -534,6 +614,45 @@ class WeightBank:
                 self.cache[key] = (Wp, Wp.float().sum(1).contiguous(), bias.contiguous())
         return self.cache[key]
 
+    def st_index(self, which, C, device):
+        key = ('st_index', which, C)
+        if key not in self.cache:
+            self.cache[key] = {'a': st_index_a, 'b': st_index_b, 'img': st_index_img}[which](C).to(device)
+        return self.cache[key]
+
+    def st_fused_weights(self, n, dtype):
+        """Packed operands of the fused SpatialTransformer block `n` (sdmi.h: sdmi_st_block): weight streams of
+        phase A / B and their fp32 epilogue vectors.  Same folds as ln_folded / ffout_proj_weights (LayerNorm
+        gamma into the weights, beta into the bias; ff.net.2 and proj_out pre-multiplied).  Weight preparation,
+        cached until the weights change."""
+        key = ('st_fused', n, dtype)
+        if key not in self.cache:
+            with torch.no_grad():
+                t = n + '.transformer_blocks.0'
+                f = lambda k: self.t[k].float()
+                C = f(n + '.proj_in.bias').numel()
+                dev = self.t[n + '.proj_in.bias'].device
+                w_in = f(n + '.proj_in.weight').reshape(C, C)
+                g1, b1 = f(t + '.norm1.weight'), f(t + '.norm1.bias')
+                wqkv = torch.cat([f(t + '.attn1.to_q.weight'), f(t + '.attn1.to_k.weight'), f(t + '.attn1.to_v.weight')])
+                wqkv_p = (wqkv * g1).to(dtype)
+                src_a = torch.cat([w_in.to(dtype).reshape(-1), wqkv_p.reshape(-1)])
+                vec_a = torch.cat([f(n + '.proj_in.bias'), wqkv_p.float().sum(1), wqkv @ b1]).contiguous()
+                wa = src_a[self.st_index('a', C, dev)].contiguous()
+                wo, bo = f(t + '.attn1.to_out.0.weight'), f(t + '.attn1.to_out.0.bias')
+                bo2 = f(t + '.attn2.to_out.0.bias')
+                g3, b3 = f(t + '.norm3.weight'), f(t + '.norm3.bias')
+                w1, bb1 = f(t + '.ff.net.0.proj.weight'), f(t + '.ff.net.0.proj.bias')
+                w1_p = (w1 * g3).to(dtype)
+                wff, bff = f(t + '.ff.net.2.weight'), f(t + '.ff.net.2.bias')
+                wpo, bpo = f(n + '.proj_out.weight').reshape(C, C), f(n + '.proj_out.bias')
+                src_b = torch.cat([wo.to(dtype).reshape(-1), wpo.to(dtype).reshape(-1), w1_p.reshape(-1),
+                                   (wpo @ wff).to(dtype).reshape(-1)])
+                wbs = src_b[self.st_index('b', C, dev)].contiguous()
+                vec_b = torch.cat([bo, bo2, w1_p.float().sum(1), w1 @ b3 + bb1, wpo @ bff + bpo]).contiguous()
+                self.cache[key] = dict(wa=wa, va=vec_a, wb=wbs, vb=vec_b, C=C)
+        return self.cache[key]
+
     def b(self, names):
         """fp32 bias vector, fused across names (view when adjacent)."""
         if names is None:
@@ -821,13 +940,33 @@ class Kern:
         B, C = kv.shape[0], kv.shape[-1] // 2
         R = heads * 8
         kexp, vexp = ops.expand_heads(kv, heads, float(C // heads) ** -0.5)
-        wq = ops.bmm_nt(kexp, wt, torch.empty((B, R, C), dtype=kv.dtype, device=kv.device))
-        colsum = ops.bmm_nt(wq, ones, torch.empty((B, R, 1), dtype=torch.float32, device=kv.device))
-        biasq = ops.bmm_nt(kexp, tb, torch.empty((B, R, 1), dtype=torch.float32, device=kv.device))
+        fused = _ST_FUSED and C in (256, 384)
+        if fused:
+            # the fused block (sdmi_st_block) takes the same operands padded to 128 score columns, as a unit
+            # stream: Wq[b] / W2[b] are produced straight into the padded storage (pads stay zero)
+            key = ('st_img_src', t, B)
+            if key not in self.wb.cache:
+                self.wb.cache[key] = (torch.zeros((B, 128 * C + C * 128), dtype=kv.dtype, device=kv.device),
+                                      torch.zeros((B, 256), dtype=torch.float32, device=kv.device))
+            src, vec = self.wb.cache[key]
+            wq = src[:, :R * C].view(B, R, C)
+            w2 = src[:, 128 * C:].view(B, C, 128)[:, :, :R]
+            colsum, biasq = vec[:, :R].unsqueeze(-1), vec[:, 128:128 + R].unsqueeze(-1)
+        else:
+            wq = torch.empty((B, R, C), dtype=kv.dtype, device=kv.device)
+            w2 = torch.empty((B, C, R), dtype=kv.dtype, device=kv.device)
+            colsum = torch.empty((B, R, 1), dtype=torch.float32, device=kv.device)
+            biasq = torch.empty((B, R, 1), dtype=torch.float32, device=kv.device)
+        ops.bmm_nt(kexp, wt, wq)
+        ops.bmm_nt(wq, ones, colsum)
+        ops.bmm_nt(kexp, tb, biasq)
         wo = self.wb.w(t + '.attn2.to_out.0.weight', kv.dtype)
-        w2 = ops.bmm_nt(wo.view(1, C, C).expand(B, -1, -1), vexp,
-                        torch.empty((B, C, R), dtype=kv.dtype, device=kv.device))
-        return dict(wq=wq, colsum=colsum.view(B, R), biasq=biasq.view(B, R), w2=w2, slots=kv.shape[1])
+        ops.bmm_nt(wo.view(1, C, C).expand(B, -1, -1), vexp, w2)
+        fold = dict(wq=wq, colsum=colsum.squeeze(-1), biasq=biasq.squeeze(-1), w2=w2, slots=kv.shape[1])
+        if fused:
+            fold['st_img'] = torch.index_select(src, 1, self.wb.st_index('img', C, kv.device))
+            fold['st_vec'] = vec
+        return fold
 
     def cross_block(self, tok, t, kvp, heads):
         """norm2 -> slot cross-attention -> to_out + residual of transformer block `t` -> new tok."""
@@ -840,6 +979,32 @@ class Kern:
         q, tres = self.ln_linear_fan(tok, t + '.norm2', t + '.attn2.to_q.weight')
         a = self.attn_cross(q, kv, heads)
         return self.linear(a, t + '.attn2.to_out.0.weight', t + '.attn2.to_out.0.bias', residual=tres)
+
+    def st_fused(self, x, n, heads, kvp):
+        """The whole SpatialTransformer block `n` in two launches (sdmi.h: sdmi_st_block) -- bf16 inference,
+        C = 256 / 384, 64 | tokens per image <= 256, folded slot cross-attention (<= 7 slots).  None when the
+        block does not qualify (the caller runs the per-layer launches)."""
+        fold = kvp.get('fold') if isinstance(kvp, dict) else None
+        B, H, W, C = x.shape
+        S = H * W
+        if not (_ST_FUSED and fold is not None and 'st_img' in fold and x.dtype == torch.bfloat16 and
+                C in (256, 384) and heads * 32 == C and S % 64 == 0 and S <= 256 and x.is_contiguous()):
+            return None
+        wts = self.wb.st_fused_weights(n, x.dtype)
+        tok = torch.empty((B, S, C), dtype=x.dtype, device=x.device)
+        qkv = torch.empty((B, S, 3 * C), dtype=x.dtype, device=x.device)
+        out = torch.empty_like(x)
+        # algorithmic work of the block (bench.py's roofline legs): its GEMMs + the two attention contractions
+        g = st_geometry(C)
+        flops = 2.0 * B * S * (C * C * 4 + C * C + 2 * 128 * C + 8 * C * C + 5 * C * C) + 4.0 * B * S * S * C
+        wbytes = 2.0 * (wts['wa'].numel() + wts['wb'].numel()) + 2.0 * fold['st_img'].numel()
+        call('sdmi_st_block', _st(), x=_p(x), tok=_p(tok), qkv=_p(qkv), out=_p(out),
+             gn_gamma=_p(self.wb.f(n + '.norm.weight')), gn_beta=_p(self.wb.f(n + '.norm.bias')),
+             wstream_a=_p(wts['wa']), vec_a=_p(wts['va']), wstream_b=_p(wts['wb']), vec_b=_p(wts['vb']),
+             wstream_img=_p(fold['st_img']), vec_img=_p(fold['st_vec']), B=B, S=S, C=C, slots=fold['slots'],
+             phase=0, gn_eps=1e-6, ln_eps=1e-5, attn_scale=32.0 ** -0.5,
+             _meta=dict(flops=flops, bytes=2.0 * B * S * C * 2 + wbytes))
+        return out
 
     def geglu(self, h):
         return ops.geglu(h)

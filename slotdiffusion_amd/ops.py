@@ -190,9 +190,10 @@ def cross_scores(tok, wq, colsum, biasq, eps, slots=7):
     R = wq.shape[1]
     out = torch.empty((B, HW, R), dtype=tok.dtype, device=tok.device)
     call('sdmi_igemm', _stream(), a=_p(tok), w=_p(wq), out=_p(out), bias=_p(biasq), dtype=_dt(tok),
-         out_dtype=_dt(out), M=HW, N=R, K=C, lda=tok.stride(1), ldw=C, ldc=R, B=HW, H=1, W=1, Cin=C, Ho=1,
+         out_dtype=_dt(out), M=HW, N=R, K=C, lda=tok.stride(1), ldw=wq.stride(1), ldc=R, B=HW, H=1, W=1, Cin=C, Ho=1,
          Wo=1, KH=1, KW=1, stride=1, act=0, alpha=1.0, bias_m=0, split_k=1, batch=B, sa=tok.stride(0),
-         sw=R * C, sc=HW * R, ln_colsum=_p(colsum), ln_eps=float(eps), s_colsum=R, s_bias=R, softmax8=int(slots))
+         sw=wq.stride(0), sc=HW * R, ln_colsum=_p(colsum), ln_eps=float(eps), s_colsum=colsum.stride(0),
+         s_bias=biasq.stride(0), softmax8=int(slots))
     return out
 
 
