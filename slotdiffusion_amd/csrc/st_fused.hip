@@ -27,6 +27,7 @@
 // on the host (kern.WeightBank.st_stream_*) into per-wave streams of units in consumption order, each unit
 // the exact XOR-swizzled LDS image of 16 weight rows x 64 k, so the fetch side is `base + g * 2048`.
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -44,6 +45,11 @@ __device__ __forceinline__ unsigned st_pack2(float lo, float hi) { return f32x2_
 // Epilogue vectors (biases, LayerNorm-fold column sums): lane group lg's four of the 16 floats of a slice.
 __device__ __forceinline__ f32x4 st_vec4(const float* base16, int lg) {
   return *reinterpret_cast<const f32x4*>(base16 + 4 * lg);
+}
+
+__device__ __forceinline__ int st_xcd_id(int bid, int nwg) {
+  const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
 }
 
 template <int C>
@@ -120,6 +126,22 @@ struct StRing {
 #endif
 // Workgroup barrier that leaves the DMA queue alone: `__syncthreads()` carries a fence that waits vmcnt(0) while
 // LDS-DMA is in flight (it is a pending LDS write); LDS stores / reads of this wave are retired explicitly.
+#ifdef ST_TIMELINE      // experiment: s_memtime of wave 0 at the phase boundaries of phase B -> p.gn_gamma[wg][8] (u64)
+#define ST_STAMP(i) do { if (threadIdx.x == 0) ((unsigned long long*)p.gn_gamma)[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define ST_STAMP(i)
+#endif
+#ifdef ST_TIMELINE
+#define ST_TL_DECL unsigned long long tl_t = 0, tl_a[4] = {0, 0, 0, 0};
+#define ST_TL_BEGIN tl_t = __builtin_amdgcn_s_memtime();
+#define ST_TL_LAP(i) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); tl_a[i] += n_ - tl_t; tl_t = n_; } while (0)
+#define ST_TL_FLUSH do { if (threadIdx.x == 0) for (int i_ = 0; i_ < 4; ++i_) ((unsigned long long*)p.gn_gamma)[blockIdx.x * 16 + 12 + i_] = tl_a[i_]; } while (0)
+#else
+#define ST_TL_DECL
+#define ST_TL_BEGIN
+#define ST_TL_LAP(i)
+#define ST_TL_FLUSH
+#endif
 #define ST_BARRIER()                                         \
   do {                                                       \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       \
@@ -232,7 +254,10 @@ __global__ __launch_bounds__(512, 2) void st_block_a_kernel(SdmiStBlockArgs p) {
   const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, lg = lane >> 4;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wgs_per_img = p.S / 64;
-  const int b = blockIdx.x / wgs_per_img, rb = blockIdx.x - b * wgs_per_img;
+  // block b runs on XCD b % 8 (observed placement; speed only): every XCD gets a contiguous range of workgroup
+  // ids, so the S / 64 workgroups of an image share one L2 (they all read the image's x / K / V)
+  const int vid = st_xcd_id((int)blockIdx.x, (int)gridDim.x);
+  const int b = vid / wgs_per_img, rb = vid - b * wgs_per_img;
   const long long row0 = (long long)b * p.S + rb * 64;       // first token row of this workgroup
 
   StRing<D> rg;
@@ -258,13 +283,23 @@ __global__ __launch_bounds__(512, 2) void st_block_a_kernel(SdmiStBlockArgs p) {
     float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;
     const int vr = tid / VPR, vc = tid - vr * VPR;
     if (vr < RPP) {
-      for (int r = vr; r < p.S; r += RPP) {
-        float f[8];
-        unpack16<bf16_t>(*reinterpret_cast<const uint4*>(xi + (long long)r * C + vc * 8), f);
-        s0 += (f[0] + f[1]) + (f[2] + f[3]);
-        s1 += (f[4] + f[5]) + (f[6] + f[7]);
-        q0 += f[0] * f[0] + f[1] * f[1] + f[2] * f[2] + f[3] * f[3];
-        q1 += f[4] * f[4] + f[5] * f[5] + f[6] * f[6] + f[7] * f[7];
+      // (four rows in flight: one load per iteration behind its own wait cost a memory latency per row)
+      for (int r0 = vr; r0 < p.S; r0 += 4 * RPP) {
+        uint4 v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int r = r0 + j * RPP;
+          v[j] = r < p.S ? *reinterpret_cast<const uint4*>(xi + (long long)r * C + vc * 8) : make_uint4(0u, 0u, 0u, 0u);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float f[8];
+          unpack16<bf16_t>(v[j], f);
+          s0 += (f[0] + f[1]) + (f[2] + f[3]);
+          s1 += (f[4] + f[5]) + (f[6] + f[7]);
+          q0 += f[0] * f[0] + f[1] * f[1] + f[2] * f[2] + f[3] * f[3];
+          q1 += f[4] * f[4] + f[5] * f[5] + f[6] * f[6] + f[7] * f[7];
+        }
       }
       f32x4 v = {s0, q0, s1, q1};
       *reinterpret_cast<f32x4*>(red + (vr * VPR + vc) * 4) = v;      // [row slot][vector][{s, q} x 2 halves]
@@ -291,7 +326,10 @@ __global__ __launch_bounds__(512, 2) void st_block_a_kernel(SdmiStBlockArgs p) {
   {
     const float* st = red + 512 * 4;
     const bf16_t* xr = (const bf16_t*)p.x + row0 * C;
-    for (int i = tid; i < 64 * VPR; i += 512) {
+    static_assert((64 * VPR) % 512 == 0, "whole passes");
+#pragma unroll
+    for (int it = 0; it < 64 * VPR / 512; ++it) {
+      const int i = tid + it * 512;
       const int r = i / VPR, vc = i - r * VPR;
       float f[8], gm[8], bt[8];
       unpack16<bf16_t>(*reinterpret_cast<const uint4*>(xr + (long long)r * C + vc * 8), f);
@@ -418,9 +456,13 @@ __global__ __launch_bounds__(512, 2) void st_block_b_kernel(SdmiStBlockArgs p) {
   const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, lg = lane >> 4;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wgs_per_img = p.S / 64;
-  const int b = blockIdx.x / wgs_per_img, rb = blockIdx.x - b * wgs_per_img;
+  // block b runs on XCD b % 8 (observed placement; speed only): every XCD gets a contiguous range of workgroup
+  // ids, so the S / 64 workgroups of an image share one L2 (they all read the image's x / K / V)
+  const int vid = st_xcd_id((int)blockIdx.x, (int)gridDim.x);
+  const int b = vid / wgs_per_img, rb = vid - b * wgs_per_img;
   const long long row0 = (long long)b * p.S + rb * 64;
   const int S = p.S;
+  ST_STAMP(0);
 
   // =========================== self-attention: 64 queries x HEADS heads over S keys ===========================
   // (attention.hip's transposed matrix-core formulation: a wave owns 32 queries of one head; four heads per round)
@@ -430,32 +472,54 @@ __global__ __launch_bounds__(512, 2) void st_block_b_kernel(SdmiStBlockArgs p) {
     const int ql = lane & 31, hh = lane >> 5;
     const bf16_t* qkv_img = (const bf16_t*)p.qkv + (long long)b * S * 3 * C;
     const int head_bytes = S * (ST_KP + ST_VP);
-    const lds_char* Ks = smem + hs * head_bytes;
-    const lds_char* Vs = Ks + S * ST_KP;
     const float sc2 = p.attn_scale * 1.4426950408889634f;
     const int g4 = lane >> 4, t16 = lane & 15;
-    const lds_char* kfrag = Ks + ql * ST_KP + hh * 16;
-    const lds_char* vfrag = Vs + (4 * hh + (t16 >> 2)) * ST_VP + ((g4 & 1) * 16 + (t16 & 3) * 4) * 2;
+    // K / V of `hb` heads are staged at a time: all of them when they fit (S = 64: one staging pass for the block),
+    // four otherwise; the loads of a pass are in flight together (a load per iteration behind its own wait cost a
+    // memory latency each: 27 of the kernel's 72 us at S = 256).
+    const bool all_heads = HEADS * head_bytes <= 160 * 1024;
+    const int hb = all_heads ? HEADS : 4;
+    bf16x8 bq[HEADS / 4][2];
 #pragma unroll
-    for (int rd = 0; rd < HEADS / 4; ++rd) {
-      if (rd) __syncthreads();
-      // stage K, V of heads 4 rd .. 4 rd + 3: 32 16-byte pieces per key row
-      for (int i = tid; i < S * 32; i += 512) {
-        const int row = i >> 5, rem = i & 31;
-        const int isv = rem >> 4, h4 = (rem >> 2) & 3, c = rem & 3;
-        const u32x4 v = *reinterpret_cast<const u32x4*>(qkv_img + (long long)row * 3 * C + (1 + isv) * C +
-                                                        (rd * 4 + h4) * 32 + c * 8);
-        lds_char* dst = smem + h4 * head_bytes + (isv ? S * ST_KP + row * ST_VP : row * ST_KP) + c * 16;
-        *reinterpret_cast<__attribute__((address_space(3))) u32x4*>(dst) = v;
+    for (int ri = 0; ri < HEADS / 4; ++ri) {
+      const bf16_t* qp = (const bf16_t*)p.qkv + (row0 + qh * 32 + ql) * 3 * C + (ri * 4 + hs) * 32 + hh * 8;
+      bq[ri][0] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(qp));
+      bq[ri][1] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(qp + 16));
+    }
+    auto stage = [&](int h0, auto nb_) __attribute__((always_inline)) {
+      constexpr int NB = decltype(nb_)::value;
+      const int ppr = hb * 8;                              // 16-byte pieces per key row: [K of hb heads | V of hb heads]
+      for (int i0 = tid; i0 < S * ppr; i0 += NB * 512) {
+        u32x4 v[NB];
+        int dsto[NB];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+          const int i = i0 + j * 512, row = i / ppr, rem = i - row * ppr;
+          const int isv = rem >= hb * 4, r2 = rem - isv * hb * 4, hl = r2 >> 2, c = r2 & 3;
+          v[j] = *reinterpret_cast<const u32x4*>(qkv_img + (long long)row * 3 * C + (1 + isv) * C + (h0 + hl) * 32 + c * 8);
+          dsto[j] = hl * head_bytes + (isv ? S * ST_KP + row * ST_VP : row * ST_KP) + c * 16;
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) *reinterpret_cast<__attribute__((address_space(3))) u32x4*>(smem + dsto[j]) = v[j];
       }
-      const int h = rd * 4 + hs;
-      bf16x8 bq[2];
-      {
-        const bf16_t* qp = (const bf16_t*)p.qkv + (row0 + qh * 32 + ql) * 3 * C + h * 32 + hh * 8;
-        bq[0] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(qp));
-        bq[1] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(qp + 16));
+    };
+#pragma unroll
+    for (int ri = 0; ri < HEADS / 4; ++ri) {
+      if (ri == 0 || !all_heads) {
+        if (ri) __syncthreads();
+        const int per_thread = S * hb / 64;                // pieces per thread of this pass
+        if (per_thread % 16 == 0) stage(ri * 4, std::integral_constant<int, 16>());
+        else if (per_thread % 12 == 0) stage(ri * 4, std::integral_constant<int, 12>());
+        else stage(ri * 4, std::integral_constant<int, 4>());
+        __syncthreads();
+        if (ri == 0) ST_STAMP(8);
       }
-      __syncthreads();
+      const int hl = (all_heads ? ri * 4 : 0) + hs;
+      const lds_char* Ks = smem + hl * head_bytes;
+      const lds_char* Vs = Ks + S * ST_KP;
+      const lds_char* kfrag = Ks + ql * ST_KP + hh * 16;
+      const lds_char* vfrag = Vs + (4 * hh + (t16 >> 2)) * ST_VP + ((g4 & 1) * 16 + (t16 & 3) * 4) * 2;
+      const int rd = ri;
       f32x16 o;
 #pragma unroll
       for (int r = 0; r < 16; ++r) o[r] = 0.f;
@@ -467,7 +531,7 @@ __global__ __launch_bounds__(512, 2) void st_block_b_kernel(SdmiStBlockArgs p) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
           const u32x4 a = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(kfrag + kb * 32 * ST_KP + ks * 32);
-          s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), bq[ks], s, 0, 0, 0);
+          s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), bq[ri][ks], s, 0, 0, 0);
         }
         float bmax = -INFINITY;
 #pragma unroll
@@ -511,7 +575,9 @@ __global__ __launch_bounds__(512, 2) void st_block_b_kernel(SdmiStBlockArgs p) {
         opack[rd][2 * j + 1] = st_pack2(o[4 * j + 2] * inv, o[4 * j + 3] * inv);
       }
     }
+    ST_STAMP(9);
     __syncthreads();                      // the staging region becomes operand buffers + rings
+    ST_STAMP(10);
   }
 
   // the token residual of the first epilogue: fetched and RETIRED before any weight DMA is issued (st_vec4's note)
@@ -525,6 +591,10 @@ __global__ __launch_bounds__(512, 2) void st_block_b_kernel(SdmiStBlockArgs p) {
         rsd[s][tt] = *reinterpret_cast<const uint2*>(tok + (long long)(tt * 16 + l15) * C + (w * NSL + s) * 16 + 4 * lg);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
+  ST_STAMP(11);
+  // the second-dispatched half of the workgroup loses issue arbitration to the first on every SIMD and arrives last
+  // at each hand-off barrier (the FF loop's wave 0 spent 22 % of its time waiting there): static priority for it
+  if (w >= 4) __builtin_amdgcn_s_setprio(1);
   // ================================ weight stream + ring of this wave ================================
   StRing<D> rg;
   rg.rs_sh = __builtin_amdgcn_make_buffer_rsrc(
@@ -562,6 +632,7 @@ __global__ __launch_bounds__(512, 2) void st_block_b_kernel(SdmiStBlockArgs p) {
     }
   }
   ST_BARRIER();                           // attention output complete in Y
+  ST_STAMP(1);
 
   int yaddr[4], gaddr[4], woff[2];
 #pragma unroll
@@ -601,6 +672,7 @@ __global__ __launch_bounds__(512, 2) void st_block_b_kernel(SdmiStBlockArgs p) {
   };
 
   // (epilogue operands are fetched BEFORE the GEMM they follow -- see phase A)
+  ST_STAMP(2);
   // ---- attn1.to_out + tok  -> x1
   f32x4 ev0[NSL];
 #pragma unroll
@@ -626,6 +698,7 @@ __global__ __launch_bounds__(512, 2) void st_block_b_kernel(SdmiStBlockArgs p) {
   res_to_y();
   ST_BARRIER();
 
+  ST_STAMP(3);
   // ---- folded slot cross-attention: P = softmax8(LN-fold(x1) Wq[b]^T) ; x2 = P W2[b]^T + bo2 + x1
   {
     f32x4 sc[1][4];
@@ -692,6 +765,7 @@ __global__ __launch_bounds__(512, 2) void st_block_b_kernel(SdmiStBlockArgs p) {
   res_to_y();
   ST_BARRIER();
 
+  ST_STAMP(4);
   // ---- merged (ff.net.2 ; proj_out): out = [g | x2] [Wpo Wff | Wpo]^T + b' + x.  First the x2 part (also
   //      yields the LayerNorm-fold statistics of x2 for the feed-forward), then the hidden chunks.
 #ifdef ST_VERIFY
@@ -705,6 +779,8 @@ __global__ __launch_bounds__(512, 2) void st_block_b_kernel(SdmiStBlockArgs p) {
   st_ln_stats(sx, sxx, 1.f / (float)C, p.ln_eps, mean, rstd);
   const float* cs_ff = vb + 2 * C;
   const float* bi_ff = vb + 10 * C;
+  ST_TL_DECL
+  ST_TL_BEGIN
 #pragma unroll 1
   for (int hc = 0; hc < G::NHC; ++hc) {
     f32x4 vg[2][4];                                     // [value | gate] columns hc * 128 + w * 16 + 4 lg ..
@@ -714,11 +790,13 @@ __global__ __launch_bounds__(512, 2) void st_block_b_kernel(SdmiStBlockArgs p) {
     const f32x4 big = st_vec4(bi_ff + 4 * C + hc * 128 + w * 16, lg);
 #pragma unroll
     for (int tt = 0; tt < 4; ++tt) vg[0][tt] = vg[1][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    ST_TL_LAP(3);
 #ifdef ST_VERIFY
     rg.tag = 4;
 #endif
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt) st_gemm_step<D, 2, false>(rg, Y, yaddr, kt, 16 * PITCH, woff, vg, sx, sxx);
+    ST_TL_LAP(0);
     lds_char* gb = Gb + (G::GBUF == 2 ? (hc & 1) * G::G_BYTES : 0);
     if (G::GBUF == 1) ST_BARRIER();                     // the previous chunk's readers are done
     {
@@ -740,13 +818,17 @@ __global__ __launch_bounds__(512, 2) void st_block_b_kernel(SdmiStBlockArgs p) {
         *reinterpret_cast<__attribute__((address_space(3))) u32x2*>(gb + r * 256 + phys * 16 + (lg & 1) * 8) = u32x2{o.x, o.y};
       }
     }
+    ST_TL_LAP(1);
     ST_BARRIER();
+    ST_TL_LAP(2);
 #ifdef ST_VERIFY
     rg.tag = 5;
 #endif
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) st_gemm_step<D, NSL, false>(rg, gb, gaddr, kt, 16 * 256, woff, acc, sx, sxx);
   }
+  ST_STAMP(5);
+  ST_TL_FLUSH;
   // ---- + b' + x  -> out   (only dummy re-fetches are in flight now: drain them, then ordinary loads are safe)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   {
@@ -779,6 +861,7 @@ __global__ __launch_bounds__(512, 2) void st_block_b_kernel(SdmiStBlockArgs p) {
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  ST_STAMP(6);
 }
 
 template <int C>

@@ -68,6 +68,9 @@ _FF_MERGE = os.environ.get('SDMI_FF_MERGE', '1') != '0'
 _CROSS_FOLD = os.environ.get('SDMI_CROSS_FOLD', '1') != '0'
 _LN_FOLD = os.environ.get('SDMI_LN_FOLD', '1') != '0'
 _ST_FUSED = os.environ.get('SDMI_ST_FUSED', '1') != '0'     # fused SpatialTransformer block (sdmi_st_block)
+# ... only when its grid (one workgroup per 64 token rows) fills a good part of the chip: at B = 64 the 8^2 level gives 64
+# workgroups that each stream the block's 4 MB of weights -- 119 us against 108 us for the per-layer launches
+_ST_MIN_WGS = int(os.environ.get('SDMI_ST_MIN_WGS', '128'))
 
 
 def _copy_group(items):
@@ -988,7 +991,8 @@ class Kern:
         B, H, W, C = x.shape
         S = H * W
         if not (_ST_FUSED and fold is not None and 'st_img' in fold and x.dtype == torch.bfloat16 and
-                C in (256, 384) and heads * 32 == C and S % 64 == 0 and S <= 256 and x.is_contiguous()):
+                C in (256, 384) and heads * 32 == C and S % 64 == 0 and S <= 256 and x.is_contiguous() and
+                B * S // 64 >= _ST_MIN_WGS):
             return None
         wts = self.wb.st_fused_weights(n, x.dtype)
         tok = torch.empty((B, S, C), dtype=x.dtype, device=x.device)

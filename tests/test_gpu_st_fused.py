@@ -36,6 +36,7 @@ def test_fused_block_matches_oracle_and_per_layer_launches(name, hw, B):
     from oracle import slotdiff_oracle as O
     from slotdiffusion_amd import kern
     m = _model()
+    kern._ST_MIN_WGS = 0                 # (the production gate keeps small grids on the per-layer launches)
     K, u = m.K(), m.unet()
     n = u.P + name
     heads = u.heads_of[name]
@@ -73,6 +74,7 @@ def test_fused_block_engages_in_the_sampler_and_keeps_eps():
     """UNet eps with the fused blocks against the per-layer launches on the same inputs (the sampler fixtures of
     test_gpu_model.py cover the path end to end against the reference)."""
     from slotdiffusion_amd import kern, ops
+    kern._ST_MIN_WGS = 0
     m = _model(seed=5)
     B = 2
     g = torch.Generator().manual_seed(2)
