@@ -367,6 +367,7 @@ def main():
     B = args.batch if args.batch > 0 else bc['batch']
     n_img = B * (frames or 1)                 # images per step and GPU (a clip counts its frames)
     img = synth_batch(B, rank, dev, res, frames)
+    parallel.use_bf16_wire(dtype == torch.bfloat16)      # gradient buckets on a bf16 wire when the model computes in bf16
     if dist is not None:                      # every rank starts from rank 0's parameters
         parallel.broadcast_parameters(model.arena())
         model.weights_updated()

@@ -211,6 +211,9 @@ class WeightBank:
         self.pair_min_steps = int(os.environ.get('SDMI_PAIR_MIN_STEPS', '8'))  # 64-row steps per wgrad workgroup
         self.pair_wt64 = int(os.environ.get('SDMI_PAIR_WT64_BELOW', '96'))     # 64 x 64 dW tiles below this many wgrad workgroups (0: never)
         self._pfold = None
+        # gradient destinations a side-stream launch of this backward wrote: a main-stream writer of the same
+        # destination (pair launch, pending fold) waits for that stream first
+        self._side_dst = {}
         # dgrad operands: key -> [buffer, epoch, (stable source view | None, geometry)]
         self._wd, self._wd_epoch, self._wd_stale, self._wd_table = {}, 0, False, None
 
@@ -377,11 +380,19 @@ class WeightBank:
         if dst_ptrs is not None and pf[0]['dw'] not in dst_ptrs and (not pf[0]['dbias'] or pf[0]['dbias'] not in dst_ptrs):
             return
         self._pfold = None
+        self._after_side_writers(pf[0]['dw'], pf[0]['dbias'])
         import ctypes
         arr = (_lib.CSTRUCT['SdmiWgradArgs'] * 1)()
         for k, v in pf[0].items():
             setattr(arr[0], k, v)
         call('sdmi_wgrad_fold_group', _st(), problems=ctypes.addressof(arr), n=1)
+
+    def _after_side_writers(self, *ptrs):
+        """Main stream waits for side streams that have launches into any of these destinations in flight."""
+        for p_ in ptrs:
+            side = self._side_dst.pop(p_, None) if p_ else None
+            if side is not None:
+                torch.cuda.current_stream().wait_stream(side)
 
     def pair_launch(self, dkw, wkw, keep):
         """One sdmi_bwd_pair launch: dkw / wkw are the sdmi_igemm / sdmi_wgrad fields of the layer's data
@@ -407,6 +418,7 @@ class WeightBank:
             wt = 64
             tiles_w, n_d, splits = plan(64, self.pair_slots * 3 // 2, max(2, self.pair_min_steps // 2))
         self.flush_pending_fold((wkw['dw'], wkw['dbias']))      # this parameter again: fold first
+        self._after_side_writers(wkw['dw'], wkw['dbias'])
         ws = None
         if splits > 1:
             ws = torch.empty((splits * (N * K + N),), dtype=torch.float32, device=keep[0].device)
@@ -419,6 +431,7 @@ class WeightBank:
         w.splits, w.workspace, w.defer_fold = splits, _p(ws), 1
         pf, self._pfold = self._pfold, None
         if pf is not None:
+            self._after_side_writers(pf[0]['dw'], pf[0]['dbias'])
             for k, v in pf[0].items():
                 setattr(f, k, v)
         call('sdmi_bwd_pair', _st(), dgrad=ctypes.addressof(d), wgrad=ctypes.addressof(w),
@@ -441,6 +454,7 @@ class WeightBank:
             torch.cuda.current_stream().wait_stream(side)
         self.flush_folds()
         self._pending.clear()
+        self._side_dst.clear()
         self._join_queued = False
 
     def invalidate(self):
@@ -1235,8 +1249,6 @@ class GemmFn(torch.autograd.Function):
                                 K=K, lda=lda, ldy=ldy, B=B, H=H, W=W_, Cin=Cin, Ho=Ho, Wo=Wo, KH=1, KW=1,
                                 stride=1, pad_t=0, pad_l=0, ups=0, accumulate=1),
                            (x, dy), tiles, (M + 63) // 64, (x.numel() + dy.numel()) * 2)
-        elif os.environ.get('SDMI_EXP_SKIP_WGRAD') == '1':
-            pass            # measurement only (wrong gradients): the step without weight gradients
         else:
             # ---- data + weight gradient in ONE launch (sdmi_bwd_pair) when both are of the same loader
             # class: 1x1 / linear, or a stride-1 same-size convolution
@@ -1278,6 +1290,9 @@ class GemmFn(torch.autograd.Function):
                               H, W_, Ho, Wo, kh, kw, stride, pad, ups, is_conv)
             if side is not None:
                 wb.defer(x, dy)
+                wb._side_dst[_p(dst)] = side
+                if bdst is not None:
+                    wb._side_dst[_p(bdst)] = side
         # ---- data gradient: the forward kernel on the flipped operand
         dx = None
         if need_dx:
@@ -1369,13 +1384,6 @@ class GemmFn(torch.autograd.Function):
                 btmp = torch.empty((N,), dtype=torch.float32, device=x.device)
                 if acc:
                     ops.zero_(btmp)
-        if os.environ.get('SDMI_EXP_WGRAD_TINY') == '1':   # measurement only: same launches, ~no work
-            if is_conv:
-                B, Ho = 1, min(Ho, max(1, 64 // Wo))
-                M = B * Ho * Wo
-            else:
-                M = B = min(M, 64)
-            splits = 1
         # direct destinations with split partials: the fold is deferred to the autograd join and done
         # for 16 layers per launch (wb.queue_fold) instead of one small launch behind every layer
         defer = int(wb.defer_fold and direct and splits > 1 and not stage_bias)

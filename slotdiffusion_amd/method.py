@@ -50,7 +50,10 @@ class Method:
         self.model, self.datamodule, self.params = model, datamodule, params
         self.ckp_path, self.local_rank, self.use_ddp = ckp_path, local_rank, use_ddp
         from . import configure_runtime
-        configure_runtime(warn=False)     # effective when the method is built before the first device call
+        # effective when the method is built before the first device call; INTEGRATION.md: call
+        # slotdiffusion_amd.configure_runtime() before build_model(...).cuda() -- one warning when it is too late
+        configure_runtime(warn=not getattr(Method, '_warned_runtime', False))
+        Method._warned_runtime = True
         if use_fp16:                      # the reference's --fp16 switch = our bf16 compute path
             model.set_compute_dtype('bf16')
         self.world = torch.distributed.get_world_size() if use_ddp else 1
@@ -94,6 +97,7 @@ class Method:
         total, losses = self._loss(batch)
         total.backward()
         if self.world > 1:
+            parallel.use_bf16_wire(getattr(self.model, 'compute_dtype', None) == torch.bfloat16)
             parallel.allreduce_gradients(self.model.grad_arena(), self.world)
         self.optimizer.step()
         return total.detach()
@@ -155,6 +159,9 @@ class Method:
         seed = getattr(self.model, 'step_seed', None)
         if seed is not None:
             ckp['step_seed'] = int(seed)
+        eseed = getattr(self.model, 'eval_seed', None)       # validation t / noise draws continue too
+        if eseed is not None:
+            ckp['eval_seed'] = int(eseed)
         if self.model.arena().is_cuda:           # t / noise draws continue the same stream
             ckp['cuda_rng_state'] = torch.cuda.get_rng_state(self.model.arena().device)
         torch.save(ckp, path)
@@ -174,6 +181,9 @@ class Method:
         if 'step_seed' in ckp:
             dev = self.model.arena().device
             self.model.step_seed = torch.full((1,), ckp['step_seed'], dtype=torch.int64, device=dev)
+        if 'eval_seed' in ckp:
+            dev = self.model.arena().device
+            self.model.eval_seed = torch.full((1,), ckp['eval_seed'], dtype=torch.int64, device=dev)
 
 
 def build_method(**kwargs):

@@ -76,12 +76,20 @@ class FusedAdam:
                 'total_steps': self.total_steps, 'warmup': self.warmup, 'min_lr_ratio': self.min_lr_ratio}
 
     def load_state_dict(self, sd):
-        # a resumed run continues the SAME schedule: a different length / warm-up / floor is a
-        # configuration error, not something to paper over
-        for k, mine in (('total_steps', self.total_steps), ('warmup', self.warmup),
-                        ('min_lr_ratio', self.min_lr_ratio)):
-            if k in sd and sd[k] is not None and mine is not None and abs(float(sd[k]) - float(mine)) > 1e-9:
-                raise ValueError(f'optimizer checkpoint was written with {k}={sd[k]}, this run has {mine}')
+        """The reference loads the scheduler state and continues (nerv trainer); so does this: a checkpoint written
+        with another schedule length / warm-up / floor wins over this run's values, with a warning (a changed
+        max_epochs or dataset length must not make a checkpoint unloadable).  A checkpoint from before the floor was
+        recorded has none: 0."""
+        import warnings
+        for k, default in (('total_steps', None), ('warmup', None), ('min_lr_ratio', 0.0)):
+            mine = getattr(self, k)
+            theirs = sd.get(k, default)
+            if theirs is None:
+                continue
+            if mine is not None and abs(float(theirs) - float(mine)) > 1e-9:
+                warnings.warn(f'optimizer checkpoint was written with {k}={theirs}, this run was configured with '
+                              f'{mine}: continuing the checkpoint\'s schedule')
+            setattr(self, k, type(mine)(theirs) if mine is not None else theirs)
         self.m.copy_(sd['m'])
         self.v.copy_(sd['v'])
         self.step_count = int(sd['step_count'])
@@ -164,6 +172,9 @@ class GraphedTrainStep:
         if getattr(model, 'step_seed', None) is None or model.step_seed.device != dev:
             model.step_seed = torch.zeros(1, dtype=torch.int64, device=dev)   # dropout seed word
         self.world = world
+        if allreduce is not None:
+            from . import parallel
+            parallel.use_bf16_wire(getattr(model, 'compute_dtype', None) == torch.bfloat16)
         if allreduce is not None and world is None:
             import torch.distributed as dist
             self.world = dist.get_world_size()
@@ -257,7 +268,9 @@ class GraphedTrainStep:
         g = self.model.grad_arena()
         works = []
         for lo, hi in runs:
-            works += parallel.allreduce_range_async(g, lo, hi)
+            # >= 4 buckets over the denoiser's range (135 M floats: ~70 MB each on a bf16 wire), one for small runs:
+            # the ring of the first bucket is busy while the next one is still being converted
+            works += parallel.allreduce_range_async(g, lo, hi, n_buckets=(4 if hi - lo > (16 << 20) else 1))
         return works
 
     def _finish_reduce(self, works):

@@ -31,10 +31,28 @@ def respawn_under_launcher(n_ranks, script, argv, port=None):
     os.execve(sys.executable, cmd, env)
 
 
+_BF16_WIRE_DEFAULT = False
+
+
+def use_bf16_wire(flag):
+    """Default wire format of the gradient buckets for this process (GraphedTrainStep / Method / bench.py set it
+    from the model's compute dtype); SDMI_GRAD_BF16=0 / 1 overrides."""
+    global _BF16_WIRE_DEFAULT
+    _BF16_WIRE_DEFAULT = bool(flag)
+
+
 def grad_bf16_enabled():
-    """SDMI_GRAD_BF16=1: gradients cross xGMI as bf16 (277 MB instead of 554 MB per step for
-    SADiffusion); accumulation inside the collective is RCCL's, the average is applied in fp32."""
-    return os.environ.get('SDMI_GRAD_BF16', '0') == '1'
+    """Gradients cross xGMI as bf16 (277 MB instead of 554 MB per step for SADiffusion) when the model computes
+    in bf16 -- the default since round 4 -- or SDMI_GRAD_BF16=1; SDMI_GRAD_BF16=0 keeps fp32 buckets.
+    Bound: a rank rounds its fp32 partial to bf16 (<= 2^-9 relative), the ring adds w - 1 times in
+    bf16 (<= 2^-9 of the running sum each), so an element of the sum is off by <= w 2^-9 of sum |g_r| in the worst
+    case (1.6 % at w = 8) and by ~sqrt(w / 3) 2^-9 = 0.32 % rms; tests/test_parallel_cpu.py measures 0.35 % rel-L2
+    for an 8-rank ring on CPU -- below the 0.47 % by which the bf16 compute path's gradients themselves differ
+    from the fp32 path's (tests/test_gpu_bench_path.py).  The average and everything behind it stay fp32."""
+    e = os.environ.get('SDMI_GRAD_BF16')
+    if e in ('0', '1'):
+        return e == '1'
+    return _BF16_WIRE_DEFAULT
 
 
 def _to_bf16(x):

@@ -198,10 +198,18 @@ def test_lr_schedule_closed_form():
     # a resumed optimiser must continue the same schedule
     sd = opt3.state_dict()
     assert sd['min_lr_ratio'] == 0.01
-    with pytest.raises(ValueError):
-        FusedAdam(Fake(), lr=4e-4, total_steps=total + 1, warmup_pct=pct, min_lr_ratio=0.01).load_state_dict(sd)
-    with pytest.raises(ValueError):
-        opt.load_state_dict(sd)             # floor 0 vs 0.01
+    # ... like the reference (the trainer loads the scheduler state and continues): a run configured with another
+    # length / floor adopts the checkpoint's schedule, with a warning
+    o4 = FusedAdam(Fake(), lr=4e-4, total_steps=total + 1, warmup_pct=pct, min_lr_ratio=0.0)
+    with pytest.warns(UserWarning):
+        o4.load_state_dict(sd)
+    assert o4.total_steps == total and o4.min_lr_ratio == 0.01 and abs(o4.lr_scale(total) - 0.01) < 1e-12
+    # a checkpoint from before the floor was recorded: floor 0, explicitly
+    old_sd = {k: v for k, v in sd.items() if k != 'min_lr_ratio'}
+    o5 = FusedAdam(Fake(), lr=4e-4, total_steps=total, warmup_pct=pct, min_lr_ratio=0.01)
+    with pytest.warns(UserWarning):
+        o5.load_state_dict(old_sd)
+    assert o5.min_lr_ratio == 0.0
 
 
 def test_method_schedule_floor_follows_the_reference_method():

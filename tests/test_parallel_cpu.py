@@ -36,7 +36,15 @@ def _worker(rank, world, port, n, ret):
         parallel.allreduce_gradients(g16, world, n_buckets=3)
         del os.environ['SDMI_GRAD_BF16']
         rel = float((g16 - ref).norm() / ref.norm())
-        ok1 = ok1 and rel < 1e-2 and rel > 0 and g16.dtype == torch.float32
+        # two ranks: one rounding of each partial + one bf16 add -> ~2^-9 rms; bound 2^-8
+        ok1 = ok1 and rel < 2.0 ** -8 and rel > 0 and g16.dtype == torch.float32
+        # default follows the compute dtype (parallel.use_bf16_wire), the environment overrides it
+        parallel.use_bf16_wire(True)
+        ok1 = ok1 and parallel.grad_bf16_enabled()
+        os.environ['SDMI_GRAD_BF16'] = '0'
+        ok1 = ok1 and not parallel.grad_bf16_enabled()
+        del os.environ['SDMI_GRAD_BF16']
+        parallel.use_bf16_wire(False)
         params = torch.full((1000,), float(rank))
         parallel.broadcast_parameters(params, src=0)
         ok2 = bool((params == 0).all())
@@ -55,6 +63,23 @@ def test_gradient_allreduce_two_ranks_gloo():
         r = dict(ret)
     assert r[0][:2] == (True, True) and r[1][:2] == (True, True)
     assert (r[0][2], r[0][3]) == (0, 7) and (r[1][2], r[1][3]) == (7, 13)
+
+
+def test_bf16_wire_error_of_an_eight_rank_ring():
+    """The bound DESIGN 6 states for the bf16 wire at 8 ranks, measured on a CPU emulation of the ring (each rank's
+    fp32 partial rounded to bf16, seven bf16 adds in ring order, fp32 average): rel-L2 of the averaged gradient
+    against the fp32 exchange ~0.35 %, every element within 8 * 2^-9 of sum |g_r| / 8."""
+    w, n = 8, 200003
+    parts = [torch.randn(n, generator=torch.Generator().manual_seed(500 + r)) * (0.5 + r / 4) for r in range(w)]
+    ref = sum(parts) / w
+    acc = parts[0].bfloat16()
+    for r in range(1, w):
+        acc = (acc + parts[r].bfloat16())            # bf16 + bf16 -> bf16 (rounded)
+    got = acc.float() / w
+    rel = float((got - ref).norm() / ref.norm())
+    bound = (w * 2.0 ** -9) * sum(p.abs() for p in parts) / w
+    assert 0 < rel < 5e-3, rel
+    assert bool(((got - ref).abs() <= bound + 1e-12).all())
 
 
 def test_bucket_bounds_cover_everything():
