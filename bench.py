@@ -147,7 +147,7 @@ def cpu_baseline(model, cfg, mode, quick=False):
 # kernels behind the C-ABI entry points the roofline legs price (csrc/igemm.hip, wgrad.hip, norm.hip, norm_bwd.hip)
 FAMILIES = {
     'sdmi_igemm': ('igemm_kernel', 'igemm_kernel_tall', 'igemm_dma_kernel', 'igemm_sym_kernel', 'conv3x3_c64_kernel',
-                   'splitk_epilogue_kernel', 'bwd_pair_kernel'),
+                   'splitk_epilogue_kernel', 'bwd_pair_kernel', 'st_block_a_kernel', 'st_block_b_kernel'),
     'sdmi_wgrad': ('wgrad_kernel', 'wgrad_tr_kernel', 'wgrad3x3_c64_kernel', 'wgrad_group_kernel', 'wgrad_group_reduce_kernel',
                    'wgrad_reduce_kernel'),
     'sdmi_groupnorm': ('gn_fused_kernel', 'gn_fused2_kernel', 'gn_stats_kernel', 'gn_apply_kernel'),
@@ -562,7 +562,8 @@ def main():
         # the igemm family = sdmi_igemm launches + the fused data / weight gradient launches (sdmi_bwd_pair:
         # igemm's tile body + the weight-gradient body in one kernel; its flops count both gradients)
         pr = summ.get('sdmi_bwd_pair', {})
-        ig = {k: summ['sdmi_igemm'].get(k, 0.0) + pr.get(k, 0.0) for k in ('calls', 'ms', 'flops', 'bytes')}
+        stb = summ.get('sdmi_st_block', {})          # fused SpatialTransformer blocks: their GEMMs + attention contractions
+        ig = {k: summ['sdmi_igemm'].get(k, 0.0) + pr.get(k, 0.0) + stb.get(k, 0.0) for k in ('calls', 'ms', 'flops', 'bytes')}
         ig_flops = ig['flops']
         ig_ms, ig_kernels = fam_ms('sdmi_igemm')
         if trace is None:
@@ -573,7 +574,7 @@ def main():
         fam_time = ig_ms + (fam_ms('sdmi_wgrad')[0] if wg else 0.0)
         rf = {
             'bound': 'mfma', 'kernel': 'igemm family (sdmi_igemm: implicit-GEMM conv/linear fwd + dgrad; sdmi_bwd_pair: '
-                                       'dgrad + wgrad of a layer in one launch): '
+                                       'dgrad + wgrad of a layer in one launch; sdmi_st_block: fused SpatialTransformer block): '
                                        + ', '.join(FAMILIES['sdmi_igemm']),
             'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak,
             'timing_source': tnote if trace is not None else f'eager HIP-event pass (fallback: {tnote})',

@@ -389,7 +389,7 @@ int sdmi_quant_fp8(const SdmiQuantFp8Args* a, void* stream);
  * video_based/models/unet/attention.py:297-308, 247-251, 182-206, 44-65 (10-13 launches of sdmi_groupnorm,
  * sdmi_igemm, sdmi_attention per block otherwise).
  *   x, tok, out [B][S][C] bf16; qkv [B][S][3C] bf16 (tok / qkv: workspaces written by phase A, read by B).
- *   C = 256 or 384 (heads = C / 32, head dim 32); S = tokens per image, a multiple of 64, <= 256.
+ *   C = 256 or 384 (heads = C / 32, head dim 32); S = tokens per image, a multiple of `rows`, <= 256.
  *   wstream_a / wstream_b: weights pre-packed into per-wave unit streams (2 KB units = the LDS image of 16
  *     weight rows x 64 k, in the order the kernel consumes them; python: kern.WeightBank.st_pack).
  *   wstream_img [B][...]: the per-image operands of the folded slot cross-attention (kern.Kern.cross_prepare)
@@ -407,6 +407,7 @@ typedef struct {
   const void* wstream_img; const float* vec_img;
   int B, S, C, slots, phase;
   float gn_eps, ln_eps, attn_scale;
+  int rows;   /* token rows per workgroup: 0 / 64, or 32 (twice the workgroups: small grids, e.g. 64 images at 8^2) */
 } SdmiStBlockArgs;
 int sdmi_st_block(const SdmiStBlockArgs* a, void* stream);
 

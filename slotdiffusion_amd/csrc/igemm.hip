@@ -606,13 +606,14 @@ static int dma64_min() {
   return v;
 }
 
-// SDMI_IGEMM_SYM: LDS stages of the symmetric-wave kernel (2: two workgroups per CU, 3 / 4: one), 0 = off
+// SDMI_IGEMM_SYM: LDS stages of the symmetric-wave kernel (2: two workgroups per CU, 3 / 4: one), 0 = off,
+// unset = by shape (see dispatch)
 static int sym_stages() {
   static int v = -1;
   if (v < 0) {
     const char* e = getenv("SDMI_IGEMM_SYM");
-    v = e ? atoi(e) : 0;
-    if (v != 0 && (v < 2 || v > 4)) v = 4;
+    v = e ? atoi(e) : -1;                 // -1 (default): two stages where there are >= 2 tiles per CU
+    if (v > 0 && (v < 2 || v > 4)) v = 4;
   }
   return v;
 }
@@ -702,7 +703,11 @@ int dispatch(const SdmiGemmArgs& p, hipStream_t st) {
   const bool fits31 = a_bytes < (1ll << 31) && w_bytes < (1ll << 31);
   // symmetric-wave kernel (igemm_sym.h): 128 x 128 tiles, bf16, 1x1 / plain convolutions, plain epilogue
   if constexpr (sizeof(T) == 2) {
-    const int sym = sym_stages();
+    // default (-1): the two-stage form (two workgroups per CU) where the launch has at least two 128 x 128 tiles
+    // per CU -- +5 ... 8 % there in dependent chains (32^2 / 64^2 convolutions at B = 64); at one tile per CU the
+    // loader / MFMA kernels stay (profiles/r04_sym_timeline.txt: the four DMA issues of a wave cost as much as its MFMAs)
+    int sym = sym_stages();
+    if (sym < 0) sym = t128 >= 2 * device_cus() ? 2 : 0;
     const int bk = 64;
     bool ok = sym && shape == T128x128 && wide && split_k == 1 && batch == 1 && p.osy == 0 && fits31 && !p.ln_colsum &&
               !p.geglu && !p.softmax8 && !p.out2 && (is1x1 || (plain && p.KH * p.KW <= 32 && p.Cin % bk == 0));

@@ -23,6 +23,16 @@
 
 namespace {
 
+#ifdef SDMI_SYM_TIMELINE   // experiment (tools/exp/sym_timeline.py): s_memtime sums of wave 0 per workgroup -> p.workspace
+#define SYM_TL_DECL unsigned long long tl_t = __builtin_amdgcn_s_memtime(), tl_a[6] = {0, 0, 0, 0, 0, 0};
+#define SYM_TL_LAP(i) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); tl_a[i] += n_ - tl_t; tl_t = n_; } while (0)
+#define SYM_TL_FLUSH do { if (threadIdx.x == 0 && p.workspace) for (int i_ = 0; i_ < 6; ++i_) ((unsigned long long*)p.workspace)[blockIdx.x * 8 + i_] = tl_a[i_]; } while (0)
+#else
+#define SYM_TL_DECL
+#define SYM_TL_LAP(i)
+#define SYM_TL_FLUSH
+#endif
+
 template <int MODE, int NSTAGE, bool XS = false>
 __global__ __launch_bounds__(512, (NSTAGE == 2 ? 4 : 2)) void igemm_sym_kernel(SdmiGemmArgs p, int tiles_m, int tiles_n, int hw_shift) {
   typedef bf16_t T;
@@ -169,6 +179,8 @@ __global__ __launch_bounds__(512, (NSTAGE == 2 ? 4 : 2)) void igemm_sym_kernel(S
 #pragma unroll
   for (int s = 0; s < NSTAGE - 1; ++s) issue();
   int stage = 0;
+  SYM_TL_DECL
+  SYM_TL_LAP(5);                            // prologue: tile setup + first DMA issues
   for (int ti = 0; ti < my_tiles; ++ti) {
     int m0, n0;
     tile_of((int)blockIdx.x + ti * (int)gridDim.x, m0, n0);
@@ -179,9 +191,12 @@ __global__ __launch_bounds__(512, (NSTAGE == 2 ? 4 : 2)) void igemm_sym_kernel(S
       for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.f;
     for (int t = 0; t < n_kt; ++t) {
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTAGE - 2) * NLOAD) : "memory");   // this wave's pieces of the K tile
+      SYM_TL_LAP(0);
       __builtin_amdgcn_s_barrier();          // everybody's pieces landed; the previous stage is free
       asm volatile("" ::: "memory");
+      SYM_TL_LAP(1);
       issue();                               // K tile + NSTAGE - 1 -> the stage the previous K tile vacated
+      SYM_TL_LAP(2);
       const char* base = smem + stage * STAGE;
       if (++stage == NSTAGE) stage = 0;
       u32x4 fa[2][2], fb[2];
@@ -195,6 +210,10 @@ __global__ __launch_bounds__(512, (NSTAGE == 2 ? 4 : 2)) void igemm_sym_kernel(S
           acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[ks & 1][i]),
                                                               __builtin_bit_cast(bf16x8, fb[ks & 1]), acc[i][0], 0, 0, 0);
       }
+#ifdef SDMI_SYM_TIMELINE
+      asm volatile("s_nop 0" :: "v"(acc[0][0][0]), "v"(acc[1][0][0]));      // (the MFMAs of this K tile have issued)
+#endif
+      SYM_TL_LAP(3);
     }
     // The streamlined epilogue is called directly: behind the generic one (loads and stores under per-element
     // branches) the compiler's wait-count pass carries pending-load state around the loop and parks an
@@ -208,7 +227,9 @@ __global__ __launch_bounds__(512, (NSTAGE == 2 ? 4 : 2)) void igemm_sym_kernel(S
       wave_epilogue<2, 1>(p, acc, mw0, nw0, 0, hw_shift, l, 0);
       __builtin_amdgcn_s_waitcnt(0x0F70);       // vmcnt(0)
     }
+    SYM_TL_LAP(4);
   }
+  SYM_TL_FLUSH;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no DMA may outlive the workgroup's LDS
 }
 

@@ -52,22 +52,25 @@ __device__ __forceinline__ int st_xcd_id(int bid, int nwg) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
 }
 
-template <int C>
+template <int C, int TT>
 struct StGeom {
+  static constexpr int ROWS = 16 * TT;          // token rows of a workgroup (TT 16-row tiles: 64, or 32 for small grids)
   static constexpr int NSL = C / 128;          // 16-column slices per wave of an N = C GEMM
   static constexpr int KT = C / 64;            // 64-wide K tiles of a K = C GEMM
   static constexpr int HEADS = C / 32;
   static constexpr int R = HEADS * 8;          // head-expanded slot rows of the folded cross-attention
   static constexpr int RP = 128;               // ... padded (N of the score GEMM, K of the output GEMM)
   static constexpr int NHC = C / 32;           // hidden chunks of 128 (4C hidden units)
+  static constexpr int PITCH = C * 2;          // row pitch of the activation operand buffer
+  static constexpr int Y_BYTES = ROWS * PITCH;
+  static constexpr int G_BYTES = ROWS * 256;   // one GEGLU chunk / the cross-attention probabilities
+  static constexpr int FREE2 = 160 * 1024 - Y_BYTES - 2 * G_BYTES;     // what two chunk buffers leave for the rings
 #ifdef ST_D
   static constexpr int D = ST_D;
 #else
-  static constexpr int D = NSL <= 3 ? 6 : 8;   // ring depth in units per wave
+  // ring depth in units per wave: as deep as the LDS allows next to two chunk buffers (8 at most), 6 otherwise
+  static constexpr int D = FREE2 >= 8 * 8 * ST_UNIT ? 8 : (FREE2 >= 8 * 7 * ST_UNIT ? 7 : 6);
 #endif
-  static constexpr int PITCH = C * 2;          // row pitch of the activation operand buffer
-  static constexpr int Y_BYTES = 64 * PITCH;
-  static constexpr int G_BYTES = 64 * 256;     // one GEGLU chunk / the cross-attention probabilities
   static constexpr int GBUF = (Y_BYTES + 2 * G_BYTES + 8 * D * ST_UNIT <= 160 * 1024) ? 2 : 1;
 #ifdef ST_RING_FIRST
   static constexpr int RING_OFF = 0;
@@ -152,10 +155,10 @@ struct StRing {
 // One K tile (64 k = two MFMA k-steps) of a GEMM whose wave block is NU 16-column slices x 64 rows:
 // acc[s][tt] += W_unit(s) . act[rows 16 tt ..][k tile kt].  STATS: LayerNorm-fold row sums from the
 // activation fragments (lane: row lane & 15 of tile tt, its 8 k of each 32).
-template <int D, int NU, bool STATS, int EXTRA = 0>
+template <int D, int NU, bool STATS, int EXTRA = 0, int TT = 4>
 __device__ __forceinline__ void st_gemm_step(StRing<D>& rg, const lds_char* act, const int (&yaddr)[4], int kt,
-                                             int tt_stride, const int (&woff)[2], f32x4 (&acc)[NU][4],
-                                             float (&sx)[4], float (&sxx)[4]) {
+                                             int tt_stride, const int (&woff)[2], f32x4 (&acc)[NU][TT],
+                                             float (&sx)[TT], float (&sxx)[TT]) {
 #ifdef ST_STEP_BARRIER       // experiment: the eight waves in lock step (the default lets them run free)
   __builtin_amdgcn_s_barrier();
 #endif
@@ -163,15 +166,15 @@ __device__ __forceinline__ void st_gemm_step(StRing<D>& rg, const lds_char* act,
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks) {
     const int kk = kt * 2 + ks;
-    bf16x8 b[4];
+    bf16x8 b[TT];
 #pragma unroll
-    for (int tt = 0; tt < 4; ++tt)
+    for (int tt = 0; tt < TT; ++tt)
       b[tt] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(
                                              act + yaddr[kk & 3] + tt * tt_stride + (kk >> 2) * 256));
     if constexpr (STATS) {
       const sdmi_bf16x2 ones = __builtin_bit_cast(sdmi_bf16x2, 0x3F803F80u);
 #pragma unroll
-      for (int tt = 0; tt < 4; ++tt) {
+      for (int tt = 0; tt < TT; ++tt) {
         const sdmi_bf16x2 v0 = {b[tt][0], b[tt][1]}, v1 = {b[tt][2], b[tt][3]}, v2 = {b[tt][4], b[tt][5]},
                           v3 = {b[tt][6], b[tt][7]};
         sx[tt] = __builtin_amdgcn_fdot2_f32_bf16(v0, ones, sx[tt], false);
@@ -202,7 +205,7 @@ __device__ __forceinline__ void st_gemm_step(StRing<D>& rg, const lds_char* act,
       }
 #endif
 #pragma unroll
-      for (int tt = 0; tt < 4; ++tt) acc[s][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[tt], acc[s][tt], 0, 0, 0);
+      for (int tt = 0; tt < TT; ++tt) acc[s][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[tt], acc[s][tt], 0, 0, 0);
     }
   }
   // The units just multiplied are free: refill their ring positions -- but only once this step's fragment reads have
@@ -226,10 +229,11 @@ __device__ __forceinline__ void st_gemm_step(StRing<D>& rg, const lds_char* act,
 }
 
 // row statistics of the LayerNorm fold: after all K tiles, fold the four 8-k lane groups of a row
-__device__ __forceinline__ void st_ln_stats(float (&sx)[4], float (&sxx)[4], float inv_k, float eps, float (&mean)[4],
-                                            float (&rstd)[4]) {
+template <int TT>
+__device__ __forceinline__ void st_ln_stats(float (&sx)[TT], float (&sxx)[TT], float inv_k, float eps, float (&mean)[TT],
+                                            float (&rstd)[TT]) {
 #pragma unroll
-  for (int tt = 0; tt < 4; ++tt) {
+  for (int tt = 0; tt < TT; ++tt) {
     float a = sx[tt], b = sxx[tt];
     a += __shfl_xor(a, 16, 64);
     b += __shfl_xor(b, 16, 64);
@@ -243,9 +247,10 @@ __device__ __forceinline__ void st_ln_stats(float (&sx)[4], float (&sxx)[4], flo
 // ---------------------------------------------------------------------------------------------------------
 // phase A: GroupNorm -> proj_in -> tok ; LayerNorm-fold -> q | k | v
 // ---------------------------------------------------------------------------------------------------------
-template <int C>
+template <int C, int TT>
 __global__ __launch_bounds__(512, 2) void st_block_a_kernel(SdmiStBlockArgs p) {
-  typedef StGeom<C> G;
+  typedef StGeom<C, TT> G;
+  constexpr int ROWS = G::ROWS;
   constexpr int NSL = G::NSL, KT = G::KT, D = G::D, PITCH = G::PITCH;
   extern __shared__ __attribute__((aligned(16))) char smem_[];
   lds_char* const smem = (lds_char*)smem_;
@@ -253,12 +258,12 @@ __global__ __launch_bounds__(512, 2) void st_block_a_kernel(SdmiStBlockArgs p) {
   float* const red = (float*)(smem_ + G::Y_OFF + G::Y_BYTES);          // GroupNorm partials (the chunk buffer's region)
   const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, lg = lane >> 4;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wgs_per_img = p.S / 64;
+  const int wgs_per_img = p.S / ROWS;
   // block b runs on XCD b % 8 (observed placement; speed only): every XCD gets a contiguous range of workgroup
-  // ids, so the S / 64 workgroups of an image share one L2 (they all read the image's x / K / V)
+  // ids, so the S / ROWS workgroups of an image share one L2 (they all read the image's x / K / V)
   const int vid = st_xcd_id((int)blockIdx.x, (int)gridDim.x);
   const int b = vid / wgs_per_img, rb = vid - b * wgs_per_img;
-  const long long row0 = (long long)b * p.S + rb * 64;       // first token row of this workgroup
+  const long long row0 = (long long)b * p.S + rb * ROWS;     // first token row of this workgroup
 
   StRing<D> rg;
   rg.rs_sh = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.wstream_a + (long long)w * G::UA * ST_UNIT), 0,
@@ -326,9 +331,9 @@ __global__ __launch_bounds__(512, 2) void st_block_a_kernel(SdmiStBlockArgs p) {
   {
     const float* st = red + 512 * 4;
     const bf16_t* xr = (const bf16_t*)p.x + row0 * C;
-    static_assert((64 * VPR) % 512 == 0, "whole passes");
+    static_assert((ROWS * VPR) % 512 == 0, "whole passes");
 #pragma unroll
-    for (int it = 0; it < 64 * VPR / 512; ++it) {
+    for (int it = 0; it < ROWS * VPR / 512; ++it) {
       const int i = tid + it * 512;
       const int r = i / VPR, vc = i - r * VPR;
       float f[8], gm[8], bt[8];
@@ -357,20 +362,22 @@ __global__ __launch_bounds__(512, 2) void st_block_a_kernel(SdmiStBlockArgs p) {
   for (int j = 0; j < 4; ++j) yaddr[j] = l15 * PITCH + ((((4 * j + lg) ^ l15) & 15) * 16);
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks) woff[ks] = l15 * 128 + (((4 * ks + lg) ^ ((l15 >> 1) & 7)) * 16);
-  float sx[4] = {0.f, 0.f, 0.f, 0.f}, sxx[4] = {0.f, 0.f, 0.f, 0.f};
+  float sx[TT], sxx[TT];
+#pragma unroll
+  for (int tt = 0; tt < TT; ++tt) sx[tt] = sxx[tt] = 0.f;
 
   // Epilogue operands are fetched BEFORE the GEMM they follow: a vector load issued behind the weight DMAs
   // would make its consumer wait for every DMA in front of it (vmcnt retires in order) -- a ring drain.
   // ---- proj_in: tok = gn(x) Win^T + bin
-  f32x4 acc[NSL][4], ev0[NSL], ev1[NSL];
+  f32x4 acc[NSL][TT], ev0[NSL], ev1[NSL];
 #pragma unroll
   for (int s = 0; s < NSL; ++s) {
     ev0[s] = st_vec4(p.vec_a + (w * NSL + s) * 16, lg);
 #pragma unroll
-    for (int tt = 0; tt < 4; ++tt) acc[s][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int tt = 0; tt < TT; ++tt) acc[s][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
 #pragma unroll
-  for (int kt = 0; kt < KT; ++kt) st_gemm_step<D, NSL, false>(rg, Y, yaddr, kt, 16 * PITCH, woff, acc, sx, sxx);
+  for (int kt = 0; kt < KT; ++kt) st_gemm_step<D, NSL, false, 0, TT>(rg, Y, yaddr, kt, 16 * PITCH, woff, acc, sx, sxx);
   ST_BARRIER();                                      // every wave is done reading gn(x)
   {
     bf16_t* tok = (bf16_t*)p.tok + row0 * C;
@@ -380,7 +387,7 @@ __global__ __launch_bounds__(512, 2) void st_block_a_kernel(SdmiStBlockArgs p) {
       const f32x4 bi = ev0[s];
       const int c = n0 >> 3;
 #pragma unroll
-      for (int tt = 0; tt < 4; ++tt) {
+      for (int tt = 0; tt < TT; ++tt) {
         const int r = tt * 16 + l15;
         uint2 o;
         o.x = st_pack2(acc[s][tt][0] + bi[0], acc[s][tt][1] + bi[1]);
@@ -394,7 +401,7 @@ __global__ __launch_bounds__(512, 2) void st_block_a_kernel(SdmiStBlockArgs p) {
   ST_BARRIER();
 
   // ---- q | k | v = LayerNorm(tok) W^T through the fold: three passes of N = C over the same operand
-  float mean[4], rstd[4];
+  float mean[TT], rstd[TT];
 #pragma unroll 1
   for (int pass = 0; pass < 3; ++pass) {
 #ifdef ST_VERIFY
@@ -407,18 +414,18 @@ __global__ __launch_bounds__(512, 2) void st_block_a_kernel(SdmiStBlockArgs p) {
       ev0[s] = st_vec4(colsum + (w * NSL + s) * 16, lg);
       ev1[s] = st_vec4(bias + (w * NSL + s) * 16, lg);
 #pragma unroll
-      for (int tt = 0; tt < 4; ++tt) acc[s][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int tt = 0; tt < TT; ++tt) acc[s][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     // (the NSL * 4 row stores of the epilogue before this pass are younger than every DMA in flight)
     if (pass == 0) {
-      st_gemm_step<D, NSL, true, NSL * 4>(rg, Y, yaddr, 0, 16 * PITCH, woff, acc, sx, sxx);
+      st_gemm_step<D, NSL, true, NSL * TT, TT>(rg, Y, yaddr, 0, 16 * PITCH, woff, acc, sx, sxx);
 #pragma unroll
-      for (int kt = 1; kt < KT; ++kt) st_gemm_step<D, NSL, true>(rg, Y, yaddr, kt, 16 * PITCH, woff, acc, sx, sxx);
-      st_ln_stats(sx, sxx, 1.f / (float)C, p.ln_eps, mean, rstd);
+      for (int kt = 1; kt < KT; ++kt) st_gemm_step<D, NSL, true, 0, TT>(rg, Y, yaddr, kt, 16 * PITCH, woff, acc, sx, sxx);
+      st_ln_stats<TT>(sx, sxx, 1.f / (float)C, p.ln_eps, mean, rstd);
     } else {
-      st_gemm_step<D, NSL, false, NSL * 4>(rg, Y, yaddr, 0, 16 * PITCH, woff, acc, sx, sxx);
+      st_gemm_step<D, NSL, false, NSL * TT, TT>(rg, Y, yaddr, 0, 16 * PITCH, woff, acc, sx, sxx);
 #pragma unroll
-      for (int kt = 1; kt < KT; ++kt) st_gemm_step<D, NSL, false>(rg, Y, yaddr, kt, 16 * PITCH, woff, acc, sx, sxx);
+      for (int kt = 1; kt < KT; ++kt) st_gemm_step<D, NSL, false, 0, TT>(rg, Y, yaddr, kt, 16 * PITCH, woff, acc, sx, sxx);
     }
     bf16_t* qkv = (bf16_t*)p.qkv + row0 * 3 * C + pass * C;
 #pragma unroll
@@ -427,7 +434,7 @@ __global__ __launch_bounds__(512, 2) void st_block_a_kernel(SdmiStBlockArgs p) {
       const f32x4 cs = ev0[s];
       const f32x4 bi = ev1[s];
 #pragma unroll
-      for (int tt = 0; tt < 4; ++tt) {
+      for (int tt = 0; tt < TT; ++tt) {
         const int r = tt * 16 + l15;
         float v[4];
 #pragma unroll
@@ -445,9 +452,10 @@ __global__ __launch_bounds__(512, 2) void st_block_a_kernel(SdmiStBlockArgs p) {
 // ---------------------------------------------------------------------------------------------------------
 // phase B
 // ---------------------------------------------------------------------------------------------------------
-template <int C>
+template <int C, int TT>
 __global__ __launch_bounds__(512, 2) void st_block_b_kernel(SdmiStBlockArgs p) {
-  typedef StGeom<C> G;
+  typedef StGeom<C, TT> G;
+  constexpr int ROWS = G::ROWS;
   constexpr int NSL = G::NSL, KT = G::KT, D = G::D, PITCH = G::PITCH, HEADS = G::HEADS, R = G::R;
   extern __shared__ __attribute__((aligned(16))) char smem_[];
   lds_char* const smem = (lds_char*)smem_;
@@ -455,12 +463,12 @@ __global__ __launch_bounds__(512, 2) void st_block_b_kernel(SdmiStBlockArgs p) {
   lds_char* const Gb = smem + G::Y_OFF + G::Y_BYTES;
   const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, lg = lane >> 4;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wgs_per_img = p.S / 64;
+  const int wgs_per_img = p.S / ROWS;
   // block b runs on XCD b % 8 (observed placement; speed only): every XCD gets a contiguous range of workgroup
-  // ids, so the S / 64 workgroups of an image share one L2 (they all read the image's x / K / V)
+  // ids, so the S / ROWS workgroups of an image share one L2 (they all read the image's x / K / V)
   const int vid = st_xcd_id((int)blockIdx.x, (int)gridDim.x);
   const int b = vid / wgs_per_img, rb = vid - b * wgs_per_img;
-  const long long row0 = (long long)b * p.S + rb * 64;
+  const long long row0 = (long long)b * p.S + rb * ROWS;
   const int S = p.S;
   ST_STAMP(0);
 
@@ -468,7 +476,10 @@ __global__ __launch_bounds__(512, 2) void st_block_b_kernel(SdmiStBlockArgs p) {
   // (attention.hip's transposed matrix-core formulation: a wave owns 32 queries of one head; four heads per round)
   unsigned opack[HEADS / 4][8];
   {
-    const int hs = w >> 1, qh = w & 1;
+    // 64 rows: two 32-query halves x four heads per round; 32 rows: waves 0-3 take the four heads, waves 4-7 only
+    // stage and keep the barriers
+    const int hs = TT == 4 ? (w >> 1) : (w & 3), qh = TT == 4 ? (w & 1) : 0;
+    const bool att_active = TT == 4 || w < 4;
     const int ql = lane & 31, hh = lane >> 5;
     const bf16_t* qkv_img = (const bf16_t*)p.qkv + (long long)b * S * 3 * C;
     const int head_bytes = S * (ST_KP + ST_VP);
@@ -520,6 +531,7 @@ __global__ __launch_bounds__(512, 2) void st_block_b_kernel(SdmiStBlockArgs p) {
       const lds_char* kfrag = Ks + ql * ST_KP + hh * 16;
       const lds_char* vfrag = Vs + (4 * hh + (t16 >> 2)) * ST_VP + ((g4 & 1) * 16 + (t16 & 3) * 4) * 2;
       const int rd = ri;
+      if (!att_active) continue;
       f32x16 o;
 #pragma unroll
       for (int r = 0; r < 16; ++r) o[r] = 0.f;
@@ -581,13 +593,13 @@ __global__ __launch_bounds__(512, 2) void st_block_b_kernel(SdmiStBlockArgs p) {
   }
 
   // the token residual of the first epilogue: fetched and RETIRED before any weight DMA is issued (st_vec4's note)
-  uint2 rsd[NSL][4];
+  uint2 rsd[NSL][TT];
   {
     const bf16_t* tok = (const bf16_t*)p.tok + row0 * C;
 #pragma unroll
     for (int s = 0; s < NSL; ++s)
 #pragma unroll
-      for (int tt = 0; tt < 4; ++tt)
+      for (int tt = 0; tt < TT; ++tt)
         rsd[s][tt] = *reinterpret_cast<const uint2*>(tok + (long long)(tt * 16 + l15) * C + (w * NSL + s) * 16 + 4 * lg);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
@@ -613,10 +625,11 @@ __global__ __launch_bounds__(512, 2) void st_block_b_kernel(SdmiStBlockArgs p) {
 #pragma unroll
   for (int i = 0; i < D; ++i) rg.issue_one();
   {
-    const int hs = w >> 1, qh = w & 1;
+    const int hs = TT == 4 ? (w >> 1) : (w & 3), qh = TT == 4 ? (w & 1) : 0;
     const int ql = lane & 31, hh = lane >> 5;
     // attention output -> operand buffer: row qh * 32 + ql, channels h * 32 + 8 j + 4 hh .. + 4
     const int r = qh * 32 + ql;
+    if (TT == 4 || w < 4)
 #pragma unroll
     for (int rd = 0; rd < HEADS / 4; ++rd) {
       const int h = rd * 4 + hs;
@@ -643,24 +656,24 @@ __global__ __launch_bounds__(512, 2) void st_block_b_kernel(SdmiStBlockArgs p) {
   }
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks) woff[ks] = l15 * 128 + (((4 * ks + lg) ^ ((l15 >> 1) & 7)) * 16);
-  float sx[4], sxx[4], mean[4], rstd[4];
+  float sx[TT], sxx[TT], mean[TT], rstd[TT];
   const float* vb = p.vec_b;              // [bo | bo2 | colsum_ff (8C) | bias_ff (8C) | bias_out]  fp32
   const float* vi = p.vec_img + (long long)b * 256;   // per image: [colsum_q (128) | bias_q (128)]
 
   // residual stream of this wave's columns, fp32: res[s][tt][j] = row 16 tt + l15, column (w NSL + s) 16 + 4 lg + j
-  f32x4 res[NSL][4], acc[NSL][4];
+  f32x4 res[NSL][TT], acc[NSL][TT];
   auto zero_acc = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int s = 0; s < NSL; ++s)
 #pragma unroll
-      for (int tt = 0; tt < 4; ++tt) acc[s][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int tt = 0; tt < TT; ++tt) acc[s][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
   };
   auto res_to_y = [&]() __attribute__((always_inline)) {      // bf16 copy of the residual stream = next GEMM's operand
 #pragma unroll
     for (int s = 0; s < NSL; ++s) {
       const int c = ((w * NSL + s) * 16 + 4 * lg) >> 3;
 #pragma unroll
-      for (int tt = 0; tt < 4; ++tt) {
+      for (int tt = 0; tt < TT; ++tt) {
         const int r = tt * 16 + l15;
         const int phys = (c & ~15) | ((c ^ r) & 15);
         uint2 o;
@@ -679,13 +692,13 @@ __global__ __launch_bounds__(512, 2) void st_block_b_kernel(SdmiStBlockArgs p) {
   for (int s = 0; s < NSL; ++s) ev0[s] = st_vec4(vb + (w * NSL + s) * 16, lg);
   zero_acc();
 #pragma unroll
-  for (int kt = 0; kt < KT; ++kt) st_gemm_step<D, NSL, false>(rg, Y, yaddr, kt, 16 * PITCH, woff, acc, sx, sxx);
+  for (int kt = 0; kt < KT; ++kt) st_gemm_step<D, NSL, false, 0, TT>(rg, Y, yaddr, kt, 16 * PITCH, woff, acc, sx, sxx);
   {
 #pragma unroll
     for (int s = 0; s < NSL; ++s) {
       const f32x4 bi = ev0[s];
 #pragma unroll
-      for (int tt = 0; tt < 4; ++tt) {
+      for (int tt = 0; tt < TT; ++tt) {
         const uint2 t2 = rsd[s][tt];
         res[s][tt][0] = acc[s][tt][0] + bi[0] + __uint_as_float(t2.x << 16);
         res[s][tt][1] = acc[s][tt][1] + bi[1] + __uint_as_float(t2.x & 0xffff0000u);
@@ -701,7 +714,7 @@ __global__ __launch_bounds__(512, 2) void st_block_b_kernel(SdmiStBlockArgs p) {
   ST_STAMP(3);
   // ---- folded slot cross-attention: P = softmax8(LN-fold(x1) Wq[b]^T) ; x2 = P W2[b]^T + bo2 + x1
   {
-    f32x4 sc[1][4];
+    f32x4 sc[1][TT];
 #ifdef ST_VERIFY
     rg.tag = 1;
 #endif
@@ -711,16 +724,16 @@ __global__ __launch_bounds__(512, 2) void st_block_b_kernel(SdmiStBlockArgs p) {
 #pragma unroll
     for (int s = 0; s < NSL; ++s) ev0[s] = st_vec4(vb + C + (w * NSL + s) * 16, lg);
 #pragma unroll
-    for (int tt = 0; tt < 4; ++tt) {
+    for (int tt = 0; tt < TT; ++tt) {
       sc[0][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
       sx[tt] = sxx[tt] = 0.f;
     }
 #pragma unroll
-    for (int kt = 0; kt < KT; ++kt) st_gemm_step<D, 1, true>(rg, Y, yaddr, kt, 16 * PITCH, woff, sc, sx, sxx);
-    st_ln_stats(sx, sxx, 1.f / (float)C, p.ln_eps, mean, rstd);
+    for (int kt = 0; kt < KT; ++kt) st_gemm_step<D, 1, true, 0, TT>(rg, Y, yaddr, kt, 16 * PITCH, woff, sc, sx, sxx);
+    st_ln_stats<TT>(sx, sxx, 1.f / (float)C, p.ln_eps, mean, rstd);
     const int c = n0 >> 3;
 #pragma unroll
-    for (int tt = 0; tt < 4; ++tt) {
+    for (int tt = 0; tt < TT; ++tt) {
       float v[4];
       float mx = -INFINITY;
 #pragma unroll
@@ -752,12 +765,12 @@ __global__ __launch_bounds__(512, 2) void st_block_b_kernel(SdmiStBlockArgs p) {
 #endif
   zero_acc();
 #pragma unroll
-  for (int kt = 0; kt < 2; ++kt) st_gemm_step<D, NSL, false>(rg, Gb, gaddr, kt, 16 * 256, woff, acc, sx, sxx);
+  for (int kt = 0; kt < 2; ++kt) st_gemm_step<D, NSL, false, 0, TT>(rg, Gb, gaddr, kt, 16 * 256, woff, acc, sx, sxx);
 #pragma unroll
   for (int s = 0; s < NSL; ++s) {
     const f32x4 bi = ev0[s];
 #pragma unroll
-    for (int tt = 0; tt < 4; ++tt)
+    for (int tt = 0; tt < TT; ++tt)
 #pragma unroll
       for (int j = 0; j < 4; ++j) res[s][tt][j] += acc[s][tt][j] + bi[j];
   }
@@ -772,37 +785,37 @@ __global__ __launch_bounds__(512, 2) void st_block_b_kernel(SdmiStBlockArgs p) {
   rg.tag = 3;
 #endif
 #pragma unroll
-  for (int tt = 0; tt < 4; ++tt) sx[tt] = sxx[tt] = 0.f;
+  for (int tt = 0; tt < TT; ++tt) sx[tt] = sxx[tt] = 0.f;
   zero_acc();
 #pragma unroll
-  for (int kt = 0; kt < KT; ++kt) st_gemm_step<D, NSL, true>(rg, Y, yaddr, kt, 16 * PITCH, woff, acc, sx, sxx);
-  st_ln_stats(sx, sxx, 1.f / (float)C, p.ln_eps, mean, rstd);
+  for (int kt = 0; kt < KT; ++kt) st_gemm_step<D, NSL, true, 0, TT>(rg, Y, yaddr, kt, 16 * PITCH, woff, acc, sx, sxx);
+  st_ln_stats<TT>(sx, sxx, 1.f / (float)C, p.ln_eps, mean, rstd);
   const float* cs_ff = vb + 2 * C;
   const float* bi_ff = vb + 10 * C;
   ST_TL_DECL
   ST_TL_BEGIN
 #pragma unroll 1
   for (int hc = 0; hc < G::NHC; ++hc) {
-    f32x4 vg[2][4];                                     // [value | gate] columns hc * 128 + w * 16 + 4 lg ..
+    f32x4 vg[2][TT];                                     // [value | gate] columns hc * 128 + w * 16 + 4 lg ..
     const f32x4 csv = st_vec4(cs_ff + hc * 128 + w * 16, lg);
     const f32x4 csg = st_vec4(cs_ff + 4 * C + hc * 128 + w * 16, lg);
     const f32x4 biv = st_vec4(bi_ff + hc * 128 + w * 16, lg);
     const f32x4 big = st_vec4(bi_ff + 4 * C + hc * 128 + w * 16, lg);
 #pragma unroll
-    for (int tt = 0; tt < 4; ++tt) vg[0][tt] = vg[1][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int tt = 0; tt < TT; ++tt) vg[0][tt] = vg[1][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
     ST_TL_LAP(3);
 #ifdef ST_VERIFY
     rg.tag = 4;
 #endif
 #pragma unroll
-    for (int kt = 0; kt < KT; ++kt) st_gemm_step<D, 2, false>(rg, Y, yaddr, kt, 16 * PITCH, woff, vg, sx, sxx);
+    for (int kt = 0; kt < KT; ++kt) st_gemm_step<D, 2, false, 0, TT>(rg, Y, yaddr, kt, 16 * PITCH, woff, vg, sx, sxx);
     ST_TL_LAP(0);
     lds_char* gb = Gb + (G::GBUF == 2 ? (hc & 1) * G::G_BYTES : 0);
     if (G::GBUF == 1) ST_BARRIER();                     // the previous chunk's readers are done
     {
       const int c = (w * 16 + 4 * lg) >> 3;
 #pragma unroll
-      for (int tt = 0; tt < 4; ++tt) {
+      for (int tt = 0; tt < TT; ++tt) {
         float y[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -825,7 +838,7 @@ __global__ __launch_bounds__(512, 2) void st_block_b_kernel(SdmiStBlockArgs p) {
     rg.tag = 5;
 #endif
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt) st_gemm_step<D, NSL, false>(rg, gb, gaddr, kt, 16 * 256, woff, acc, sx, sxx);
+    for (int kt = 0; kt < 2; ++kt) st_gemm_step<D, NSL, false, 0, TT>(rg, gb, gaddr, kt, 16 * 256, woff, acc, sx, sxx);
   }
   ST_STAMP(5);
   ST_TL_FLUSH;
@@ -837,7 +850,7 @@ __global__ __launch_bounds__(512, 2) void st_block_b_kernel(SdmiStBlockArgs p) {
     for (int s = 0; s < NSL; ++s) {
       ev0[s] = st_vec4(vb + 18 * C + (w * NSL + s) * 16, lg);
 #pragma unroll
-      for (int tt = 0; tt < 4; ++tt)
+      for (int tt = 0; tt < TT; ++tt)
         rsd[s][tt] = *reinterpret_cast<const uint2*>(xr + (long long)(tt * 16 + l15) * C + (w * NSL + s) * 16 + 4 * lg);
     }
   }
@@ -848,7 +861,7 @@ __global__ __launch_bounds__(512, 2) void st_block_b_kernel(SdmiStBlockArgs p) {
       const int n0 = (w * NSL + s) * 16 + 4 * lg;
       const f32x4 bi = ev0[s];
 #pragma unroll
-      for (int tt = 0; tt < 4; ++tt) {
+      for (int tt = 0; tt < TT; ++tt) {
         const long long o_ = (long long)(tt * 16 + l15) * C + n0;
         const uint2 x2 = rsd[s][tt];
         uint2 o;
@@ -864,21 +877,22 @@ __global__ __launch_bounds__(512, 2) void st_block_b_kernel(SdmiStBlockArgs p) {
   ST_STAMP(6);
 }
 
-template <int C>
+template <int C, int TT>
 int st_launch(const SdmiStBlockArgs& a, hipStream_t st) {
-  typedef StGeom<C> G;
-  const int att = 4 * a.S * (ST_KP + ST_VP);
+  typedef StGeom<C, TT> G;
+  const int heads_bytes = a.S * (ST_KP + ST_VP);
+  const int att = (G::HEADS * heads_bytes <= 160 * 1024 ? G::HEADS : 4) * heads_bytes;
   const int smem_b = att > G::SMEM_GEMM ? att : G::SMEM_GEMM;
-  const int grid = a.B * (a.S / 64);
+  const int grid = a.B * (a.S / G::ROWS);
   if (a.phase == 0 || a.phase == 1) {
-    SDMI_OPTIN_LDS((st_block_a_kernel<C>), G::SMEM_GEMM, "st_block (phase A)");
-    hipLaunchKernelGGL((st_block_a_kernel<C>), dim3(grid), dim3(512), G::SMEM_GEMM, st, a);
+    SDMI_OPTIN_LDS((st_block_a_kernel<C, TT>), G::SMEM_GEMM, "st_block (phase A)");
+    hipLaunchKernelGGL((st_block_a_kernel<C, TT>), dim3(grid), dim3(512), G::SMEM_GEMM, st, a);
     const int rc = sdmi_check_launch("st_block (phase A)");
     if (rc) return rc;
   }
   if (a.phase == 0 || a.phase == 2) {
-    SDMI_OPTIN_LDS((st_block_b_kernel<C>), 160 * 1024, "st_block (phase B)");
-    hipLaunchKernelGGL((st_block_b_kernel<C>), dim3(grid), dim3(512), smem_b, st, a);
+    SDMI_OPTIN_LDS((st_block_b_kernel<C, TT>), 160 * 1024, "st_block (phase B)");
+    hipLaunchKernelGGL((st_block_b_kernel<C, TT>), dim3(grid), dim3(512), smem_b, st, a);
     return sdmi_check_launch("st_block (phase B)");
   }
   return SDMI_OK;
@@ -890,11 +904,13 @@ extern "C" int sdmi_st_block(const SdmiStBlockArgs* a, void* stream) {
   SDMI_REQUIRE(a && a->x && a->tok && a->qkv && a->out, "null pointer");
   SDMI_REQUIRE(a->wstream_a && a->vec_a && a->wstream_b && a->wstream_img && a->vec_b && a->vec_img, "null stream");
   SDMI_REQUIRE(a->C == 256 || a->C == 384, "C must be 256 or 384");
-  SDMI_REQUIRE(a->S >= 64 && a->S % 64 == 0 && 4 * a->S * (ST_KP + ST_VP) <= 160 * 1024,
-               "S must be a multiple of 64 and at most 256 tokens per image");
+  SDMI_REQUIRE(a->rows == 0 || a->rows == 64 || a->rows == 32, "rows per workgroup: 64 (0) or 32");
+  const int rows = a->rows ? a->rows : 64;
+  SDMI_REQUIRE(a->S >= rows && a->S % rows == 0 && a->S % 32 == 0 && 4 * a->S * (ST_KP + ST_VP) <= 160 * 1024,
+               "S must be a multiple of the rows per workgroup and at most 256 tokens per image");
   SDMI_REQUIRE(a->slots >= 1 && a->slots <= 8, "1..8 slots");
   SDMI_REQUIRE(a->phase >= 0 && a->phase <= 2, "phase: 0 = both, 1 = A, 2 = B");
   hipStream_t st = (hipStream_t)stream;
-  if (a->C == 256) return st_launch<256>(*a, st);
-  return st_launch<384>(*a, st);
+  if (rows == 64) return a->C == 256 ? st_launch<256, 4>(*a, st) : st_launch<384, 4>(*a, st);
+  return a->C == 256 ? st_launch<256, 2>(*a, st) : st_launch<384, 2>(*a, st);
 }

@@ -71,6 +71,9 @@ _ST_FUSED = os.environ.get('SDMI_ST_FUSED', '1') != '0'     # fused SpatialTrans
 # ... only when its grid (one workgroup per 64 token rows) fills a good part of the chip: at B = 64 the 8^2 level gives 64
 # workgroups that each stream the block's 4 MB of weights -- 119 us against 108 us for the per-layer launches
 _ST_MIN_WGS = int(os.environ.get('SDMI_ST_MIN_WGS', '128'))
+# token rows per workgroup: 0 = 64 when that gives >= 192 workgroups, else 32 (twice the workgroups, each multiplying
+# half the rows against the same weight stream: 64 images at 8^2 are 64 / 128 workgroups); 64 / 32 force one
+_ST_ROWS = int(os.environ.get('SDMI_ST_ROWS', '0'))
 
 
 def _copy_group(items):
@@ -1005,8 +1008,10 @@ class Kern:
         B, H, W, C = x.shape
         S = H * W
         if not (_ST_FUSED and fold is not None and 'st_img' in fold and x.dtype == torch.bfloat16 and
-                C in (256, 384) and heads * 32 == C and S % 64 == 0 and S <= 256 and x.is_contiguous() and
-                B * S // 64 >= _ST_MIN_WGS):
+                C in (256, 384) and heads * 32 == C and S % 64 == 0 and S <= 256 and x.is_contiguous()):
+            return None
+        rows = _ST_ROWS or (64 if B * S // 64 >= 192 else 32)
+        if B * S // rows < _ST_MIN_WGS:
             return None
         wts = self.wb.st_fused_weights(n, x.dtype)
         tok = torch.empty((B, S, C), dtype=x.dtype, device=x.device)
@@ -1020,7 +1025,7 @@ class Kern:
              gn_gamma=_p(self.wb.f(n + '.norm.weight')), gn_beta=_p(self.wb.f(n + '.norm.bias')),
              wstream_a=_p(wts['wa']), vec_a=_p(wts['va']), wstream_b=_p(wts['wb']), vec_b=_p(wts['vb']),
              wstream_img=_p(fold['st_img']), vec_img=_p(fold['st_vec']), B=B, S=S, C=C, slots=fold['slots'],
-             phase=0, gn_eps=1e-6, ln_eps=1e-5, attn_scale=32.0 ** -0.5,
+             phase=0, gn_eps=1e-6, ln_eps=1e-5, attn_scale=32.0 ** -0.5, rows=rows,
              _meta=dict(flops=flops, bytes=2.0 * B * S * C * 2 + wbytes))
         return out
 

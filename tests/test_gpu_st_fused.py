@@ -30,13 +30,15 @@ def _rel(a, b):
     return float((a.float().cpu() - b.float().cpu()).norm() / b.float().cpu().norm())
 
 
+@pytest.mark.parametrize('rows', [64, 32])
 @pytest.mark.parametrize('name,hw,B', [('input_blocks.4.1', 16, 3), ('output_blocks.8.1', 16, 2),
                                        ('input_blocks.7.1', 8, 5), ('output_blocks.5.1', 8, 2)])
-def test_fused_block_matches_oracle_and_per_layer_launches(name, hw, B):
+def test_fused_block_matches_oracle_and_per_layer_launches(name, hw, B, rows):
     from oracle import slotdiff_oracle as O
     from slotdiffusion_amd import kern
     m = _model()
     kern._ST_MIN_WGS = 0                 # (the production gate keeps small grids on the per-layer launches)
+    kern._ST_ROWS = rows                 # token rows per workgroup: both instantiations
     K, u = m.K(), m.unet()
     n = u.P + name
     heads = u.heads_of[name]
@@ -68,13 +70,14 @@ def test_fused_block_matches_oracle_and_per_layer_launches(name, hw, B):
     assert e_f < 1.5e-2                                   # bf16 bar of the kernel tests (rel-L2)
     assert e_f < 2.0 * e_p + 2e-3                          # and no worse than the launches it replaces
     assert all(torch.equal(fused, a) for a in again), 'fused block is not repeatable run to run'
+    kern._ST_ROWS = 0
 
 
 def test_fused_block_engages_in_the_sampler_and_keeps_eps():
     """UNet eps with the fused blocks against the per-layer launches on the same inputs (the sampler fixtures of
     test_gpu_model.py cover the path end to end against the reference)."""
     from slotdiffusion_amd import kern, ops
-    kern._ST_MIN_WGS = 0
+    kern._ST_MIN_WGS, kern._ST_ROWS = 0, 0
     m = _model(seed=5)
     B = 2
     g = torch.Generator().manual_seed(2)
