@@ -46,7 +46,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     return;
   }
   if (b < g.n_fold + g.n_wgrad) {
-    const int idx = b - g.n_fold;
+    // XCD-aware order (round 4): block b runs on XCD b % 8, so consecutive indices used to spread the ~40 dW tiles
+    // of ONE M split -- which all read the same rows of x and dY -- over all eight L2s (the 400 MB per launch the
+    // round-3 counters showed against ~100 MB of operands).  Each XCD now owns a contiguous range of (split, tile)
+    // indices: a split's rows are fetched into one or two L2s.  Same work per workgroup, bit-identical results.
+    const int j = b - g.n_fold;
+    const int xc = j & 7, q8 = g.n_wgrad >> 3, r8 = g.n_wgrad & 7;
+    const int idx = (xc < r8 ? xc * (q8 + 1) : r8 * (q8 + 1) + (xc - r8) * q8) + (j >> 3);
     const int split = idx / g.w_per_split;
     wgrad_tr_body<WT, WT, MODE>(w, g.w_tiles_n, g.w_tiles_k, g.w_mps, idx - split * g.w_per_split, split);
     return;

@@ -307,7 +307,15 @@ __global__ __launch_bounds__(512) void wgrad_kernel(SdmiWgradArgs p, int tiles_n
 template <int TN, int TK, int MODE>
 __global__ __launch_bounds__(512) void wgrad_tr_kernel(SdmiWgradArgs p, int tiles_n, int tiles_k,
                                                        int m_per_split) {
-  wgrad_tr_body<TN, TK, MODE>(p, tiles_n, tiles_k, m_per_split, blockIdx.x, blockIdx.y);
+  // XCD-aware order (as in bwd_pair.hip): the tiles of one M split read the same rows of x and dY, so each XCD takes a
+  // contiguous range of (split, tile) indices instead of every eighth one (the dispatcher walks x fastest and places
+  // linear block id b on XCD b % 8).  Same work per workgroup, bit-identical results.
+  const int gx = (int)gridDim.x, nb = gx * (int)gridDim.y;
+  const int j = (int)blockIdx.y * gx + (int)blockIdx.x;
+  const int xc = j & 7, q8 = nb >> 3, r8 = nb & 7;
+  const int idx = (xc < r8 ? xc * (q8 + 1) : r8 * (q8 + 1) + (xc - r8) * q8) + (j >> 3);
+  const int split = idx / gx;
+  wgrad_tr_body<TN, TK, MODE>(p, tiles_n, tiles_k, m_per_split, idx - split * gx, split);
 }
 
 // ------------------------------------------------------------------------------------------
