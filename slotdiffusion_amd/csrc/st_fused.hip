@@ -120,12 +120,13 @@ struct StRing {
   }
 };
 
-// EXTRA != 0: the step follows an epilogue that issued global stores; its wait is a full vmcnt(0) instead of
-// counting the stores into the allowance (four times per phase A launch: not worth an assumption).
+// EXTRA = global stores of the epilogue in front of this step: they are younger than every DMA in flight and
+// vmcnt retires in issue order, so they simply stay outstanding on top of the D - n units (a vmcnt(0) here waited
+// for the stores' round trip: ~2 k cycles per q / k / v pass of phase A).  -DST_DRAIN: vmcnt(0) everywhere (experiment).
 #if defined(ST_DRAIN)
 #define ST_WAIT_UNITS(D_, n_, extra_) asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #else
-#define ST_WAIT_UNITS(D_, n_, extra_) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((extra_) ? 0 : 2 * ((D_) - (n_))) : "memory")
+#define ST_WAIT_UNITS(D_, n_, extra_) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * ((D_) - (n_)) + (extra_)) : "memory")
 #endif
 // Workgroup barrier that leaves the DMA queue alone: `__syncthreads()` carries a fence that waits vmcnt(0) while
 // LDS-DMA is in flight (it is a pending LDS write); LDS stores / reads of this wave are retired explicitly.
@@ -144,6 +145,11 @@ struct StRing {
 #define ST_TL_BEGIN
 #define ST_TL_LAP(i)
 #define ST_TL_FLUSH
+#endif
+#ifdef ST_TIMELINE
+#define STA_STAMP(i) do { if (threadIdx.x == 0) ((unsigned long long*)p.vec_img)[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STA_STAMP(i)
 #endif
 #define ST_BARRIER()                                         \
   do {                                                       \
@@ -278,6 +284,7 @@ __global__ __launch_bounds__(512, 2) void st_block_a_kernel(SdmiStBlockArgs p) {
 #endif
 #pragma unroll
   for (int i = 0; i < D; ++i) rg.issue_one();               // weights in flight under the GroupNorm
+  STA_STAMP(0);
 
   // ---- GroupNorm statistics of the image (32 groups): thread -> (row slot, 16-byte vector column)
   constexpr int VPR = C / 8;                    // vectors per row
@@ -288,16 +295,16 @@ __global__ __launch_bounds__(512, 2) void st_block_a_kernel(SdmiStBlockArgs p) {
     float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;
     const int vr = tid / VPR, vc = tid - vr * VPR;
     if (vr < RPP) {
-      // (four rows in flight: one load per iteration behind its own wait cost a memory latency per row)
-      for (int r0 = vr; r0 < p.S; r0 += 4 * RPP) {
-        uint4 v[4];
+      // (eight rows in flight: one load per iteration behind its own wait cost a memory latency per row)
+      for (int r0 = vr; r0 < p.S; r0 += 8 * RPP) {
+        uint4 v[8];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < 8; ++j) {
           const int r = r0 + j * RPP;
           v[j] = r < p.S ? *reinterpret_cast<const uint4*>(xi + (long long)r * C + vc * 8) : make_uint4(0u, 0u, 0u, 0u);
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < 8; ++j) {
           float f[8];
           unpack16<bf16_t>(v[j], f);
           s0 += (f[0] + f[1]) + (f[2] + f[3]);
@@ -326,6 +333,7 @@ __global__ __launch_bounds__(512, 2) void st_block_a_kernel(SdmiStBlockArgs p) {
       red[512 * 4 + tid * 2 + 1] = rsqrtf(var + p.gn_eps);
     }
     ST_BARRIER();
+  STA_STAMP(1);
   }
   // ---- normalise this workgroup's 64 rows into the operand buffer
   {
@@ -355,6 +363,7 @@ __global__ __launch_bounds__(512, 2) void st_block_a_kernel(SdmiStBlockArgs p) {
     }
   }
   ST_BARRIER();
+  STA_STAMP(2);
 
   // lane constants of the GEMM core
   int yaddr[4], woff[2];
@@ -379,6 +388,7 @@ __global__ __launch_bounds__(512, 2) void st_block_a_kernel(SdmiStBlockArgs p) {
 #pragma unroll
   for (int kt = 0; kt < KT; ++kt) st_gemm_step<D, NSL, false, 0, TT>(rg, Y, yaddr, kt, 16 * PITCH, woff, acc, sx, sxx);
   ST_BARRIER();                                      // every wave is done reading gn(x)
+  STA_STAMP(3);
   {
     bf16_t* tok = (bf16_t*)p.tok + row0 * C;
 #pragma unroll
@@ -399,6 +409,7 @@ __global__ __launch_bounds__(512, 2) void st_block_a_kernel(SdmiStBlockArgs p) {
     }
   }
   ST_BARRIER();
+  STA_STAMP(4);
 
   // ---- q | k | v = LayerNorm(tok) W^T through the fold: three passes of N = C over the same operand
   float mean[TT], rstd[TT];
@@ -447,6 +458,7 @@ __global__ __launch_bounds__(512, 2) void st_block_a_kernel(SdmiStBlockArgs p) {
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no DMA may outlive the workgroup's LDS
+  STA_STAMP(5);
 }
 
 // ---------------------------------------------------------------------------------------------------------

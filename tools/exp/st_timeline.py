@@ -28,6 +28,14 @@ for name, hw in (('input_blocks.4.1', 16), ('input_blocks.7.1', 8)):
                     gn_beta=_p(wb.f(n + '.norm.bias')), wstream_a=_p(wts['wa']), vec_a=_p(wts['va']),
                     wstream_b=_p(wts['wb']), vec_b=_p(wts['vb']), wstream_img=_p(fold['st_img']),
                     vec_img=_p(fold['st_vec']), B=B, S=S, C=C, slots=7, gn_eps=1e-6, ln_eps=1e-5, attn_scale=32.0 ** -0.5)
+        sa = torch.zeros(nwg * 8, dtype=torch.int64, device=dev)
+        a1 = dict(args); a1['vec_img'] = _p(sa)
+        for rep in range(3):
+            _lib.call('sdmi_st_block', _st(), phase=1, **a1)
+        torch.cuda.synchronize()
+        ta = sa.view(nwg, 8)[:, :6].double().cpu()
+        da = ta[:, 1:] - ta[:, :-1]
+        print(f'{name} C={C} S={S} phase A (cycles, median workgroup):', ' | '.join(f'{nm} {float(da[:, i].median()):.0f}' for i, nm in enumerate(('GroupNorm statistics', 'normalise -> operand buffer', 'proj_in GEMM', 'tok epilogue', 'q | k | v passes'))))
         _lib.call('sdmi_st_block', _st(), phase=1, **args)
         a2 = dict(args); a2['gn_gamma'] = _p(stamps)
         for rep in range(3):
