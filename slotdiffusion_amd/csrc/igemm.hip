@@ -732,6 +732,36 @@ int dispatch(const SdmiGemmArgs& p, hipStream_t st) {
 #undef SDMI_SYM
     }
   }
+  // symmetric-wave kernel + split-K for the deep-K plain convolutions that would otherwise take 64 x 64 tiles (the
+  // 8^2 / 4^2 levels at B = 64): a 64 x 64 tile asks for 128 B/clk of operand feed at full matrix rate, a 128 x 128
+  // tile for 64 (~38 are there), and the K split supplies the workgroups
+  if constexpr (sizeof(T) == 2) {
+    static int sym_split = -1;
+    if (sym_split < 0) {
+      const char* e = getenv("SDMI_IGEMM_SYM_SPLIT");
+      sym_split = e ? atoi(e) : 0;
+    }
+    if (sym_split && shape == T64x64 && !is1x1 && plain && !p.a2 && p.split_k == 0 && p.workspace && batch == 1 && p.osy == 0 &&
+        fits31 && p.KH * p.KW <= 32 && p.Cin % 64 == 0 && kbytes >= 2048 && p.N > 64 && p.M >= 512 && !p.ln_colsum && !p.geglu &&
+        !p.softmax8 && !p.out2) {
+      const int n_cu = device_cus();
+      const int nk = (p.K + 63) / 64;
+      int sk = (int)((2 * n_cu + t128 - 1) / t128);
+      if (sk > 16) sk = 16;
+      if (sk > nk / 4) sk = nk / 4;
+      if (sk >= 2) {
+        int rc = launch_sym<2, 2>(p, hw_shift, st, n_cu, sk);
+        if (rc) return rc;
+        SdmiGemmArgs q = p;
+        q.split_k = sk;
+        const long long total = (long long)p.M * p.N;
+        int blocks = (int)((total + 255) / 256);
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(blocks), dim3(256), 0, st, q, hw_shift);
+        return sdmi_check_launch("igemm splitk epilogue");
+      }
+    }
+  }
   if (p.a2) {       // extra A sources (sdmi.h: a2 / a3): 1x1, or a stride-1 "same" convolution on the fast path
     const int bk = (wide ? 128 : 64) / (int)sizeof(T);
     const long long a2_bytes = (long long)p.M * p.lda2 * (long long)sizeof(T);

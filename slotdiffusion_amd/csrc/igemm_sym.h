@@ -34,7 +34,8 @@ namespace {
 #endif
 
 template <int MODE, int NSTAGE, bool XS = false>
-__global__ __launch_bounds__(512, (NSTAGE == 2 ? 4 : 2)) void igemm_sym_kernel(SdmiGemmArgs p, int tiles_m, int tiles_n, int hw_shift) {
+__global__ __launch_bounds__(512, (NSTAGE == 2 ? 4 : 2)) void igemm_sym_kernel(SdmiGemmArgs p, int tiles_m, int tiles_n, int hw_shift,
+                                                                              int kt_per_split) {
   typedef bf16_t T;
   constexpr int VEC = 8, BK = 64, BM = 128, BN = 128;
   constexpr int STAGE = (BM + BN) * 128;
@@ -52,9 +53,13 @@ __global__ __launch_bounds__(512, (NSTAGE == 2 ? 4 : 2)) void igemm_sym_kernel(S
     n0 = (id - tm * tiles_n) * BN;
   };
   const int my_tiles = ((int)blockIdx.x < nwg) ? (nwg - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
-  const int n_kt = (p.K + BK - 1) / BK;
+  // split-K (grid y = K slice): partial sums to p.workspace, folded by splitk_epilogue_kernel
+  const int nk_total = (p.K + BK - 1) / BK;
+  const int kt_begin = (int)blockIdx.y * kt_per_split;
+  const int kt_end = kt_begin + kt_per_split < nk_total ? kt_begin + kt_per_split : nk_total;
+  const int n_kt = kt_end > kt_begin ? kt_end - kt_begin : 0;
   const int total = my_tiles * n_kt;
-  if (total == 0) return;
+  if (total == 0 && p.split_k <= 1) return;      // (an empty K slice still writes its zero partial)
 
   const int tid = threadIdx.x, l = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -71,7 +76,13 @@ __global__ __launch_bounds__(512, (NSTAGE == 2 ? 4 : 2)) void igemm_sym_kernel(S
   auto begin_tile = [&]() __attribute__((always_inline)) {
     int m0, n0;
     tile_of((int)blockIdx.x + ld_tile * (int)gridDim.x, m0, n0);
-    k0 = 0; ci = 0; kh = 0; kw = 0;
+    k0 = kt_begin * BK; ci = 0; kh = 0; kw = 0;
+    if (MODE == 2) {
+      const int tap = k0 / p.Cin;
+      ci = k0 - tap * p.Cin;
+      kh = tap / p.KW;
+      kw = tap - kh * p.KW;
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int row = (w + 8 * i) * 8 + (l >> 3);
@@ -176,8 +187,10 @@ __global__ __launch_bounds__(512, (NSTAGE == 2 ? 4 : 2)) void igemm_sym_kernel(S
 
   // Steps past the last one re-fetch clamped rows of a non-existent tile into a stage nobody reads any
   // more: the number of DMA groups in flight stays static, so a fixed vmcnt works.
+  if (total > 0) {
 #pragma unroll
-  for (int s = 0; s < NSTAGE - 1; ++s) issue();
+    for (int s = 0; s < NSTAGE - 1; ++s) issue();
+  }
   int stage = 0;
   SYM_TL_DECL
   SYM_TL_LAP(5);                            // prologue: tile setup + first DMA issues
@@ -220,11 +233,11 @@ __global__ __launch_bounds__(512, (NSTAGE == 2 ? 4 : 2)) void igemm_sym_kernel(S
     // `s_waitcnt vmcnt(4)` in front of the fragment reads of EVERY K tile -- a drain of the prefetched stages.
     // The generic path (edge tiles, fp32 out) therefore ends in a compiler-visible vmcnt(0).
     const int mw0 = m0 + wm * 64, nw0 = n0 + wn * 32;
-    if (p.out_dtype == SDMI_BF16 && !p.bias_m && mw0 + 64 <= p.M && nw0 + 32 <= p.N && (!p.rowvec || hw_shift >= 3) &&
+    if (p.split_k <= 1 && p.out_dtype == SDMI_BF16 && !p.bias_m && mw0 + 64 <= p.M && nw0 + 32 <= p.N && (!p.rowvec || hw_shift >= 3) &&
         (long long)p.M * (p.ldc > p.ldr ? p.ldc : p.ldr) < (1ll << 30)) {
       wave_epilogue_fast<2, 1>(p, acc, mw0, nw0, 0, hw_shift, l);
     } else {
-      wave_epilogue<2, 1>(p, acc, mw0, nw0, 0, hw_shift, l, 0);
+      wave_epilogue<2, 1>(p, acc, mw0, nw0, 0, hw_shift, l, (int)blockIdx.y);
       __builtin_amdgcn_s_waitcnt(0x0F70);       // vmcnt(0)
     }
     SYM_TL_LAP(4);
@@ -234,17 +247,18 @@ __global__ __launch_bounds__(512, (NSTAGE == 2 ? 4 : 2)) void igemm_sym_kernel(S
 }
 
 template <int MODE, int NSTAGE, bool XS = false>
-int launch_sym(const SdmiGemmArgs& p, int hw_shift, hipStream_t st, int n_cu) {
+int launch_sym(const SdmiGemmArgs& p, int hw_shift, hipStream_t st, int n_cu, int split_k = 1) {
   constexpr int smem = NSTAGE * 256 * 128;
   auto kern = igemm_sym_kernel<MODE, NSTAGE, XS>;
   SDMI_OPTIN_LDS(kern, smem, "igemm (symmetric waves)");
   SdmiGemmArgs q = p;
-  q.split_k = 1;
+  q.split_k = split_k;
   const int tiles_m = (p.M + 127) / 128, tiles_n = (p.N + 127) / 128;
-  int cap = n_cu * (smem <= 80 * 1024 ? 2 : 1);
+  const int nk = (p.K + 63) / 64, ktps = (nk + split_k - 1) / split_k;
+  int cap = n_cu * (smem <= 80 * 1024 ? 2 : 1) / split_k;
   cap = cap < 8 ? 8 : (cap & ~7);
   const int nwg = tiles_m * tiles_n;
-  hipLaunchKernelGGL(kern, dim3(nwg <= cap ? nwg : cap), dim3(512), smem, st, q, tiles_m, tiles_n, hw_shift);
+  hipLaunchKernelGGL(kern, dim3(nwg <= cap ? nwg : cap, split_k), dim3(512), smem, st, q, tiles_m, tiles_n, hw_shift, ktps);
   return sdmi_check_launch("igemm (symmetric waves)");
 }
 

@@ -65,20 +65,11 @@ struct StGeom {
   static constexpr int Y_BYTES = ROWS * PITCH;
   static constexpr int G_BYTES = ROWS * 256;   // one GEGLU chunk / the cross-attention probabilities
   static constexpr int FREE2 = 160 * 1024 - Y_BYTES - 2 * G_BYTES;     // what two chunk buffers leave for the rings
-#ifdef ST_D
-  static constexpr int D = ST_D;
-#else
   // ring depth in units per wave: as deep as the LDS allows next to two chunk buffers (8 at most), 6 otherwise
   static constexpr int D = FREE2 >= 8 * 8 * ST_UNIT ? 8 : (FREE2 >= 8 * 7 * ST_UNIT ? 7 : 6);
-#endif
   static constexpr int GBUF = (Y_BYTES + 2 * G_BYTES + 8 * D * ST_UNIT <= 160 * 1024) ? 2 : 1;
-#ifdef ST_RING_FIRST
-  static constexpr int RING_OFF = 0;
-  static constexpr int Y_OFF = 8 * D * ST_UNIT;
-#else
   static constexpr int Y_OFF = 0;
   static constexpr int RING_OFF = Y_BYTES + GBUF * G_BYTES;
-#endif
   static constexpr int SMEM_GEMM = Y_BYTES + GBUF * G_BYTES + 8 * D * ST_UNIT;
   // units per wave
   static constexpr int UA = KT * NSL + 3 * KT * NSL;                       // phase A: proj_in, q, k, v
@@ -99,9 +90,6 @@ struct StRing {
   int pos_con;          // ring position of the next unit to consume
   lds_char* ring;       // this wave's ring
   int voff;             // lane * 16
-#ifdef ST_VERIFY
-  const char* sh_ptr; const char* img_ptr; int g_con; unsigned* dbg; int tag;
-#endif
 
   __device__ __forceinline__ void issue_one() {
     int g = g_iss < total ? g_iss : total - 1;          // (steps past the end re-fetch the last unit: static vmcnt)
@@ -199,17 +187,6 @@ __device__ __forceinline__ void st_gemm_step(StRing<D>& rg, const lds_char* act,
       if (pos >= D) pos -= D;
       const bf16x8 a = __builtin_bit_cast(
           bf16x8, *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(rg.ring + pos * ST_UNIT + woff[ks]));
-#ifdef ST_VERIFY
-      {   // the unit as it lies in memory (its image there IS the LDS image) against what the ring holds
-        const int g = rg.g_con + s;
-        const char* src = (g >= rg.n1 && g < rg.n1 + rg.n_img) ? rg.img_ptr + (long long)(g - rg.n1) * ST_UNIT
-                                                               : rg.sh_ptr + (long long)(g >= rg.n1 ? g - rg.n_img : g) * ST_UNIT;
-        const u32x4 ex = *reinterpret_cast<const u32x4*>(src + woff[ks]);
-        const u32x4 got = __builtin_bit_cast(u32x4, a);
-        if (ex.x != got.x || ex.y != got.y || ex.z != got.z || ex.w != got.w)
-          atomicAdd(rg.dbg + (rg.tag * 8 + (threadIdx.x >> 6)), 1u);
-      }
-#endif
 #pragma unroll
       for (int tt = 0; tt < TT; ++tt) acc[s][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[tt], acc[s][tt], 0, 0, 0);
     }
@@ -227,9 +204,6 @@ __device__ __forceinline__ void st_gemm_step(StRing<D>& rg, const lds_char* act,
 #endif
   rg.pos_con += NU;
   if (rg.pos_con >= D) rg.pos_con -= D;
-#ifdef ST_VERIFY
-  rg.g_con += NU;
-#endif
 #pragma unroll
   for (int s = 0; s < NU; ++s) rg.issue_one();
 }
@@ -278,10 +252,6 @@ __global__ __launch_bounds__(512, 2) void st_block_a_kernel(SdmiStBlockArgs p) {
   rg.g_iss = 0; rg.n1 = G::UA; rg.n_img = 0; rg.total = G::UA; rg.pos_iss = 0; rg.pos_con = 0;
   rg.ring = smem + G::RING_OFF + w * D * ST_UNIT;
   rg.voff = lane * 16;
-#ifdef ST_VERIFY
-  rg.sh_ptr = (const char*)p.wstream_a + (long long)w * G::UA * ST_UNIT; rg.img_ptr = rg.sh_ptr; rg.g_con = 0;
-  rg.dbg = (unsigned*)p.vec_img; rg.tag = 0;          // (debug build: vec_img doubles as the mismatch counters)
-#endif
 #pragma unroll
   for (int i = 0; i < D; ++i) rg.issue_one();               // weights in flight under the GroupNorm
   STA_STAMP(0);
@@ -415,9 +385,6 @@ __global__ __launch_bounds__(512, 2) void st_block_a_kernel(SdmiStBlockArgs p) {
   float mean[TT], rstd[TT];
 #pragma unroll 1
   for (int pass = 0; pass < 3; ++pass) {
-#ifdef ST_VERIFY
-    rg.tag = 1 + pass;
-#endif
     const float* colsum = p.vec_a + C + pass * C;
     const float* bias = p.vec_a + 4 * C + pass * C;
 #pragma unroll
@@ -629,11 +596,6 @@ __global__ __launch_bounds__(512, 2) void st_block_b_kernel(SdmiStBlockArgs p) {
   rg.pos_iss = 0; rg.pos_con = 0;
   rg.ring = smem + G::RING_OFF + w * D * ST_UNIT;
   rg.voff = lane * 16;
-#ifdef ST_VERIFY
-  rg.sh_ptr = (const char*)p.wstream_b + (long long)w * (G::UB1 + G::UB2) * ST_UNIT;
-  rg.img_ptr = (const char*)p.wstream_img + ((long long)b * 8 + w) * G::UIMG * ST_UNIT;
-  rg.g_con = 0; rg.dbg = (unsigned*)p.gn_gamma; rg.tag = 0;   // (debug build: gn_gamma doubles as the counters in phase B)
-#endif
 #pragma unroll
   for (int i = 0; i < D; ++i) rg.issue_one();
   {
@@ -727,9 +689,6 @@ __global__ __launch_bounds__(512, 2) void st_block_b_kernel(SdmiStBlockArgs p) {
   // ---- folded slot cross-attention: P = softmax8(LN-fold(x1) Wq[b]^T) ; x2 = P W2[b]^T + bo2 + x1
   {
     f32x4 sc[1][TT];
-#ifdef ST_VERIFY
-    rg.tag = 1;
-#endif
     const int n0 = w * 16 + 4 * lg;                   // column of the padded score matrix
     const f32x4 cs = st_vec4(vi + w * 16, lg);
     const f32x4 bi = st_vec4(vi + 128 + w * 16, lg);
@@ -772,9 +731,6 @@ __global__ __launch_bounds__(512, 2) void st_block_b_kernel(SdmiStBlockArgs p) {
     }
   }
   ST_BARRIER();
-#ifdef ST_VERIFY
-  rg.tag = 2;
-#endif
   zero_acc();
 #pragma unroll
   for (int kt = 0; kt < 2; ++kt) st_gemm_step<D, NSL, false, 0, TT>(rg, Gb, gaddr, kt, 16 * 256, woff, acc, sx, sxx);
@@ -793,9 +749,6 @@ __global__ __launch_bounds__(512, 2) void st_block_b_kernel(SdmiStBlockArgs p) {
   ST_STAMP(4);
   // ---- merged (ff.net.2 ; proj_out): out = [g | x2] [Wpo Wff | Wpo]^T + b' + x.  First the x2 part (also
   //      yields the LayerNorm-fold statistics of x2 for the feed-forward), then the hidden chunks.
-#ifdef ST_VERIFY
-  rg.tag = 3;
-#endif
 #pragma unroll
   for (int tt = 0; tt < TT; ++tt) sx[tt] = sxx[tt] = 0.f;
   zero_acc();
@@ -816,9 +769,6 @@ __global__ __launch_bounds__(512, 2) void st_block_b_kernel(SdmiStBlockArgs p) {
 #pragma unroll
     for (int tt = 0; tt < TT; ++tt) vg[0][tt] = vg[1][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
     ST_TL_LAP(3);
-#ifdef ST_VERIFY
-    rg.tag = 4;
-#endif
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt) st_gemm_step<D, 2, false, 0, TT>(rg, Y, yaddr, kt, 16 * PITCH, woff, vg, sx, sxx);
     ST_TL_LAP(0);
@@ -846,9 +796,6 @@ __global__ __launch_bounds__(512, 2) void st_block_b_kernel(SdmiStBlockArgs p) {
     ST_TL_LAP(1);
     ST_BARRIER();
     ST_TL_LAP(2);
-#ifdef ST_VERIFY
-    rg.tag = 5;
-#endif
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) st_gemm_step<D, NSL, false, 0, TT>(rg, gb, gaddr, kt, 16 * 256, woff, acc, sx, sxx);
   }
