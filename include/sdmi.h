@@ -113,8 +113,22 @@ typedef struct {
    * keeps h for the backward (attention.py:44-48) without a separate GEGLU launch. */
   void* out2;
   int ldc2;
+  /* defer_epilogue != 0: when the launcher splits K (see sdmi_igemm_split_plan), the partials are LEFT in
+   * `workspace` ([splits][M][N] fp32) and nothing is written to `out`: the reduction + bias / rowvec /
+   * residual terms are finished by the next kernel's prologue -- sdmi_groupnorm's `part` source (the
+   * GroupNorm that reads this convolution, unet.py:243-250) -- or by sdmi_splitk_finish.  Requires
+   * act = none, ldc = N, no fused prologue / epilogue forms.  Ignored when K is not split. */
+  int defer_epilogue;
 } SdmiGemmArgs;
 int sdmi_igemm(const SdmiGemmArgs* a, void* stream);
+/* Host-side query, no launch (stream ignored): the number of K slices sdmi_igemm would use for these
+ * arguments (1 = no split-K).  A caller that wants the next kernel to finish the reduction sets
+ * defer_epilogue when this returns > 1. */
+int sdmi_igemm_split_plan(const SdmiGemmArgs* a, void* stream);
+/* Stand-alone second stage of a deferred split-K launch: a->split_k = the slice count the launch used
+ * (sdmi_igemm_split_plan), every other field as passed to sdmi_igemm.  Sums the partials in slice order
+ * and applies alpha / bias / rowvec / residual / act -> out. */
+int sdmi_splitk_finish(const SdmiGemmArgs* a, void* stream);
 
 /* wgrad: dW[n][kh][kw][ci] = sum_m dY[m][n] * A[m][(kh,kw,ci)]  (fp32 output, [N][K] like W).
  * Replaces the weight-gradient half of Conv2d/Linear backward (torch autograd in the reference). */
@@ -210,6 +224,21 @@ typedef struct {
    * unet.py:571-573, without materialising it).  C1 is a multiple of the 16-byte vector. */
   const void* x2;
   int C1;
+  /* optional (bf16): the input is NOT x but the unfinished result of a split-K sdmi_igemm launched with
+   * defer_epilogue -- part [part_splits][B*HW][C] fp32 partial sums; the kernel forms
+   *   in = bf16( sum_k part[k] * part_alpha + part_bias[c] + part_rowvec[b][c] + part_residual[b][hw][c] )
+   * (same order of operations and the same rounding as the GEMM's own split-K epilogue, so results are
+   * bit-identical to the two launches it replaces), stores it at raw_out (the tensor's other readers: skip
+   * branch, UNet concat) and normalises it.  x is not read.  With x2 the partials stand for the FIRST of the two
+   * concatenated tensors ([B*HW][C1]: C1 replaces C in the layouts above). */
+  const float* part;
+  int part_splits;
+  float part_alpha;
+  const float* part_bias;     /* [C] or NULL */
+  const float* part_rowvec;   /* [B][part_ldrv] or NULL */
+  int part_ldrv;
+  const void* part_residual;  /* [B][HW][C] bf16 or NULL */
+  void* raw_out;              /* [B][HW][C] bf16 */
 } SdmiGroupNormArgs;
 int sdmi_groupnorm_stats(const SdmiGroupNormArgs* a, void* stream);
 int sdmi_groupnorm_apply(const SdmiGroupNormArgs* a, void* stream);

@@ -159,9 +159,15 @@ def _meta(fname, kw):
     return {}
 
 
+# ops.py: finishes split-K launches whose second stage was left to the next kernel before any OTHER kernel runs
+pre_call = None
+
+
 def call(fname, stream, **kw):
     """Invoke `fname` with its argument struct filled from keyword args (missing fields = 0).
     `_meta` (optional dict: flops / bytes of the launch) only feeds KernelTimer."""
+    if pre_call is not None:
+        pre_call()
     meta = kw.pop('_meta', None)
     kt = KernelTimer.active
     if kt is not None:

@@ -10,7 +10,9 @@
 // thread with the narrowest workgroup that achieves it, else the fewest vectors per thread.
 // SDMI_GN_T / SDMI_GN_S override (kernel experiments).
 struct GnGeom { int T, S, need; };   // need = vectors per thread the slab takes
-static inline GnGeom gn_pick(int B, int HW, int C, int groups, int vec, int nv_of_T[3]) {
+// min_slab: smallest slab (bytes of 16-byte vectors) a channel chunk may shrink to -- the partials-source form of the
+// forward kernel reads 4 x splits the bytes per element and wants the read spread over more workgroups.
+static inline GnGeom gn_pick(int B, int HW, int C, int groups, int vec, int nv_of_T[3], int min_slab = 8192) {
   static int env_T = -1, env_S = -1;
   if (env_T < 0) {
     const char* e = getenv("SDMI_GN_T");
@@ -28,7 +30,7 @@ static inline GnGeom gn_pick(int B, int HW, int C, int groups, int vec, int nv_o
     if (env_S && env_S != S) continue;
     const int cv = cvt / S;
     if (S > 1 && cv * 16 < 64) break;                          // row segments shorter than 64 B
-    if (S > 1 && (long long)HW * cv * 16 < 8192) break;        // < 8 KB of slab per workgroup
+    if (S > 1 && (long long)HW * cv * 16 < min_slab) break;    // < 8 KB of slab per workgroup
     int cvp = 1;
     while (cvp < cv) cvp <<= 1;
     for (int ti = 0; ti < 3; ++ti) {

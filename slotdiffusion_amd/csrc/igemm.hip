@@ -514,6 +514,14 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(SdmiGemmArgs p, in
   }
 }
 
+static int launch_splitk_epilogue(const SdmiGemmArgs& q, int hw_shift, hipStream_t st) {
+  const long long total = (long long)q.M * q.N;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(blocks), dim3(256), 0, st, q, hw_shift);
+  return sdmi_check_launch("igemm splitk epilogue");
+}
+
 static int device_cus();
 
 template <typename T, int BM, int BN, int BKB, int MODE, int EPI = 0, bool XS = false>
@@ -541,13 +549,7 @@ int launch_cfg(const SdmiGemmArgs& p, int split_k, int hw_shift, hipStream_t st)
   hipLaunchKernelGGL(kern, grid, dim3(512), smem, st, q, tiles_m, tiles_n, ktps, hw_shift);
   int rc = sdmi_check_launch("igemm");
   if (rc) return rc;
-  if (split_k > 1) {
-    const long long total = (long long)p.M * p.N;
-    int blocks = (int)((total + 255) / 256);
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(blocks), dim3(256), 0, st, q, hw_shift);
-    rc = sdmi_check_launch("igemm splitk epilogue");
-  }
+  if (split_k > 1 && !p.defer_epilogue) rc = launch_splitk_epilogue(q, hw_shift, st);
   return rc;
 }
 
@@ -586,13 +588,7 @@ int launch_dma(const SdmiGemmArgs& p, int hw_shift, hipStream_t st, int split_k 
   hipLaunchKernelGGL(kern, grid, dim3(threads), smem, st, q, tiles_m, tiles_n, ktps, hw_shift);
   int rc = sdmi_check_launch("igemm (lds-dma)");
   if (rc) return rc;
-  if (split_k > 1) {
-    const long long total = (long long)p.M * p.N;
-    int blocks = (int)((total + 255) / 256);
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(blocks), dim3(256), 0, st, q, hw_shift);
-    rc = sdmi_check_launch("igemm splitk epilogue");
-  }
+  if (split_k > 1 && !p.defer_epilogue) rc = launch_splitk_epilogue(q, hw_shift, st);
   return rc;
 }
 
@@ -618,8 +614,9 @@ static int sym_stages() {
   return v;
 }
 
+// plan_only: return the K split the launch would use (sdmi_igemm_split_plan), no launch
 template <typename T>
-int dispatch(const SdmiGemmArgs& p, hipStream_t st) {
+int dispatch(const SdmiGemmArgs& p, hipStream_t st, bool plan_only = false) {
   constexpr int VEC = 16 / sizeof(T);
   const bool is1x1 = p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad_t == 0 && p.pad_l == 0 &&
                      !p.ups && p.zins <= 1;
@@ -679,6 +676,7 @@ int dispatch(const SdmiGemmArgs& p, hipStream_t st) {
     while (t64 * split_k < sk_target && split_k * 2 <= nk / 4 && split_k < 16) split_k *= 2;
   }
   if (split_k > 1 && !p.workspace) split_k = 1;
+  if (plan_only) return split_k;
   const bool plain = !is1x1 && !p.ups && p.zins <= 1;
   // direct 3x3 kernel for the 64 -> 64 channel convolutions at full resolution
   if (sizeof(T) == 2 && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad_t == 1 && p.pad_l == 1 &&
@@ -741,7 +739,7 @@ int dispatch(const SdmiGemmArgs& p, hipStream_t st) {
       const char* e = getenv("SDMI_IGEMM_SYM_SPLIT");
       sym_split = e ? atoi(e) : 0;
     }
-    if (sym_split && shape == T64x64 && !is1x1 && plain && !p.a2 && p.split_k == 0 && p.workspace && batch == 1 && p.osy == 0 &&
+    if (sym_split && !p.defer_epilogue && shape == T64x64 && !is1x1 && plain && !p.a2 && p.split_k == 0 && p.workspace && batch == 1 && p.osy == 0 &&
         fits31 && p.KH * p.KW <= 32 && p.Cin % 64 == 0 && kbytes >= 2048 && p.N > 64 && p.M >= 512 && !p.ln_colsum && !p.geglu &&
         !p.softmax8 && !p.out2) {
       const int n_cu = device_cus();
@@ -935,7 +933,27 @@ extern "C" int sdmi_igemm(const SdmiGemmArgs* a, void* stream) {
   SDMI_REQUIRE(a->osy == 0 || !a->residual || a->ldr == a->ldc,
                "sub-sampled output: the residual shares the output's layout");
   SDMI_REQUIRE(a->osy == 0 || (!a->rowvec && !a->act && !a->bias_m), "sub-sampled output: plain epilogue only");
+  SDMI_REQUIRE(!a->defer_epilogue || (a->workspace && !a->act && a->ldc == a->N && !a->bias_m && !a->ln_colsum &&
+                                      !a->geglu && !a->softmax8 && !a->out2 && a->osy == 0 && !(a->batch > 1)),
+               "defer_epilogue: plain epilogue (alpha / bias / rowvec / residual), ldc = N, workspace required");
   hipStream_t st = (hipStream_t)stream;
   if (a->dtype == SDMI_FP8) return dispatch<fp8_t>(*a, st);
   return a->dtype == SDMI_BF16 ? dispatch<bf16_t>(*a, st) : dispatch<float>(*a, st);
+}
+
+extern "C" int sdmi_igemm_split_plan(const SdmiGemmArgs* a, void*) {
+  if (!a || a->M <= 0 || a->N <= 0 || a->K <= 0) return 1;
+  if (a->dtype == SDMI_FP8) return dispatch<fp8_t>(*a, nullptr, true);
+  return a->dtype == SDMI_BF16 ? dispatch<bf16_t>(*a, nullptr, true) : dispatch<float>(*a, nullptr, true);
+}
+
+extern "C" int sdmi_splitk_finish(const SdmiGemmArgs* a, void* stream) {
+  SDMI_REQUIRE(a && a->workspace && a->out && a->split_k > 1 && a->M > 0 && a->N > 0, "bad args");
+  int hw_shift = -1;
+  const int hw = a->Ho * a->Wo;
+  if (hw > 0 && (hw & (hw - 1)) == 0) {
+    hw_shift = 0;
+    while ((1 << hw_shift) < hw) ++hw_shift;
+  }
+  return launch_splitk_epilogue(*a, hw_shift, (hipStream_t)stream);
 }

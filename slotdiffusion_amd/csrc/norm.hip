@@ -319,7 +319,9 @@ __global__ __launch_bounds__(THREADS) void gn_fused_kernel(SdmiGroupNormArgs p) 
 //     barrier, no single-thread fp64 division + sqrt on the critical path (v_rsq_f64 + one Newton step);
 //   * lane coordinates by shifts (CVp is a power of two), gamma / beta as 16-byte loads, the activation
 //     hoisted out of the element loop, SiLU through v_rcp_f32 (common.h).
-template <typename T, int THREADS, int NV, bool F8 = false>
+//   * PART (bf16): the slab is not read from x but formed from the split-K partials of the GEMM in front
+//     (sdmi.h: part) -- the launch-boundary reduce: the second stage of that GEMM costs no launch of its own.
+template <typename T, int THREADS, int NV, bool F8 = false, bool PART = false>
 __global__ __launch_bounds__(THREADS) void gn_fused2_kernel(SdmiGroupNormArgs p) {
   constexpr int VEC = Elem<T>::VEC;
   constexpr int VSH = VEC == 8 ? 3 : 2;
@@ -349,10 +351,57 @@ __global__ __launch_bounds__(THREADS) void gn_fused2_kernel(SdmiGroupNormArgs p)
   int xp;
   const T* xb = gn_src<T>(p, b, c_lo + cl0, xp);
   uint4 xr[NV];
+  if constexpr (PART) {
+    // in = bf16(sum_k part[k] * alpha + bias + rowvec + residual): igemm.hip's splitk_epilogue_kernel, same order
+    // (two-source input: the partials are the FIRST tensor, [B][HW][C1]; a vector never straddles C1)
+    static_assert(VEC == 8, "partials source: bf16 storage");
+    const int pc = p.x2 ? p.C1 : p.C;
+    const bool from_p = c_lo + cl0 < pc;
+    const long long total = (long long)p.B * p.HW * pc;
+    float eb[VEC], er[VEC];
 #pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    const int row = r0 + i * R;
-    if (act_c && row < p.HW) xr[i] = *reinterpret_cast<const uint4*>(xb + (long long)row * xp);
+    for (int j = 0; j < VEC; ++j) eb[j] = er[j] = 0.f;
+    if (from_p && p.part_bias) load_fvec<VEC>(p.part_bias + c_lo + cl0, eb);
+    if (from_p && p.part_rowvec) load_fvec<VEC>(p.part_rowvec + (long long)b * p.part_ldrv + c_lo + cl0, er);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int row = r0 + i * R;
+      if (act_c && row < p.HW && !from_p) xr[i] = *reinterpret_cast<const uint4*>(xb + (long long)row * xp);
+      if (act_c && row < p.HW && from_p) {
+        const long long e = ((long long)b * p.HW + row) * pc + c_lo + cl0;
+        const float* pp = p.part + e;
+        float v[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) v[j] = 0.f;
+#pragma unroll 4
+        for (int k = 0; k < p.part_splits; ++k) {
+          const float4 lo = *reinterpret_cast<const float4*>(pp + (long long)k * total);
+          const float4 hi = *reinterpret_cast<const float4*>(pp + (long long)k * total + 4);
+          v[0] += lo.x; v[1] += lo.y; v[2] += lo.z; v[3] += lo.w;
+          v[4] += hi.x; v[5] += hi.y; v[6] += hi.z; v[7] += hi.w;
+        }
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          v[j] *= p.part_alpha;
+          if (p.part_bias) v[j] += eb[j];
+          if (p.part_rowvec) v[j] += er[j];
+        }
+        if (p.part_residual) {
+          float rr[VEC];
+          unpack16<T>(*reinterpret_cast<const uint4*>((const T*)p.part_residual + e), rr);
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) v[j] += rr[j];
+        }
+        xr[i] = pack16<T>(v);
+        *reinterpret_cast<uint4*>((T*)p.raw_out + e) = xr[i];
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int row = r0 + i * R;
+      if (act_c && row < p.HW) xr[i] = *reinterpret_cast<const uint4*>(xb + (long long)row * xp);
+    }
   }
   float gam[VEC], bet[VEC];                               // fetched next to the slab (one latency chain)
   load_fvec<VEC>(p.gamma + c_lo + cl0, gam);
@@ -666,10 +715,77 @@ extern "C" int sdmi_groupnorm_apply(const SdmiGroupNormArgs* a, void* stream) {
   return sdmi_check_launch("groupnorm_apply");
 }
 
+// Partials source without a single-pass kernel behind it (shape / fp8 output): the reduction as its own launch,
+// the norm then reads raw_out.  Same arithmetic as the fused form.
+__global__ __launch_bounds__(256) void gn_part_reduce_kernel(SdmiGroupNormArgs p) {
+  const int pc = p.x2 ? p.C1 : p.C;
+  const long long total = (long long)p.B * p.HW * pc;
+  const long long nvec = total / 8;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long long)gridDim.x * 256) {
+    const long long e = i * 8;
+    const int c = (int)(e % pc);
+    const int b = (int)(e / ((long long)p.HW * pc));
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = 0.f;
+    for (int k = 0; k < p.part_splits; ++k) {
+      const float4 lo = *reinterpret_cast<const float4*>(p.part + (long long)k * total + e);
+      const float4 hi = *reinterpret_cast<const float4*>(p.part + (long long)k * total + e + 4);
+      v[0] += lo.x; v[1] += lo.y; v[2] += lo.z; v[3] += lo.w;
+      v[4] += hi.x; v[5] += hi.y; v[6] += hi.z; v[7] += hi.w;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      v[j] *= p.part_alpha;
+      if (p.part_bias) v[j] += p.part_bias[c + j];
+      if (p.part_rowvec) v[j] += p.part_rowvec[(long long)b * p.part_ldrv + c + j];
+    }
+    if (p.part_residual) {
+      float rr[8];
+      unpack16<bf16_t>(*reinterpret_cast<const uint4*>((const bf16_t*)p.part_residual + e), rr);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] += rr[j];
+    }
+    *reinterpret_cast<uint4*>((bf16_t*)p.raw_out + e) = pack16<bf16_t>(v);
+  }
+}
+
+static constexpr int GN_PART_MIN_SLAB = 2048;
+
+static bool gn_v2_enabled() {
+  static int v2 = -1;
+  if (v2 < 0) {
+    const char* e = getenv("SDMI_GN_V2");
+    v2 = e ? atoi(e) : 1;
+  }
+  return v2 != 0;
+}
+
 extern "C" int sdmi_groupnorm(const SdmiGroupNormArgs* a, void* stream) {
   int rc = gn_validate(a);
   if (rc) return rc;
   SDMI_REQUIRE(a->y || a->y8, "null output");
+  SdmiGroupNormArgs loc;
+  if (a->part) {
+    SDMI_REQUIRE(a->dtype == SDMI_BF16 && a->part_splits > 1 && a->raw_out && a->raw_out != a->y &&
+                     ((uintptr_t)a->part & 15) == 0,
+                 "partials source: bf16, raw_out required");
+    int nv_of_T[3] = {16, 16, 16};
+    const GnGeom gg = gn_pick(a->B, a->HW, a->C, a->groups, 8, nv_of_T, GN_PART_MIN_SLAB);
+    const int cpg = a->C / a->groups;
+    if (a->y8 || !gg.T || !gn_v2_enabled() || !(cpg * 2 == 8 || cpg >= 7)) {
+      const long long nvec = (long long)a->B * a->HW * (a->x2 ? a->C1 : a->C) / 8;
+      int blocks = (int)((nvec + 255) / 256);
+      if (blocks > 2048) blocks = 2048;
+      hipLaunchKernelGGL(gn_part_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *a);
+      rc = sdmi_check_launch("groupnorm (partials reduce)");
+      if (rc) return rc;
+      loc = *a;
+      loc.part = nullptr;
+      loc.x = a->raw_out;
+      a = &loc;
+    }
+  }
   SDMI_REQUIRE(!a->y8 || a->dtype == SDMI_BF16, "fp8 output: bf16 input only");
   SDMI_REQUIRE(!a->x2 || (a->C1 > 0 && a->C1 < a->C && a->C1 % (a->dtype == SDMI_BF16 ? 8 : 4) == 0 &&
                           (a->C - a->C1) % (a->dtype == SDMI_BF16 ? 8 : 4) == 0 && a->y != a->x),
@@ -678,7 +794,7 @@ extern "C" int sdmi_groupnorm(const SdmiGroupNormArgs* a, void* stream) {
   // single-pass kernel when the image (or a whole-group channel chunk of it) fits a workgroup's registers
   {
     int nv_of_T[3] = {16, 16, 16};
-    const GnGeom gg = gn_pick(a->B, a->HW, a->C, a->groups, vec, nv_of_T);
+    const GnGeom gg = gn_pick(a->B, a->HW, a->C, a->groups, vec, nv_of_T, a->part ? GN_PART_MIN_SLAB : 8192);
     if (gg.T) {
       hipStream_t st = (hipStream_t)stream;
       dim3 grid(a->B, gg.S);
@@ -688,17 +804,15 @@ extern "C" int sdmi_groupnorm(const SdmiGroupNormArgs* a, void* stream) {
       const int RR = cvp < 64 ? gg.T / 64 : gg.T / cvp;
       const size_t smem = ((size_t)RR * cvp * vec * 2 + 2 * 128) * sizeof(float);
       // second form (two group slots per lane): a 16-byte vector must span at most two groups
-      static int v2 = -1;
-      if (v2 < 0) {
-        const char* e = getenv("SDMI_GN_V2");
-        v2 = e ? atoi(e) : 1;
-      }
       const int cpg = a->C / a->groups;
-      const bool two = v2 && (cpg * 2 == vec || cpg >= vec - 1);
+      const bool two = gn_v2_enabled() && (cpg * 2 == vec || cpg >= vec - 1);
+      const bool from_part = a->part != nullptr;          // (validated above: implies the second form, bf16, no fp8)
       const size_t smem2 = (size_t)RR * cvp * (vec == 4 ? 32 : 16) + (size_t)cvp * 32;
 #define GN_GO3(T_, TH, NV_, F8_)                                                                   \
   do {                                                                                             \
-    if (two) {                                                                                     \
+    if (two && from_part) {                                                                        \
+      hipLaunchKernelGGL((gn_fused2_kernel<T_, TH, NV_, F8_, sizeof(T_) == 2 && !F8_>), grid, dim3(TH), smem2, st, *a); \
+    } else if (two) {                                                                              \
       hipLaunchKernelGGL((gn_fused2_kernel<T_, TH, NV_, F8_>), grid, dim3(TH), smem2, st, *a);     \
     } else {                                                                                       \
       SDMI_OPTIN_LDS((gn_fused_kernel<T_, TH, NV_, F8_>), 80 * 1024, "groupnorm");                 \

@@ -6,9 +6,13 @@ kernel calls instead of nn.Module graphs.  `K` is a kernel provider (kern.Kern f
 kern.KernGrad for training -- same program, autograd-recording kernels).  Reference call sites
 are cited per function.
 """
+import os
+
 import torch
 
 from . import ops, spec
+
+_DEFER_SPLITK = os.environ.get('SDMI_DEFER_SPLITK', '1') != '0'
 
 
 # ------------------------------------------------------------------------------------------
@@ -247,6 +251,13 @@ class UNetRunner:
 
     def forward(self, K, x, rowvecs, ctx_kv):
         """x [B,h,w,Cpad] compute dtype -> eps [B,h,w,4] fp32 (3 channels + zero pad)."""
+        if not K.training and _DEFER_SPLITK:
+            # inference: a split-K convolution leaves its second stage to the GroupNorm behind it (ops.defer_splitk)
+            with ops.defer_splitk():
+                return self._forward(K, x, rowvecs, ctx_kv)
+        return self._forward(K, x, rowvecs, ctx_kv)
+
+    def _forward(self, K, x, rowvecs, ctx_kv):
         names = [n for n, _ in self.res_names]
         rowvecs = dict(zip(names, K.rowvec_slices(rowvecs, [self.emb_off[n] for n in names])))
         hs = []

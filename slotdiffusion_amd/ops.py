@@ -60,6 +60,54 @@ def splitk_workspace(M, N, K, elt, device):
     return None
 
 
+# Deferred split-K second stages (inference; sdmi.h: defer_epilogue).  Inside `defer_splitk()` a convolution whose
+# launch splits K leaves its partials in the workspace; if the very next kernel is the GroupNorm that reads the result
+# (unet.py:243-250: conv -> GroupNorm32 -> SiLU), that kernel's prologue finishes the reduction (sdmi_groupnorm: part)
+# and also stores the tensor for its other readers.  ANY other launch first finishes what is pending (`_lib.pre_call`),
+# so a pending tensor is never read unfinished; results are bit-identical either way.
+class _PendingSplit:
+    __slots__ = ('out', 'kw', 'splits', 'keep')
+
+    def __init__(self, out, kw, splits, keep):
+        self.out, self.kw, self.splits, self.keep = out, kw, splits, keep
+
+
+_PENDING = {}            # out.data_ptr() -> _PendingSplit
+_DEFER = [0]
+
+
+def _finish_split(p):
+    kw = dict(p.kw)
+    kw['split_k'] = p.splits
+    call('sdmi_splitk_finish', _stream(), **kw)
+
+
+def flush_pending():
+    while _PENDING:
+        _, p = _PENDING.popitem()
+        _finish_split(p)
+
+
+class defer_splitk:
+    """Context: split-K convolutions may leave their second stage to the GroupNorm behind them."""
+
+    def __enter__(self):
+        _DEFER[0] += 1
+        _lib.pre_call = _pre_call
+        return self
+
+    def __exit__(self, *a):
+        _DEFER[0] -= 1
+        flush_pending()
+        if _DEFER[0] == 0:
+            _lib.pre_call = None
+
+
+def _pre_call():
+    if _PENDING:
+        flush_pending()
+
+
 def quant_fp8(x, scale, out=None):
     """Per-tensor e4m3fn quantisation of a contiguous [..., C] tensor (C % 16 == 0): uint8 bytes of
     clamp(x * scale, +-448).  Operands of the SDMI_FP8 igemm path."""
@@ -107,16 +155,25 @@ def conv2d(x, w, bias=None, *, kh=3, kw=3, stride=1, pad=(1, 1, 1, 1), ups=False
     if x.dtype == torch.uint8:
         assert out_dtype is not None and w.dtype == torch.uint8
     ws = splitk_workspace(M, N, K, x.element_size(), x.device) if split_k != 1 else None
-    call('sdmi_igemm', _stream(), a=_p(x), w=_p(w), out=_p(out), bias=_p(bias), rowvec=_p(rowvec),
-         residual=_p(residual), workspace=_p(ws), dtype=_dt(x), out_dtype=_DT[odt], M=M, N=N, K=K,
-         lda=C1, ldw=K, ldc=ldc, ldr=(residual.shape[-1] if residual is not None else 0),
-         a2=_p(x2), lda2=(x2.shape[-1] if x2 is not None else 0), K1=(kh * kw * C1 if x2 is not None else 0),
-         a3=_p(x3), lda3=(x3.shape[-1] if x3 is not None else 0),
-         K2=(kh * kw * C1 + x2.shape[-1] if x3 is not None else 0),
-         B=B, H=H, W=W, Cin=Cin, Ho=Ho, Wo=Wo, KH=kh, KW=kw, stride=stride, pad_t=pad[0],
-         pad_l=pad[2], ups=int(ups), act=ACT[act], alpha=float(alpha), bias_m=0,
-         ldrv=(rowvec.stride(0) if rowvec is not None else 0),
-         split_k=(split_k if ws is not None or split_k == 1 else 1), batch=1)
+    kwargs = dict(
+        a=_p(x), w=_p(w), out=_p(out), bias=_p(bias), rowvec=_p(rowvec),
+        residual=_p(residual), workspace=_p(ws), dtype=_dt(x), out_dtype=_DT[odt], M=M, N=N, K=K,
+        lda=C1, ldw=K, ldc=ldc, ldr=(residual.shape[-1] if residual is not None else 0),
+        a2=_p(x2), lda2=(x2.shape[-1] if x2 is not None else 0), K1=(kh * kw * C1 if x2 is not None else 0),
+        a3=_p(x3), lda3=(x3.shape[-1] if x3 is not None else 0),
+        K2=(kh * kw * C1 + x2.shape[-1] if x3 is not None else 0),
+        B=B, H=H, W=W, Cin=Cin, Ho=Ho, Wo=Wo, KH=kh, KW=kw, stride=stride, pad_t=pad[0],
+        pad_l=pad[2], ups=int(ups), act=ACT[act], alpha=float(alpha), bias_m=0,
+        ldrv=(rowvec.stride(0) if rowvec is not None else 0),
+        split_k=(split_k if ws is not None or split_k == 1 else 1), batch=1)
+    if _DEFER[0] and ws is not None and split_k == 0 and act is None and ldc == N and N > 64 and N % 8 == 0 and \
+            odt == torch.bfloat16 and (residual is None or (residual.is_contiguous() and residual.shape[-1] == N)):
+        splits = _lib.query('sdmi_igemm_split_plan', **kwargs)
+        if splits > 1:
+            call('sdmi_igemm', _stream(), defer_epilogue=1, **kwargs)
+            _PENDING[out.data_ptr()] = _PendingSplit(out, kwargs, splits, (ws, bias, rowvec, residual, float(alpha)))
+            return out
+    call('sdmi_igemm', _stream(), **kwargs)
     return out
 
 
@@ -225,6 +282,15 @@ def group_norm(x, gamma, beta, *, eps, act=None, groups=32, residual=None, out=N
         kw = dict(y=_p(out))
     if x2 is not None:
         kw.update(x2=_p(x2), C1=C1)
+    pend = _PENDING.pop(x.data_ptr(), None) if _PENDING else None
+    if pend is not None:
+        if not x.is_contiguous() or x.dtype != torch.bfloat16 or pend.out.numel() != x.numel():
+            _finish_split(pend)               # (not a form the norm's prologue takes: the stand-alone second stage)
+        else:                                 # this launch finishes the split-K reduction of its input
+            ws, pb, prv, pres, palpha = pend.keep
+            kw.update(part=_p(ws), part_splits=pend.splits, part_alpha=palpha, part_bias=_p(pb),
+                      part_rowvec=_p(prv), part_ldrv=(prv.stride(0) if prv is not None else 0),
+                      part_residual=_p(pres), raw_out=_p(x))
     kw.update(x=_p(x), gamma=_p(gamma), beta=_p(beta), stats=_p(stats),
               partial=_p(partial), dtype=_dt(x), B=B, HW=HW, C=C, groups=groups, eps=eps,
               act=ACT[act], nsplit=nsplit, residual=_p(residual))
