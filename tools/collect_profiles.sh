@@ -29,6 +29,7 @@ cp $O/coco/coco_kernel_stats.csv $O/${TAG}_coco224_sample_b16_fp8_kernel_stats.c
 cp $O/train/train_kernel_stats.csv $O/${TAG}_train_b64_bf16_kernel_stats.csv 2>/dev/null
 cp $O/sample/sample_kernel_stats.csv $O/${TAG}_sample_b64_bf16_kernel_stats.csv 2>/dev/null
 python tools/trace_step.py $O/train/train_kernel_trace.csv 60 > $O/${TAG}_train_step_breakdown.txt 2>&1
+python tools/trace_eval.py $O/sample/sample_kernel_trace.csv > $O/${TAG}_sample_eval_launches.txt 2>&1
 for mode in train sample; do
   python tools/pmc_summary.py "$O/pmc_${mode}_*/**/*counter_collection.csv" > $O/${TAG}_${mode}_pmc_by_kernel.csv 2>&1
 done
