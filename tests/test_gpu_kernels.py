@@ -459,6 +459,25 @@ def test_vq_nearest_bit_exact():
     _, idx_ref = O.vq_quantize(W, zt, 'p')
     idx, _ = ops.vq_nearest(F.pad(zt.permute(0, 2, 3, 1), (0, 1)).contiguous().to(DEV), cb.to(DEV))
     assert torch.equal(idx.cpu(), idx_ref)
+    # ragged codebooks (the kernel scans pairs of codes in chunks of 64: pads must never win) and exact
+    # duplicates (ties -> the FIRST index, also across chunk and half-scan boundaries)
+    for n in (1, 2, 5, 63, 64, 65, 130, 1000, 4095):
+        cbn = cb[:n].contiguous()
+        zq_ref, idx_ref = O.vq_quantize({'p.quantize.embedding.weight': cbn}, z[:1], 'p')
+        idx, zq = ops.vq_nearest(zp[:1].contiguous(), cbn.to(DEV))
+        assert torch.equal(idx.cpu(), idx_ref), n
+        assert torch.equal(zq.cpu()[..., :3], zq_ref.permute(0, 2, 3, 1)), n
+    # few latents: the LDS-scan kernel (the codes-in-registers kernel serves >= 512 latents)
+    zs_ = z[:1, :, :8, :8].contiguous()
+    for n in (5, 130, 4096):
+        cbn = cb[:n].contiguous()
+        _, idx_ref = O.vq_quantize({'p.quantize.embedding.weight': cbn}, zs_, 'p')
+        idx, _ = ops.vq_nearest(F.pad(zs_.permute(0, 2, 3, 1), (0, 1)).contiguous().to(DEV), cbn.to(DEV))
+        assert torch.equal(idx.cpu(), idx_ref), n
+    dup = torch.cat([cb[:70], cb[:70], cb[:2000], cb[:70]])
+    _, idx_ref = O.vq_quantize({'p.quantize.embedding.weight': dup}, z[:2], 'p')
+    idx, _ = ops.vq_nearest(zp[:2].contiguous(), dup.to(DEV))
+    assert torch.equal(idx.cpu(), idx_ref) and int(idx.max()) < 2140
 
 
 def test_elementwise_family():
