@@ -707,7 +707,7 @@ int dispatch(const SdmiGemmArgs& p, hipStream_t st, bool plan_only = false) {
     int sym = sym_stages();
     if (sym < 0) sym = t128 >= 2 * device_cus() ? 2 : 0;
     const int bk = 64;
-    bool ok = sym && shape == T128x128 && wide && split_k == 1 && batch == 1 && p.osy == 0 && fits31 && !p.ln_colsum &&
+    bool ok = sym && shape == T128x128 && wide && split_k == 1 && batch == 1 && fits31 && !p.ln_colsum &&
               !p.geglu && !p.softmax8 && !p.out2 && (is1x1 || (plain && p.KH * p.KW <= 32 && p.Cin % bk == 0));
     if (ok && p.a2) {
       const long long a2_bytes = (long long)p.M * p.lda2 * 2, a3_bytes = p.a3 ? (long long)p.M * p.lda3 * 2 : 0;
@@ -887,7 +887,7 @@ int dispatch(const SdmiGemmArgs& p, hipStream_t st, bool plan_only = false) {
     // 4^2 levels' convolutions 12 - 17 % faster in dependent chains (29.0 -> 24.3 us 384 -> 384 @8^2, 50.6 -> 41.9
     // 768 -> 384), sampling pass 94.7 -> 92.9 ms, train step 29.58 -> 29.33 ms (same-box A/B, twice each).
     const int dma64 = dma64_min();
-    if (dma64 && shape == T64x64 && !p.a2 && kbytes >= dma64 && fits31 && p.osy == 0 && batch == 1) {
+    if (dma64 && shape == T64x64 && !p.a2 && kbytes >= dma64 && fits31 && batch == 1) {
       if (is1x1) return launch_dma<T, 64, 64, 4, 1, 4>(p, hw_shift, st, split_k);
       if (plain && p.KH * p.KW <= 32 && p.Cin % 64 == 0) return launch_dma<T, 64, 64, 4, 2, 4>(p, hw_shift, st, split_k);
     }

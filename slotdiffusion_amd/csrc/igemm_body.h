@@ -29,6 +29,14 @@ __device__ __forceinline__ void wave_epilogue_fast(const SdmiGemmArgs& p, f32x16
   const int col_l = lane & 31, row_l = (lane >> 5) * 4;
   const int mwu = __builtin_amdgcn_readfirstlane(mw0);          // wave-uniform by construction
   const unsigned ldc2 = (unsigned)p.ldc * 2u, ldr2 = (unsigned)p.ldr * 2u;
+  // Sub-sampled placement (sdmi.h: osy; epilogue_fast_ok admits Ho * Wo = 2^k with Wo = 4 or a power of two >= 8):
+  // rows 8g .. 8g+7 of a tile are eight consecutive pixels of one output row -- or two rows of four -- so a row's
+  // offset is still (wave-uniform pixel of row 8g) + (r & 3) pixel steps, and the half-waves sit four pixel steps
+  // (or one row step) apart.  The residual shares the output's layout (ldr = ldc).
+  const bool sub = p.osy > 0;
+  const unsigned step2 = sub ? (unsigned)p.osx * ldc2 : ldc2;                      // bytes between rows m, m + 1
+  const unsigned half2 = sub ? (p.Wo >= 8 ? 4u * (unsigned)p.osx : (unsigned)(p.osy * p.oW)) * ldc2 : 4u * ldc2;
+  const int wo_shift = sub ? 31 - __builtin_clz((unsigned)p.Wo) : 0;
   bf16_t* ob = (bf16_t*)p.out + (long long)zb * p.sc;
   const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc((void*)ob, 0, 0x7fffffff, 0x00020000);
   const bool has_res = p.residual != nullptr;
@@ -37,6 +45,18 @@ __device__ __forceinline__ void wave_epilogue_fast(const SdmiGemmArgs& p, f32x16
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const int mrow = mwu + i * 32;                               // uniform: first row of this row tile
+    unsigned g2[4];                                              // byte offset of row mrow + 8g (uniform)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      if (sub) {
+        const int m8 = mrow + 8 * g;
+        const int b = m8 >> hw_shift, rem = m8 & ((1 << hw_shift) - 1);
+        const int oy = rem >> wo_shift, ox = rem & (p.Wo - 1);
+        g2[g] = (unsigned)((b * p.oH + oy * p.osy + p.ooy) * p.oW + ox * p.osx + p.oox) * ldc2;
+      } else {
+        g2[g] = (unsigned)(mrow + 8 * g) * ldc2;
+      }
+    }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int n = nw0 + j * 32 + col_l;
@@ -55,13 +75,15 @@ __device__ __forceinline__ void wave_epilogue_fast(const SdmiGemmArgs& p, f32x16
 #pragma unroll
         for (int r = 0; r < 16; ++r) add[r] = bn;
       }
-      const int vo_c = (int)((unsigned)row_l * ldc2 + (unsigned)n * 2u);        // lane part of the offsets
+      const int vo_c = (int)((unsigned)(row_l >> 2) * half2 + (unsigned)n * 2u);   // lane part of the offsets
       if (has_res) {
-        const int vo_r = (int)((unsigned)row_l * ldr2 + (unsigned)n * 2u);
+        const int vo_r = sub ? vo_c : (int)((unsigned)row_l * ldr2 + (unsigned)n * 2u);
         unsigned short rr[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-          rr[r] = __builtin_amdgcn_raw_buffer_load_b16(rsR, vo_r, (int)((unsigned)(mrow + (r & 3) + 8 * (r >> 2)) * ldr2), 0);
+          rr[r] = __builtin_amdgcn_raw_buffer_load_b16(
+              rsR, vo_r, sub ? (int)(g2[r >> 2] + (unsigned)(r & 3) * step2)
+                             : (int)((unsigned)(mrow + (r & 3) + 8 * (r >> 2)) * ldr2), 0);
 #pragma unroll
         for (int r = 0; r < 16; ++r) add[r] += bf16_to_f32(rr[r]);
       }
@@ -82,12 +104,25 @@ __device__ __forceinline__ void wave_epilogue_fast(const SdmiGemmArgs& p, f32x16
       for (int r = 0; r < 16; r += 2) {
         const uint32_t pk = f32x2_to_bf16x2(v[r], v[r + 1]);
         __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(pk & 0xffffu), rsO, vo_c,
-                                              (int)((unsigned)(mrow + (r & 3) + 8 * (r >> 2)) * ldc2), 0);
+                                              (int)(g2[r >> 2] + (unsigned)(r & 3) * step2), 0);
         __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(pk >> 16), rsO, vo_c,
-                                              (int)((unsigned)(mrow + ((r + 1) & 3) + 8 * ((r + 1) >> 2)) * ldc2), 0);
+                                              (int)(g2[(r + 1) >> 2] + (unsigned)((r + 1) & 3) * step2), 0);
       }
     }
   }
+}
+
+// The streamlined epilogue serves: interior blocks, bf16 out, offsets within 31 bits; plain placement, or a
+// sub-sampled one whose 8-row groups are whole pixel runs (see wave_epilogue_fast).
+template <int TM, int TN>
+__device__ __forceinline__ bool epilogue_fast_ok(const SdmiGemmArgs& p, int mw0, int nw0, int hw_shift) {
+  if (!(p.split_k <= 1 && p.out_dtype == SDMI_BF16 && !p.bias_m && mw0 + TM * 32 <= p.M && nw0 + TN * 32 <= p.N &&
+        (!p.rowvec || hw_shift >= 3)))
+    return false;
+  if (p.osy > 0)
+    return hw_shift >= 3 && (p.Wo & (p.Wo - 1)) == 0 && p.Wo >= 4 && (!p.residual || p.ldr == p.ldc) &&
+           (long long)p.B * p.oH * p.oW * p.ldc < (1ll << 30);
+  return (long long)p.M * (p.ldc > p.ldr ? p.ldc : p.ldr) < (1ll << 30);
 }
 
 // Epilogue of one MFMA wave's (TM*32)x(TN*32) accumulator block whose top-left output element is
@@ -99,9 +134,7 @@ __device__ __forceinline__ void wave_epilogue(const SdmiGemmArgs& p, f32x16 (&ac
   // ---- epilogue. C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
   // the common case takes the streamlined path: plain placement, bf16 out, the whole wave block inside
   // the output, row offsets within 31 bits
-  if (p.split_k <= 1 && p.osy == 0 && p.out_dtype == SDMI_BF16 && !p.bias_m && mw0 + TM * 32 <= p.M &&
-      nw0 + TN * 32 <= p.N && (!p.rowvec || hw_shift >= 3) &&
-      (long long)p.M * (p.ldc > p.ldr ? p.ldc : p.ldr) < (1ll << 30)) {
+  if (epilogue_fast_ok<TM, TN>(p, mw0, nw0, hw_shift)) {
     wave_epilogue_fast<TM, TN>(p, acc, mw0, nw0, zb, hw_shift, lane);
     return;
   }

@@ -233,8 +233,7 @@ __global__ __launch_bounds__(512, (NSTAGE == 2 ? 4 : 2)) void igemm_sym_kernel(S
     // `s_waitcnt vmcnt(4)` in front of the fragment reads of EVERY K tile -- a drain of the prefetched stages.
     // The generic path (edge tiles, fp32 out) therefore ends in a compiler-visible vmcnt(0).
     const int mw0 = m0 + wm * 64, nw0 = n0 + wn * 32;
-    if (p.split_k <= 1 && p.out_dtype == SDMI_BF16 && !p.bias_m && mw0 + 64 <= p.M && nw0 + 32 <= p.N && (!p.rowvec || hw_shift >= 3) &&
-        (long long)p.M * (p.ldc > p.ldr ? p.ldc : p.ldr) < (1ll << 30)) {
+    if (epilogue_fast_ok<2, 1>(p, mw0, nw0, hw_shift)) {
       wave_epilogue_fast<2, 1>(p, acc, mw0, nw0, 0, hw_shift, l);
     } else {
       wave_epilogue<2, 1>(p, acc, mw0, nw0, 0, hw_shift, l, (int)blockIdx.y);

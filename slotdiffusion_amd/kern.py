@@ -68,6 +68,7 @@ _FF_MERGE = os.environ.get('SDMI_FF_MERGE', '1') != '0'
 _CROSS_FOLD = os.environ.get('SDMI_CROSS_FOLD', '1') != '0'
 _LN_FOLD = os.environ.get('SDMI_LN_FOLD', '1') != '0'
 _ST_FUSED = os.environ.get('SDMI_ST_FUSED', '1') != '0'     # fused SpatialTransformer block (sdmi_st_block)
+_UPS_PARITY = os.environ.get('SDMI_UPS_PARITY', '1') != '0'   # upsample convolutions as four 2x2 parity convolutions
 # ... only when its grid (one workgroup per 64 token rows) fills a good part of the chip: at B = 64 the 8^2 level gives 64
 # workgroups that each stream the block's 4 MB of weights -- 119 us against 108 us for the per-layer launches
 _ST_MIN_WGS = int(os.environ.get('SDMI_ST_MIN_WGS', '128'))
@@ -165,6 +166,28 @@ def st_index_img(C):
                 e.append((128 * C, 128, (w * g['NSL'] + s_) * 16, k2 * 64))
         ent.append(e)
     return _st_unit_index(ent)
+
+
+def ups_parity_split(w):
+    """Nearest-2x upsampling followed by a 3x3 convolution (unet.py:108-121) reads only 2 x 2 DISTINCT input pixels
+    per output pixel: output parity (py, px) is a 2 x 2 convolution of the low-resolution input whose taps are sums
+    of the 3 x 3 taps that fall on the same input pixel -- rows: parity 0 -> {w0 | w1 + w2} at offsets (-1, 0)
+    (pad top 1), parity 1 -> {w0 + w1 | w2} at offsets (0, +1) (pad bottom 1); columns alike.  16 instead of 36
+    multiply-adds per output pixel and input channel.  w [Cout, Cin, 3, 3] fp32 -> {(py, px): [Cout, 2*2*Cin] fp32}
+    (tap-major K, the layout sdmi_igemm takes)."""
+    co, ci = w.shape[0], w.shape[1]
+    taps = {0: ((0,), (1, 2)), 1: ((0, 1), (2,))}
+    out = {}
+    for py in (0, 1):
+        for px in (0, 1):
+            we = torch.zeros((co, 2, 2, ci), dtype=torch.float32, device=w.device)
+            for r in (0, 1):
+                for c in (0, 1):
+                    for ky in taps[py][r]:
+                        for kx in taps[px][c]:
+                            we[:, r, c, :] += w[:, :, ky, kx]
+            out[py, px] = we.reshape(co, 4 * ci)
+    return out
 
 
 class WeightBank:
@@ -587,6 +610,15 @@ class WeightBank:
                 self.cache[key] = (w, b.contiguous())
         return self.cache[key]
 
+    def ups_parity_weights(self, wname, dtype):
+        """{(py, px): [Cout][2][2][Cin] in `dtype`} of an upsample convolution (ups_parity_split).  Cached."""
+        key = ('upsparity', wname, dtype)
+        if key not in self.cache:
+            with torch.no_grad():
+                self.cache[key] = {k: v.to(dtype).contiguous()
+                                   for k, v in ups_parity_split(self.t[wname].float()).items()}
+        return self.cache[key]
+
     def ffout_proj_weights(self, t, n, dtype):
         """Feed-forward output and proj_out of a SpatialTransformer are two linear layers with only a
         residual add in between (attention.py:250-251, 305-308):
@@ -814,6 +846,18 @@ class Kern:
                 return ops.conv2d(x.a, self.wb.w(wname, x.dtype), self.wb.b(bname), kh=1, kw=1, pad=pad,
                                   rowvec=rowvec, residual=residual, out_dtype=out_dtype, ldc=ldc, x2=x.b)
             x = x.materialize()
+        if ups and _UPS_PARITY and kh == 3 and kw == 3 and stride == 1 and pad == (1, 1, 1, 1) and \
+                x.dtype == torch.bfloat16 and x.shape[-1] % 64 == 0 and rowvec is None and residual is None and \
+                out_dtype is None and ldc is None:
+            # nearest-2x upsample + 3x3 convolution = four 2x2 convolutions of the low-resolution input, one per
+            # output parity, written interleaved (WeightBank.ups_parity_weights): 2.25x fewer multiply-adds
+            B, H, W_, _ = x.shape
+            ws = self.wb.ups_parity_weights(wname, x.dtype)
+            out = torch.empty((B, 2 * H, 2 * W_, ws[0, 0].shape[0]), dtype=x.dtype, device=x.device)
+            for (py, px), w in ws.items():
+                ops.conv2d(x, w, self.wb.b(bname), kh=2, kw=2, pad=(1 - py, py, 1 - px, px), out=out,
+                           split_k=1, sub=(2, 2, py, px))
+            return out
         if x.dtype == torch.uint8 or self.fp8_ok(x, wname, kh * kw, ups):
             # BASELINE "fp8 MFMA UNet": e4m3fn operands (activations at a fixed scale -- written by
             # the GroupNorm in front when there is one -- weights at 448 / amax), fp32 accumulation,

@@ -123,10 +123,12 @@ def quant_fp8(x, scale, out=None):
 
 def conv2d(x, w, bias=None, *, kh=3, kw=3, stride=1, pad=(1, 1, 1, 1), ups=False, cout=None,
            rowvec=None, residual=None, act=None, out=None, out_dtype=None, ldc=None,
-           split_k=0, alpha=1.0, x2=None, x3=None):
+           split_k=0, alpha=1.0, x2=None, x3=None, sub=None):
     """x [B,H,W,Cin] NHWC; w [Cout][kh][kw][Cin] (flat or 4-D channels_last view).
     pad = (top, bottom, left, right).  Returns [B,Ho,Wo,ldc or Cout].
-    uint8 x / w = e4m3fn operands (quant_fp8): out_dtype is required, alpha undoes the scales."""
+    uint8 x / w = e4m3fn operands (quant_fp8): out_dtype is required, alpha undoes the scales.
+    sub = (sy, sx, oy, ox) with `out` [B, sy*Ho, sx*Wo, ldc]: output pixel (y, x) is stored at (sy*y + oy, sx*x + ox)
+    (sdmi.h: osy / osx / ooy / oox; bias-only epilogue, no split-K)."""
     _need_gpu(x, w)
     B, H, W, Cin = x.shape
     assert x.is_contiguous()
@@ -166,6 +168,10 @@ def conv2d(x, w, bias=None, *, kh=3, kw=3, stride=1, pad=(1, 1, 1, 1), ups=False
         pad_l=pad[2], ups=int(ups), act=ACT[act], alpha=float(alpha), bias_m=0,
         ldrv=(rowvec.stride(0) if rowvec is not None else 0),
         split_k=(split_k if ws is not None or split_k == 1 else 1), batch=1)
+    if sub is not None:
+        assert split_k == 1 and rowvec is None and residual is None and act is None and x2 is None
+        assert tuple(out.shape[:3]) == (B, sub[0] * Ho, sub[1] * Wo) and out.is_contiguous()
+        kwargs.update(oH=sub[0] * Ho, oW=sub[1] * Wo, osy=sub[0], osx=sub[1], ooy=sub[2], oox=sub[3])
     if _DEFER[0] and ws is not None and split_k == 0 and act is None and ldc == N and N > 64 and N % 8 == 0 and \
             odt == torch.bfloat16 and (residual is None or (residual.is_contiguous() and residual.shape[-1] == N)):
         splits = _lib.query('sdmi_igemm_split_plan', **kwargs)

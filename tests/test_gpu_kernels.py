@@ -723,3 +723,29 @@ def test_softmax_rows(shape, dtype):
     tol = 1e-6 if dtype == torch.float32 else 4e-3
     assert float((y.float().cpu() - ref).abs().max()) <= tol
     assert float((y.float().cpu().sum(-1) - 1).abs().max()) <= (1e-5 if dtype == torch.float32 else 2e-2)
+
+
+@pytest.mark.parametrize('B,H,ci,co', [(3, 8, 256, 256), (2, 4, 512, 512), (2, 16, 128, 192)])
+def test_upsample_conv_as_four_parity_convs(B, H, ci, co):
+    """nearest-2x + 3x3 convolution (unet.py:108-121) as four 2x2 convolutions of the low-resolution input
+    (kern.ups_parity_split, sdmi.h: osy / osx) against torch fp32 and against the in-gather form it replaces."""
+    from slotdiffusion_amd import kern
+    ops = _ops()
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(B, ci, H, H, generator=g)
+    w = torch.randn(co, ci, 3, 3, generator=g) * (ci * 9) ** -0.5
+    b = torch.randn(co, generator=g)
+    xb, wb_ = x.bfloat16().float(), w.bfloat16().float()
+    ref = F.conv2d(F.interpolate(xb, scale_factor=2, mode='nearest'), wb_, b, padding=1).permute(0, 2, 3, 1)
+    xd = x.permute(0, 2, 3, 1).contiguous().bfloat16().to(DEV)
+    old = ops.conv2d(xd, w.permute(0, 2, 3, 1).contiguous().bfloat16().to(DEV), b.to(DEV), ups=True)
+    out = torch.full((B, 2 * H, 2 * H, co), float('nan'), dtype=torch.bfloat16, device=DEV)
+    for (py, px), wp in kern.ups_parity_split(w).items():
+        ops.conv2d(xd, wp.bfloat16().to(DEV), b.to(DEV), kh=2, kw=2, pad=(1 - py, py, 1 - px, px), out=out,
+                   split_k=1, sub=(2, 2, py, px))
+    torch.cuda.synchronize()
+    assert torch.isfinite(out.float()).all()              # every output pixel written by exactly one parity
+    e_new = float((out.float().cpu() - ref).norm() / ref.norm())
+    e_old = float((old.float().cpu() - ref).norm() / ref.norm())
+    print(f'ups conv {ci}->{co} @{H}: parity form {e_new:.2e}, in-gather form {e_old:.2e} (rel-L2 vs torch fp32)')
+    assert e_new < 6e-3 and e_old < 6e-3                  # bf16 operands, fp32 accumulation, bf16 output

@@ -15,7 +15,7 @@ with open(sys.argv[1]) as f:
         rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'], wgs,
                      int(r['Workgroup_Size_X'])))
 rows.sort()
-marks = [i for i, r in enumerate(rows) if 'vq_kernel' in r[2]]
+marks = [i for i, r in enumerate(rows) if '::vq_' in r[2]]
 k = int(sys.argv[2]) if len(sys.argv) > 2 else -8
 seg = rows[marks[k] + 1:marks[k + 1] + 1]
 span = seg[-1][1] - seg[0][0]
