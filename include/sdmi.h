@@ -119,6 +119,14 @@ typedef struct {
    * GroupNorm that reads this convolution, unet.py:243-250) -- or by sdmi_splitk_finish.  Requires
    * act = none, ldc = N, no fused prologue / epilogue forms.  Ignored when K is not split. */
   int defer_epilogue;
+  /* gn_part != NULL (bf16 out; M, N multiples of 128; Ho*Wo a power of two >= 32; N / gn_groups a power of two
+   * <= 32; no split-K): the epilogue ALSO writes the GroupNorm statistics of its output -- per image b, 32-row
+   * block k and group g the sum and the sum of squares of the ROUNDED outputs,
+   *   gn_part[((b * (Ho*Wo/32) + k) * gn_groups + g) * 2 + {0, 1}],
+   * each entry by exactly one wave (no atomics).  This is the `partial` operand of sdmi_groupnorm_apply with
+   * nsplit = Ho*Wo/32: the GroupNorm behind the convolution (unet.py:243-250) needs no statistics pass. */
+  float* gn_part;
+  int gn_groups;
 } SdmiGemmArgs;
 int sdmi_igemm(const SdmiGemmArgs* a, void* stream);
 /* Host-side query, no launch (stream ignored): the number of K slices sdmi_igemm would use for these

@@ -933,6 +933,15 @@ extern "C" int sdmi_igemm(const SdmiGemmArgs* a, void* stream) {
   SDMI_REQUIRE(a->osy == 0 || !a->residual || a->ldr == a->ldc,
                "sub-sampled output: the residual shares the output's layout");
   SDMI_REQUIRE(a->osy == 0 || (!a->rowvec && !a->act && !a->bias_m), "sub-sampled output: plain epilogue only");
+  if (a->gn_part) {
+    const int hw = a->Ho * a->Wo, cpg = a->gn_groups > 0 ? a->N / a->gn_groups : 0;
+    SDMI_REQUIRE(a->out_dtype == SDMI_BF16 && a->dtype != SDMI_F32 && a->M % 128 == 0 && a->N % 128 == 0 && hw >= 32 &&
+                     (hw & (hw - 1)) == 0 && a->gn_groups > 0 && a->N % a->gn_groups == 0 && cpg >= 1 && cpg <= 32 &&
+                     (cpg & (cpg - 1)) == 0 && a->split_k == 1 && !a->bias_m && !a->ln_colsum && !a->geglu &&
+                     !a->softmax8 && !a->out2 && a->osy == 0 && !(a->batch > 1) && a->ldc == a->N &&
+                     (long long)a->M * (a->ldc > a->ldr ? a->ldc : a->ldr) < (1ll << 30),
+                 "gn_part: bf16, whole 128 x 128 tiles, Ho*Wo = 2^k >= 32, N / gn_groups a power of two <= 32, plain epilogue");
+  }
   SDMI_REQUIRE(!a->defer_epilogue || (a->workspace && !a->act && a->ldc == a->N && !a->bias_m && !a->ln_colsum &&
                                       !a->geglu && !a->softmax8 && !a->out2 && a->osy == 0 && !(a->batch > 1)),
                "defer_epilogue: plain epilogue (alpha / bias / rowvec / residual), ldc = N, workspace required");

@@ -100,6 +100,31 @@ __device__ __forceinline__ void wave_epilogue_fast(const SdmiGemmArgs& p, f32x16
 #pragma unroll
         for (int r = 0; r < 16; ++r) v[r] = act_apply<true>(v[r], SDMI_ACT_GELU);
       }
+      if (p.gn_part) {
+        // GroupNorm statistics of this 32 x 32 tile (sdmi.h: gn_part): sums of the ROUNDED values over the lane's 16
+        // rows, the other half-wave's 16, then the cpg lanes (columns) of a group; one lane per group stores them
+        float gs = 0.f, gq = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          const uint32_t pk = f32x2_to_bf16x2(v[r], v[r + 1]);
+          const float lo = __uint_as_float(pk << 16), hi = __uint_as_float(pk & 0xffff0000u);
+          gs += lo + hi;
+          gq = fmaf(lo, lo, fmaf(hi, hi, gq));
+        }
+        gs += __shfl_xor(gs, 32, 64);
+        gq += __shfl_xor(gq, 32, 64);
+        const int cpg = p.N / p.gn_groups;
+        for (int o = 1; o < cpg; o <<= 1) {
+          gs += __shfl_xor(gs, o, 64);
+          gq += __shfl_xor(gq, o, 64);
+        }
+        if (lane < 32 && (col_l & (cpg - 1)) == 0) {
+          const int b = mrow >> hw_shift, blk = (mrow & ((1 << hw_shift) - 1)) >> 5;
+          float* dst = p.gn_part + ((((long long)b << (hw_shift - 5)) + blk) * p.gn_groups + n / cpg) * 2;
+          dst[0] = gs;
+          dst[1] = gq;
+        }
+      }
 #pragma unroll
       for (int r = 0; r < 16; r += 2) {
         const uint32_t pk = f32x2_to_bf16x2(v[r], v[r + 1]);

@@ -89,15 +89,38 @@ template <typename T, bool F8 = false>
 __global__ __launch_bounds__(256) void gn_apply_kernel(SdmiGroupNormArgs p, int rows_per) {
   constexpr int VEC = Elem<T>::VEC;
   __shared__ float s_stats[128][2];
+  __shared__ double s_fold[8][32][2];
   const int b = blockIdx.y;
-  // mean / rstd of this image's groups from the split partials (fp64 combine, fixed order)
+  // mean / rstd of this image's groups from the split partials (fp64 combine, fixed order).  With many partials
+  // (the producing convolution wrote one per 32 rows: sdmi.h gn_part) eight threads per group fold a strided eighth
+  // each with their loads in flight together -- one thread walking 32 dependent-latency loads cost ~10 us per launch.
+  const bool wide = p.groups <= 32 && p.nsplit >= 8;
+  if (wide) {
+    const int g = threadIdx.x & 31, j = threadIdx.x >> 5;      // 256 threads: 8 folders per group
+    if (g < p.groups) {
+      double s = 0.0, ss = 0.0;
+      for (int k = j; k < p.nsplit; k += 8) {
+        const float2 q = *reinterpret_cast<const float2*>(p.partial + (((long long)b * p.nsplit + k) * p.groups + g) * 2);
+        s += (double)q.x;
+        ss += (double)q.y;
+      }
+      s_fold[j][g][0] = s;
+      s_fold[j][g][1] = ss;
+    }
+    __syncthreads();
+  }
   if ((int)threadIdx.x < p.groups) {
     const int g = threadIdx.x;
     double s = 0.0, ss = 0.0;
-    for (int k = 0; k < p.nsplit; ++k) {
-      const float* q = p.partial + (((long long)b * p.nsplit + k) * p.groups + g) * 2;
-      s += (double)q[0];
-      ss += (double)q[1];
+    if (wide) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { s += s_fold[j][g][0]; ss += s_fold[j][g][1]; }
+    } else {
+      for (int k = 0; k < p.nsplit; ++k) {
+        const float* q = p.partial + (((long long)b * p.nsplit + k) * p.groups + g) * 2;
+        s += (double)q[0];
+        ss += (double)q[1];
+      }
     }
     const double n = (double)p.HW * (p.C / p.groups);
     const double mean = s / n;

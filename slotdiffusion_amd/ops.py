@@ -103,7 +103,18 @@ class defer_splitk:
             _lib.pre_call = None
 
 
+# GroupNorm statistics written by the producing convolution's epilogue (sdmi.h: gn_part; inference, inside
+# defer_splitk()): (out tensor, partial sums, nsplit, groups) of the LAST convolution launched.  Valid only for the
+# launch that directly follows it -- the GroupNorm reading `out` then runs as the apply pass alone.
+_GN_LAST = [None]
+# Measured SLOWER in the sampler (the 32 x 32-tile statistics cost the symmetric-wave kernel +2.8 us per
+# launch, and the apply pass with 8 - 32 partials to fold per group is a two-round-trip latency chain like the
+# single-pass kernel it replaces: 75.4 -> 76.8 ms per pass): off unless SDMI_GN_EPILOGUE_STATS=1.
+GN_EPILOGUE_STATS = __import__('os').environ.get('SDMI_GN_EPILOGUE_STATS', '0') != '0'
+
+
 def _pre_call():
+    _GN_LAST[0] = None
     if _PENDING:
         flush_pending()
 
@@ -179,7 +190,17 @@ def conv2d(x, w, bias=None, *, kh=3, kw=3, stride=1, pad=(1, 1, 1, 1), ups=False
             call('sdmi_igemm', _stream(), defer_epilogue=1, **kwargs)
             _PENDING[out.data_ptr()] = _PendingSplit(out, kwargs, splits, (ws, bias, rowvec, residual, float(alpha)))
             return out
+    gn = None
+    hw = Ho * Wo
+    if _DEFER[0] and GN_EPILOGUE_STATS and sub is None and odt == torch.bfloat16 and x.dtype != torch.float32 and \
+            ws is None and M % 128 == 0 and N % 128 == 0 and N % 32 == 0 and (N // 32) in (4, 8, 16, 32) and \
+            hw >= 32 and hw & (hw - 1) == 0 and ldc == N and act is None and B * hw * N < (1 << 30):
+        # the GroupNorm (32 groups) that may follow gets its statistics from this launch's epilogue
+        gn = torch.empty((B, hw // 32, 32, 2), dtype=torch.float32, device=x.device)
+        kwargs.update(gn_part=_p(gn), gn_groups=32, split_k=1)
     call('sdmi_igemm', _stream(), **kwargs)
+    if gn is not None:
+        _GN_LAST[0] = (out, gn, hw // 32, 32)
     return out
 
 
@@ -288,6 +309,16 @@ def group_norm(x, gamma, beta, *, eps, act=None, groups=32, residual=None, out=N
         kw = dict(y=_p(out))
     if x2 is not None:
         kw.update(x2=_p(x2), C1=C1)
+    last = _GN_LAST[0]
+    if last is not None and x2 is None and last[0].data_ptr() == x.data_ptr() and last[0].numel() == x.numel() and \
+            last[3] == groups and x.is_contiguous():
+        # statistics came with the producing convolution: the apply pass alone (one read, one write, no reduction)
+        kw.update(x=_p(x), gamma=_p(gamma), beta=_p(beta), stats=_p(stats), partial=_p(last[1]), dtype=_dt(x), B=B,
+                  HW=HW, C=C, groups=groups, eps=eps, act=ACT[act], nsplit=last[2], residual=_p(residual))
+        if drop is not None and drop[0] > 0.0:
+            kw.update(drop_p=float(drop[0]), drop_seed=int(drop[1]), drop_seed_dev=_p(drop[2]))
+        call('sdmi_groupnorm_apply', _stream(), **kw)
+        return (out, stats) if return_stats else out
     pend = _PENDING.pop(x.data_ptr(), None) if _PENDING else None
     if pend is not None:
         if not x.is_contiguous() or x.dtype != torch.bfloat16 or pend.out.numel() != x.numel():

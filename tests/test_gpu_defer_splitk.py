@@ -117,3 +117,43 @@ def test_unet_eps_is_unchanged_and_launches_drop():
     print('C-ABI calls per evaluation:', sum(out[False, 'n'].values()), '->', sum(out[True, 'n'].values()),
           '(second stages inside sdmi_igemm are not calls of their own); stand-alone second stages left:',
           out[True, 'n'].get('sdmi_splitk_finish', 0))
+
+
+@pytest.mark.parametrize('B,hw,cin,cout,two', [(32, 16, 256, 256, False), (16, 32, 128, 128, False), (64, 8, 512, 512, False),
+                                               (32, 16, 256, 256, True)])
+def test_groupnorm_statistics_from_the_convolution_epilogue(B, hw, cin, cout, two):
+    """sdmi.h: gn_part -- the producing convolution writes per-(image, 32-row block, group) sums of its rounded
+    outputs; the GroupNorm behind it is the apply pass alone.  Statistics against fp64 sums of the stored tensor,
+    the normalised tensor against the single-pass kernel (one bf16 ulp: other fold order)."""
+    from slotdiffusion_amd import ops, _lib
+    x, w, bias, rv, res, gamma, beta = _case(B, hw, cin, cout, 21, True, True)
+    x2 = torch.randn(B, hw, hw, 128).bfloat16().cuda() if two else None        # merged skip source (a2)
+    if two:
+        w = torch.cat([w.reshape(cout, -1), (torch.randn(cout, 128) * 0.05).bfloat16().cuda()], 1).contiguous()
+    h_ref = ops.conv2d(x, w, bias, rowvec=rv, residual=res, x2=x2)
+    y_ref, st_ref = ops.group_norm(h_ref, gamma, beta, eps=1e-5, act='silu', return_stats=True)
+    names = []
+    orig = _lib._call
+
+    def spy(fname, stream, **kw):
+        names.append(fname)
+        return orig(fname, stream, **kw)
+    _lib._call = spy
+    flag = ops.GN_EPILOGUE_STATS
+    ops.GN_EPILOGUE_STATS = True                         # (off by default: measured slower in the sampler)
+    try:
+        with ops.defer_splitk():
+            h = ops.conv2d(x, w, bias, rowvec=rv, residual=res, x2=x2)
+            part = ops._GN_LAST[0][1].clone() if ops._GN_LAST[0] is not None else None
+            y, st = ops.group_norm(h, gamma, beta, eps=1e-5, act='silu', return_stats=True)
+    finally:
+        _lib._call = orig
+        ops.GN_EPILOGUE_STATS = flag
+    torch.cuda.synchronize()
+    assert part is not None and names == ['sdmi_igemm', 'sdmi_groupnorm_apply'], names
+    assert torch.equal(h, h_ref)
+    hd = h.double().view(B, hw * hw // 32, 32, 32, cout // 32)          # [b, block, row, group, channel]
+    s_ref = torch.stack([hd.sum((2, 4)), (hd * hd).sum((2, 4))], -1)
+    assert float((part.double() - s_ref).abs().max() / s_ref.abs().max()) < 1e-5
+    assert float((st - st_ref).abs().max()) < 1e-3 * float(st_ref.abs().max())
+    assert _close(y, y_ref)
