@@ -448,6 +448,31 @@ typedef struct {
 } SdmiStBlockArgs;
 int sdmi_st_block(const SdmiStBlockArgs* a, void* stream);
 
+/* Folded slot cross-attention of one transformer block in ONE launch (bf16 inference; attention.py:182-206,
+ * 247-251: norm2 -> CrossAttention(slots) -> to_out + residual), per image b with the operands of
+ * kern.Kern.cross_prepare (the slot keys folded into the query projection, the values into the output projection):
+ *   P   = softmax over each head's `slots` scores of  LayerNorm(tok[b]) wq[b]^T + biasq[b]     [HW][R]
+ *   out = P w2[b]^T + bias + tok[b]                                                            [HW][C]
+ * tok / out [B][HW][C] bf16 (out may not alias tok); wq [B][R][ld_wq], w2 [B][C][ld_w2] bf16 with image strides
+ * s_wq / s_w2 (elements); colsum [B][s_colsum], biasq [B][s_bias] fp32 -- the LayerNorm-fold terms of sdmi_igemm's
+ * ln_colsum form (wq carries the norm's gamma); R = heads * 8 score columns, column 8 h + j = slot j of head h,
+ * j >= slots are pads (probability 0); bias [C] fp32 or NULL.  One workgroup per 16 tokens of an image: replaces
+ * the two batched sdmi_igemm launches (softmax8 epilogue + output projection) where an image has few tokens. */
+typedef struct {
+  const void* tok; void* out;
+  const void* wq; const void* w2;
+  const float* colsum; const float* biasq; const float* bias;
+  int B, HW, C, R, slots;
+  int ld_wq, ld_w2;
+  long long s_wq, s_w2, s_colsum, s_bias;
+  float ln_eps;
+  /* packed != 0: wq / w2 are stored per image in MFMA-fragment order -- [tile of 16 rows][k step of 32][lane][8]
+   * with lane = (k sub-group of 8) * 16 + row in tile, i.e. every 16-byte operand load of a wave is 1 KB of
+   * consecutive memory (kern.cross_fold_pack); ld_wq / ld_w2 are ignored, s_wq / s_w2 still step images. */
+  int packed;
+} SdmiCrossFoldArgs;
+int sdmi_cross_fold(const SdmiCrossFoldArgs* a, void* stream);
+
 /* Head-expanded slot keys / values for the folded cross-attention (engine.UNetRunner.cross_fold):
  * kv [B][S][ldkv] holds K in columns [0, C) and V in [C, 2C); row h * 8 + j (j < S <= 7) of
  * kexp / vexp [B][heads * 8][C] is slot j's key (times `scale`) / value restricted to the channels of

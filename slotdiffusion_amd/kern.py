@@ -68,6 +68,8 @@ _FF_MERGE = os.environ.get('SDMI_FF_MERGE', '1') != '0'
 _CROSS_FOLD = os.environ.get('SDMI_CROSS_FOLD', '1') != '0'
 _LN_FOLD = os.environ.get('SDMI_LN_FOLD', '1') != '0'
 _ST_FUSED = os.environ.get('SDMI_ST_FUSED', '1') != '0'     # fused SpatialTransformer block (sdmi_st_block)
+# folded slot cross-attention as ONE launch (sdmi_cross_fold) up to this many tokens per image (0 = off)
+_CROSS_ONE = int(os.environ.get('SDMI_CROSS_ONE', '64'))
 _UPS_PARITY = os.environ.get('SDMI_UPS_PARITY', '1') != '0'   # upsample convolutions as four 2x2 parity convolutions
 # ... only when its grid (one workgroup per 64 token rows) fills a good part of the chip: at B = 64 the 8^2 level gives 64
 # workgroups that each stream the block's 4 MB of weights -- 119 us against 108 us for the per-layer launches
@@ -666,6 +668,12 @@ class WeightBank:
                 self.cache[key] = (Wp, Wp.float().sum(1).contiguous(), bias.contiguous())
         return self.cache[key]
 
+    def cf_index(self, rows, cols, device):
+        key = ('cf_index', rows, cols)
+        if key not in self.cache:
+            self.cache[key] = ops.cross_fold_pack_index(rows, cols).to(device)
+        return self.cache[key]
+
     def st_index(self, which, C, device):
         key = ('st_index', which, C)
         if key not in self.cache:
@@ -1036,6 +1044,19 @@ class Kern:
         """norm2 -> slot cross-attention -> to_out + residual of transformer block `t` -> new tok."""
         fold = kvp.get('fold') if isinstance(kvp, dict) else None
         if fold is not None:
+            B, HW, C = tok.shape
+            # few tokens per image (the 4^2 / 8^2 levels): the layer is a per-image weight stream -- one launch, one
+            # workgroup per 16 tokens (sdmi_cross_fold) instead of two batched GEMMs on mostly empty 64 x 64 tiles
+            if _CROSS_ONE and HW % 16 == 0 and HW <= _CROSS_ONE and tok.is_contiguous() and \
+                    (C, fold['wq'].shape[1]) in ops.CROSS_FOLD_SHAPES:
+                if 'cf_wq' not in fold:          # once per sampling call: the operands in MFMA-fragment order
+                    R = fold['wq'].shape[1]
+                    iq = self.wb.cf_index(R, C, tok.device)
+                    i2 = self.wb.cf_index(C, R, tok.device)
+                    fold['cf_wq'] = torch.index_select(fold['wq'].reshape(B, R * C), 1, iq)
+                    fold['cf_w2'] = torch.index_select(fold['w2'].reshape(B, C * R), 1, i2)
+                return ops.cross_fold(tok, fold['cf_wq'], fold['colsum'], fold['biasq'], fold['cf_w2'],
+                                      self.wb.b(t + '.attn2.to_out.0.bias'), 1e-5, fold['slots'], packed=True)
             P = ops.cross_scores(tok, fold['wq'], fold['colsum'], fold['biasq'], 1e-5, fold['slots'])
             return ops.bmm_nt(P, fold['w2'], torch.empty_like(tok), bias=self.wb.b(t + '.attn2.to_out.0.bias'),
                               residual=tok)

@@ -281,6 +281,34 @@ def cross_scores(tok, wq, colsum, biasq, eps, slots=7):
     return out
 
 
+CROSS_FOLD_SHAPES = ((512, 128), (384, 96), (256, 64), (128, 32))       # (C, R) instantiations of sdmi_cross_fold
+
+
+def cross_fold_pack_index(rows, cols):
+    """Gather index that re-lays a [rows, cols] operand in MFMA-fragment order (sdmi.h: SdmiCrossFoldArgs.packed):
+    [tile of 16 rows][k step of 32][lane][8], lane = (k sub-group) * 16 + row in tile."""
+    t, ks, lane, e = torch.meshgrid(torch.arange(rows // 16), torch.arange(cols // 32), torch.arange(64),
+                                    torch.arange(8), indexing='ij')
+    return ((t * 16 + (lane & 15)) * cols + ks * 32 + (lane >> 4) * 8 + e).reshape(-1)
+
+
+def cross_fold(tok, wq, colsum, biasq, w2, bias, eps, slots=7, packed=False):
+    """The folded slot cross-attention layer in one launch (sdmi.h: sdmi_cross_fold): out = softmax_slots(LayerNorm(tok)
+    wq^T + biasq) w2^T + bias + tok.  tok [B,HW,C] contiguous; wq [B,R,C], w2 [B,C,R] (row / image pitches free), or
+    packed: both [B, R*C] in fragment order (cross_fold_pack_index)."""
+    _need_gpu(tok, wq, w2)
+    B, HW, C = tok.shape
+    R = wq.shape[1] // C if packed else wq.shape[1]
+    assert tok.is_contiguous() and wq.stride(-1) == 1 and w2.stride(-1) == 1
+    out = torch.empty_like(tok)
+    call('sdmi_cross_fold', _stream(), tok=_p(tok), out=_p(out), wq=_p(wq), w2=_p(w2), colsum=_p(colsum),
+         biasq=_p(biasq), bias=_p(bias), B=B, HW=HW, C=C, R=R, slots=int(slots),
+         ld_wq=(0 if packed else wq.stride(1)), ld_w2=(0 if packed else w2.stride(1)), s_wq=wq.stride(0),
+         s_w2=w2.stride(0), s_colsum=colsum.stride(0), s_bias=biasq.stride(0), ln_eps=float(eps), packed=int(packed),
+         _meta=dict(flops=4.0 * B * HW * R * C, bytes=2.0 * (2 * B * HW * C + 2 * B * R * C)))
+    return out
+
+
 # ------------------------------------------------------------------------------------------
 # normalisation
 # ------------------------------------------------------------------------------------------

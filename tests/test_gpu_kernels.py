@@ -749,3 +749,44 @@ def test_upsample_conv_as_four_parity_convs(B, H, ci, co):
     e_old = float((old.float().cpu() - ref).norm() / ref.norm())
     print(f'ups conv {ci}->{co} @{H}: parity form {e_new:.2e}, in-gather form {e_old:.2e} (rel-L2 vs torch fp32)')
     assert e_new < 6e-3 and e_old < 6e-3                  # bf16 operands, fp32 accumulation, bf16 output
+
+
+@pytest.mark.parametrize('B,HW,C,slots,padded', [(64, 16, 512, 7, False), (5, 64, 384, 7, True), (3, 16, 256, 5, True),
+                                                  (2, 32, 128, 7, False)])
+def test_cross_fold_one_launch(B, HW, C, slots, padded):
+    """sdmi_cross_fold against the two batched launches it replaces (softmax8 igemm + output projection) and a
+    torch fp32 restatement of the folded layer."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(7)
+    R = C // 4
+    tok = torch.randn(B, HW, C, generator=g).bfloat16().to(DEV)
+    if padded:          # operands inside the fused block's padded per-image storage (row / image pitches differ)
+        src = torch.zeros(B, 128 * C + C * 128).bfloat16().to(DEV)
+        wq = src[:, :R * C].view(B, R, C)
+        w2 = src[:, 128 * C:].view(B, C, 128)[:, :, :R]
+    else:
+        wq = torch.empty(B, R, C).bfloat16().to(DEV)
+        w2 = torch.empty(B, C, R).bfloat16().to(DEV)
+    wq.copy_((torch.randn(B, R, C, generator=g) * C ** -0.5).bfloat16())
+    w2.copy_((torch.randn(B, C, R, generator=g) * 0.3).bfloat16())
+    colsum = wq.float().sum(-1).contiguous()
+    biasq = torch.randn(B, R, generator=g).to(DEV)
+    bias = torch.randn(C, generator=g).to(DEV)
+    out = ops.cross_fold(tok, wq, colsum, biasq, w2, bias, 1e-5, slots)
+    packed = ops.cross_fold(tok, torch.index_select(wq.reshape(B, R * C), 1, ops.cross_fold_pack_index(R, C).to(DEV)),
+                            colsum, biasq,
+                            torch.index_select(w2.reshape(B, C * R), 1, ops.cross_fold_pack_index(C, R).to(DEV)),
+                            bias, 1e-5, slots, packed=True)
+    P = ops.cross_scores(tok, wq, colsum, biasq, 1e-5, slots)
+    two = ops.bmm_nt(P, w2, torch.empty_like(tok), bias=bias, residual=tok)
+    x = tok.float()
+    n = (x - x.mean(-1, keepdim=True)) * torch.rsqrt(x.var(-1, unbiased=False, keepdim=True) + 1e-5)
+    sc = (n @ wq.float().transpose(1, 2) + biasq[:, None]).view(B, HW, R // 8, 8)
+    sc[..., slots:] = float('-inf')
+    ref = torch.softmax(sc, -1).view(B, HW, R) @ w2.float().transpose(1, 2) + bias + x
+    torch.cuda.synchronize()
+    e1 = float((out.float() - ref).norm() / ref.norm())
+    e2 = float((two.float() - ref).norm() / ref.norm())
+    print(f'cross_fold C={C} HW={HW}: one launch {e1:.2e}, two launches {e2:.2e} (rel-L2 vs torch fp32)')
+    assert e1 < 6e-3 and e1 < 2 * e2 + 1e-3
+    assert torch.equal(packed, out)                       # fragment-order operands: the same arithmetic
