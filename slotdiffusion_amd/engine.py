@@ -13,6 +13,7 @@ import torch
 from . import ops, spec
 
 _DEFER_SPLITK = os.environ.get('SDMI_DEFER_SPLITK', '1') != '0'
+_DEFER_TRAIN = os.environ.get('SDMI_DEFER_TRAIN', '0') != '0'      # experiment: also in the training forward
 
 
 # ------------------------------------------------------------------------------------------
@@ -251,7 +252,7 @@ class UNetRunner:
 
     def forward(self, K, x, rowvecs, ctx_kv):
         """x [B,h,w,Cpad] compute dtype -> eps [B,h,w,4] fp32 (3 channels + zero pad)."""
-        if not K.training and _DEFER_SPLITK:
+        if (not K.training or _DEFER_TRAIN) and _DEFER_SPLITK:
             # inference: a split-K convolution leaves its second stage to the GroupNorm behind it (ops.defer_splitk)
             with ops.defer_splitk():
                 return self._forward(K, x, rowvecs, ctx_kv)
