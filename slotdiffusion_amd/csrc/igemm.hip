@@ -602,6 +602,16 @@ static int dma64_min() {
   return v;
 }
 
+// SDMI_IGEMM_T12864: LDS stages of the 128 x 64-tile LDS-DMA kernel (4: one workgroup per CU, 3: two), 0 = off
+static int t12864_stages() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("SDMI_IGEMM_T12864");
+    v = e ? atoi(e) : 0;      // faster per launch in isolation, slower inside the sampler and the train step (dispatch)
+  }
+  return v;
+}
+
 // SDMI_IGEMM_SYM: LDS stages of the symmetric-wave kernel (2: two workgroups per CU, 3 / 4: one), 0 = off,
 // unset = by shape (see dispatch)
 static int sym_stages() {
@@ -783,6 +793,11 @@ int dispatch(const SdmiGemmArgs& p, hipStream_t st, bool plan_only = false) {
       if (shape == T128x128)
         return is1x1 ? launch_cfg<T, 128, 128, 128, 1, 0, true>(p, split_k, hw_shift, st)
                      : launch_cfg<T, 128, 128, 128, 2, 0, true>(p, split_k, hw_shift, st);
+      if constexpr (sizeof(T) == 2) {
+        if (t12864_stages() && !is1x1 && split_k == 1 && batch == 1 && p.M % 128 == 0 && p.N % 64 == 0 &&
+            (long long)(p.M / 128) * (p.N / 64) >= 128)
+          return launch_dma<T, 128, 64, 4, 2, 4, true>(p, hw_shift, st);
+      }
       if (sizeof(T) == 2 && dma64_min())
         return is1x1 ? launch_dma<T, 64, 64, 4, 1, 4, true>(p, hw_shift, st, split_k)
                      : launch_dma<T, 64, 64, 4, 2, 4, true>(p, hw_shift, st, split_k);
@@ -886,6 +901,22 @@ int dispatch(const SdmiGemmArgs& p, hipStream_t st, bool plan_only = false) {
     // LDS-DMA kernel on 64 x 64 tiles (4 stages of 16 KB: two workgroups per CU), split-K as below: the 8^2 /
     // 4^2 levels' convolutions 12 - 17 % faster in dependent chains (29.0 -> 24.3 us 384 -> 384 @8^2, 50.6 -> 41.9
     // 768 -> 384), sampling pass 94.7 -> 92.9 ms, train step 29.58 -> 29.33 ms (same-box A/B, twice each).
+    // 128 x 64 tiles for the 64 x 64-tile convolutions whose grid allows it (the 8^2 level at B = 64: 192 instead of
+    // 384 workgroups): these launches are bound by the LDS-DMA issue rate, i.e. by operand bytes per tile
+    // = K (BM + BN) 2 -- 1.5x the bytes for 2x the flops.  tools/exp/conv_chain.py SHAPES=low, us per launch:
+    // 384 -> 384 25.1 -> 23.6, 768 -> 384 42.2 -> 36.1, 640 -> 384 34.0 -> 30.5, 256 -> 384 17.2 -> 16.6 (four LDS
+    // stages, one workgroup per CU; three stages = two per CU: 22.9 / 39.5 / 33.2 / 16.5).  Inside the replayed
+    // sampler the same build is SLOWER (same box, twice each: 74.84 -> 75.41 ms per pass) and so is the train step
+    // (26.78 -> 26.97 ms): 192 workgroups leave a quarter of the CUs idle for the whole launch, and behind a
+    // GroupNorm the operands come from L2, where the 64 x 64 grid's 384 shorter workgroups overlap better.  Off.
+    if (t12864_stages() && sizeof(T) == 2 && shape == T64x64 && !p.a2 && split_k == 1 && batch == 1 && fits31 &&
+        kbytes >= 2048 && p.M % 128 == 0 && p.N % 64 == 0 && (long long)(p.M / 128) * (p.N / 64) >= 128 && !is1x1 &&
+        plain && p.KH * p.KW <= 32 && p.Cin % 64 == 0 && !p.ln_colsum && !p.geglu && !p.softmax8 && !p.out2) {
+      if constexpr (sizeof(T) == 2) {
+        if (t12864_stages() == 3) return launch_dma<T, 128, 64, 3, 2, 4>(p, hw_shift, st);
+        return launch_dma<T, 128, 64, 4, 2, 4>(p, hw_shift, st);
+      }
+    }
     const int dma64 = dma64_min();
     if (dma64 && shape == T64x64 && !p.a2 && kbytes >= dma64 && fits31 && batch == 1) {
       if (is1x1) return launch_dma<T, 64, 64, 4, 1, 4>(p, hw_shift, st, split_k);
