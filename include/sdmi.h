@@ -377,6 +377,10 @@ int sdmi_slot_attention(const SdmiSlotAttnArgs* a, void* stream);
 typedef struct {
   const float* z; const float* codebook; long long* idx; float* zq;
   int R, dim, ldz, n_codes; float scale;
+  /* optional: the latent is formed on load as (zc0 * z + zc1 * z2) / zdiv, the operations and their order those of
+   * sdmi_lincomb (the sampler's x0 = (x_t - sigma_t eps) / alpha_t, dpm_solver.py:345-361, without a launch of its
+   * own; only the first `dim` channels of z2 are read, so the pad channel of eps need not be zeroed). */
+  const float* z2; float zc0, zc1, zdiv;
 } SdmiVqArgs;
 int sdmi_vq_nearest(const SdmiVqArgs* a, void* stream);
 

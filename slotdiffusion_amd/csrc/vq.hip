@@ -20,6 +20,17 @@
 namespace {
 
 typedef float vq_f2 __attribute__((ext_vector_type(2)));
+
+// channel c of latent row zr (optionally the linear combination of sdmi.h: z2), scaled
+__device__ __forceinline__ float vq_chan(const SdmiVqArgs& p, const float* zr, const float* z2r, int c) {
+  float v = zr[c];
+  if (z2r) {
+    const float t0 = p.zc0 * v, t1 = p.zc1 * z2r[c];
+    v = t0 + t1;
+    if (p.zdiv != 0.f) v = v / p.zdiv;
+  }
+  return v * p.scale;
+}
 constexpr int VQ_CH = 32;            // pairs per chunk
 
 __device__ __forceinline__ vq_f2 vq_dist2(const float* cbp, vq_f2 z0, vq_f2 z1, vq_f2 z2, vq_f2 zz) {
@@ -55,7 +66,8 @@ __global__ __launch_bounds__(256) void vq_kernel(SdmiVqArgs p) {
   const int half = threadIdx.x & 1;
   const bool live = r < p.R;
   const float* zr = p.z + (long long)(live ? r : 0) * p.ldz;
-  const float z0 = zr[0] * p.scale, z1 = zr[1] * p.scale, z2 = zr[2] * p.scale;
+  const float* z2r = p.z2 ? p.z2 + (long long)(live ? r : 0) * p.ldz : nullptr;
+  const float z0 = vq_chan(p, zr, z2r, 0), z1 = vq_chan(p, zr, z2r, 1), z2 = vq_chan(p, zr, z2r, 2);
   const float q0 = z0 * z0, q1 = z1 * z1, q2 = z2 * z2;
   const float zz = (q0 + q1) + q2;
   const vq_f2 z0v = {z0, z0}, z1v = {z1, z1}, z2v = {z2, z2}, zzv = {zz, zz};
@@ -161,7 +173,8 @@ __global__ __launch_bounds__(256) void vq_reg_kernel(SdmiVqArgs p) {
   // every wave holds the workgroup's latents, one per lane
   const int r = r0 + lane;
   const float* zr = p.z + (long long)(r < p.R ? r : 0) * p.ldz;
-  const float z0 = zr[0] * p.scale, z1 = zr[1] * p.scale, z2 = zr[2] * p.scale;
+  const float* z2r = p.z2 ? p.z2 + (long long)(r < p.R ? r : 0) * p.ldz : nullptr;
+  const float z0 = vq_chan(p, zr, z2r, 0), z1 = vq_chan(p, zr, z2r, 1), z2 = vq_chan(p, zr, z2r, 2);
   const float zq0 = z0 * z0, zq1 = z1 * z1, zq2 = z2 * z2;
   const float zz = (zq0 + zq1) + zq2;
   float keep_d = INFINITY;

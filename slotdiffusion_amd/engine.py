@@ -250,15 +250,16 @@ class UNetRunner:
                 h = K.conv(h, n + '.conv.weight', n + '.conv.bias', ups=True)
         return h, cat
 
-    def forward(self, K, x, rowvecs, ctx_kv):
-        """x [B,h,w,Cpad] compute dtype -> eps [B,h,w,4] fp32 (3 channels + zero pad)."""
+    def forward(self, K, x, rowvecs, ctx_kv, zero_pad=True):
+        """x [B,h,w,Cpad] compute dtype -> eps [B,h,w,4] fp32 (3 channels + zero pad; zero_pad=False leaves the pad
+        channel unwritten for a reader that takes three channels only)."""
         if (not K.training or _DEFER_TRAIN) and _DEFER_SPLITK:
             # inference: a split-K convolution leaves its second stage to the GroupNorm behind it (ops.defer_splitk)
             with ops.defer_splitk():
-                return self._forward(K, x, rowvecs, ctx_kv)
-        return self._forward(K, x, rowvecs, ctx_kv)
+                return self._forward(K, x, rowvecs, ctx_kv, zero_pad)
+        return self._forward(K, x, rowvecs, ctx_kv, zero_pad)
 
-    def _forward(self, K, x, rowvecs, ctx_kv):
+    def _forward(self, K, x, rowvecs, ctx_kv, zero_pad=True):
         names = [n for n, _ in self.res_names]
         rowvecs = dict(zip(names, K.rowvec_slices(rowvecs, [self.emb_off[n] for n in names])))
         hs = []
@@ -277,6 +278,8 @@ class UNetRunner:
             h, _ = self._run(K, blk, K.concat(h, hs.pop()), rowvecs, ctx_kv)
         P = self.P
         h = K.gn(h, P + 'out.0', eps=1e-5, act='silu')
+        if not zero_pad and not K.training:
+            return K.conv(h, P + 'out.2.weight', P + 'out.2.bias', out_dtype=torch.float32, ldc=4, zero_pad=False)
         return K.conv(h, P + 'out.2.weight', P + 'out.2.bias', out_dtype=torch.float32, ldc=4)
 
 

@@ -848,7 +848,7 @@ class Kern:
         self.wb = wb
 
     def conv(self, x, wname, bname=None, *, kh=3, kw=3, stride=1, pad=(1, 1, 1, 1), ups=False,
-             rowvec=None, residual=None, out_dtype=None, ldc=None):
+             rowvec=None, residual=None, out_dtype=None, ldc=None, zero_pad=True):
         if isinstance(x, CatPair):
             if kh == 1 and kw == 1 and stride == 1 and not ups:
                 return ops.conv2d(x.a, self.wb.w(wname, x.dtype), self.wb.b(bname), kh=1, kw=1, pad=pad,
@@ -877,7 +877,7 @@ class Kern:
                               out_dtype=out_dtype or self.wb.dtype, ldc=ldc, alpha=inv / FP8_ACT_SCALE)
         return ops.conv2d(x, self.wb.w(wname, x.dtype), self.wb.b(bname), kh=kh, kw=kw,
                           stride=stride, pad=pad, ups=ups, rowvec=rowvec, residual=residual,
-                          out_dtype=out_dtype, ldc=ldc)
+                          out_dtype=out_dtype, ldc=ldc, zero_pad=zero_pad)
 
     def fp8_ok(self, x, wname, taps, ups):
         """fp8 operands for the UNet's 3x3 convolutions (bf16 storage path, >= 64 input channels in

@@ -17,6 +17,7 @@ import torch
 from . import dpm, engine, kern, ops, spec
 from .module import FlatModule, _Node
 
+_VQ_COMB = os.environ.get('SDMI_VQ_COMB', '1') != '0'      # sampler: x0 formed inside the VQ search
 _DTYPES = {'fp32': torch.float32, 'float32': torch.float32, 'bf16': torch.bfloat16,
            'bfloat16': torch.bfloat16}
 
@@ -533,6 +534,12 @@ class SADiffusion(SlotModelBase):
         def data_pred(xc, e):
             rv = rv_all[nfe[0]:nfe[0] + 1].expand(B, -1)      # pitch-0 view: same row for all b
             nfe[0] += 1
+            if not (x_start or v_pred) and _VQ_COMB:
+                # x0 = (x_t - sigma_t eps) / alpha_t is formed inside the VQ search (sdmi.h: SdmiVqArgs.z2): no launch
+                # of its own, and the pad channel of eps is never read (no zero fill either)
+                eps = u.forward(Kp, self._unet_in(xc), rv, ctx_kv, zero_pad=False)
+                return ops.vq_nearest(xc, code, scale=self.z_scale, want_idx=False,
+                                      comb=(1.0, -e['sigma'], eps, e['alpha']))[1]
             eps = u.forward(Kp, self._unet_in(xc), rv, ctx_kv)
             if x_start:        # model_wrapper 'x_start' (dpm_solver.py:358-361): output -> noise
                 eps = ops.lincomb(1.0, xc, -e['alpha'], eps, div=e['sigma'])

@@ -134,7 +134,7 @@ def quant_fp8(x, scale, out=None):
 
 def conv2d(x, w, bias=None, *, kh=3, kw=3, stride=1, pad=(1, 1, 1, 1), ups=False, cout=None,
            rowvec=None, residual=None, act=None, out=None, out_dtype=None, ldc=None,
-           split_k=0, alpha=1.0, x2=None, x3=None, sub=None):
+           split_k=0, alpha=1.0, x2=None, x3=None, sub=None, zero_pad=True):
     """x [B,H,W,Cin] NHWC; w [Cout][kh][kw][Cin] (flat or 4-D channels_last view).
     pad = (top, bottom, left, right).  Returns [B,Ho,Wo,ldc or Cout].
     uint8 x / w = e4m3fn operands (quant_fp8): out_dtype is required, alpha undoes the scales.
@@ -162,7 +162,7 @@ def conv2d(x, w, bias=None, *, kh=3, kw=3, stride=1, pad=(1, 1, 1, 1), ups=False
     ldc = ldc or N
     if out is None:
         out = torch.empty((B, Ho, Wo, ldc), dtype=odt, device=x.device)
-        if ldc != N:                      # channel-pad columns must read as zeros downstream
+        if ldc != N and zero_pad:         # channel-pad columns must read as zeros downstream
             zero_(out)
     M = B * Ho * Wo
     if x.dtype == torch.uint8:
@@ -424,15 +424,21 @@ def slot_attention(k, v, slots_in, P, *, iters, eps, trace=None):
 # ------------------------------------------------------------------------------------------
 # VQ + elementwise
 # ------------------------------------------------------------------------------------------
-def vq_nearest(z, codebook, *, scale=1.0, want_idx=True, want_zq=True):
-    """z [..., ldz] fp32 NHWC latent (first 3 channels used). -> (idx int64 [...], zq like z)."""
+def vq_nearest(z, codebook, *, scale=1.0, want_idx=True, want_zq=True, comb=None):
+    """z [..., ldz] fp32 NHWC latent (first 3 channels used). -> (idx int64 [...], zq like z).
+    comb = (c0, c1, z2, div): the latent is (c0 * z + c1 * z2) / div, formed on load with lincomb's arithmetic."""
     _need_gpu(z, codebook)
     ldz = z.shape[-1]
     R = z.numel() // ldz
     idx = torch.empty(z.shape[:-1], dtype=torch.int64, device=z.device) if want_idx else None
     zq = torch.empty_like(z) if want_zq else None
+    kw = {}
+    if comb is not None:
+        c0, c1, z2, div = comb
+        assert z2.shape == z.shape and z2.is_contiguous() and z2.dtype == torch.float32
+        kw = dict(z2=_p(z2), zc0=float(c0), zc1=float(c1), zdiv=float(div))
     call('sdmi_vq_nearest', _stream(), z=_p(z), codebook=_p(codebook), idx=_p(idx), zq=_p(zq), R=R,
-         dim=codebook.shape[1], ldz=ldz, n_codes=codebook.shape[0], scale=scale)
+         dim=codebook.shape[1], ldz=ldz, n_codes=codebook.shape[0], scale=scale, **kw)
     return idx, zq
 
 

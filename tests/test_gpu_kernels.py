@@ -467,6 +467,16 @@ def test_vq_nearest_bit_exact():
         idx, zq = ops.vq_nearest(zp[:1].contiguous(), cbn.to(DEV))
         assert torch.equal(idx.cpu(), idx_ref), n
         assert torch.equal(zq.cpu()[..., :3], zq_ref.permute(0, 2, 3, 1)), n
+    # the latent formed on load as a linear combination (the sampler's x0): lincomb's arithmetic, no launch
+    e_ = torch.randn(4, 32, 32, 4, generator=g).to(DEV)
+    e_[..., 3] = float('nan')                              # the pad channel of the second operand is never read
+    x0 = ops.lincomb(1.0, zp, -0.731, torch.nan_to_num(e_), div=0.682)
+    i_ref, q_ref = ops.vq_nearest(x0, cb.to(DEV), scale=1.7)
+    i_c, q_c = ops.vq_nearest(zp, cb.to(DEV), scale=1.7, comb=(1.0, -0.731, e_, 0.682))
+    assert torch.equal(i_c, i_ref) and torch.equal(q_c, q_ref)
+    i_c, _ = ops.vq_nearest(zp[:1, :8, :8].contiguous(), cb.to(DEV), scale=1.7,
+                            comb=(1.0, -0.731, e_[:1, :8, :8].contiguous(), 0.682))       # (LDS-scan kernel)
+    assert torch.equal(i_c, ops.vq_nearest(x0[:1, :8, :8].contiguous(), cb.to(DEV), scale=1.7)[0])
     # few latents: the LDS-scan kernel (the codes-in-registers kernel serves >= 512 latents)
     zs_ = z[:1, :, :8, :8].contiguous()
     for n in (5, 130, 4096):
