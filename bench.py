@@ -367,7 +367,9 @@ def main():
     B = args.batch if args.batch > 0 else bc['batch']
     n_img = B * (frames or 1)                 # images per step and GPU (a clip counts its frames)
     img = synth_batch(B, rank, dev, res, frames)
-    parallel.use_bf16_wire(dtype == torch.bfloat16)      # gradient buckets on a bf16 wire when the model computes in bf16
+    # gradient buckets on a bf16 wire when the model computes in bf16: an explicit opt-in of this benchmark (the library
+    # default is fp32 like the reference's DDP), SDMI_GRAD_BF16=0 / 1 overrides
+    wire = parallel.resolve_wire('bf16' if dtype == torch.bfloat16 else 'fp32')
     if dist is not None:                      # every rank starts from rank 0's parameters
         parallel.broadcast_parameters(model.arena())
         model.weights_updated()
@@ -444,15 +446,18 @@ def main():
     model.train()
     opt = FusedAdam(model, lr=1e-4, dec_lr=2e-4, clip_grad=bc['clip_grad'], total_steps=100000)
     garena = model.grad_arena()
+    reducer = parallel.GradReducer(garena, world, wire) if dist is not None else None
 
     def train_step(reduce=True):
         opt.zero_grad()
         out = model(dict(img=img))
         loss = model.calc_train_loss(dict(img=img), out)['denoise_loss']
         loss.backward()
-        if dist is not None and reduce:          # gradients only: the flat fp32 arena in a few large buckets
-            parallel.allreduce_gradients(garena, world, n_buckets=4)
-        opt.step()
+        if dist is not None and reduce:          # gradients only: the flat arena in a few large buckets
+            r = reducer.reduce_all(4)
+            opt.step(grad_src=r.grad_src, grad_scale=r.grad_scale)
+        else:
+            opt.step()
         return loss
 
     train_rate = None
@@ -467,7 +472,7 @@ def main():
             # world > 1: backward split at the slots, denoiser gradients all-reduced under the
             # encoder's backward (optim.GraphedTrainStep)
             graphed = GraphedTrainStep(model, opt, dict(img=img),
-                                       allreduce=(True if dist is not None else None), world=world)
+                                       allreduce=(True if dist is not None else None), world=world, wire=wire)
             run_step = lambda: graphed(dict(img=img))
         dt_t = timed(run_step, args.steps, args.warmup, marked=True)
         train_rate = world * n_img * args.steps / dt_t
@@ -480,7 +485,7 @@ def main():
             # the exchange by itself (all ranks idle otherwise) and what of it the step exposes:
             # the same graphed step without the collective, timed the same way
             def only_reduce():
-                parallel.allreduce_gradients(garena, world, n_buckets=4)
+                reducer.reduce_all(4)
             dt_ar = timed(only_reduce, 3, 1)
             dt_nored = None
             if not args.no_graph:
@@ -488,8 +493,8 @@ def main():
                 dt_nored = timed(lambda: nored(dict(img=img)), args.steps, 1)
             comm = {'rccl_ranks': dist.get_world_size(), 'backend': dist.get_backend(),
                     'devices': [f'cuda:{i}' for i in range(world)],
-                    'grad_dtype_on_wire': 'bf16' if parallel.grad_bf16_enabled() else 'fp32',
-                    'grad_bytes_per_step': garena.numel() * (2 if parallel.grad_bf16_enabled() else 4),
+                    'grad_dtype_on_wire': wire,
+                    'grad_bytes_per_step': garena.numel() * (2 if wire == 'bf16' else 4),
                     'all_reduce_ms': 1e3 * dt_ar / 3,
                     'exposed_comm_ms': (1e3 * (dt_t - dt_nored) / args.steps) if dt_nored else None}
 

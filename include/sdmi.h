@@ -660,14 +660,22 @@ int sdmi_gru_gates_bwd(const SdmiGruGatesBwdArgs* a, void* stream);
  * Optimiser: global-norm clip + Adam over a flat fp32 arena (two lr groups), and bf16 shadow
  * refresh.  Replaces torch.optim.Adam + clip_grad_norm_ (nerv trainer; vb/method.py:291-341).
  * ------------------------------------------------------------------------------------------ */
-typedef struct { const float* g; float* partial; long long n; int nblk; } SdmiSqSumArgs;
+typedef struct {
+  const void* g; float* partial; long long n; int nblk;
+  int g_dtype;                 /* SDMI_F32 (default) or SDMI_BF16: the gradients as they came off a bf16 wire */
+} SdmiSqSumArgs;
 int sdmi_sqsum_partial(const SdmiSqSumArgs* a, void* stream);
 typedef struct {
-  float* p; const float* g; float* m; float* v; void* shadow_bf16; /* optional */
+  float* p; const void* g; float* m; float* v; void* shadow_bf16; /* optional */
   const float* sq_partial; int nblk;     /* global norm^2 = sum(sq_partial[0..nblk)) */
   long long n; float lr, beta1, beta2, eps, clip; int step;
   const float* lr_dev;         /* optional device scalar overriding `lr` (graph-replayable schedule) */
   const int* step_dev;         /* optional device step counter overriding `step` */
+  float gscale;                /* gradients (and the norm the clip sees) are g * gscale; 0 = 1.  Data parallel: g is
+                                  the SUM over ranks as the all-reduce left it, gscale = 1 / world -- no separate
+                                  averaging pass over the arena */
+  int g_dtype;                 /* SDMI_F32 (default) or SDMI_BF16: `g` points at the bf16 wire buffer (same offsets
+                                  as the fp32 gradient arena) -- no widening pass after a bf16 all-reduce */
 } SdmiAdamArgs;
 int sdmi_adam_clip(const SdmiAdamArgs* a, void* stream);
 

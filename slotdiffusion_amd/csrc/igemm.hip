@@ -31,6 +31,11 @@
 #include "igemm_body.h"
 #include "igemm_sym.h"
 
+// 256 x 128 ping-pong kernel: its own translation unit (igemm_pp.hip)
+int sdmi_launch_pp(const SdmiGemmArgs& p, bool is1x1, int hw_shift, hipStream_t st, int n_cu);
+// 3x3 stride-1 convolution with the activation patch staged once per 64-channel chunk (igemm_halo.h)
+int sdmi_launch_halo(const SdmiGemmArgs& p, int logw, int hw_shift, hipStream_t st, int n_cu);
+
 namespace {
 
 // ------------------------------------------------------------------------------------------
@@ -709,6 +714,49 @@ int dispatch(const SdmiGemmArgs& p, hipStream_t st, bool plan_only = false) {
       ((long long)p.B * p.H * p.W + (long long)(p.KH + 1) * p.W) * p.lda * (long long)sizeof(T);
   const long long w_bytes = (long long)p.N * (p.geglu ? 2 : 1) * p.ldw * (long long)sizeof(T);
   const bool fits31 = a_bytes < (1ll << 31) && w_bytes < (1ll << 31);
+  // 3x3 stride-1 same-size convolutions on power-of-two images of 16 / 32 / 64 columns whose 256-pixel tiles are whole
+  // image rows (igemm_halo.h): the activation patch of a tile goes to LDS once per 64-channel chunk and serves all nine
+  // taps -- 21 KB of operand traffic per K tile instead of 48
+  if constexpr (sizeof(T) == 2) {
+    static int halo_min = -1;                // SDMI_IGEMM_HALO: fewest 256 x 128 tiles that take it (0 = off)
+    if (halo_min < 0) {
+      const char* e = getenv("SDMI_IGEMM_HALO");
+      halo_min = e ? atoi(e) : 192;
+    }
+    const long long t256 = ((long long)(p.M + 255) / 256) * ((p.N + 127) / 128);
+    const int logw = p.W == 16 ? 4 : (p.W == 32 ? 5 : (p.W == 64 ? 6 : 0));
+    if (halo_min > 0 && logw && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad_t == 1 && p.pad_l == 1 && plain && !p.a2 &&
+        p.H == p.Ho && p.W == p.Wo && hw_shift >= 8 && p.Cin % 64 == 0 && p.N > 64 && t256 >= halo_min && split_k == 1 &&
+        batch == 1 && fits31 && p.osy == 0 && !p.ln_colsum && !p.geglu && !p.softmax8 && !p.out2 && !p.defer_epilogue &&
+        !p.gn_part && p.out_dtype == SDMI_BF16)
+      return sdmi_launch_halo(p, logw, hw_shift, st, device_cus());
+  }
+  // ping-pong kernel (igemm_pp.h): 256 x 128 tiles, one workgroup per CU -- bf16, 1x1 / plain convolutions, plain
+  // epilogue, launches with about a tile per CU or more and a K loop deep enough to amortise prologue + epilogue
+  if constexpr (sizeof(T) == 2) {
+    static int pp_min = -1, pp_minkt = -1;   // SDMI_IGEMM_PP: fewest 256 x 128 tiles that take it (0 = off)
+    if (pp_min < 0) {
+      const char* e = getenv("SDMI_IGEMM_PP");
+      pp_min = e ? atoi(e) : 192;
+      const char* e2 = getenv("SDMI_IGEMM_PP_MINKT");
+      pp_minkt = e2 ? atoi(e2) : 8;
+    }
+    const long long t256 = ((long long)(p.M + 255) / 256) * ((p.N + 127) / 128);
+    bool ok = pp_min > 0 && p.N > 64 && t256 >= pp_min && (p.K + 63) / 64 >= pp_minkt && split_k == 1 && batch == 1 &&
+              fits31 && !p.ln_colsum && !p.geglu && !p.softmax8 && !p.out2 && !p.defer_epilogue &&
+              (is1x1 || (plain && p.KH * p.KW <= 32 && p.Cin % 64 == 0));
+    if (ok && p.a2) {
+      const long long a2_bytes = (long long)p.M * p.lda2 * 2, a3_bytes = p.a3 ? (long long)p.M * p.lda3 * 2 : 0;
+      const int kend2 = p.a3 ? p.K2 : p.K;
+      const bool same = p.stride == 1 && p.H == p.Ho && p.W == p.Wo;
+      ok = (is1x1 || same) && p.K1 == p.KH * p.KW * p.Cin && kend2 > p.K1 && (!p.a3 || p.K > p.K2) && p.K1 % 64 == 0 &&
+           (kend2 - p.K1) % 64 == 0 && (p.K - kend2) % 64 == 0 && p.lda2 % VEC == 0 && (!p.a3 || p.lda3 % VEC == 0) &&
+           a2_bytes < (1ll << 31) && a3_bytes < (1ll << 31);
+    }
+    if (ok) {
+      return sdmi_launch_pp(p, is1x1, hw_shift, st, device_cus());
+    }
+  }
   // symmetric-wave kernel (igemm_sym.h): 128 x 128 tiles, bf16, 1x1 / plain convolutions, plain epilogue
   if constexpr (sizeof(T) == 2) {
     // default (-1): the two-stage form (two workgroups per CU) where the launch has at least two 128 x 128 tiles

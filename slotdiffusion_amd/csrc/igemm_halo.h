@@ -1,0 +1,272 @@
+// 3x3 stride-1 convolution as a ping-pong implicit GEMM whose activation operand is staged ONCE per 64-channel chunk
+// (round 5).
+//
+// igemm_pp.h's ablations (profiles/r05_pp_ablation.txt; 3x3 256 -> 256 at 32^2, B = 64, us per launch): full kernel 87.7,
+// MFMAs + fragment reads without any operand fetch 51.0 (the matrix pipes at the clock the chip sustains under this
+// load, ~1.67 GHz), with the weight pieces only 59.2, with the activation pieces only 69.7 -- the activation operand
+// of an implicit GEMM (every input pixel fetched again for each of the nine taps: 32 KB per K tile, cold in the
+// vector L1) is what a 3x3 convolution waits for.  Here a workgroup's 256 output pixels are TH = 256 / W whole image
+// rows, and per 64-channel chunk the (TH + 2) x (W + 2) pixel patch around them -- zero columns left and right, zero
+// rows above / below the image -- goes into LDS once (43 KB at W = 32) and serves all nine taps: a tap only shifts the
+// fragment address by (kh (W + 2) + kw) patch pixels.  Activation traffic per K tile 32 KB -> 4.8 KB; with the 16 KB
+// weight tile 21 KB instead of 48.
+//   * structure, hazards and the staggered groups: igemm_pp.h (four barrier intervals per K tile, 8 MFMAs each);
+//   * LDS: two patch buffers (chunk c + 1 arrives while chunk c is multiplied: wave w issues patch piece 8 t + w
+//     during tap t <= 6) + three 16 KB weight stages (the tile of step s + 2 is issued during step s); a wave waits
+//     for the weight pieces of step s + 1 at the end of step s with vmcnt(2 or 3) -- patch pieces are older than the
+//     weight pieces behind them, so they have landed by then too;
+//   * the patch image is pixel-major, 128 B per pixel, 16-byte chunk c of patch pixel q at chunk c ^ ((q >> 1) & 7)
+//     (the DMA writes lane-linear: each lane FETCHES the chunk that belongs at its position); a fragment read
+//     computes the same key from its shifted pixel index: one add, one bit-field extract, one xor per k-step;
+//   * K order (chunk, tap): the weight tile of a step is columns (tap Cin + 64 chunk) of the [N][9 Cin] filter;
+//   * accumulators in C^T layout, row-major epilogue through a wave-private patch (epi_rows.h) in the patch buffer of
+//     the tile's last chunk.
+#pragma once
+#include "igemm_body.h"
+#include "epi_rows.h"
+
+namespace {
+
+template <int LOGW>
+__global__ __launch_bounds__(512, 2) void igemm_halo_kernel(SdmiGemmArgs p, int tiles_m, int tiles_n, int hw_shift) {
+  typedef bf16_t T;
+  constexpr int W = 1 << LOGW, TH = 256 / W, PW = W + 2, PH = TH + 2, Q = PH * PW;
+  constexpr int NPIECE = (Q + 7) / 8;                  // 1 KB pieces (8 patch pixels) of a chunk's patch
+  constexpr int ABUF = NPIECE * 1024, BSTAGE = 128 * 128, NBST = 3;
+  constexpr int ATAPS = 7;                             // taps during which the next patch is issued (7 x 8 waves >= NPIECE)
+  static_assert(ATAPS * 8 >= NPIECE && ABUF >= 8 * EPI_ROWS_PATCH, "patch geometry");
+  constexpr unsigned OOB = 0x80000000u;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const Bst = smem + 2 * ABUF;
+
+  const int nwg = tiles_m * tiles_n;
+  auto tile_of = [&](int vb, int& m0, int& n0) __attribute__((always_inline)) {
+    const int xcd = vb & 7, q = nwg >> 3, r = nwg & 7;
+    const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (vb >> 3);
+    const int tm = id / tiles_n;
+    m0 = tm * 256;
+    n0 = (id - tm * tiles_n) * 128;
+  };
+  const int my_tiles = ((int)blockIdx.x < nwg) ? (nwg - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+  const int nchunk = p.Cin >> 6;
+  if (my_tiles == 0) return;
+
+  const int tid = threadIdx.x, l = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = w >> 2;
+  // ------------------------------------ operand fetch state ------------------------------------
+  // the activation base is biased by -(W + 1) pixels: patch pixel (py, px) of a tile whose first pixel is P0 lies at
+  // P0 + py W + px in biased coordinates (offsets >= 0; the pixels in front of the tensor are never valid)
+  const T* Ag = (const T*)p.a - (long long)(W + 1) * p.lda;
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)Ag, 0, (int)OOB, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)OOB, 0x00020000);
+  // patch pieces of this wave: piece 8 t + w (t < ATAPS); lane l: patch pixel q = 8 piece + (l >> 3), chunk position
+  // l & 7.  Low bits of a_vo: 1 = never valid (zero column / beyond the patch), 2 = row above, 4 = row below the tile
+  unsigned a_vo[ATAPS], a_cur[ATAPS];
+#pragma unroll
+  for (int t = 0; t < ATAPS; ++t) {
+    const int q = (8 * t + w) * 8 + (l >> 3);
+    const int py = q / PW, px = q - py * PW;
+    const int kc = (l & 7) ^ ((q >> 1) & 7);
+    unsigned f = 0;
+    if (q >= Q || px == 0 || px == PW - 1) f |= 1u;
+    if (py == 0) f |= 2u;
+    if (py == PH - 1) f |= 4u;
+    a_vo[t] = ((unsigned)(py * W + px) * (unsigned)p.lda * 2u + (unsigned)kc * 16u) | f;
+    a_cur[t] = OOB;
+  }
+  unsigned b_vo[2];
+  // A side: the chunk being fetched (tile a_ti, chunk a_c); B side: the step being fetched (tile b_ti, chunk b_c, tap b_t)
+  int a_ti = 0, a_c = 0, a_buf = 0;
+  unsigned a_so = 0;
+  auto a_begin_tile = [&]() __attribute__((always_inline)) {
+    int m0, n0;
+    tile_of((int)blockIdx.x + a_ti * (int)gridDim.x, m0, n0);
+    const bool live = a_ti < my_tiles;
+    const int y0 = (m0 & ((1 << hw_shift) - 1)) >> LOGW;            // first image row of the tile
+    const unsigned mask = 1u | (y0 == 0 ? 2u : 0u) | (y0 + TH == p.H ? 4u : 0u);
+#pragma unroll
+    for (int t = 0; t < ATAPS; ++t) a_cur[t] = (!live || (a_vo[t] & mask)) ? OOB : (a_vo[t] & ~15u);
+    a_so = (unsigned)m0 * (unsigned)p.lda * 2u;
+  };
+  auto issue_a = [&](int t) __attribute__((always_inline)) {        // piece 8 t + w of chunk (a_ti, a_c) -> buffer a_buf
+    if (8 * t + w < NPIECE)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void*)(smem + a_buf * ABUF + (8 * t + w) * 1024), 16, (int)a_cur[t],
+                                               (int)(a_so + (unsigned)a_c * 128u), 0, 0);
+  };
+  auto a_advance = [&]() __attribute__((always_inline)) {           // next chunk to fetch
+    a_buf ^= 1;
+    if (++a_c == nchunk) {
+      a_c = 0;
+      ++a_ti;
+      a_begin_tile();
+    }
+  };
+  int b_ti = 0, b_c = 0, b_t = 0, b_stage = 0;
+  auto b_begin_tile = [&]() __attribute__((always_inline)) {
+    int m0, n0;
+    tile_of((int)blockIdx.x + b_ti * (int)gridDim.x, m0, n0);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int row = (w + 8 * j) * 8 + (l >> 3);
+      const int kc = (l & 7) ^ ((4 * (w & 1) + (l >> 4)) & 7);
+      const int n = min(n0 + row, p.N - 1);
+      b_vo[j] = ((unsigned)n * (unsigned)p.ldw + kc * 8) * 2u;
+    }
+  };
+  auto issue_b = [&](int j) __attribute__((always_inline)) {        // piece w + 8 j of step (b_ti, b_c, b_t) -> stage b_stage
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_void*)(Bst + b_stage * BSTAGE + (w + 8 * j) * 1024), 16, (int)b_vo[j],
+                                             (int)((unsigned)(b_t * p.Cin + b_c * 64) * 2u), 0, 0);
+  };
+  auto b_advance = [&]() __attribute__((always_inline)) {
+    if (++b_stage == NBST) b_stage = 0;
+    if (++b_t == 9) {
+      b_t = 0;
+      if (++b_c == nchunk) {
+        b_c = 0;
+        ++b_ti;
+        b_begin_tile();
+      }
+    }
+  };
+
+  // ------------------------------------ MFMA side (per wave) ------------------------------------
+  const int wm = w & 3, wn = w >> 2;
+  const int R = l & 31, hsel = l >> 5;
+  int qb[2];                                           // patch pixel of tap (0, 0) for this lane's row of row block i
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = wm * 64 + i * 32 + R;
+    qb[i] = (r >> LOGW) * PW + (r & (W - 1));
+  }
+  int swz[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) swz[ks] = ((2 * ks + hsel) ^ ((R >> 1) & 7)) * 16;
+  const int b_off = (wn * 64 + R) * 128;
+  u32x4 fa[2][2], fb[2][2];                            // [k-step of the half][row / column block]
+  f32x16 acc[2][2];
+  auto read_half = [&](const char* Ab, const char* Bb, int dq, int h) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int q = qb[i] + dq;
+      const int key = (q >> 1) & 7;
+      const char* row = Ab + q * 128;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) fa[s][i] = *reinterpret_cast<const u32x4*>(row + (((2 * (2 * h + s) + hsel) ^ key) << 4));
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      fb[s][0] = *reinterpret_cast<const u32x4*>(Bb + b_off + swz[2 * h + s]);
+      fb[s][1] = *reinterpret_cast<const u32x4*>(Bb + b_off + 4096 + swz[2 * h + s]);
+    }
+  };
+  auto mfma_half = [&]() __attribute__((always_inline)) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fb[s][j]),
+                                                              __builtin_bit_cast(bf16x8, fa[s][i]), acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+#define HALO_BARRIER()                       \
+  do {                                       \
+    __builtin_amdgcn_sched_barrier(0);       \
+    __builtin_amdgcn_s_barrier();            \
+    asm volatile("" ::: "memory");           \
+    __builtin_amdgcn_sched_barrier(0);       \
+  } while (0)
+
+  // ---- prologue: the whole patch of (tile 0, chunk 0), the weight tiles of steps 0 and 1
+  a_begin_tile();
+  b_begin_tile();
+#pragma unroll
+  for (int t = 0; t < ATAPS; ++t) issue_a(t);
+  a_advance();
+  issue_b(0); issue_b(1); b_advance();
+  issue_b(0); issue_b(1); b_advance();
+  asm volatile("s_waitcnt vmcnt(2)" ::: "memory");     // everything but step 1's weight pieces
+  HALO_BARRIER();
+  int c_buf = 0, c_stage = 0;                          // patch buffer / weight stage of the step being multiplied
+  for (int ti = 0; ti < my_tiles; ++ti) {
+    int m0, n0;
+    tile_of((int)blockIdx.x + ti * (int)gridDim.x, m0, n0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    if (grp == 1) HALO_BARRIER();              // stagger: group 1 runs one interval behind group 0
+    for (int c = 0; c < nchunk; ++c) {
+      const char* Ab = smem + c_buf * ABUF;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const char* Bb = Bst + c_stage * BSTAGE;
+        if (++c_stage == NBST) c_stage = 0;
+        constexpr int dummy = 0;
+        (void)dummy;
+        const int dq = (t / 3) * PW + (t % 3);
+        const bool has_a = t < ATAPS && 8 * t + w < NPIECE;        // wave-uniform
+        // ---- L(s, 0): fragments of k-steps 0, 1; a piece of the next chunk's patch; first weight piece of step s + 2
+        read_half(Ab, Bb, dq, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (t < ATAPS) issue_a(t);
+        issue_b(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        HALO_BARRIER();
+        mfma_half();
+        HALO_BARRIER();
+        // ---- L(s, 1): k-steps 2, 3; second weight piece; this wave's weight pieces of step s + 1 (and every patch
+        // piece issued before them) have landed
+        read_half(Ab, Bb, dq, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        issue_b(1);
+        b_advance();
+        if (t == ATAPS - 1) a_advance();                            // the next chunk's patch is fully issued
+        if (has_a) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        HALO_BARRIER();
+        mfma_half();
+        HALO_BARRIER();
+      }
+      c_buf ^= 1;
+    }
+    if (grp == 0) HALO_BARRIER();              // both groups store in the same interval
+    const int mw0 = m0 + wm * 64, nw0 = n0 + wn * 64;
+    if (epilogue_rows_ok(p, mw0, nw0, hw_shift)) {
+      // wave-private patch in the patch buffer the tile's last chunk vacated (c_buf already points at the other one)
+      wave_epilogue_rows(p, acc, mw0, nw0, hw_shift, l, smem + (c_buf ^ 1) * ABUF + w * EPI_ROWS_PATCH);
+    } else {
+      wave_epilogue_rows_generic(p, acc, mw0, nw0, hw_shift, l);
+      __builtin_amdgcn_s_waitcnt(0x0F70);       // vmcnt(0)
+    }
+    if (ti + 1 < my_tiles) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      HALO_BARRIER();
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no DMA may outlive the workgroup's LDS
+#undef HALO_BARRIER
+}
+
+template <int LOGW>
+int launch_halo(const SdmiGemmArgs& p, int hw_shift, hipStream_t st, int n_cu) {
+  constexpr int W = 1 << LOGW, Q = (256 / W + 2) * (W + 2);
+  constexpr int smem = 2 * ((Q + 7) / 8) * 1024 + 3 * 128 * 128;
+  auto kern = igemm_halo_kernel<LOGW>;
+  SDMI_OPTIN_LDS(kern, smem, "igemm (3x3 halo ping-pong)");
+  SdmiGemmArgs q = p;
+  q.split_k = 1;
+  const int tiles_m = p.M / 256, tiles_n = (p.N + 127) / 128;
+  int cap = n_cu < 8 ? 8 : (n_cu & ~7);
+  const int nwg = tiles_m * tiles_n;
+  hipLaunchKernelGGL(kern, dim3(nwg <= cap ? nwg : cap), dim3(512), smem, st, q, tiles_m, tiles_n, hw_shift);
+  return sdmi_check_launch("igemm (3x3 halo ping-pong)");
+}
+
+}  // namespace

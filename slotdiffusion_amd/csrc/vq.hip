@@ -45,6 +45,31 @@ __device__ __forceinline__ vq_f2 vq_dist2(const float* cbp, vq_f2 z0, vq_f2 z1, 
   return __builtin_elementwise_fma(m2, dot, t);
 }
 
+__device__ __forceinline__ float vq_dist1(float z0, float z1, float z2, float zz, float a, float b, float c, float n2) {
+  const float dot = fmaf(z2, c, fmaf(z1, b, z0 * a));
+  return fmaf(-2.f, dot, zz + n2);
+}
+
+// Non-finite latents (NaN / Inf components, or |z|^2 overflowing): the packed scan's fminf drops NaN distances, so no
+// code "attains the minimum" and the index would stay at its sentinel.  These rows take a sequential scan with
+// torch.argmin's semantics (vqvae/quantize.py:90): the first NaN distance if there is one, else the first minimum.
+__device__ __noinline__ int vq_scan_nonfinite(const SdmiVqArgs& p, float z0, float z1, float z2, float zz) {
+  float best = INFINITY;
+  int bi = 0;
+  for (int j = 0; j < p.n_codes; ++j) {
+    const float a = p.codebook[j * 3 + 0], b = p.codebook[j * 3 + 1], c = p.codebook[j * 3 + 2];
+    const float t0 = a * a, t1 = b * b, t2 = c * c;
+    // (the reference's separately rounded 2 * dot: equal to the scan's fma(-2, dot, .) except where 2 * dot overflows,
+    // which only these rows can reach -- inf - inf = NaN there, +-inf from the fused form)
+    const float dot = fmaf(z2, c, fmaf(z1, b, z0 * a));
+    const float two = 2.f * dot;
+    const float d = (zz + ((t0 + t1) + t2)) - two;
+    if (d != d) return j;
+    if (d < best) { best = d; bi = j; }
+  }
+  return bi;
+}
+
 __global__ __launch_bounds__(256) void vq_kernel(SdmiVqArgs p) {
   extern __shared__ __attribute__((aligned(16))) float cb[];  // [pairs padded to chunks][8]
   const int n_pairs = (p.n_codes + 1) / 2;
@@ -105,6 +130,7 @@ __global__ __launch_bounds__(256) void vq_kernel(SdmiVqArgs p) {
     if (ob < best || (ob == best && oi < bi)) { best = ob; bi = oi; }
   }
   if (!live || half) return;
+  if (!(zz < INFINITY)) bi = vq_scan_nonfinite(p, z0, z1, z2, zz);
   if (p.idx) p.idx[r] = bi;
   if (p.zq) {
     float* o = p.zq + (long long)r * p.ldz;
@@ -142,10 +168,6 @@ __device__ __forceinline__ float vq_wave_min(float v) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
-__device__ __forceinline__ float vq_dist1(float z0, float z1, float z2, float zz, float a, float b, float c, float n2) {
-  const float dot = fmaf(z2, c, fmaf(z1, b, z0 * a));
-  return fmaf(-2.f, dot, zz + n2);
-}
 
 template <int NP>
 __global__ __launch_bounds__(256) void vq_reg_kernel(SdmiVqArgs p) {
@@ -227,6 +249,7 @@ __global__ __launch_bounds__(256) void vq_reg_kernel(SdmiVqArgs p) {
       }
     }
   }
+  if (!(zz < INFINITY)) bi = vq_scan_nonfinite(p, z0, z1, z2, zz);
   if (p.idx) p.idx[r] = bi;
   if (p.zq) {
     float* o = p.zq + (long long)r * p.ldz;

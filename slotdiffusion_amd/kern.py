@@ -1016,11 +1016,10 @@ class Kern:
         if fused:
             # the fused block (sdmi_st_block) takes the same operands padded to 128 score columns, as a unit
             # stream: Wq[b] / W2[b] are produced straight into the padded storage (pads stay zero)
-            key = ('st_img_src', t, B)
-            if key not in self.wb.cache:
-                self.wb.cache[key] = (torch.zeros((B, 128 * C + C * 128), dtype=kv.dtype, device=kv.device),
-                                      torch.zeros((B, 256), dtype=torch.float32, device=kv.device))
-            src, vec = self.wb.cache[key]
+            # (allocated per call: the fold dict hands out VIEWS of these -- a cached buffer would be overwritten by the
+            # next context of the same batch size (cond / uncond, two live generators) while an earlier fold is alive)
+            src = torch.zeros((B, 128 * C + C * 128), dtype=kv.dtype, device=kv.device)
+            vec = torch.zeros((B, 256), dtype=torch.float32, device=kv.device)
             wq = src[:, :R * C].view(B, R, C)
             w2 = src[:, 128 * C:].view(B, C, 128)[:, :, :R]
             colsum, biasq = vec[:, :R].unsqueeze(-1), vec[:, 128:128 + R].unsqueeze(-1)

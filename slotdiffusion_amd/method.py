@@ -97,9 +97,12 @@ class Method:
         total, losses = self._loss(batch)
         total.backward()
         if self.world > 1:
-            parallel.use_bf16_wire(getattr(self.model, 'compute_dtype', None) == torch.bfloat16)
-            parallel.allreduce_gradients(self.model.grad_arena(), self.world)
-        self.optimizer.step()
+            if getattr(self, '_reducer', None) is None:
+                self._reducer = parallel.GradReducer(self.model.grad_arena(), self.world, self._get('ddp_grad_dtype'))
+            r = self._reducer.reduce_all(4)
+            self.optimizer.step(grad_src=r.grad_src, grad_scale=r.grad_scale)
+        else:
+            self.optimizer.step()
         return total.detach()
 
     def fit(self, resume_from='', san_check_val_step=0, max_steps=None):
@@ -131,7 +134,7 @@ class Method:
                     # (the capture's warm-up passes are rolled back: optim.GraphedTrainStep)
                     graphed = GraphedTrainStep(self.model, self.optimizer, batch, allreduce=ar,
                                                loss_key=key, loss_weight=self._get(f'{key}_w', 1.0),
-                                               world=self.world)
+                                               world=self.world, wire=self._get('ddp_grad_dtype'))
                 loss = graphed(batch) if graphed is not None else self._eager_step(batch)
                 self.it += 1
                 self.history.append(loss)

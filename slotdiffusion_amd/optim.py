@@ -76,20 +76,22 @@ class FusedAdam:
                 'total_steps': self.total_steps, 'warmup': self.warmup, 'min_lr_ratio': self.min_lr_ratio}
 
     def load_state_dict(self, sd):
-        """The reference loads the scheduler state and continues (nerv trainer); so does this: a checkpoint written
-        with another schedule length / warm-up / floor wins over this run's values, with a warning (a changed
-        max_epochs or dataset length must not make a checkpoint unloadable).  A checkpoint from before the floor was
-        recorded has none: 0."""
+        """The reference loads the scheduler state and continues (nerv trainer); so does this.  The schedule
+        (total_steps, warmup, min_lr_ratio) is ONE unit: a checkpoint that recorded a schedule (total_steps not None)
+        replaces this run's whole triple -- a changed max_epochs or dataset length must not make a checkpoint
+        unloadable -- and a checkpoint without one leaves this run's triple alone; every difference is reported.  A
+        checkpoint from before the floor was recorded keeps this run's floor."""
         import warnings
-        for k, default in (('total_steps', None), ('warmup', None), ('min_lr_ratio', 0.0)):
-            mine = getattr(self, k)
-            theirs = sd.get(k, default)
-            if theirs is None:
-                continue
-            if mine is not None and abs(float(theirs) - float(mine)) > 1e-9:
-                warnings.warn(f'optimizer checkpoint was written with {k}={theirs}, this run was configured with '
-                              f'{mine}: continuing the checkpoint\'s schedule')
-            setattr(self, k, type(mine)(theirs) if mine is not None else theirs)
+        mine = (self.total_steps, self.warmup, self.min_lr_ratio)
+        if sd.get('total_steps') is not None:
+            theirs = (int(sd['total_steps']), float(sd.get('warmup', 0.0) or 0.0),
+                      float(sd['min_lr_ratio']) if 'min_lr_ratio' in sd else self.min_lr_ratio)
+            if mine[0] is None or any(abs(float(a) - float(b)) > 1e-9 for a, b in zip(mine, theirs)):
+                warnings.warn(f'optimizer checkpoint was written with (total_steps, warmup, min_lr_ratio) = {theirs}, '
+                              f'this run was configured with {mine}: continuing the checkpoint\'s schedule')
+            self.total_steps, self.warmup, self.min_lr_ratio = theirs
+        elif mine[0] is not None:
+            warnings.warn(f'optimizer checkpoint carries no learning-rate schedule; keeping this run\'s {mine}')
         self.m.copy_(sd['m'])
         self.v.copy_(sd['v'])
         self.step_count = int(sd['step_count'])
@@ -114,11 +116,16 @@ class FusedAdam:
             self._lr_ev[i].record()
 
     @torch.no_grad()
-    def step(self, capturable=False):
+    def step(self, capturable=False, grad_src=None, grad_scale=1.0):
         """clip + Adam over the arena.  capturable=True reads step / lr from device memory (the
-        caller has run set_lr_for_next_step()), so the launch sequence can live in a HIP graph."""
+        caller has run set_lr_for_next_step()), so the launch sequence can live in a HIP graph.
+        grad_src / grad_scale (data parallel, parallel.GradReducer): the gradients are read from `grad_src` (the
+        fp32 arena, or the bf16 wire buffer with the same offsets) as the all-reduce left them -- the SUM over ranks --
+        and multiplied by `grad_scale` = 1 / world inside the kernels; the clip sees the norm of the scaled gradients."""
         m = self.model
-        g = m.grad_arena()
+        g = m.grad_arena() if grad_src is None else grad_src
+        assert g.numel() >= self.n_train and g.dtype in (torch.float32, torch.bfloat16)
+        g_dtype = 1 if g.dtype == torch.bfloat16 else 0
         st = torch.cuda.current_stream().cuda_stream
         if capturable:          # host bookkeeping (step_count, lr) is the replaying caller's job
             call('sdmi_counters_inc', st, step=_p(self.step_dev))
@@ -127,7 +134,7 @@ class FusedAdam:
             self.step_count += 1
             self.step_dev.fill_(self.step_count)
         call('sdmi_sqsum_partial', st, g=_p(g), partial=_p(self.partial), n=self.n_train,
-             nblk=self.nblk)
+             nblk=self.nblk, g_dtype=g_dtype)
         arena = m.arena()
         bf16 = m.compute_dtype == torch.bfloat16
         shadow = m.shadow_arena() if bf16 else None
@@ -137,7 +144,7 @@ class FusedAdam:
                  sq_partial=_p(self.partial), nblk=self.nblk, n=hi - lo, lr=0.0,
                  beta1=self.b1, beta2=self.b2, eps=self.eps, clip=self.clip,
                  step=(0 if capturable else self.step_count), lr_dev=_p(self.lr_dev[grp:]),
-                 step_dev=(_p(self.step_dev) if capturable else 0))
+                 step_dev=(_p(self.step_dev) if capturable else 0), gscale=float(grad_scale), g_dtype=g_dtype)
         m.weights_updated(shadow_fresh=True)
 
 
@@ -162,7 +169,7 @@ class GraphedTrainStep:
     update graph.  `allreduce` may be the legacy callable (whole arena, no overlap) or True."""
 
     def __init__(self, model, opt, example_batch, allreduce=None, loss_key='denoise_loss',
-                 loss_weight=1.0, world=None):
+                 loss_weight=1.0, world=None, wire=None):
         self.model, self.opt, self.allreduce = model, opt, allreduce
         self.loss_key, self.loss_weight = loss_key, loss_weight
         from . import configure_runtime
@@ -172,20 +179,22 @@ class GraphedTrainStep:
         if getattr(model, 'step_seed', None) is None or model.step_seed.device != dev:
             model.step_seed = torch.zeros(1, dtype=torch.int64, device=dev)   # dropout seed word
         self.world = world
-        if allreduce is not None:
-            from . import parallel
-            parallel.use_bf16_wire(getattr(model, 'compute_dtype', None) == torch.bfloat16)
         if allreduce is not None and world is None:
             import torch.distributed as dist
             self.world = dist.get_world_size()
+        # `allreduce=True`: the exchange is a parallel.GradReducer (wire = 'fp32' unless the caller opts into 'bf16');
+        # the update graph reads the summed gradients where the collective left them, scaled by 1 / world in-kernel
+        self.reducer = None
+        if allreduce is True:
+            from . import parallel
+            self.reducer = parallel.GradReducer(model.grad_arena(), self.world, wire)
         # overlap mode needs the denoiser / encoder split of the arena (lr group 1 = dm_decoder)
         runs = model.lr_runs()
         self.dec_runs = [(lo, hi) for lo, hi, grp in runs if grp == 1]
         self.enc_runs = [(lo, hi) for lo, hi, grp in runs if grp != 1]
         self.overlap = allreduce is True and len(self.dec_runs) > 0 and len(self.enc_runs) > 0
-        if allreduce is True and not self.overlap:        # no denoiser range to split at
-            from . import parallel
-            self.allreduce = allreduce = lambda g: parallel.allreduce_gradients(g, self.world)
+        if allreduce is True and not self.overlap:        # no denoiser range to split at: one exchange of the arena
+            self.allreduce = allreduce = lambda g: self.reducer.reduce_all(4)
         self.loss = None
         self._slots = self._dslots = None
         # The warm-up passes below (lazy operands, func attributes, allocator pool) are real steps on
@@ -264,22 +273,21 @@ class GraphedTrainStep:
         self._slots = self._dslots = None
 
     def _start_reduce(self, runs):
-        from . import parallel
-        g = self.model.grad_arena()
         works = []
         for lo, hi in runs:
             # >= 4 buckets over the denoiser's range (135 M floats: ~70 MB each on a bf16 wire), one for small runs:
             # the ring of the first bucket is busy while the next one is still being converted
-            works += parallel.allreduce_range_async(g, lo, hi, n_buckets=(4 if hi - lo > (16 << 20) else 1))
+            works += self.reducer.start(lo, hi, n_buckets=(4 if hi - lo > (16 << 20) else 1))
         return works
 
     def _finish_reduce(self, works):
-        for w in works:
-            w.wait()
-        self.model.grad_arena().mul_(1.0 / self.world)
+        self.reducer.finish(works)          # (no pass over the arena: 1 / world and the wire dtype ride in _update)
 
     def _update(self):
-        self.opt.step(capturable=True)
+        if self.reducer is not None:
+            self.opt.step(capturable=True, grad_src=self.reducer.grad_src, grad_scale=self.reducer.grad_scale)
+        else:
+            self.opt.step(capturable=True)
 
     def __call__(self, batch):
         for k, v in batch.items():

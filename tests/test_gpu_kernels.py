@@ -490,6 +490,30 @@ def test_vq_nearest_bit_exact():
     assert torch.equal(idx.cpu(), idx_ref) and int(idx.max()) < 2140
 
 
+@pytest.mark.parametrize('small', [False, True])
+def test_vq_nearest_nonfinite_latents(small):
+    """NaN / Inf latents (a diverged low-precision sampling pass) must not fault: indices stay in range and follow
+    torch.argmin (first NaN distance, else first minimum) like the reference's quantizer (quantize.py:85-94)."""
+    from oracle import slotdiff_oracle as O
+    ops = _ops()
+    g = torch.Generator().manual_seed(12)
+    cb = torch.randn(4096, 3, generator=g) / math.sqrt(3)
+    cb[5, 1] = 0.0                                         # inf * 0 -> a NaN distance next to +inf ones
+    hw = 8 if small else 32                                # 64 latents: LDS-scan kernel; 1024: codes in registers
+    z = torch.randn(1, 3, hw, hw, generator=g)
+    z[0, 0, 0, 1] = float('nan')
+    z[0, 1, 0, 2] = float('inf')
+    z[0, 2, 0, 3] = -float('inf')
+    z[0, :, 1, 0] = float('inf')
+    z[0, 0, 1, 1] = 3e38                                   # |z|^2 overflows
+    _, idx_ref = O.vq_quantize({'p.quantize.embedding.weight': cb}, z, 'p')
+    zp = F.pad(z.permute(0, 2, 3, 1), (0, 1)).contiguous().to(DEV)
+    idx, zq = ops.vq_nearest(zp, cb.to(DEV))
+    torch.cuda.synchronize()
+    assert int(idx.min()) >= 0 and int(idx.max()) < 4096
+    assert torch.equal(idx.cpu(), idx_ref), (idx.cpu() != idx_ref).nonzero()[:8]
+
+
 def test_elementwise_family():
     ops = _ops()
     g = torch.Generator().manual_seed(3)

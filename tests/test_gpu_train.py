@@ -117,6 +117,38 @@ def test_adam_clip_step_matches_oracle():
     assert worst <= 2e-6
 
 
+@pytest.mark.parametrize('g16', [False, True])
+@pytest.mark.parametrize('n,off', [(4099, 0), (1003, 1), (70001, 8)])
+def test_adam_reads_summed_gradients_scaled(n, off, g16):
+    """Data-parallel form of the update (SdmiAdamArgs.gscale / g_dtype): the kernels read the SUM over ranks where the
+    all-reduce left it -- fp32 arena or bf16 wire buffer -- and apply 1 / world themselves; equal to the oracle's
+    clip + Adam on the averaged gradients."""
+    from oracle import slotdiff_oracle as O
+    from slotdiffusion_amd import _lib
+    world = 8
+    g = torch.Generator().manual_seed(n + 7)
+    P, Gs = torch.randn(n, generator=g), torch.randn(n, generator=g) * 3 * world      # Gs: summed gradients
+    if g16:
+        Gs = Gs.bfloat16().float()
+    M, V = torch.randn(n, generator=g) * 0.1, torch.rand(n, generator=g) * 0.1
+    buf = lambda t: torch.cat([torch.zeros(off), t]).cuda()
+    p, m, v = buf(P), buf(M), buf(V)
+    gr = buf(Gs).bfloat16() if g16 else buf(Gs)
+    partial = torch.zeros(1024, device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    gd = _lib.BF16 if g16 else _lib.F32
+    _lib.call('sdmi_sqsum_partial', st, g=gr[off:].data_ptr(), partial=partial.data_ptr(), n=n, nblk=1024, g_dtype=gd)
+    _lib.call('sdmi_adam_clip', st, p=p[off:].data_ptr(), g=gr[off:].data_ptr(), m=m[off:].data_ptr(),
+              v=v[off:].data_ptr(), shadow_bf16=0, sq_partial=partial.data_ptr(), nblk=1024, n=n, lr=1e-3,
+              beta1=0.9, beta2=0.999, eps=1e-8, clip=1.0, step=3, lr_dev=0, step_dev=0, gscale=1.0 / world,
+              g_dtype=gd)
+    Pl, Ml, Vl = [P.clone()], [M.clone()], [V.clone()]
+    O.clip_and_adam(Pl, [Gs / world], Ml, Vl, 3, [1e-3], clip=1.0)
+    assert float((p[off:].cpu() - Pl[0]).abs().max()) <= 2e-6
+    assert float((m[off:].cpu() - Ml[0]).abs().max()) <= 2e-6 and float((v[off:].cpu() - Vl[0]).abs().max()) <= 2e-6
+    assert float(p[:off].abs().sum()) == 0.
+
+
 @pytest.mark.parametrize('n,off', [(4099, 0), (1003, 1), (8, 4), (3, 0)])
 def test_adam_kernel_tails_and_alignment(n, off):
     """sdmi_adam_clip on ranges whose length is not a multiple of four and whose start is not 16-byte

@@ -204,12 +204,26 @@ def test_lr_schedule_closed_form():
     with pytest.warns(UserWarning):
         o4.load_state_dict(sd)
     assert o4.total_steps == total and o4.min_lr_ratio == 0.01 and abs(o4.lr_scale(total) - 0.01) < 1e-12
-    # a checkpoint from before the floor was recorded: floor 0, explicitly
+    # a checkpoint from before the floor was recorded keeps THIS run's floor (the schedule triple is one unit: length
+    # and warm-up come from the checkpoint, a missing key does not silently zero the floor)
+    import warnings
     old_sd = {k: v for k, v in sd.items() if k != 'min_lr_ratio'}
     o5 = FusedAdam(Fake(), lr=4e-4, total_steps=total, warmup_pct=pct, min_lr_ratio=0.01)
-    with pytest.warns(UserWarning):
+    with warnings.catch_warnings():
+        warnings.simplefilter('error')                  # identical schedule: nothing to report
         o5.load_state_dict(old_sd)
-    assert o5.min_lr_ratio == 0.0
+    assert o5.min_lr_ratio == 0.01 and o5.total_steps == total and o5.warmup == w
+    # a checkpoint written WITHOUT a schedule leaves this run's whole triple alone (warm-up is not dropped) ...
+    none_sd = dict(sd, total_steps=None, warmup=0.0)
+    o6 = FusedAdam(Fake(), lr=4e-4, total_steps=total, warmup_pct=pct, min_lr_ratio=0.01)
+    with pytest.warns(UserWarning):
+        o6.load_state_dict(none_sd)
+    assert (o6.total_steps, o6.warmup, o6.min_lr_ratio) == (total, w, 0.01)
+    # ... and a run configured without one that loads a scheduled checkpoint adopts it, with a warning
+    o7 = FusedAdam(Fake(), lr=4e-4)
+    with pytest.warns(UserWarning):
+        o7.load_state_dict(sd)
+    assert (o7.total_steps, o7.warmup, o7.min_lr_ratio) == (total, w, 0.01)
 
 
 def test_method_schedule_floor_follows_the_reference_method():

@@ -38,13 +38,25 @@ def _worker(rank, world, port, n, ret):
         rel = float((g16 - ref).norm() / ref.norm())
         # two ranks: one rounding of each partial + one bf16 add -> ~2^-9 rms; bound 2^-8
         ok1 = ok1 and rel < 2.0 ** -8 and rel > 0 and g16.dtype == torch.float32
-        # default follows the compute dtype (parallel.use_bf16_wire), the environment overrides it
-        parallel.use_bf16_wire(True)
-        ok1 = ok1 and parallel.grad_bf16_enabled()
+        # the wire format is an explicit argument (library default fp32), the environment overrides it
+        ok1 = ok1 and parallel.resolve_wire() == 'fp32' and parallel.resolve_wire('bf16') == 'bf16'
         os.environ['SDMI_GRAD_BF16'] = '0'
-        ok1 = ok1 and not parallel.grad_bf16_enabled()
+        ok1 = ok1 and parallel.resolve_wire('bf16') == 'fp32'
         del os.environ['SDMI_GRAD_BF16']
-        parallel.use_bf16_wire(False)
+        # the training step's form: buckets reduced in place, the SUM stays where the collective left it (fp32 arena
+        # or the persistent bf16 buffer) and the optimiser applies grad_scale = 1 / world -- no pass over the arena
+        for wire in ('fp32', 'bf16'):
+            gl = torch.randn(n, generator=torch.Generator().manual_seed(100 + rank))
+            red = parallel.GradReducer(gl, world, wire)
+            buf0 = red.wire_buf
+            for _ in range(2):                            # persistent wire buffer: same storage every step
+                gl.copy_(torch.randn(n, generator=torch.Generator().manual_seed(100 + rank)))
+                works = red.start(0, n // 2, 2) + red.start(n // 2, n, 1)
+                red.finish(works)
+            avg = red.grad_src.float() * red.grad_scale
+            ok1 = ok1 and red.wire_buf is buf0 and float((avg - ref).norm() / ref.norm()) < (1e-6 if wire == 'fp32' else 2.0 ** -8)
+            if wire == 'bf16':                            # the arena keeps this rank's local gradients
+                ok1 = ok1 and torch.equal(gl, torch.randn(n, generator=torch.Generator().manual_seed(100 + rank)))
         params = torch.full((1000,), float(rank))
         parallel.broadcast_parameters(params, src=0)
         ok2 = bool((params == 0).all())
