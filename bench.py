@@ -146,8 +146,8 @@ def cpu_baseline(model, cfg, mode, quick=False):
 
 # kernels behind the C-ABI entry points the roofline legs price (csrc/igemm.hip, wgrad.hip, norm.hip, norm_bwd.hip)
 FAMILIES = {
-    'sdmi_igemm': ('igemm_kernel', 'igemm_kernel_tall', 'igemm_dma_kernel', 'igemm_sym_kernel', 'conv3x3_c64_kernel',
-                   'splitk_epilogue_kernel', 'bwd_pair_kernel', 'st_block_a_kernel', 'st_block_b_kernel'),
+    'sdmi_igemm': ('igemm_kernel', 'igemm_kernel_tall', 'igemm_dma_kernel', 'igemm_sym_kernel', 'igemm_pp_kernel',
+                   'igemm_halo_kernel', 'conv3x3_c64_kernel', 'splitk_epilogue_kernel', 'bwd_pair_kernel', 'st_block_a_kernel', 'st_block_b_kernel'),
     'sdmi_wgrad': ('wgrad_kernel', 'wgrad_tr_kernel', 'wgrad3x3_c64_kernel', 'wgrad_group_kernel', 'wgrad_group_reduce_kernel',
                    'wgrad_reduce_kernel'),
     'sdmi_groupnorm': ('gn_fused_kernel', 'gn_fused2_kernel', 'gn_stats_kernel', 'gn_apply_kernel'),

@@ -34,7 +34,7 @@
 // 256 x 128 ping-pong kernel: its own translation unit (igemm_pp.hip)
 int sdmi_launch_pp(const SdmiGemmArgs& p, bool is1x1, int hw_shift, hipStream_t st, int n_cu);
 // 3x3 stride-1 convolution with the activation patch staged once per 64-channel chunk (igemm_halo.h)
-int sdmi_launch_halo(const SdmiGemmArgs& p, int logw, int hw_shift, hipStream_t st, int n_cu);
+int sdmi_launch_halo(const SdmiGemmArgs& p, int logw, int nj, int hw_shift, hipStream_t st, int n_cu);
 
 namespace {
 
@@ -678,6 +678,42 @@ int dispatch(const SdmiGemmArgs& p, hipStream_t st, bool plan_only = false) {
   // K tile: 128 bytes of K per row when K is deep enough, else 64
   const int kbytes = p.K * (int)sizeof(T);
   const bool wide = kbytes >= 512;
+  const bool plain = !is1x1 && !p.ups && p.zins <= 1;
+  // the scalar-offset loaders (MODE 1 / 2) address operands with 31-bit byte offsets
+  const long long a_bytes =
+      ((long long)p.B * p.H * p.W + (long long)(p.KH + 1) * p.W) * p.lda * (long long)sizeof(T);
+  const long long w_bytes = (long long)p.N * (p.geglu ? 2 : 1) * p.ldw * (long long)sizeof(T);
+  const bool fits31 = a_bytes < (1ll << 31) && w_bytes < (1ll << 31);
+  // 3x3 stride-1 same-size convolutions on power-of-two images of 16 / 32 / 64 columns whose 256-pixel tiles are whole
+  // image rows (igemm_halo.h): the activation patch of a tile goes to LDS once per 64-channel chunk and serves all nine
+  // taps -- 21 KB of operand traffic per K tile instead of 48.  256 x 128 tiles when they fill the chip, else 256 x 64
+  // (the 16^2 level at B = 64: 64 row tiles); decided before the K split (these launches never split K)
+  int halo_nj = 0, halo_logw = 0;
+  if constexpr (sizeof(T) == 2) {
+    static int halo_min = -1;                // SDMI_IGEMM_HALO: fewest tiles that take it (0 = off)
+    if (halo_min < 0) {
+      const char* e = getenv("SDMI_IGEMM_HALO");
+      halo_min = e ? atoi(e) : 192;
+    }
+    static int halo_nj1 = -1;                // SDMI_IGEMM_HALO_NJ1=1: 256 x 64 tiles where 256 x 128 leave CUs idle
+    if (halo_nj1 < 0) {                      // (off: 26.3 vs 27.3 us at 256 -> 256 @16^2, 44.2 vs 41.4 us at 512 -> 256:
+      const char* e = getenv("SDMI_IGEMM_HALO_NJ1");   //  the narrow tile doubles the weight bytes per flop)
+      halo_nj1 = e ? atoi(e) : 0;
+    }
+    const long long tm256 = (long long)(p.M + 255) / 256;
+    const int nj = (tm256 * ((p.N + 127) / 128) >= halo_min || !halo_nj1) ? 2 : 1;
+    const long long t256 = tm256 * ((p.N + 64 * nj - 1) / (64 * nj));
+    halo_logw = p.W == 16 ? 4 : (p.W == 32 ? 5 : (p.W == 64 ? 6 : 0));
+    if (halo_min > 0 && halo_logw && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad_t == 1 && p.pad_l == 1 && plain &&
+        !p.a2 && p.H == p.Ho && p.W == p.Wo && hw_shift >= 8 && p.Cin % 64 == 0 && p.N >= 64 && t256 >= halo_min &&
+        p.split_k <= 1 && batch == 1 && fits31 && p.osy == 0 && !p.ln_colsum && !p.geglu && !p.softmax8 && !p.out2 &&
+        !p.gn_part && !p.defer_epilogue && p.out_dtype == SDMI_BF16)
+      halo_nj = nj;
+  }
+  if (halo_nj) {
+    if (plan_only) return 1;
+    return sdmi_launch_halo(p, halo_logw, halo_nj, hw_shift, st, device_cus());
+  }
   int split_k = 1;
   if (p.split_k > 0) split_k = p.split_k;       // caller override
   else if (!big && batch == 1 && p.workspace && p.osy == 0) {
@@ -692,7 +728,6 @@ int dispatch(const SdmiGemmArgs& p, hipStream_t st, bool plan_only = false) {
   }
   if (split_k > 1 && !p.workspace) split_k = 1;
   if (plan_only) return split_k;
-  const bool plain = !is1x1 && !p.ups && p.zins <= 1;
   // direct 3x3 kernel for the 64 -> 64 channel convolutions at full resolution
   if (sizeof(T) == 2 && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad_t == 1 && p.pad_l == 1 &&
       !p.a2 && !p.ups && p.zins <= 1 && p.osy == 0 && p.Cin == 64 && p.N <= 64 && p.N > 32 && batch == 1 &&
@@ -709,35 +744,13 @@ int dispatch(const SdmiGemmArgs& p, hipStream_t st, bool plan_only = false) {
     hipLaunchKernelGGL(conv3x3_c64_kernel, dim3(grid), dim3(256), D33_SMEM, st, q, hw_shift);
     return sdmi_check_launch("igemm (direct 3x3 c64)");
   }
-  // the scalar-offset loaders (MODE 1 / 2) address operands with 31-bit byte offsets
-  const long long a_bytes =
-      ((long long)p.B * p.H * p.W + (long long)(p.KH + 1) * p.W) * p.lda * (long long)sizeof(T);
-  const long long w_bytes = (long long)p.N * (p.geglu ? 2 : 1) * p.ldw * (long long)sizeof(T);
-  const bool fits31 = a_bytes < (1ll << 31) && w_bytes < (1ll << 31);
-  // 3x3 stride-1 same-size convolutions on power-of-two images of 16 / 32 / 64 columns whose 256-pixel tiles are whole
-  // image rows (igemm_halo.h): the activation patch of a tile goes to LDS once per 64-channel chunk and serves all nine
-  // taps -- 21 KB of operand traffic per K tile instead of 48
-  if constexpr (sizeof(T) == 2) {
-    static int halo_min = -1;                // SDMI_IGEMM_HALO: fewest 256 x 128 tiles that take it (0 = off)
-    if (halo_min < 0) {
-      const char* e = getenv("SDMI_IGEMM_HALO");
-      halo_min = e ? atoi(e) : 192;
-    }
-    const long long t256 = ((long long)(p.M + 255) / 256) * ((p.N + 127) / 128);
-    const int logw = p.W == 16 ? 4 : (p.W == 32 ? 5 : (p.W == 64 ? 6 : 0));
-    if (halo_min > 0 && logw && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad_t == 1 && p.pad_l == 1 && plain && !p.a2 &&
-        p.H == p.Ho && p.W == p.Wo && hw_shift >= 8 && p.Cin % 64 == 0 && p.N > 64 && t256 >= halo_min && split_k == 1 &&
-        batch == 1 && fits31 && p.osy == 0 && !p.ln_colsum && !p.geglu && !p.softmax8 && !p.out2 && !p.defer_epilogue &&
-        !p.gn_part && p.out_dtype == SDMI_BF16)
-      return sdmi_launch_halo(p, logw, hw_shift, st, device_cus());
-  }
   // ping-pong kernel (igemm_pp.h): 256 x 128 tiles, one workgroup per CU -- bf16, 1x1 / plain convolutions, plain
   // epilogue, launches with about a tile per CU or more and a K loop deep enough to amortise prologue + epilogue
   if constexpr (sizeof(T) == 2) {
     static int pp_min = -1, pp_minkt = -1;   // SDMI_IGEMM_PP: fewest 256 x 128 tiles that take it (0 = off)
     if (pp_min < 0) {
       const char* e = getenv("SDMI_IGEMM_PP");
-      pp_min = e ? atoi(e) : 192;
+      pp_min = e ? atoi(e) : 0;       // off: no faster than the 128 x 128 kernels without the halo staging
       const char* e2 = getenv("SDMI_IGEMM_PP_MINKT");
       pp_minkt = e2 ? atoi(e2) : 8;
     }

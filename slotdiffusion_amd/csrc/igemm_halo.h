@@ -27,14 +27,19 @@
 
 namespace {
 
-template <int LOGW>
+// LOGW: log2 of the image width (16 / 32 / 64 columns).  NJ: 32-column blocks per wave -- 2: 256 x 128 tiles (64 x 64
+// wave blocks, two segments of 8 MFMAs per K tile); 1: 256 x 64 tiles (64 x 32 wave blocks, one segment of 8 MFMAs per
+// K tile) for the layers whose 256 x 128 grid would leave half the chip idle (the 16^2 level at B = 64).
+template <int LOGW, int NJ>
 __global__ __launch_bounds__(512, 2) void igemm_halo_kernel(SdmiGemmArgs p, int tiles_m, int tiles_n, int hw_shift) {
   typedef bf16_t T;
   constexpr int W = 1 << LOGW, TH = 256 / W, PW = W + 2, PH = TH + 2, Q = PH * PW;
   constexpr int NPIECE = (Q + 7) / 8;                  // 1 KB pieces (8 patch pixels) of a chunk's patch
-  constexpr int ABUF = NPIECE * 1024, BSTAGE = 128 * 128, NBST = 3;
+  constexpr int BN = 64 * NJ;
+  constexpr int ABUF = NPIECE * 1024, BSTAGE = BN * 128, NBST = 3;
   constexpr int ATAPS = 7;                             // taps during which the next patch is issued (7 x 8 waves >= NPIECE)
-  static_assert(ATAPS * 8 >= NPIECE && ABUF >= 8 * EPI_ROWS_PATCH, "patch geometry");
+  constexpr int KSEG = NJ == 2 ? 2 : 4, NSEG = 4 / KSEG; // k-steps per LOAD / MFMA segment: 8 MFMAs per segment either way
+  static_assert(ATAPS * 8 >= NPIECE && ABUF >= 8 * EpiRows<NJ>::PATCH, "patch geometry");
   constexpr unsigned OOB = 0x80000000u;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const Bst = smem + 2 * ABUF;
@@ -45,7 +50,7 @@ __global__ __launch_bounds__(512, 2) void igemm_halo_kernel(SdmiGemmArgs p, int 
     const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (vb >> 3);
     const int tm = id / tiles_n;
     m0 = tm * 256;
-    n0 = (id - tm * tiles_n) * 128;
+    n0 = (id - tm * tiles_n) * BN;
   };
   const int my_tiles = ((int)blockIdx.x < nwg) ? (nwg - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
   const int nchunk = p.Cin >> 6;
@@ -75,7 +80,7 @@ __global__ __launch_bounds__(512, 2) void igemm_halo_kernel(SdmiGemmArgs p, int 
     a_vo[t] = ((unsigned)(py * W + px) * (unsigned)p.lda * 2u + (unsigned)kc * 16u) | f;
     a_cur[t] = OOB;
   }
-  unsigned b_vo[2];
+  unsigned b_vo[NJ];
   // A side: the chunk being fetched (tile a_ti, chunk a_c); B side: the step being fetched (tile b_ti, chunk b_c, tap b_t)
   int a_ti = 0, a_c = 0, a_buf = 0;
   unsigned a_so = 0;
@@ -107,7 +112,7 @@ __global__ __launch_bounds__(512, 2) void igemm_halo_kernel(SdmiGemmArgs p, int 
     int m0, n0;
     tile_of((int)blockIdx.x + b_ti * (int)gridDim.x, m0, n0);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < NJ; ++j) {
       const int row = (w + 8 * j) * 8 + (l >> 3);
       const int kc = (l & 7) ^ ((4 * (w & 1) + (l >> 4)) & 7);
       const int n = min(n0 + row, p.N - 1);
@@ -142,32 +147,31 @@ __global__ __launch_bounds__(512, 2) void igemm_halo_kernel(SdmiGemmArgs p, int 
   int swz[4];
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) swz[ks] = ((2 * ks + hsel) ^ ((R >> 1) & 7)) * 16;
-  const int b_off = (wn * 64 + R) * 128;
-  u32x4 fa[2][2], fb[2][2];                            // [k-step of the half][row / column block]
-  f32x16 acc[2][2];
-  auto read_half = [&](const char* Ab, const char* Bb, int dq, int h) __attribute__((always_inline)) {
+  const int b_off = (wn * 32 * NJ + R) * 128;
+  u32x4 fa[KSEG][2], fb[KSEG][NJ];                     // [k-step of the segment][row / column block]
+  f32x16 acc[2][NJ];
+  auto read_seg = [&](const char* Ab, const char* Bb, int dq, int h) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int q = qb[i] + dq;
       const int key = (q >> 1) & 7;
       const char* row = Ab + q * 128;
 #pragma unroll
-      for (int s = 0; s < 2; ++s) fa[s][i] = *reinterpret_cast<const u32x4*>(row + (((2 * (2 * h + s) + hsel) ^ key) << 4));
+      for (int s = 0; s < KSEG; ++s) fa[s][i] = *reinterpret_cast<const u32x4*>(row + (((2 * (KSEG * h + s) + hsel) ^ key) << 4));
     }
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      fb[s][0] = *reinterpret_cast<const u32x4*>(Bb + b_off + swz[2 * h + s]);
-      fb[s][1] = *reinterpret_cast<const u32x4*>(Bb + b_off + 4096 + swz[2 * h + s]);
-    }
+    for (int s = 0; s < KSEG; ++s)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) fb[s][j] = *reinterpret_cast<const u32x4*>(Bb + b_off + j * 4096 + swz[KSEG * h + s]);
   };
-  auto mfma_half = [&]() __attribute__((always_inline)) {
+  auto mfma_seg = [&]() __attribute__((always_inline)) {
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int s = 0; s < 2; ++s)
+    for (int s = 0; s < KSEG; ++s)
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fb[s][j]),
                                                               __builtin_bit_cast(bf16x8, fa[s][i]), acc[i][j], 0, 0, 0);
     __builtin_amdgcn_s_setprio(0);
@@ -186,9 +190,14 @@ __global__ __launch_bounds__(512, 2) void igemm_halo_kernel(SdmiGemmArgs p, int 
 #pragma unroll
   for (int t = 0; t < ATAPS; ++t) issue_a(t);
   a_advance();
-  issue_b(0); issue_b(1); b_advance();
-  issue_b(0); issue_b(1); b_advance();
-  asm volatile("s_waitcnt vmcnt(2)" ::: "memory");     // everything but step 1's weight pieces
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) issue_b(j);
+    b_advance();
+  }
+  if (NJ == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");     // everything but step 1's weight pieces
+  else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
   HALO_BARRIER();
   int c_buf = 0, c_stage = 0;                          // patch buffer / weight stage of the step being multiplied
   for (int ti = 0; ti < my_tiles; ++ti) {
@@ -197,7 +206,7 @@ __global__ __launch_bounds__(512, 2) void igemm_halo_kernel(SdmiGemmArgs p, int 
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < NJ; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     if (grp == 1) HALO_BARRIER();              // stagger: group 1 runs one interval behind group 0
@@ -207,42 +216,48 @@ __global__ __launch_bounds__(512, 2) void igemm_halo_kernel(SdmiGemmArgs p, int 
       for (int t = 0; t < 9; ++t) {
         const char* Bb = Bst + c_stage * BSTAGE;
         if (++c_stage == NBST) c_stage = 0;
-        constexpr int dummy = 0;
-        (void)dummy;
         const int dq = (t / 3) * PW + (t % 3);
         const bool has_a = t < ATAPS && 8 * t + w < NPIECE;        // wave-uniform
-        // ---- L(s, 0): fragments of k-steps 0, 1; a piece of the next chunk's patch; first weight piece of step s + 2
-        read_half(Ab, Bb, dq, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (t < ATAPS) issue_a(t);
-        issue_b(0);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        HALO_BARRIER();
-        mfma_half();
-        HALO_BARRIER();
-        // ---- L(s, 1): k-steps 2, 3; second weight piece; this wave's weight pieces of step s + 1 (and every patch
-        // piece issued before them) have landed
-        read_half(Ab, Bb, dq, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        issue_b(1);
-        b_advance();
-        if (t == ATAPS - 1) a_advance();                            // the next chunk's patch is fully issued
-        if (has_a) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        HALO_BARRIER();
-        mfma_half();
-        HALO_BARRIER();
+#pragma unroll
+        for (int h = 0; h < NSEG; ++h) {
+          // ---- L(s, h): the segment's fragments; in the first segment a piece of the next chunk's patch and the first
+          // weight piece of step s + 2, in the second the other weight piece.  Behind the LAST segment's issues this
+          // wave's weight pieces of step s + 1 (and every patch piece issued before them) must have landed.
+          read_seg(Ab, Bb, dq, h);
+          __builtin_amdgcn_sched_barrier(0);
+          if (h == 0) {
+            if (t < ATAPS) issue_a(t);
+            issue_b(0);
+          }
+          if constexpr (NJ == 2) {
+            if (h == NSEG - 1) issue_b(1);
+          }
+          if (h == NSEG - 1) {
+            b_advance();
+            if (t == ATAPS - 1) a_advance();                          // the next chunk's patch is fully issued
+            if (NJ == 2) {
+              if (has_a) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+              else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            } else {
+              if (has_a) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+              else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+            }
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          HALO_BARRIER();
+          mfma_seg();
+          HALO_BARRIER();
+        }
       }
       c_buf ^= 1;
     }
     if (grp == 0) HALO_BARRIER();              // both groups store in the same interval
-    const int mw0 = m0 + wm * 64, nw0 = n0 + wn * 64;
-    if (epilogue_rows_ok(p, mw0, nw0, hw_shift)) {
+    const int mw0 = m0 + wm * 64, nw0 = n0 + wn * 32 * NJ;
+    if (epilogue_rows_ok<NJ>(p, mw0, nw0, hw_shift)) {
       // wave-private patch in the patch buffer the tile's last chunk vacated (c_buf already points at the other one)
-      wave_epilogue_rows(p, acc, mw0, nw0, hw_shift, l, smem + (c_buf ^ 1) * ABUF + w * EPI_ROWS_PATCH);
+      wave_epilogue_rows<NJ>(p, acc, mw0, nw0, hw_shift, l, smem + (c_buf ^ 1) * ABUF + w * EpiRows<NJ>::PATCH);
     } else {
-      wave_epilogue_rows_generic(p, acc, mw0, nw0, hw_shift, l);
+      wave_epilogue_rows_generic<NJ>(p, acc, mw0, nw0, hw_shift, l);
       __builtin_amdgcn_s_waitcnt(0x0F70);       // vmcnt(0)
     }
     if (ti + 1 < my_tiles) {
@@ -254,15 +269,15 @@ __global__ __launch_bounds__(512, 2) void igemm_halo_kernel(SdmiGemmArgs p, int 
 #undef HALO_BARRIER
 }
 
-template <int LOGW>
+template <int LOGW, int NJ>
 int launch_halo(const SdmiGemmArgs& p, int hw_shift, hipStream_t st, int n_cu) {
   constexpr int W = 1 << LOGW, Q = (256 / W + 2) * (W + 2);
-  constexpr int smem = 2 * ((Q + 7) / 8) * 1024 + 3 * 128 * 128;
-  auto kern = igemm_halo_kernel<LOGW>;
+  constexpr int smem = 2 * ((Q + 7) / 8) * 1024 + 3 * 64 * NJ * 128;
+  auto kern = igemm_halo_kernel<LOGW, NJ>;
   SDMI_OPTIN_LDS(kern, smem, "igemm (3x3 halo ping-pong)");
   SdmiGemmArgs q = p;
   q.split_k = 1;
-  const int tiles_m = p.M / 256, tiles_n = (p.N + 127) / 128;
+  const int tiles_m = p.M / 256, tiles_n = (p.N + 64 * NJ - 1) / (64 * NJ);
   int cap = n_cu < 8 ? 8 : (n_cu & ~7);
   const int nwg = tiles_m * tiles_n;
   hipLaunchKernelGGL(kern, dim3(nwg <= cap ? nwg : cap), dim3(512), smem, st, q, tiles_m, tiles_n, hw_shift);

@@ -290,11 +290,11 @@ __global__ __launch_bounds__(512, 2) void igemm_pp_kernel(SdmiGemmArgs p, int ti
     // its reads of it: group 0 passed the un-stagger barrier behind group 1's last MFMA segment).  The barrier behind
     // the epilogue keeps the next K tile's DMA pieces (they refill that stage) off the other waves' patches.
     const int mw0 = m0 + wm * 64, nw0 = n0 + wn * 64;
-    if (epilogue_rows_ok(p, mw0, nw0, hw_shift)) {
+    if (epilogue_rows_ok<2>(p, mw0, nw0, hw_shift)) {
       char* patch = smem + (stage == 0 ? NSTAGE - 1 : stage - 1) * STAGE + w * EPI_ROWS_PATCH;
-      wave_epilogue_rows(p, acc, mw0, nw0, hw_shift, l, patch);
+      wave_epilogue_rows<2>(p, acc, mw0, nw0, hw_shift, l, patch);
     } else {
-      wave_epilogue_rows_generic(p, acc, mw0, nw0, hw_shift, l);
+      wave_epilogue_rows_generic<2>(p, acc, mw0, nw0, hw_shift, l);
       __builtin_amdgcn_s_waitcnt(0x0F70);       // vmcnt(0)
     }
     if (ti + 1 < my_tiles) {

@@ -58,7 +58,8 @@ def _worker(rank, world, port, out_dir):
         s0 = GraphedTrainStep(m, opt0, batch, allreduce=True, world=world)
         s0(batch)
         torch.cuda.synchronize()
-        torch.save(m.grad_arena().detach().cpu(), os.path.join(out_dir, f'grad{rank}.pt'))
+        # (the exchange leaves the SUM over ranks where the optimiser reads it; 1 / world rides in the Adam kernels)
+        torch.save((s0.reducer.grad_src.float() * s0.reducer.grad_scale).detach().cpu(), os.path.join(out_dir, f'grad{rank}.pt'))
         step = GraphedTrainStep(m, opt, batch, allreduce=True, world=world)   # split backward,
         assert step.overlap                                                  # overlapped all-reduce
         step(batch)                                   # 2 warm-up steps inside + 1 replay

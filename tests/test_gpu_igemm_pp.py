@@ -44,7 +44,8 @@ def test_pp_conv3x3_plain(B, H, C, N):
 @pytest.mark.parametrize('B,H,C,N', [(256, 16, 256, 256),     # W = 16: a tile is a whole image (top and bottom rows zero)
                                       (16, 64, 128, 128),      # W = 64: four image rows per tile, 50-piece patches
                                       (64, 32, 64, 128),       # one 64-channel chunk per tile (patch buffers alternate per tile)
-                                      (64, 32, 384, 384)])     # six chunks, three column tiles, three tiles per workgroup
+                                      (64, 32, 384, 384),      # six chunks, three column tiles, three tiles per workgroup
+                                      (200, 16, 128, 192)])    # W = 16, ragged N (1.5 column tiles)
 def test_halo_conv3x3_geometries(B, H, C, N):
     """The halo-staged 3x3 kernel (csrc/igemm_halo.h) at the image widths it serves; bias + residual + row vector."""
     ops = _ops()
