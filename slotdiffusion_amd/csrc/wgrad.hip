@@ -565,6 +565,181 @@ static int launch_wgrad3x3_c64(const SdmiWgradArgs& a, hipStream_t st) {
   return sdmi_check_launch("wgrad (direct 3x3 c64)");
 }
 
+// ------------------------------------------------------------------------------------------
+// The same direct weight gradient for ANY 3x3 stride-1 layer on a 16 / 32 / 64-column power-of-two image (round 5;
+// the twin of igemm_halo.h): grid = (M-split slots, pairs), pair (nb, cb) = 64 output channels x 64 input channels.
+// A workgroup walks 256-pixel tiles (TH = 256 / W whole image rows) of its slot: the tile's dY (256 px x its 64
+// output channels) and the (TH + 2) x (W + 2) pixel input patch (its 64 input channels, zeros outside the image) are
+// staged ONCE and serve all 9 taps -- as an implicit GEMM the activation rows are fetched again for every tap and the
+// dY rows for every 128-column block of the filter.  Wave roles, fragment addressing (transposing LDS reads over
+// pixel-major operands) and the partial layout [slot][N][9 Cin] are wgrad3x3_c64_kernel's; the usual deterministic fold
+// follows.  The dY column sums (bias gradient) are taken by the pairs with cb = 0.
+template <int LOGW>
+__global__ __launch_bounds__(256) void wgrad3x3_halo_kernel(SdmiWgradArgs p, int ncb) {
+  constexpr int W = 1 << LOGW, TH = 256 / W, PW = W + 2, PH = TH + 2, HALO = PH * PW, KPR = W / 16;
+  constexpr int HV = (HALO * 8 + 255) / 256, DV = 8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const Xs = smem;
+  char* const Ys = smem + HALO * W33_PIX;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int pair = blockIdx.y, nb = pair / ncb, cb = pair - nb * ncb;
+  const bf16_t* __restrict__ Ag = (const bf16_t*)p.a + cb * 64;
+  const bf16_t* __restrict__ Yg = (const bf16_t*)p.dy + nb * 64;
+  const int tiles_y = p.H / TH;
+  const int n_tiles = p.B * tiles_y;
+  const int split = blockIdx.x, nsplit = gridDim.x;
+  const bool want_bias = cb == 0;
+
+  u32x4 prex[HV], prey[DV];
+  float bsum[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) bsum[j] = 0.f;
+  auto fetch = [&](int t) __attribute__((always_inline)) {
+    const int b = t / tiles_y, ty = t - b * tiles_y;
+    const int iy0 = ty * TH - 1;
+#pragma unroll
+    for (int i = 0; i < HV; ++i) {
+      const int v = tid + i * 256, px = v >> 3, ch = v & 7;
+      const int hy = px / PW, hx = px - hy * PW;
+      const int iy = iy0 + hy, ix = hx - 1;
+      const bool ok = px < HALO && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)W;
+      prex[i] = ok ? *reinterpret_cast<const u32x4*>(Ag + ((long long)(b * p.H + iy) * W + ix) * p.lda + ch * 8)
+                   : u32x4{0u, 0u, 0u, 0u};
+    }
+#pragma unroll
+    for (int i = 0; i < DV; ++i) {
+      const int v = tid + i * 256, px = v >> 3, ch = v & 7;
+      prey[i] = *reinterpret_cast<const u32x4*>(Yg + ((long long)t * 256 + px) * p.ldy + ch * 8);
+    }
+  };
+  auto stash = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < HV; ++i) {
+      const int v = tid + i * 256, px = v >> 3, ch = v & 7;
+      if (px < HALO) *reinterpret_cast<u32x4*>(Xs + px * W33_PIX + ch * 16) = prex[i];
+    }
+#pragma unroll
+    for (int i = 0; i < DV; ++i) {
+      const int v = tid + i * 256, px = v >> 3, ch = v & 7;
+      *reinterpret_cast<u32x4*>(Ys + px * W33_PIX + ch * 16) = prey[i];
+      if (want_bias) {
+        float f[8];
+        unpack16<bf16_t>(__builtin_bit_cast(uint4, prey[i]), f);     // column sums of dY: channels (tid & 7) * 8 ...
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bsum[j] += f[j];
+      }
+    }
+  };
+
+  const int g = lane >> 4, tt = lane & 15;
+  const int lrow = (g >> 1) * 8 + (tt >> 2), lcol = (g & 1) * 16 + (tt & 3) * 4;
+  const int chh = wave & 1, tp0 = wave >> 1;
+  const char* const yb = Ys + lrow * W33_PIX + (chh * 32 + lcol) * 2;
+  const char* const xb = Xs + lrow * W33_PIX + lcol * 2;
+  int tapoff[5];
+#pragma unroll
+  for (int u = 0; u < 5; ++u) {
+    const int tap = tp0 + 2 * u, kh = tap / 3, kw = tap - kh * 3;
+    tapoff[u] = (kh * PW + kw) * W33_PIX;
+  }
+  const int n_units = tp0 == 0 ? 5 : 4;
+  f32x16 acc[5][2];
+#pragma unroll
+  for (int u = 0; u < 5; ++u)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[u][j][r] = 0.f;
+
+  auto read_y = [&](int ks) __attribute__((always_inline)) {
+    const char* q = yb + ks * 16 * W33_PIX;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(SDMI_LDS_V4(q));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(SDMI_LDS_V4(q + 4 * W33_PIX));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  };
+  auto read_x = [&](int ks, int toff, s16x8 (&fx)[2]) __attribute__((always_inline)) {
+    const char* q = xb + ((ks / KPR) * PW + (ks % KPR) * 16) * W33_PIX + toff;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(SDMI_LDS_V4(q + j * 64));
+      const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(SDMI_LDS_V4(q + j * 64 + 4 * W33_PIX));
+      fx[j] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+  };
+
+  int t = split;
+  if (t < n_tiles) fetch(t);
+  for (; t < n_tiles; t += nsplit) {
+    __syncthreads();                       // previous tile's fragment reads are done
+    stash();
+    __syncthreads();
+    if (t + nsplit < n_tiles) fetch(t + nsplit);     // in flight under the MFMAs below
+    s16x8 fy = read_y(0), fx[3][2];            // unit u uses buffer u % 3 (five units: two would collide)
+    read_x(0, tapoff[0], fx[0]);
+    for (int ks = 0; ks < 16; ++ks) {
+      s16x8 fy_n = fy;
+#pragma unroll
+      for (int u = 0; u < 5; ++u) {
+        if (u + 1 < 5) {
+          if (u + 1 < n_units) read_x(ks, tapoff[u + 1], fx[(u + 1) % 3]);
+        } else if (ks + 1 < 16) {
+          fy_n = read_y(ks + 1);
+          read_x(ks + 1, tapoff[0], fx[0]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (u < n_units) {
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[u][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                __builtin_bit_cast(bf16x8, fy), __builtin_bit_cast(bf16x8, fx[u % 3][j]), acc[u][j], 0, 0, 0);
+        }
+      }
+      fy = fy_n;
+    }
+  }
+
+  // ---- this workgroup's partials: rows [64 nb, +64), columns tap * Cin + [64 cb, +64) of slot `split`'s dW [N][9 Cin]
+  float* const ws = p.workspace + (long long)split * p.N * p.K;
+  const int col = lane & 31, row_l = (lane >> 5) * 4;
+#pragma unroll
+  for (int u = 0; u < 5; ++u) {
+    if (u < n_units) {
+      const int tap = tp0 + 2 * u;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int n = nb * 64 + chh * 32 + (r & 3) + 8 * (r >> 2) + row_l;
+          ws[(long long)n * p.K + tap * p.Cin + cb * 64 + j * 32 + col] = acc[u][j][r];
+        }
+    }
+  }
+  if (!want_bias) return;
+  __syncthreads();
+  float* red = reinterpret_cast<float*>(smem);       // [256][8]
+#pragma unroll
+  for (int j = 0; j < 8; ++j) red[tid * 8 + j] = bsum[j];
+  __syncthreads();
+  if (tid < 64) {
+    const int c = tid >> 3, j = tid & 7;              // channel tid = chunk c, element j
+    float sacc = 0.f;
+    for (int r = 0; r < 32; ++r) sacc += red[(r * 8 + c) * 8 + j];
+    p.workspace[(long long)nsplit * p.N * p.K + (long long)split * p.N + nb * 64 + tid] = sacc;
+  }
+}
+
+template <int LOGW>
+static int launch_wgrad3x3_halo(const SdmiWgradArgs& a, hipStream_t st) {
+  constexpr int W = 1 << LOGW, HALO = (256 / W + 2) * (W + 2);
+  constexpr int smem = (HALO + 256) * W33_PIX;
+  auto kern = wgrad3x3_halo_kernel<LOGW>;
+  SDMI_OPTIN_LDS(kern, smem, "wgrad (direct 3x3, halo)");
+  const int ncb = a.Cin / 64, nnb = a.N / 64;
+  hipLaunchKernelGGL(kern, dim3(a.splits, nnb * ncb), dim3(256), smem, st, a, ncb);
+  return sdmi_check_launch("wgrad (direct 3x3, halo)");
+}
+
 static bool wgrad_is1x1(const SdmiWgradArgs& a) {
   return a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad_t == 0 && a.pad_l == 0 && !a.ups &&
          a.H == a.Ho && a.W == a.Wo;
@@ -611,6 +786,22 @@ int dispatch_wgrad_bf16(const SdmiWgradArgs& a, hipStream_t st) {
         a.N == 64 && a.K == 576 && a.H == a.Ho && a.W == a.Wo && a.W % 64 == 0 && a.H % 4 == 0 && a.splits >= 2 &&
         (long long)a.B * (a.H / 4) * (a.W / 64) >= a.splits && (long long)a.B * a.H * a.W * (a.lda > a.ldy ? a.lda : a.ldy) < (1ll << 40))
       return launch_wgrad3x3_c64(a, st);
+  }
+  // ... and for every other 3x3 stride-1 layer on 16 / 32 / 64-column power-of-two images (pairs of 64 output x 64
+  // input channels; the caller sizes `splits` so that pairs x splits fills the chip: kern.py)
+  {
+    static int halo = -1;
+    if (halo < 0) {
+      const char* e = getenv("SDMI_WGRAD_HALO");
+      halo = e ? atoi(e) : 1;
+    }
+    const int logw = a.W == 16 ? 4 : (a.W == 32 ? 5 : (a.W == 64 ? 6 : 0));
+    const long long hw = (long long)a.H * a.W;
+    if (halo && logw && a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad_t == 1 && a.pad_l == 1 && !a.ups && a.H == a.Ho &&
+        a.W == a.Wo && a.Cin % 64 == 0 && a.N % 64 == 0 && a.K == 9 * a.Cin && hw % 256 == 0 && (hw & (hw - 1)) == 0 &&
+        a.splits >= 1 && a.M / 256 >= a.splits && (a.N / 64) * (a.Cin / 64) * a.splits >= 128 &&
+        (long long)a.M * (a.lda > a.ldy ? a.lda : a.ldy) < (1ll << 40))
+      return logw == 4 ? launch_wgrad3x3_halo<4>(a, st) : (logw == 5 ? launch_wgrad3x3_halo<5>(a, st) : launch_wgrad3x3_halo<6>(a, st));
   }
 #define WG_TR(TN, TK)                                                              \
   (is1x1 && fits ? launch_wgrad_tr<TN, TK, 1>(a, st)                               \

@@ -68,10 +68,13 @@ _FF_MERGE = os.environ.get('SDMI_FF_MERGE', '1') != '0'
 _CROSS_FOLD = os.environ.get('SDMI_CROSS_FOLD', '1') != '0'
 _LN_FOLD = os.environ.get('SDMI_LN_FOLD', '1') != '0'
 _ST_FUSED = os.environ.get('SDMI_ST_FUSED', '1') != '0'     # fused SpatialTransformer block (sdmi_st_block)
-# data gradients of 3x3 layers through the halo-staged kernel as their own launch (un-paired) when they have at least this
-# many 256 x 128 tiles.  0 (default) = keep them in the pair launch: measured 27.2 -> 27.55 ms per train step with 192 --
-# the halo kernel fills a CU's LDS, so the un-paired weight gradients of the side streams no longer co-reside with it
-_HALO_DGRAD = int(os.environ.get('SDMI_HALO_DGRAD', '0'))
+# 3x3 layers whose data gradient has at least this many 256 x 128 tiles leave the pair launch: data gradient through the
+# halo-staged kernel (igemm_halo.h), weight gradient through its twin on channel pairs (wgrad3x3_halo_kernel) on a side
+# stream.  Same-box A/B of the train step (two runs each): paired 26.61 / 26.60 ms, un-paired with the implicit-GEMM weight
+# gradient 26.84 / 26.89 (the halo kernel fills a CU's LDS: the side-stream launches no longer co-reside), un-paired with
+# the direct weight gradient 26.43 / 26.37; threshold 128 instead of 192: another 0.02.  0 = keep every layer paired.
+_HALO_DGRAD = int(os.environ.get('SDMI_HALO_DGRAD', '128'))
+_WGRAD_HALO = os.environ.get('SDMI_WGRAD_HALO', '1') != '0'    # direct 3x3 weight gradient on channel pairs (wgrad3x3_halo_kernel)
 # folded slot cross-attention as ONE launch (sdmi_cross_fold) up to this many tokens per image (0 = off)
 _CROSS_ONE = int(os.environ.get('SDMI_CROSS_ONE', '64'))
 _UPS_PARITY = os.environ.get('SDMI_UPS_PARITY', '1') != '0'   # upsample convolutions as four 2x2 parity convolutions
@@ -1311,6 +1314,15 @@ class GemmFn(torch.autograd.Function):
                 and B * (H // 4) * (W_ // 64) >= 2 * _n_cus(x.device)):
             # the direct 3x3 kernel (wgrad.hip: wgrad3x3_c64_kernel): one persistent workgroup per CU and slot
             splits = _n_cus(x.device)
+        elif (dt == torch.bfloat16 and is_conv and kh == 3 and kw == 3 and stride == 1 and not ups and _WGRAD_HALO
+                and tuple(pad) == (1, 1, 1, 1) and W_ in (16, 32, 64) and Cin % 64 == 0 and N % 64 == 0 and Ho == H and Wo == W_
+                and (H * W_) % 256 == 0 and ((H * W_) & (H * W_ - 1)) == 0):
+            # the direct 3x3 kernel on (64 output x 64 input channel) pairs (wgrad.hip: wgrad3x3_halo_kernel): one
+            # persistent workgroup per CU -- slots x pairs fills the chip
+            pairs = (N // 64) * (Cin // 64)
+            halo_splits = max(1, min(_n_cus(x.device) // pairs, M // 256))
+            if pairs * halo_splits >= 128:
+                splits = halo_splits
         bdst = _grads_of(wb, bnames) if bnames is not None else None
         lda = Cin if is_conv else x.stride(-2)
         if (wb.group_wgrad and dt == torch.bfloat16 and kh == 1 and kw == 1 and stride == 1 and not ups

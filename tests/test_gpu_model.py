@@ -78,7 +78,7 @@ def test_vqvae_fp32():
     _dump()
     assert REPORT['x0_maxerr'] <= 1e-4
     assert REPORT['vq_idx_agree'] == 1.0 and REPORT['x0_vq_maxerr'] == 0.0
-    assert REPORT['x0_decoded_maxerr'] <= 2e-4
+    assert REPORT['x0_decoded_maxerr'] <= 1e-4        # (measured 2.1e-5: the same bar as every other fp32 tensor)
 
 
 def test_unet_eps_and_loss_fp32():

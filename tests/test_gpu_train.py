@@ -374,7 +374,9 @@ def test_train_step_bf16_gradients_close():
     REPORT['bf16_grad_cosine_min'] = min(cos)
     _dump()
     assert abs(float(loss) - float(G['train_loss'])) < 0.05
-    assert REPORT['bf16_grad_norm_median_rel'] < 0.05 and min(cos) > 0.85
+    # measured on MI355X (round 5): median 0.6 %, p95 0.9 %, worst per-tensor cosine 0.9888 -- bars at ~2-3x the
+    # measurement, so one layer drifting cannot hide behind the others
+    assert REPORT['bf16_grad_norm_median_rel'] < 0.02 and REPORT['bf16_grad_norm_p95_rel'] < 0.03 and min(cos) > 0.98
 
 
 # ---- per-kernel backward checks ----------------------------------------------------------
@@ -458,6 +460,53 @@ def test_wgrad_and_dgrad_kernels(case, dtype):
     e = float((dx.float().cpu() - ref_dx).norm() / ref_dx.norm())
     assert e <= tol, f'dgrad rel err {e}'
 
+
+
+@pytest.mark.parametrize('case', [(8, 128, 128, 32, 32),      # 4 channel pairs x 32 slots, one tile per slot
+                                  (20, 128, 192, 32, 22),     # 6 pairs, ragged tiles per slot (80 tiles over 22 slots)
+                                  (64, 128, 64, 16, 64),      # W = 16: a tile is a whole image
+                                  (4, 64, 128, 64, 64)])      # W = 64: four image rows per tile
+def test_wgrad3x3_halo_kernel(case):
+    """Direct 3x3 weight gradient on (64 output x 64 input channel) pairs (csrc/wgrad.hip: wgrad3x3_halo_kernel) against
+    torch's convolution backward; the implicit-GEMM kernel (SDMI_WGRAD_HALO=0 is a process-level switch, so: a launch
+    whose split count keeps it off the direct kernel) must agree to fp32 accumulation-order noise."""
+    from slotdiffusion_amd import _lib
+    from slotdiffusion_amd.kern import _DT
+    B, Cin, Cout, H, splits = case
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(sum(case))
+    q = lambda t: t.to(dtype).float()
+    x = q(torch.randn(B, Cin, H, H, generator=g)).requires_grad_(True)
+    w = q(torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)).requires_grad_(True)
+    y = F.conv2d(x, w, None, padding=1)
+    dy = q(torch.randn(y.shape, generator=g))
+    y.backward(dy)
+    xd = x.detach().permute(0, 2, 3, 1).contiguous().to(dtype).cuda()
+    dyd = dy.permute(0, 2, 3, 1).contiguous().to(dtype).cuda()
+    M, K = B * H * H, 9 * Cin
+
+    def run(splits, accumulate=0, init=0.0):
+        ws = torch.empty(splits * (Cout * K + Cout), device='cuda')
+        dw_ = torch.full((Cout, K), init, device='cuda')
+        db_ = torch.full((Cout,), init, device='cuda')
+        _lib.call('sdmi_wgrad', torch.cuda.current_stream().cuda_stream, a=xd.data_ptr(), dy=dyd.data_ptr(),
+                  dw=dw_.data_ptr(), dbias=db_.data_ptr(), workspace=ws.data_ptr(), dtype=_DT[dtype], M=M, N=Cout, K=K,
+                  lda=Cin, ldy=Cout, B=B, H=H, W=H, Cin=Cin, Ho=H, Wo=H, KH=3, KW=3, stride=1, pad_t=1, pad_l=1, ups=0,
+                  splits=splits, accumulate=accumulate)
+        return dw_, db_
+
+    assert (Cout // 64) * (Cin // 64) * splits >= 128 and M // 256 >= splits      # the direct kernel's dispatch condition
+    dw, db = run(splits)
+    ref_dw = w.grad.permute(0, 2, 3, 1).reshape(Cout, K)
+    e = float((dw.cpu() - ref_dw).norm() / ref_dw.norm())
+    assert e <= 2e-3, f'wgrad rel err {e}'        # (bf16 operands, fp32 accumulation: the products are exact)
+    ref_db = dy.sum((0, 2, 3))
+    assert float((db.cpu() - ref_db).norm() / ref_db.norm()) <= 1e-4
+    dwg, dbg = run(2)                               # implicit-GEMM kernel (2 slots: below the direct kernel's grid)
+    assert float((dw - dwg).norm() / dwg.norm()) <= 1e-5 and float((db - dbg).norm() / dbg.norm()) <= 1e-5
+    dwa, dba = run(splits, accumulate=1, init=-1.0)
+    assert float((dwa + 1.0 - dw).abs().max()) <= 1e-5 * max(1.0, float(dw.abs().max())) + 1e-5
+    assert torch.equal(run(splits)[0], dw)          # deterministic fold
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
