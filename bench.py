@@ -163,7 +163,7 @@ def kernel_base_name(k):
     return re.sub(r'[<(].*', '', k).strip()
 
 
-def _rocprof_child(extra_prof_args, argv, child_flags, timeout=900):
+def _rocprof_child(extra_prof_args, argv, child_flags, timeout=900, extra_env=None):
     """Run this same command under rocprofv3 (same box) -> (output dir, note) or (None, reason)."""
     import shutil
     import subprocess
@@ -173,6 +173,7 @@ def _rocprof_child(extra_prof_args, argv, child_flags, timeout=900):
         return None, 'rocprofv3 not found'
     d = tempfile.mkdtemp(prefix='sdmi_trace_', dir='/tmp')
     env = dict(os.environ, TMPDIR='/tmp')
+    env.update({k: v.replace('%d', d) for k, v in (extra_env or {}).items()})
     cmd = [exe, '--kernel-trace'] + extra_prof_args + ['--output-format', 'csv', '-d', d, '-o', 't', '--',
                                                      sys.executable, os.path.abspath(__file__)] + argv + child_flags
     try:
@@ -234,6 +235,64 @@ def replayed_trace(argv, steps, mode):
         shutil.rmtree(d, ignore_errors=True)
 
 
+# entry point -> the kernels of which each of its calls launches exactly ONE (second stages -- split-K epilogues, folds,
+# the statistics pass of a two-pass GroupNorm -- are extra dispatches of the same call)
+PRIMARY = {
+    'sdmi_igemm': ('igemm_kernel', 'igemm_kernel_tall', 'igemm_dma_kernel', 'igemm_sym_kernel', 'igemm_pp_kernel',
+                   'igemm_halo_kernel', 'conv3x3_c64_kernel'),
+    'sdmi_wgrad': ('wgrad_kernel', 'wgrad_tr_kernel', 'wgrad3x3_c64_kernel', 'wgrad3x3_halo_kernel'),
+    'sdmi_groupnorm': ('gn_fused_kernel', 'gn_fused2_kernel', 'gn_apply_kernel'),
+    'sdmi_groupnorm_bwd': ('gn_bwd_fused_kernel', 'gn_bwd_fused2_kernel', 'gn_bwd_apply_kernel'),
+}
+
+
+def _attribute_calls(log_path, rows, lo, hi, per_kernel):
+    """Algorithmic bytes per kernel: the child's call log (slotdiffusion_amd/_lib.py: SDMI_CALL_LOG, launch order) against
+    the dispatch order of the same pass -- the k-th call of an entry point is the k-th dispatch among that entry's
+    primary kernels.  Adds `alg_bytes` / `alg_n` to per_kernel; returns a note when a sequence does not line up."""
+    try:
+        calls = [ln.rstrip('\n').split('\t') for ln in open(log_path)]
+    except OSError as e:
+        return f'call log: {e}'
+    marks = [i for i, c in enumerate(calls) if c[0] == 'sdmi_sqerr_rows']
+    if len(marks) < 2:
+        return 'call log: markers not found'
+    seg = calls[marks[-2] + 1:marks[-1]]
+    disp = sorted({(did, kernel_base_name(k)) for did, k, _, _ in rows if lo < did < hi})
+    bad = []
+    for entry, prim in PRIMARY.items():
+        ds = [k for _, k in disp if k in prim]
+        cs = [float(c[1]) for c in seg if c[0] == entry]
+        if len(ds) != len(cs):
+            if ds or cs:
+                bad.append(f'{entry}: {len(cs)} calls vs {len(ds)} primary dispatches')
+            continue
+        for k, b in zip(ds, cs):
+            e = per_kernel.setdefault(k, {})
+            e['alg_bytes'] = e.get('alg_bytes', 0.0) + b
+            e['alg_n'] = e.get('alg_n', 0) + 1
+    return ('call attribution skipped for ' + '; '.join(bad)) if bad else None
+
+
+def write_pmc_table(path, pk, fs, wsc):
+    """Per-kernel counters of the step between the markers as CSV: MFMA-busy fraction, observed HBM-side bytes per launch
+    (calibrated FETCH_SIZE + WRITE_SIZE) against the algorithmic bytes of the launches that produced them."""
+    names = sorted(pk, key=lambda k: -pk[k].get('GRBM_GUI_ACTIVE', 0.0))
+    with open(path, 'w') as f:
+        f.write('kernel,dispatches,GRBM_GUI_ACTIVE,SQ_VALU_MFMA_BUSY_CYCLES,mfma_busy_frac,FETCH_SIZE_KiB,WRITE_SIZE_KiB,'
+                'observed_bytes_per_launch,algorithmic_bytes_per_launch,observed_over_algorithmic\n')
+        for k in names:
+            e = pk[k]
+            n = max([len(e.get('_ids_' + c, ())) for c in ('FETCH_SIZE', 'WRITE_SIZE', 'GRBM_GUI_ACTIVE')] + [1])
+            act = e.get('GRBM_GUI_ACTIVE', 0.0)
+            busy = e.get('SQ_VALU_MFMA_BUSY_CYCLES', 0.0)
+            obs = (fs * e.get('FETCH_SIZE', 0.0) + wsc * e.get('WRITE_SIZE', 0.0)) * 1024.0 / n
+            alg = e['alg_bytes'] / e['alg_n'] if e.get('alg_n') else None
+            f.write(f'"{k}",{n},{act:.6g},{busy:.6g},{(busy / (act / 8.0 * 1024.0)) if act else 0.0:.4f},'
+                    f'{e.get("FETCH_SIZE", 0.0):.6g},{e.get("WRITE_SIZE", 0.0):.6g},{obs:.6g},'
+                    f'{"" if alg is None else f"{alg:.6g}"},{"" if not alg else f"{obs / alg:.3f}"}\n')
+
+
 def pmc_pass(argv, mode):
     """HBM traffic and MFMA busy fraction of the igemm family OBSERVED BY THIS RUN: two `rocprofv3
     --kernel-trace --pmc` child passes of this command (eager launches so that every dispatch is
@@ -257,7 +316,9 @@ def pmc_pass(argv, mode):
     per_kernel = {}
     notes = []
     for counters in (['SQ_VALU_MFMA_BUSY_CYCLES', 'GRBM_GUI_ACTIVE', 'FETCH_SIZE'], ['WRITE_SIZE']):
-        d, note = _rocprof_child(['--pmc'] + counters, argv, flags)
+        first = counters[0] != 'WRITE_SIZE'
+        d, note = _rocprof_child(['--pmc'] + counters, argv, flags,
+                                 extra_env=({'SDMI_CALL_LOG': '%d/calls.tsv'} if first else None))
         if d is None:
             notes.append(f'{"+".join(counters)}: {note}')
             continue
@@ -281,6 +342,10 @@ def pmc_pass(argv, mode):
                     e[c] = e.get(c, 0.0) + v
                     e['_max_' + c] = max(e.get('_max_' + c, 0.0), v)      # largest single dispatch
                     e.setdefault('_ids_' + c, set()).add(did)
+            if first:
+                note = _attribute_calls(os.path.join(d, 'calls.tsv'), rows, lo, hi, per_kernel)
+                if note:
+                    notes.append(note)
         except Exception as e:          # noqa: BLE001
             notes.append(f'{"+".join(counters)}: {type(e).__name__}: {e}')
         finally:
@@ -310,6 +375,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-pmc', action='store_true', help='skip the rocprofv3 --pmc child passes (traffic = null)')
+    ap.add_argument('--pmc-table', default='', help='write the per-kernel counters of the PMC passes here as CSV '
+                    '(%%m = train / sample): MFMA busy, observed vs algorithmic bytes per launch')
     ap.add_argument('--big-batch', type=int, default=256,
                     help='extra sampling measurement at this batch (0 = off): the chip is far from '
                          'full at the configured B = 64')
@@ -650,6 +717,11 @@ def main():
             f"; FETCH_SIZE x {fs:.3f} ({'calibrated on sqsum_kernel, ' + str(n_known * 4) + ' bytes read' if 'fetch_scale' in cal else 'guide default: 128-byte requests tallied at 64 B'})"
             f", WRITE_SIZE x {wsc:.3f} ({'calibrated on the arena zero fill, ' + str(n_known * 4) + ' bytes written' if 'write_scale' in cal else 'uncalibrated'})"
             + (' -- ' + '; '.join(pm['notes']) if pm.get('notes') else ''))
+        if args.pmc_table:
+            try:
+                write_pmc_table(args.pmc_table.replace('%m', mode), pk, fs, wsc)
+            except OSError as e:
+                rf['traffic_source'] += f' -- table not written: {e}'
         rf['traffic_dispatches'] = n_disp
         rf['traffic_ratio_to_algorithmic'] = (rf['traffic'] / rf['algorithmic_bytes_per_launch']) if rf['traffic'] else None
 

@@ -146,8 +146,9 @@ def _meta(fname, kw):
         out = kw['M'] * kw['N'] * (2 if kw.get('residual', 0) else 1)
         return dict(flops=2.0 * kw['M'] * kw['N'] * kw['K'] * b,
                     bytes=float(b * src * elt + wts * elt + b * out * oelt), fp8=int(elt == 1))
-    if fname == 'sdmi_wgrad':
-        return dict(flops=2.0 * kw['M'] * kw['N'] * kw['K'])
+    if fname == 'sdmi_wgrad':          # x and dY read once, dW written once (fp32)
+        return dict(flops=2.0 * kw['M'] * kw['N'] * kw['K'],
+                    bytes=float((kw['B'] * kw['H'] * kw['W'] * kw['Cin'] + kw['M'] * kw['N']) * elt + kw['N'] * kw['K'] * 4))
     if fname == 'sdmi_groupnorm':          # x in, y out (+ residual in)
         n = kw['B'] * kw['HW'] * kw['C']
         return dict(bytes=float(n * elt * (3 if kw.get('residual', 0) else 2)))
@@ -163,12 +164,31 @@ def _meta(fname, kw):
 pre_call = None
 
 
+# SDMI_CALL_LOG=path (measurement only; bench.py's PMC child passes): one line per C-ABI call -- entry point, algorithmic
+# bytes, flops -- in launch order, so that the profiler's per-dispatch counters can be set against the algorithmic
+# bytes of the launch that produced them
+_CALL_LOG = None
+
+
+def _log_call(fname, kw, meta):
+    global _CALL_LOG
+    if _CALL_LOG is None:
+        path = os.environ.get('SDMI_CALL_LOG')
+        _CALL_LOG = open(path, 'a') if path else False
+    if _CALL_LOG:
+        m = meta if meta is not None else _meta(fname, kw)
+        _CALL_LOG.write(f"{fname}\t{m.get('bytes', 0.0):.0f}\t{m.get('flops', 0.0):.0f}\n")
+        _CALL_LOG.flush()
+
+
 def call(fname, stream, **kw):
     """Invoke `fname` with its argument struct filled from keyword args (missing fields = 0).
     `_meta` (optional dict: flops / bytes of the launch) only feeds KernelTimer."""
     if pre_call is not None:
         pre_call()
     meta = kw.pop('_meta', None)
+    if _CALL_LOG is not False:
+        _log_call(fname, kw, meta)
     kt = KernelTimer.active
     if kt is not None:
         import torch

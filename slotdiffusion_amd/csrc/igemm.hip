@@ -700,14 +700,20 @@ int dispatch(const SdmiGemmArgs& p, hipStream_t st, bool plan_only = false) {
       const char* e = getenv("SDMI_IGEMM_HALO_NJ1");   //  the narrow tile doubles the weight bytes per flop)
       halo_nj1 = e ? atoi(e) : 0;
     }
+    static int halo_c64 = -1;                // SDMI_IGEMM_HALO_C64=1: the 64 -> 64 channel layers through 256 x 64 halo tiles
+    if (halo_c64 < 0) {                      // (off: 135.1 vs 120.4 us at 128^2 against conv3x3_c64_kernel, whose filter stays
+      const char* e = getenv("SDMI_IGEMM_HALO_C64");   //  in LDS; train step +0.4 ms)
+      halo_c64 = e ? atoi(e) : 0;
+    }
     const long long tm256 = (long long)(p.M + 255) / 256;
-    const int nj = (tm256 * ((p.N + 127) / 128) >= halo_min || !halo_nj1) ? 2 : 1;
+    const int nj = p.N <= 64 ? 1 : ((tm256 * ((p.N + 127) / 128) >= halo_min || !halo_nj1) ? 2 : 1);
     const long long t256 = tm256 * ((p.N + 64 * nj - 1) / (64 * nj));
-    halo_logw = p.W == 16 ? 4 : (p.W == 32 ? 5 : (p.W == 64 ? 6 : 0));
+    // tile width = image width (16 / 32 / 64), or 64-column tiles of four rows on wider images (128^2: the 64-channel layers)
+    halo_logw = p.W == 16 ? 4 : (p.W == 32 ? 5 : ((p.W % 64 == 0 && p.H % 4 == 0) ? 6 : 0));
     if (halo_min > 0 && halo_logw && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad_t == 1 && p.pad_l == 1 && plain &&
-        !p.a2 && p.H == p.Ho && p.W == p.Wo && hw_shift >= 8 && p.Cin % 64 == 0 && p.N >= 64 && t256 >= halo_min &&
-        p.split_k <= 1 && batch == 1 && fits31 && p.osy == 0 && !p.ln_colsum && !p.geglu && !p.softmax8 && !p.out2 &&
-        !p.gn_part && !p.defer_epilogue && p.out_dtype == SDMI_BF16)
+        !p.a2 && p.H == p.Ho && p.W == p.Wo && hw_shift >= 8 && p.Cin % 64 == 0 && p.N >= 64 && (p.N > 64 || halo_c64) &&
+        t256 >= halo_min && p.split_k <= 1 && batch == 1 && fits31 && p.osy == 0 && !p.ln_colsum && !p.geglu && !p.softmax8 &&
+        !p.out2 && !p.gn_part && !p.defer_epilogue && p.out_dtype == SDMI_BF16)
       halo_nj = nj;
   }
   if (halo_nj) {

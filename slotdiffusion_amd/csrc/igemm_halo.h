@@ -27,7 +27,7 @@
 
 namespace {
 
-// LOGW: log2 of the image width (16 / 32 / 64 columns).  NJ: 32-column blocks per wave -- 2: 256 x 128 tiles (64 x 64
+// LOGW: log2 of the tile width = the image width (16 / 32 / 64 columns), or 6 on images of a multiple of 64 columns.  NJ: 32-column blocks per wave -- 2: 256 x 128 tiles (64 x 64
 // wave blocks, two segments of 8 MFMAs per K tile); 1: 256 x 64 tiles (64 x 32 wave blocks, one segment of 8 MFMAs per
 // K tile) for the layers whose 256 x 128 grid would leave half the chip idle (the 16^2 level at B = 64).
 template <int LOGW, int NJ>
@@ -60,24 +60,31 @@ __global__ __launch_bounds__(512, 2) void igemm_halo_kernel(SdmiGemmArgs p, int 
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grp = w >> 2;
   // ------------------------------------ operand fetch state ------------------------------------
-  // the activation base is biased by -(W + 1) pixels: patch pixel (py, px) of a tile whose first pixel is P0 lies at
-  // P0 + py W + px in biased coordinates (offsets >= 0; the pixels in front of the tensor are never valid)
-  const T* Ag = (const T*)p.a - (long long)(W + 1) * p.lda;
+  // Tile = TH rows x W columns of one image whose width p.W is W (the 16 / 32 / 64-column levels) or a multiple of it
+  // (W = 64 on wider images: the tile's left / right patch columns are then real pixels except at the image border).
+  // The activation base is biased by -(p.W + 1) pixels: patch pixel (py, px) of a tile whose first pixel is P0 lies at
+  // P0 + py p.W + px in biased coordinates (offsets >= 0; the pixels in front of the tensor are never valid)
+  const int tpx = p.W >> LOGW, per_img = (p.H / TH) * tpx;            // tiles per row band / per image
+  auto tile_pix0 = [&](int m0, unsigned& mask) __attribute__((always_inline)) {
+    const int tm = m0 >> 8, b = tm / per_img, r = tm - b * per_img;
+    const int ty = r / tpx, tx = r - ty * tpx;
+    mask = (ty == 0 ? 1u : 0u) | ((ty + 1) * TH == p.H ? 2u : 0u) | (tx == 0 ? 4u : 0u) | ((tx + 1) * W == p.W ? 8u : 0u);
+    return (b * p.H + ty * TH) * p.W + tx * W;
+  };
+  const T* Ag = (const T*)p.a - (long long)(p.W + 1) * p.lda;
   const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)Ag, 0, (int)OOB, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)OOB, 0x00020000);
   // patch pieces of this wave: piece 8 t + w (t < ATAPS); lane l: patch pixel q = 8 piece + (l >> 3), chunk position
-  // l & 7.  Low bits of a_vo: 1 = never valid (zero column / beyond the patch), 2 = row above, 4 = row below the tile
+  // l & 7.  Low four bits of a_vo: 1 / 2 = row above / below the tile, 4 / 8 = column left / right of it (zero when the
+  // tile touches that image border); pixels beyond the patch are out of range for good
   unsigned a_vo[ATAPS], a_cur[ATAPS];
 #pragma unroll
   for (int t = 0; t < ATAPS; ++t) {
     const int q = (8 * t + w) * 8 + (l >> 3);
     const int py = q / PW, px = q - py * PW;
     const int kc = (l & 7) ^ ((q >> 1) & 7);
-    unsigned f = 0;
-    if (q >= Q || px == 0 || px == PW - 1) f |= 1u;
-    if (py == 0) f |= 2u;
-    if (py == PH - 1) f |= 4u;
-    a_vo[t] = ((unsigned)(py * W + px) * (unsigned)p.lda * 2u + (unsigned)kc * 16u) | f;
+    const unsigned f = (py == 0 ? 1u : 0u) | (py == PH - 1 ? 2u : 0u) | (px == 0 ? 4u : 0u) | (px == PW - 1 ? 8u : 0u);
+    a_vo[t] = q >= Q ? OOB : (((unsigned)(py * p.W + px) * (unsigned)p.lda * 2u + (unsigned)kc * 16u) | f);
     a_cur[t] = OOB;
   }
   unsigned b_vo[NJ];
@@ -88,11 +95,11 @@ __global__ __launch_bounds__(512, 2) void igemm_halo_kernel(SdmiGemmArgs p, int 
     int m0, n0;
     tile_of((int)blockIdx.x + a_ti * (int)gridDim.x, m0, n0);
     const bool live = a_ti < my_tiles;
-    const int y0 = (m0 & ((1 << hw_shift) - 1)) >> LOGW;            // first image row of the tile
-    const unsigned mask = 1u | (y0 == 0 ? 2u : 0u) | (y0 + TH == p.H ? 4u : 0u);
+    unsigned mask;
+    const int pix0 = tile_pix0(live ? m0 : 0, mask);
 #pragma unroll
     for (int t = 0; t < ATAPS; ++t) a_cur[t] = (!live || (a_vo[t] & mask)) ? OOB : (a_vo[t] & ~15u);
-    a_so = (unsigned)m0 * (unsigned)p.lda * 2u;
+    a_so = (unsigned)pix0 * (unsigned)p.lda * 2u;
   };
   auto issue_a = [&](int t) __attribute__((always_inline)) {        // piece 8 t + w of chunk (a_ti, a_c) -> buffer a_buf
     if (8 * t + w < NPIECE)
@@ -252,7 +259,9 @@ __global__ __launch_bounds__(512, 2) void igemm_halo_kernel(SdmiGemmArgs p, int 
       c_buf ^= 1;
     }
     if (grp == 0) HALO_BARRIER();              // both groups store in the same interval
-    const int mw0 = m0 + wm * 64, nw0 = n0 + wn * 32 * NJ;
+    // (a wave's 64 rows are consecutive pixels: whole image rows, or one 64-pixel run of a wider image)
+    unsigned mask_;
+    const int mw0 = tile_pix0(m0, mask_) + ((wm * 64) >> LOGW) * p.W + ((wm * 64) & (W - 1)), nw0 = n0 + wn * 32 * NJ;
     if (epilogue_rows_ok<NJ>(p, mw0, nw0, hw_shift)) {
       // wave-private patch in the patch buffer the tile's last chunk vacated (c_buf already points at the other one)
       wave_epilogue_rows<NJ>(p, acc, mw0, nw0, hw_shift, l, smem + (c_buf ^ 1) * ABUF + w * EpiRows<NJ>::PATCH);

@@ -45,7 +45,8 @@ def test_pp_conv3x3_plain(B, H, C, N):
                                       (16, 64, 128, 128),      # W = 64: four image rows per tile, 50-piece patches
                                       (64, 32, 64, 128),       # one 64-channel chunk per tile (patch buffers alternate per tile)
                                       (64, 32, 384, 384),      # six chunks, three column tiles, three tiles per workgroup
-                                      (200, 16, 128, 192)])    # W = 16, ragged N (1.5 column tiles)
+                                      (200, 16, 128, 192),     # W = 16, ragged N (1.5 column tiles)
+                                      (4, 128, 128, 128)])     # 128-column image: 4 x 64-pixel tiles with real left / right neighbours
 def test_halo_conv3x3_geometries(B, H, C, N):
     """The halo-staged 3x3 kernel (csrc/igemm_halo.h) at the image widths it serves; bias + residual + row vector."""
     ops = _ops()

@@ -8,8 +8,9 @@ mkdir -p $O
 cd $R
 last() { grep '^{' | tail -1; }
 # the two headline lines: full contract (roofline from the replayed trace, CPU baseline)
-timeout 900 python bench.py 2> $O/train.err | last > $O/${TAG}_bench_train.json
-timeout 900 python bench.py --mode sample 2> $O/sample.err | last > $O/${TAG}_bench_sample.json
+# (--pmc-table: the per-kernel counters of the run's own PMC child passes -- MFMA busy, observed vs algorithmic bytes)
+timeout 900 python bench.py --pmc-table $O/${TAG}_%m_pmc_by_kernel.csv 2> $O/train.err | last > $O/${TAG}_bench_train.json
+timeout 900 python bench.py --mode sample --pmc-table $O/${TAG}_%m_pmc_by_kernel.csv 2> $O/sample.err | last > $O/${TAG}_bench_sample.json
 # secondary configurations (no CPU baseline leg)
 timeout 600 python bench.py --mode sample --dtype fp8 --no-cpu-baseline 2> $O/sample_fp8.err | last > $O/${TAG}_bench_sample_fp8.json
 timeout 600 python bench.py --config coco224 --mode sample --dtype bf16 --no-cpu-baseline 2> $O/coco_bf16.err | last > $O/${TAG}_bench_coco_bf16.json

@@ -9,15 +9,7 @@ cd /tmp && export TMPDIR=/tmp
 # 1. kernel-trace + stats of the bench command (graph replay), train and sampling
 timeout 600 rocprofv3 --kernel-trace --stats -d $O/train -o train --output-format csv -- python $R/bench.py --only-train --no-cpu-baseline --no-roofline --steps 5 --warmup 2 > $O/train_trace.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats -d $O/sample -o sample --output-format csv -- python $R/bench.py --mode sample --big-batch 0 --no-cpu-baseline --no-roofline --steps 3 --warmup 1 > $O/sample_trace.log 2>&1
-# 2. PMC passes (separate runs, kernel-trace only), eager mode so that kernels are attributable
-for mode in train sample; do
-  if [ $mode = train ]; then ARGS="--only-train --no-graph --no-cpu-baseline --no-roofline --steps 2 --warmup 1"; else ARGS="--mode sample --big-batch 0 --no-graph --no-cpu-baseline --no-roofline --steps 1 --warmup 1"; fi
-  timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_BF16 -d $O/pmc_${mode}_1 -o p --output-format csv -- python $R/bench.py $ARGS > $O/pmc_${mode}_1.log 2>&1
-  if [ $mode = train ]; then     # TCC passes: train only (see the note above)
-    timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_${mode}_2 -o p --output-format csv -- python $R/bench.py $ARGS > $O/pmc_${mode}_2.log 2>&1
-    timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_${mode}_3 -o p --output-format csv -- python $R/bench.py $ARGS > $O/pmc_${mode}_3.log 2>&1
-  fi
-done
+# 2. (the per-kernel PMC tables come from bench.py --pmc-table: tools/collect_bench.sh)
 # 3. the fp8 sampling configuration and the COCO-224 / DINO configuration (kernel stats only)
 timeout 600 rocprofv3 --kernel-trace --stats -d $O/sample_fp8 -o sample_fp8 --output-format csv -- python $R/bench.py --mode sample --dtype fp8 --big-batch 0 --no-cpu-baseline --no-roofline --steps 3 --warmup 1 > $O/sample_fp8_trace.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats -d $O/coco -o coco --output-format csv -- python $R/bench.py --config coco224 --mode sample --dtype fp8 --no-cpu-baseline --no-roofline --steps 2 --warmup 1 > $O/coco_trace.log 2>&1
@@ -30,8 +22,5 @@ cp $O/train/train_kernel_stats.csv $O/${TAG}_train_b64_bf16_kernel_stats.csv 2>/
 cp $O/sample/sample_kernel_stats.csv $O/${TAG}_sample_b64_bf16_kernel_stats.csv 2>/dev/null
 python tools/trace_step.py $O/train/train_kernel_trace.csv 60 > $O/${TAG}_train_step_breakdown.txt 2>&1
 python tools/trace_eval.py $O/sample/sample_kernel_trace.csv > $O/${TAG}_sample_eval_launches.txt 2>&1
-for mode in train sample; do
-  python tools/pmc_summary.py "$O/pmc_${mode}_*/**/*counter_collection.csv" > $O/${TAG}_${mode}_pmc_by_kernel.csv 2>&1
-done
-rm -rf $O/train/*trace.csv $O/sample/*trace.csv $O/sample_fp8/*trace.csv $O/coco/*trace.csv $O/coco_train/*trace.csv $O/pmc_*/*counter_collection.csv $O/pmc_*/*kernel_trace.csv
+rm -rf $O/train/*trace.csv $O/sample/*trace.csv $O/sample_fp8/*trace.csv $O/coco/*trace.csv $O/coco_train/*trace.csv
 ls -la $O | head -40
