@@ -29,6 +29,7 @@
 #endif
 
 #include "igemm_body.h"
+#include "epi_rows.h"
 #include "igemm_sym.h"
 
 // 256 x 128 ping-pong kernel: its own translation unit (igemm_pp.hip)
@@ -333,6 +334,10 @@ constexpr int D33_HALO = 6 * 66, D33_HALO_V = (D33_HALO * 8 + 255) / 256;     //
 constexpr int D33_STAGE = 32 * D33_PIX;                       // per-wave epilogue staging (32 px x 32 ch fp32)
 constexpr int D33_SMEM = 64 * D33_WROW + D33_HALO * D33_PIX + 4 * D33_STAGE;
 
+// ROWS (round 5; N = 64): MFMA operands swapped -- the accumulators hold C^T, lane = output pixel -- and the row-major
+// epilogue of epi_rows.h: a lane packs its four-channel groups, 16 ds_write_b64 + 8 ds_read_b128 per wave and 32-pixel
+// half instead of 64 scalar fp32 LDS stores per lane, residual added before the single rounding.
+template <bool ROWS>
 __global__ __launch_bounds__(256) void conv3x3_c64_kernel(SdmiGemmArgs p, int hw_shift) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const Ws = smem;
@@ -410,9 +415,12 @@ __global__ __launch_bounds__(256) void conv3x3_c64_kernel(SdmiGemmArgs p, int hw
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-              __builtin_bit_cast(bf16x8, fa[step & 1][i]), __builtin_bit_cast(bf16x8, fb[step & 1][j]),
-              acc[i][j], 0, 0, 0);
+          acc[i][j] = ROWS ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                                 __builtin_bit_cast(bf16x8, fb[step & 1][j]), __builtin_bit_cast(bf16x8, fa[step & 1][i]),
+                                 acc[i][j], 0, 0, 0)
+                           : __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                                 __builtin_bit_cast(bf16x8, fa[step & 1][i]), __builtin_bit_cast(bf16x8, fb[step & 1][j]),
+                                 acc[i][j], 0, 0, 0);
     }
     const int b = t / (tiles_y * tiles_x), r = t - b * tiles_y * tiles_x;
     const int ty = r / tiles_x, tx = r - ty * tiles_x;
@@ -422,6 +430,12 @@ __global__ __launch_bounds__(256) void conv3x3_c64_kernel(SdmiGemmArgs p, int hw
     // time) and writes whole 128-byte pixel rows: bias / per-image row vector in registers,
     // residual + activation on the way out.
     char* stg = smem + 64 * D33_WROW + D33_HALO * D33_PIX + wave * D33_STAGE;
+    if constexpr (ROWS) {
+      static_assert(D33_STAGE >= EpiRows<2>::PATCH, "epilogue patch");
+      if (epilogue_rows_ok<2>(p, m0, 0, hw_shift)) wave_epilogue_rows<2>(p, acc, m0, 0, hw_shift, lane, stg);
+      else wave_epilogue_rows_generic<2>(p, acc, m0, 0, hw_shift, lane);
+      continue;
+    }
     const float* rv = p.rowvec ? p.rowvec + (long long)b * p.ldrv : nullptr;
     const bf16_t* resp = (const bf16_t*)p.residual;
     bf16_t* outp = (bf16_t*)p.out;
@@ -741,13 +755,21 @@ int dispatch(const SdmiGemmArgs& p, hipStream_t st, bool plan_only = false) {
       p.out_dtype == SDMI_BF16 && p.ldc % 8 == 0 && p.N % 8 == 0 && !p.bias_m &&
       (!p.residual || p.ldr % 8 == 0) &&
       (long long)p.B * (p.H / 4) * (p.W / 64) >= 2 * device_cus()) {
-    SDMI_OPTIN_LDS(conv3x3_c64_kernel, D33_SMEM, "igemm (direct 3x3 c64)");
+    static int c64_rows = -1;               // SDMI_C64_ROWS=1: the row-major epilogue of epi_rows.h for N = 64 launches
+    if (c64_rows < 0) {                     // (off: 119.1 vs 124.4 us per launch in a dependent chain at 128^2, and the train
+      const char* e = getenv("SDMI_C64_ROWS");   //  step 27.39 vs 27.23 ms -- same box, two runs each: the chain does not decide)
+      c64_rows = e ? atoi(e) : 0;
+    }
+    const bool rows = c64_rows && p.N == 64;
+    SDMI_OPTIN_LDS(conv3x3_c64_kernel<false>, D33_SMEM, "igemm (direct 3x3 c64)");
+    SDMI_OPTIN_LDS(conv3x3_c64_kernel<true>, D33_SMEM, "igemm (direct 3x3 c64, row-major epilogue)");
     SdmiGemmArgs q = p;
     q.split_k = 1;
     int grid = device_cus();
     const long long n_tiles = (long long)p.B * (p.H / 4) * (p.W / 64);
     if (grid > n_tiles) grid = (int)n_tiles;
-    hipLaunchKernelGGL(conv3x3_c64_kernel, dim3(grid), dim3(256), D33_SMEM, st, q, hw_shift);
+    if (rows) hipLaunchKernelGGL(conv3x3_c64_kernel<true>, dim3(grid), dim3(256), D33_SMEM, st, q, hw_shift);
+    else hipLaunchKernelGGL(conv3x3_c64_kernel<false>, dim3(grid), dim3(256), D33_SMEM, st, q, hw_shift);
     return sdmi_check_launch("igemm (direct 3x3 c64)");
   }
   // ping-pong kernel (igemm_pp.h): 256 x 128 tiles, one workgroup per CU -- bf16, 1x1 / plain convolutions, plain
