@@ -65,6 +65,13 @@ def splitk_workspace(M, N, K, elt, device):
 # (unet.py:243-250: conv -> GroupNorm32 -> SiLU), that kernel's prologue finishes the reduction (sdmi_groupnorm: part)
 # and also stores the tensor for its other readers.  ANY other launch first finishes what is pending (`_lib.pre_call`),
 # so a pending tensor is never read unfinished; results are bit-identical either way.
+# The protection covers readers that go through `_lib.call` only -- a torch op, `.cpu()` or a side-stream reader of a
+# pending tensor inside the context would see unwritten memory.  Every consumer inside `UNetRunner.forward` is a library
+# call; SDMI_DEBUG_DEFER=1 makes a violation visible instead of silent: a deferring convolution first fills its output
+# with NaN (the finishing kernel overwrites every element), so any reader that slipped past the hook yields NaN.
+_DEBUG_DEFER = __import__('os').environ.get('SDMI_DEBUG_DEFER', '0') != '0'
+
+
 class _PendingSplit:
     __slots__ = ('out', 'kw', 'splits', 'keep')
 
@@ -187,6 +194,8 @@ def conv2d(x, w, bias=None, *, kh=3, kw=3, stride=1, pad=(1, 1, 1, 1), ups=False
             odt == torch.bfloat16 and (residual is None or (residual.is_contiguous() and residual.shape[-1] == N)):
         splits = _lib.query('sdmi_igemm_split_plan', **kwargs)
         if splits > 1:
+            if _DEBUG_DEFER:
+                out.fill_(float('nan'))
             call('sdmi_igemm', _stream(), defer_epilogue=1, **kwargs)
             _PENDING[out.data_ptr()] = _PendingSplit(out, kwargs, splits, (ws, bias, rowvec, residual, float(alpha)))
             return out

@@ -157,3 +157,22 @@ def test_groupnorm_statistics_from_the_convolution_epilogue(B, hw, cin, cout, tw
     assert float((part.double() - s_ref).abs().max() / s_ref.abs().max()) < 1e-5
     assert float((st - st_ref).abs().max()) < 1e-3 * float(st_ref.abs().max())
     assert _close(y, y_ref)
+
+
+def test_debug_mode_poisons_unfinished_outputs(monkeypatch):
+    """SDMI_DEBUG_DEFER=1 (ops._DEBUG_DEFER): a deferring convolution fills its output with NaN first, so a reader that
+    bypasses the `_lib.call` hook sees NaN instead of stale memory -- and the regular consumers still see the finished,
+    bit-identical result (the finishing kernels overwrite every element)."""
+    from slotdiffusion_amd import ops
+    x, w, bias, rv, res, gamma, beta = _case(64, 4, 512, 512, 9, True, True)
+    h_ref = ops.conv2d(x, w, bias, rowvec=rv, residual=res)
+    y_ref = ops.group_norm(h_ref, gamma, beta, eps=1e-5, act='silu')
+    monkeypatch.setattr(ops, '_DEBUG_DEFER', True)
+    with ops.defer_splitk():
+        h = ops.conv2d(x, w, bias, rowvec=rv, residual=res)
+        assert ops._PENDING
+        peek = h.float().clone()                       # a torch-side reader: NOT covered by the hook
+        y = ops.group_norm(h, gamma, beta, eps=1e-5, act='silu')
+    torch.cuda.synchronize()
+    assert bool(torch.isnan(peek).all())               # ... and now visibly so
+    assert torch.equal(h, h_ref) and _close(y, y_ref)
