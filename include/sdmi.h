@@ -100,9 +100,9 @@ typedef struct {
   int lda2, K1;
   const void* a3;
   int lda3, K2;
-  /* softmax8 = S in 1..7 (with ln_colsum): the epilogue finishes with a softmax over every aligned group
-   * of 8 output columns of which the first S are scores (the others are pads: treated as -inf, written
-   * as 0) -- the S slot scores of one attention head.  With batch > 1, ln_colsum / bias advance by s_colsum / s_bias entries per batch:
+  /* softmax8 = S in 1..16 (with ln_colsum): the epilogue finishes with a softmax over every aligned group
+   * of 8 (S <= 8) or 16 (S > 8: the video configurations' 11 / 15 slots) output columns of which the first S are
+   * scores (the others are pads: treated as -inf, written as 0) -- the S slot scores of one attention head.  With batch > 1, ln_colsum / bias advance by s_colsum / s_bias entries per batch:
    * slot cross-attention as two per-image GEMMs (attention.py:182-206 with the 7 keys folded into the
    * query weights, the values into the output projection; see engine.UNetRunner.cross_fold). */
   int softmax8;
@@ -446,7 +446,7 @@ typedef struct {
   const void* wstream_a; const float* vec_a;
   const void* wstream_b; const float* vec_b;
   const void* wstream_img; const float* vec_img;
-  int B, S, C, slots, phase;
+  int B, S, C, slots, phase;        /* slots <= 8: 8-column score groups; 9..16 (C = 256 only: heads * 16 = 128 columns): 16 */
   float gn_eps, ln_eps, attn_scale;
   int rows;   /* token rows per workgroup: 0 / 64, or 32 (twice the workgroups: small grids, e.g. 64 images at 8^2) */
 } SdmiStBlockArgs;
@@ -478,11 +478,12 @@ typedef struct {
 int sdmi_cross_fold(const SdmiCrossFoldArgs* a, void* stream);
 
 /* Head-expanded slot keys / values for the folded cross-attention (engine.UNetRunner.cross_fold):
- * kv [B][S][ldkv] holds K in columns [0, C) and V in [C, 2C); row h * 8 + j (j < S <= 7) of
- * kexp / vexp [B][heads * 8][C] is slot j's key (times `scale`) / value restricted to the channels of
- * head h, zero elsewhere; rows j >= S are zero. */
+ * kv [B][S][ldkv] holds K in columns [0, C) and V in [C, 2C); row h * gw + j (j < S <= gw) of
+ * kexp / vexp [B][heads * gw][C] is slot j's key (times `scale`) / value restricted to the channels of
+ * head h, zero elsewhere; rows j >= S are zero.  gw = group width: 8 (0 = 8) or 16. */
 typedef struct {
   const void* kv; void* kexp; void* vexp; int dtype; int B, S, C, heads, ldkv; float scale;
+  int gw;
 } SdmiExpandHeadsArgs;
 int sdmi_expand_heads(const SdmiExpandHeadsArgs* a, void* stream);
 

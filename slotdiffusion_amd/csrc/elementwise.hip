@@ -106,13 +106,14 @@ __global__ void quant_fp8_kernel(SdmiQuantFp8Args p) {
 
 template <typename T>
 __global__ void expand_heads_kernel(SdmiExpandHeadsArgs p) {
-  const int R = p.heads * 8, hd = p.C / p.heads;
+  const int gw = p.gw == 16 ? 16 : 8;
+  const int R = p.heads * gw, hd = p.C / p.heads;
   const long long n = (long long)p.B * R * p.C;
   GRID_STRIDE(i, n) {
     const int c = (int)(i % p.C);
     const long long br = i / p.C;
     const int row = (int)(br % R), b = (int)(br / R);
-    const int h = row >> 3, j = row & 7;
+    const int h = row / gw, j = row - h * gw;
     float k = 0.f, v = 0.f;
     if (j < p.S && c / hd == h) {
       const T* src = (const T*)p.kv + ((long long)b * p.S + j) * p.ldkv;
@@ -435,8 +436,9 @@ extern "C" int sdmi_cast2d(const SdmiCast2dArgs* a, void* stream) {
 }
 extern "C" int sdmi_expand_heads(const SdmiExpandHeadsArgs* a, void* stream) {
   SDMI_REQUIRE(a && a->kv && a->kexp && a->vexp, "null pointer");
-  SDMI_REQUIRE(a->S >= 1 && a->S <= 7 && a->heads > 0 && a->C % a->heads == 0, "1 .. 7 slots, C = heads * head_dim");
-  const int g = ew_blocks((long long)a->B * a->heads * 8 * a->C);
+  SDMI_REQUIRE((a->gw == 0 || a->gw == 8 || a->gw == 16) && a->S >= 1 && a->S <= (a->gw == 16 ? 16 : 8) && a->heads > 0 &&
+                   a->C % a->heads == 0, "1 .. gw slots (gw = 8 or 16), C = heads * head_dim");
+  const int g = ew_blocks((long long)a->B * a->heads * (a->gw == 16 ? 16 : 8) * a->C);
   if (a->dtype == SDMI_BF16) hipLaunchKernelGGL(expand_heads_kernel<bf16_t>, dim3(g), dim3(EW_THREADS), 0, ST, *a);
   else hipLaunchKernelGGL(expand_heads_kernel<float>, dim3(g), dim3(EW_THREADS), 0, ST, *a);
   return sdmi_check_launch("expand_heads");

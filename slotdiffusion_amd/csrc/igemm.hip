@@ -906,8 +906,8 @@ int dispatch(const SdmiGemmArgs& p, hipStream_t st, bool plan_only = false) {
     }
     if (epi == 5) {            // LayerNorm fold + softmax over 8-column groups (per-image batches allowed)
       if (sizeof(T) == 1 || !is1x1 || !fits31 || p.osy != 0 || p.split_k > 1 || p.bias_m || p.residual ||
-          p.rowvec || (p.N & 7)) {
-        sdmi_set_error("igemm: softmax8 epilogue needs a plain 1x1 problem with N a multiple of 8");
+          p.rowvec || (p.N & (p.softmax8 > 8 ? 15 : 7)) || p.softmax8 > 16) {
+        sdmi_set_error("igemm: softmax8 epilogue needs a plain 1x1 problem with N a multiple of the group width (8; 16 from 9 slots)");
         return SDMI_EUNSUPPORTED;
       }
       if constexpr (sizeof(T) == 2)

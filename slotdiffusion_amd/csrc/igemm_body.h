@@ -383,18 +383,21 @@ __device__ __forceinline__ void fused_epilogue(const SdmiGemmArgs& p, f32x16 (&a
           if (out_bf16) v *= act_apply<true>(g, SDMI_ACT_GELU);
           else v *= act_apply(g, SDMI_ACT_GELU);
         } else if constexpr (SM8) {
-          // softmax over the aligned 8-column group (softmax8 slot scores + pad columns): the group's lanes
-          // are 8 neighbours of this 32-lane half, every lane takes part
-          const float x = ((ncol[j] & 7) >= p.softmax8) ? -INFINITY : v;
+          // softmax over the aligned 8-column (16-column from 9 slots) group (softmax8 slot scores + pad columns):
+          // the group's lanes are neighbours of this 32-lane half, every lane takes part
+          const bool wide = p.softmax8 > 8;
+          const float x = ((ncol[j] & (wide ? 15 : 7)) >= p.softmax8) ? -INFINITY : v;
           float mx = x;
           mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
           mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
           mx = fmaxf(mx, __shfl_xor(mx, 4, 64));
+          if (wide) mx = fmaxf(mx, __shfl_xor(mx, 8, 64));
           const float e = __expf(x - mx);
           float sm = e;
           sm += __shfl_xor(sm, 1, 64);
           sm += __shfl_xor(sm, 2, 64);
           sm += __shfl_xor(sm, 4, 64);
+          if (wide) sm += __shfl_xor(sm, 8, 64);
           v = e / sm;
         } else {
           v = act_apply(v, p.act);

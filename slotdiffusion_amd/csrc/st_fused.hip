@@ -703,25 +703,31 @@ __global__ __launch_bounds__(512, 2) void st_block_b_kernel(SdmiStBlockArgs p) {
     for (int kt = 0; kt < KT; ++kt) st_gemm_step<D, 1, true, 0, TT>(rg, Y, yaddr, kt, 16 * PITCH, woff, sc, sx, sxx);
     st_ln_stats<TT>(sx, sxx, 1.f / (float)C, p.ln_eps, mean, rstd);
     const int c = n0 >> 3;
+    // score groups: 8 columns per head (two lane groups of four, lg ^ 1) up to 8 slots; from 9 slots (C = 256: 8 heads
+    // x 16 = the 128 padded columns, a wave's 16-column slice is ONE head) 16 columns = all four lane groups of a row
+    const bool wide = p.slots > 8;
+    const int Rr = wide ? HEADS * 16 : R;
 #pragma unroll
     for (int tt = 0; tt < TT; ++tt) {
       float v[4];
       float mx = -INFINITY;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const bool ok = n0 < R && (4 * (lg & 1) + j) < p.slots;
+        const bool ok = n0 < Rr && (4 * (wide ? lg : (lg & 1)) + j) < p.slots;
         v[j] = ok ? rstd[tt] * (sc[0][tt][j] - mean[tt] * cs[j]) + bi[j] : -INFINITY;
         mx = fmaxf(mx, v[j]);
       }
       mx = fmaxf(mx, __shfl_xor(mx, 16, 64));          // the group's other four columns: lane ^ 16
+      if (wide) mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       float sm = 0.f;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        v[j] = n0 < R ? __expf(v[j] - mx) : 0.f;
+        v[j] = n0 < Rr ? __expf(v[j] - mx) : 0.f;
         sm += v[j];
       }
       sm += __shfl_xor(sm, 16, 64);
-      const float inv = n0 < R ? 1.f / sm : 0.f;
+      if (wide) sm += __shfl_xor(sm, 32, 64);
+      const float inv = n0 < Rr ? 1.f / sm : 0.f;
       const int r = tt * 16 + l15;
       const int phys = (c & ~15) | ((c ^ r) & 15);
       uint2 o;
@@ -867,7 +873,8 @@ extern "C" int sdmi_st_block(const SdmiStBlockArgs* a, void* stream) {
   const int rows = a->rows ? a->rows : 64;
   SDMI_REQUIRE(a->S >= rows && a->S % rows == 0 && a->S % 32 == 0 && 4 * a->S * (ST_KP + ST_VP) <= 160 * 1024,
                "S must be a multiple of the rows per workgroup and at most 256 tokens per image");
-  SDMI_REQUIRE(a->slots >= 1 && a->slots <= 8, "1..8 slots");
+  SDMI_REQUIRE(a->slots >= 1 && (a->slots <= 8 || (a->slots <= 16 && a->C == 256)),
+               "1..8 slots (C = 256: up to 16, in 16-column score groups)");
   SDMI_REQUIRE(a->phase >= 0 && a->phase <= 2, "phase: 0 = both, 1 = A, 2 = B");
   hipStream_t st = (hipStream_t)stream;
   if (rows == 64) return a->C == 256 ? st_launch<256, 4>(*a, st) : st_launch<384, 4>(*a, st);

@@ -66,14 +66,19 @@ class CatPair:
 _RES_MERGE = os.environ.get('SDMI_RES_MERGE', '1') != '0'
 _FF_MERGE = os.environ.get('SDMI_FF_MERGE', '1') != '0'
 _CROSS_FOLD = os.environ.get('SDMI_CROSS_FOLD', '1') != '0'
+# most slots the folded cross-attention path takes (16-row groups per head from 9 slots; SDMI_CROSS_MAX_SLOTS=7: round 4)
+_CROSS_MAX_SLOTS = int(os.environ.get('SDMI_CROSS_MAX_SLOTS', '16'))
 _LN_FOLD = os.environ.get('SDMI_LN_FOLD', '1') != '0'
 _ST_FUSED = os.environ.get('SDMI_ST_FUSED', '1') != '0'     # fused SpatialTransformer block (sdmi_st_block)
 # 3x3 layers whose data gradient has at least this many 256 x 128 tiles leave the pair launch: data gradient through the
 # halo-staged kernel (igemm_halo.h), weight gradient through its twin on channel pairs (wgrad3x3_halo_kernel) on a side
-# stream.  Same-box A/B of the train step (two runs each): paired 26.61 / 26.60 ms, un-paired with the implicit-GEMM weight
-# gradient 26.84 / 26.89 (the halo kernel fills a CU's LDS: the side-stream launches no longer co-reside), un-paired with
-# the direct weight gradient 26.43 / 26.37; threshold 128 instead of 192: another 0.02.  0 = keep every layer paired.
-_HALO_DGRAD = int(os.environ.get('SDMI_HALO_DGRAD', '128'))
+# stream.  0 (default) = every layer stays paired.  Both kernels are 1.3 - 1.8x their implicit-GEMM counterparts alone, and
+# the step does not move: 26.93 / 26.90 / 26.90 ms paired against 26.92 / 26.87 / 26.94 un-paired (128; same box, rotated
+# order) -- the M-split partials of an un-paired weight gradient (256 workgroups x 147 KB = 37.7 MB per layer) need their own
+# fold launch, 35 us each next to the main stream's kernels: +1.2 ms of summed kernel time per step, hidden only because the
+# side streams overlap it; with the implicit-GEMM weight gradient next to the halo kernel the step is 0.25 ms
+# SLOWER (a kernel that fills a CU's LDS excludes the side-stream launches that used to co-reside).
+_HALO_DGRAD = int(os.environ.get('SDMI_HALO_DGRAD', '0'))
 _WGRAD_HALO = os.environ.get('SDMI_WGRAD_HALO', '1') != '0'    # direct 3x3 weight gradient on channel pairs (wgrad3x3_halo_kernel)
 # folded slot cross-attention as ONE launch (sdmi_cross_fold) up to this many tokens per image (0 = off)
 _CROSS_ONE = int(os.environ.get('SDMI_CROSS_ONE', '64'))
@@ -1008,18 +1013,21 @@ class Kern:
         return self.linear(tok, n + '.proj_out.weight', n + '.proj_out.bias', residual=xres)
 
     def cross_prepare(self, kv, t, heads):
-        """Once per sampling call (slots and weights are fixed over the NFEs): the 7 slot keys folded
+        """Once per sampling call (slots and weights are fixed over the NFEs): the slot keys (7 of the image models in
+        8-row groups per head; the video models' 11 / 15 in 16-row groups, savi_diffusion.py:143-144) folded
         into the query projection, the values into the output projection -- per image
           Wq[b] = (scale K_b restricted per head) (W_q gamma)   [heads*8, C]   (+ LayerNorm-fold terms)
           W2[b] = W_o (V_b restricted per head)^T               [C, heads*8]
         so that slot cross-attention is two small per-image GEMMs per evaluation (cross_block)."""
-        if not (_CROSS_FOLD and kv.dtype == torch.bfloat16 and kv.shape[1] <= 7):
+        if not (_CROSS_FOLD and kv.dtype == torch.bfloat16 and kv.shape[1] <= _CROSS_MAX_SLOTS):
             return None
         wt, tb, ones = self.wb.cross_fold_weights(t, kv.dtype)
         B, C = kv.shape[0], kv.shape[-1] // 2
-        R = heads * 8
-        kexp, vexp = ops.expand_heads(kv, heads, float(C // heads) ** -0.5)
-        fused = _ST_FUSED and C in (256, 384)
+        gw = 8 if kv.shape[1] <= 8 else 16             # score columns per head (softmax group width)
+        R = heads * gw
+        kexp, vexp = ops.expand_heads(kv, heads, float(C // heads) ** -0.5, gw)
+        # (the fused block pads the score matrix to 128 columns: 16-row groups fit C = 256 -- 8 heads -- only)
+        fused = _ST_FUSED and C in (256, 384) and R <= 128
         if fused:
             # the fused block (sdmi_st_block) takes the same operands padded to 128 score columns, as a unit
             # stream: Wq[b] / W2[b] are produced straight into the padded storage (pads stay zero)
@@ -1053,7 +1061,7 @@ class Kern:
             B, HW, C = tok.shape
             # few tokens per image (the 4^2 / 8^2 levels): the layer is a per-image weight stream -- one launch, one
             # workgroup per 16 tokens (sdmi_cross_fold) instead of two batched GEMMs on mostly empty 64 x 64 tiles
-            if _CROSS_ONE and HW % 16 == 0 and HW <= _CROSS_ONE and tok.is_contiguous() and \
+            if _CROSS_ONE and HW % 16 == 0 and HW <= _CROSS_ONE and tok.is_contiguous() and fold['slots'] <= 8 and \
                     (C, fold['wq'].shape[1]) in ops.CROSS_FOLD_SHAPES:
                 if 'cf_wq' not in fold:          # once per sampling call: the operands in MFMA-fragment order
                     R = fold['wq'].shape[1]
@@ -1073,7 +1081,7 @@ class Kern:
 
     def st_fused(self, x, n, heads, kvp):
         """The whole SpatialTransformer block `n` in two launches (sdmi.h: sdmi_st_block) -- bf16 inference,
-        C = 256 / 384, 64 | tokens per image <= 256, folded slot cross-attention (<= 7 slots).  None when the
+        C = 256 / 384, 64 | tokens per image <= 256, folded slot cross-attention (<= 7 slots; C = 256: <= 16).  None when the
         block does not qualify (the caller runs the per-layer launches)."""
         fold = kvp.get('fold') if isinstance(kvp, dict) else None
         B, H, W, C = x.shape

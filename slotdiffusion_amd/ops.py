@@ -261,23 +261,23 @@ def bmm_nt(a, b, out, *, alpha=1.0, bias_m=None, bias=None, residual=None):
     return out
 
 
-def expand_heads(kv, heads, scale):
-    """kv [B,S,2C] (K | V) -> (kexp, vexp) [B, heads*8, C]: slot j's key (scaled) / value restricted to
-    head h's channels in row h*8+j, zeros elsewhere (sdmi.h: sdmi_expand_heads)."""
+def expand_heads(kv, heads, scale, gw=8):
+    """kv [B,S,2C] (K | V) -> (kexp, vexp) [B, heads*gw, C]: slot j's key (scaled) / value restricted to
+    head h's channels in row h*gw+j, zeros elsewhere (sdmi.h: sdmi_expand_heads; gw = 8, or 16 from 9 slots)."""
     _need_gpu(kv)
     B, S, C2 = kv.shape
     C = C2 // 2
-    kexp = torch.empty((B, heads * 8, C), dtype=kv.dtype, device=kv.device)
+    kexp = torch.empty((B, heads * gw, C), dtype=kv.dtype, device=kv.device)
     vexp = torch.empty_like(kexp)
     call('sdmi_expand_heads', _stream(), kv=_p(kv), kexp=_p(kexp), vexp=_p(vexp), dtype=_dt(kv), B=B, S=S,
-         C=C, heads=heads, ldkv=kv.stride(1), scale=float(scale))
+         C=C, heads=heads, ldkv=kv.stride(1), scale=float(scale), gw=int(gw))
     return kexp, vexp
 
 
 def cross_scores(tok, wq, colsum, biasq, eps, slots=7):
-    """Attention probabilities of the folded slot cross-attention: softmax over each head's 7 slots of
+    """Attention probabilities of the folded slot cross-attention: softmax over each head's `slots` scores of
     LayerNorm(tok[b]) @ wq[b]^T, the norm folded into the GEMM (sdmi.h: ln_colsum, softmax8).
-    tok [B,HW,C]; wq [B,R,C] (R = heads*8); colsum / biasq [B,R] fp32 -> P [B,HW,R]."""
+    tok [B,HW,C]; wq [B,R,C] (R = heads * 8, or heads * 16 from 9 slots); colsum / biasq [B,R] fp32 -> P [B,HW,R]."""
     _need_gpu(tok, wq)
     B, HW, C = tok.shape
     R = wq.shape[1]

@@ -31,9 +31,13 @@ def _rel(a, b):
 
 
 @pytest.mark.parametrize('rows', [64, 32])
-@pytest.mark.parametrize('name,hw,B', [('input_blocks.4.1', 16, 3), ('output_blocks.8.1', 16, 2),
-                                       ('input_blocks.7.1', 8, 5), ('output_blocks.5.1', 8, 2)])
-def test_fused_block_matches_oracle_and_per_layer_launches(name, hw, B, rows):
+@pytest.mark.parametrize('name,hw,B,n_slots', [('input_blocks.4.1', 16, 3, 7), ('output_blocks.8.1', 16, 2, 7),
+                                               ('input_blocks.7.1', 8, 5, 7), ('output_blocks.5.1', 8, 2, 7),
+                                               # the video configurations' slot counts (savi_diffusion.py:143-144):
+                                               # 16-column score groups, C = 256 blocks
+                                               ('input_blocks.4.1', 16, 3, 11), ('output_blocks.8.1', 16, 2, 15),
+                                               ('input_blocks.5.1', 16, 2, 16), ('input_blocks.4.1', 16, 2, 8)])
+def test_fused_block_matches_oracle_and_per_layer_launches(name, hw, B, n_slots, rows):
     from oracle import slotdiff_oracle as O
     from slotdiffusion_amd import kern
     m = _model()
@@ -45,7 +49,7 @@ def test_fused_block_matches_oracle_and_per_layer_launches(name, hw, B, rows):
     Cc = heads * 32
     g = torch.Generator().manual_seed(11 + hw)
     x = torch.randn(B, hw, hw, Cc, generator=g).bfloat16()
-    slots = torch.randn(B, 7, 192, generator=g).bfloat16()
+    slots = torch.randn(B, n_slots, 192, generator=g).bfloat16()
     W = {k: v.detach().float().cpu() for k, v in m.state_dict().items()}
     ref = O._spatial_transformer(W, n, x.float().permute(0, 3, 1, 2), slots.float(), heads).permute(0, 2, 3, 1)
     with torch.no_grad():
@@ -65,7 +69,7 @@ def test_fused_block_matches_oracle_and_per_layer_launches(name, hw, B, rows):
         again = [K.st_fused(xd, n, heads, kvp) for _ in range(8)]
     torch.cuda.synchronize()
     e_f, e_p = _rel(fused, ref), _rel(per_layer, ref)
-    print(f'{name} C={Cc} S={hw * hw} B={B}: fused vs oracle {e_f:.3e}, per-layer launches vs oracle {e_p:.3e}')
+    print(f'{name} C={Cc} S={hw * hw} B={B} slots={n_slots}: fused vs oracle {e_f:.3e}, per-layer launches vs oracle {e_p:.3e}')
     assert torch.isfinite(fused.float()).all()
     assert e_f < 1.5e-2                                   # bf16 bar of the kernel tests (rel-L2)
     assert e_f < 2.0 * e_p + 2e-3                          # and no worse than the launches it replaces
@@ -106,3 +110,42 @@ def test_fused_block_engages_in_the_sampler_and_keeps_eps():
         kern._ST_FUSED = old
     assert sum(calls) == 10 and len(calls) == 16          # the 16^2 and 8^2 levels; the six 4^2 blocks keep their launches
     assert _rel(e_fused, e_ref) < 1.5e-2
+
+
+@pytest.mark.parametrize('n_slots', [11, 15])
+@pytest.mark.parametrize('name,hw', [('input_blocks.7.1', 8), ('input_blocks.10.1', 4), ('middle_block.1', 4),
+                                     ('output_blocks.8.1', 16)])
+def test_folded_cross_attention_with_sixteen_wide_groups(name, hw, n_slots):
+    """11 / 15 slots (video configurations) on the folded slot cross-attention outside the fused block: the per-image
+    score GEMM with the 16-column softmax epilogue + the output GEMM against the explicit q-projection / attention /
+    output-projection launches and the oracle, at the levels the fused block does not serve with these slot counts."""
+    from oracle import slotdiff_oracle as O
+    from slotdiffusion_amd import kern
+    m = _model()
+    K, u = m.K(), m.unet()
+    n = u.P + name
+    heads = u.heads_of[name]
+    Cc = heads * 32
+    B = 3
+    g = torch.Generator().manual_seed(23 + hw + n_slots)
+    x = torch.randn(B, hw, hw, Cc, generator=g).bfloat16()
+    slots = torch.randn(B, n_slots, 192, generator=g).bfloat16()
+    W = {k: v.detach().float().cpu() for k, v in m.state_dict().items()}
+    ref = O._spatial_transformer(W, n, x.float().permute(0, 3, 1, 2), slots.float(), heads).permute(0, 2, 3, 1)
+    old = kern._ST_FUSED
+    kern._ST_FUSED = False
+    try:
+        with torch.no_grad():
+            xd, ctx = x.cuda(), slots.cuda()
+            t = n + '.transformer_blocks.0'
+            kv = K.linear_multi(ctx, [(t + '.attn2.to_k.weight', t + '.attn2.to_v.weight')])[0]
+            fold = K.cross_prepare(kv, t, heads)
+            assert fold is not None and fold['wq'].shape[1] == heads * 16
+            folded = u._st(K, name, xd, heads, {'kv': kv, 'fold': fold})
+            explicit = u._st(K, name, xd, heads, {'kv': kv, 'fold': None})
+    finally:
+        kern._ST_FUSED = old
+    torch.cuda.synchronize()
+    e_f, e_x = _rel(folded, ref), _rel(explicit, ref)
+    assert torch.isfinite(folded.float()).all()
+    assert e_f < 1.5e-2 and e_f < 2.0 * e_x + 2e-3, (e_f, e_x)
