@@ -703,7 +703,8 @@ int dispatch(const SdmiGemmArgs& p, hipStream_t st, bool plan_only = false) {
   // taps -- 21 KB of operand traffic per K tile instead of 48.  256 x 128 tiles when they fill the chip, else 256 x 64
   // (the 16^2 level at B = 64: 64 row tiles); decided before the K split (these launches never split K)
   int halo_nj = 0, halo_logw = 0;
-  if constexpr (sizeof(T) == 2) {
+  if constexpr (sizeof(T) == 2) {              // (bf16: the fp8 instantiation is not built -- igemm_halo.h)
+    constexpr int CPC = 128 / (int)sizeof(T);          // channels per 128-byte chunk
     static int halo_min = -1;                // SDMI_IGEMM_HALO: fewest tiles that take it (0 = off)
     if (halo_min < 0) {
       const char* e = getenv("SDMI_IGEMM_HALO");
@@ -720,12 +721,12 @@ int dispatch(const SdmiGemmArgs& p, hipStream_t st, bool plan_only = false) {
       halo_c64 = e ? atoi(e) : 0;
     }
     const long long tm256 = (long long)(p.M + 255) / 256;
-    const int nj = p.N <= 64 ? 1 : ((tm256 * ((p.N + 127) / 128) >= halo_min || !halo_nj1) ? 2 : 1);
+    const int nj = (sizeof(T) == 2 && p.N <= 64) ? 1 : ((tm256 * ((p.N + 127) / 128) >= halo_min || !halo_nj1 || sizeof(T) == 1) ? 2 : 1);
     const long long t256 = tm256 * ((p.N + 64 * nj - 1) / (64 * nj));
     // tile width = image width (16 / 32 / 64), or 64-column tiles of four rows on wider images (128^2: the 64-channel layers)
     halo_logw = p.W == 16 ? 4 : (p.W == 32 ? 5 : ((p.W % 64 == 0 && p.H % 4 == 0) ? 6 : 0));
     if (halo_min > 0 && halo_logw && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad_t == 1 && p.pad_l == 1 && plain &&
-        !p.a2 && p.H == p.Ho && p.W == p.Wo && hw_shift >= 8 && p.Cin % 64 == 0 && p.N >= 64 && (p.N > 64 || halo_c64) &&
+        !p.a2 && p.H == p.Ho && p.W == p.Wo && hw_shift >= 8 && p.Cin % CPC == 0 && p.N >= 64 && (p.N > 64 || (halo_c64 && sizeof(T) == 2)) &&
         t256 >= halo_min && p.split_k <= 1 && batch == 1 && fits31 && p.osy == 0 && !p.ln_colsum && !p.geglu && !p.softmax8 &&
         !p.out2 && !p.gn_part && !p.defer_epilogue && p.out_dtype == SDMI_BF16)
       halo_nj = nj;

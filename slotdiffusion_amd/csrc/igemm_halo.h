@@ -30,9 +30,14 @@ namespace {
 // LOGW: log2 of the tile width = the image width (16 / 32 / 64 columns), or 6 on images of a multiple of 64 columns.  NJ: 32-column blocks per wave -- 2: 256 x 128 tiles (64 x 64
 // wave blocks, two segments of 8 MFMAs per K tile); 1: 256 x 64 tiles (64 x 32 wave blocks, one segment of 8 MFMAs per
 // K tile) for the layers whose 256 x 128 grid would leave half the chip idle (the 16^2 level at B = 64).
-template <int LOGW, int NJ>
+// T: bf16_t.  The fp8_t form (e4m3fn operands: a 128-byte patch row holds 128 channels, two 16-byte k-steps feed one
+// v_mfma_scale_f32_32x32x64_f8f6f4 as in igemm_body.h's fp8 path) is written out below and NOT instantiated: with that
+// builtin in this kernel hipcc (ROCm 7.2) allocates 256 VGPRs and spills the fragments across the segment barrier
+// (1.2 - 1.4 KB of scratch per lane, reloads + vmcnt(0) in the K loop); the same body with the bf16 MFMA in its place
+// takes 199 VGPRs and no scratch.  Left for an inline-asm MFMA or a later compiler.
+template <int LOGW, int NJ, typename T = bf16_t>
 __global__ __launch_bounds__(512, 2) void igemm_halo_kernel(SdmiGemmArgs p, int tiles_m, int tiles_n, int hw_shift) {
-  typedef bf16_t T;
+  constexpr int ELT = sizeof(T), CPC = 128 / ELT;      // bytes per element, channels per 128-byte chunk
   constexpr int W = 1 << LOGW, TH = 256 / W, PW = W + 2, PH = TH + 2, Q = PH * PW;
   constexpr int NPIECE = (Q + 7) / 8;                  // 1 KB pieces (8 patch pixels) of a chunk's patch
   constexpr int BN = 64 * NJ;
@@ -53,7 +58,7 @@ __global__ __launch_bounds__(512, 2) void igemm_halo_kernel(SdmiGemmArgs p, int 
     n0 = (id - tm * tiles_n) * BN;
   };
   const int my_tiles = ((int)blockIdx.x < nwg) ? (nwg - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
-  const int nchunk = p.Cin >> 6;
+  const int nchunk = p.Cin / CPC;
   if (my_tiles == 0) return;
 
   const int tid = threadIdx.x, l = tid & 63;
@@ -71,7 +76,7 @@ __global__ __launch_bounds__(512, 2) void igemm_halo_kernel(SdmiGemmArgs p, int 
     mask = (ty == 0 ? 1u : 0u) | ((ty + 1) * TH == p.H ? 2u : 0u) | (tx == 0 ? 4u : 0u) | ((tx + 1) * W == p.W ? 8u : 0u);
     return (b * p.H + ty * TH) * p.W + tx * W;
   };
-  const T* Ag = (const T*)p.a - (long long)(p.W + 1) * p.lda;
+  const char* Ag = (const char*)p.a - (long long)(p.W + 1) * p.lda * ELT;
   const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)Ag, 0, (int)OOB, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)OOB, 0x00020000);
   // patch pieces of this wave: piece 8 t + w (t < ATAPS); lane l: patch pixel q = 8 piece + (l >> 3), chunk position
@@ -84,7 +89,7 @@ __global__ __launch_bounds__(512, 2) void igemm_halo_kernel(SdmiGemmArgs p, int 
     const int py = q / PW, px = q - py * PW;
     const int kc = (l & 7) ^ ((q >> 1) & 7);
     const unsigned f = (py == 0 ? 1u : 0u) | (py == PH - 1 ? 2u : 0u) | (px == 0 ? 4u : 0u) | (px == PW - 1 ? 8u : 0u);
-    a_vo[t] = q >= Q ? OOB : (((unsigned)(py * p.W + px) * (unsigned)p.lda * 2u + (unsigned)kc * 16u) | f);
+    a_vo[t] = q >= Q ? OOB : (((unsigned)(py * p.W + px) * (unsigned)p.lda * (unsigned)ELT + (unsigned)kc * 16u) | f);
     a_cur[t] = OOB;
   }
   unsigned b_vo[NJ];
@@ -99,7 +104,7 @@ __global__ __launch_bounds__(512, 2) void igemm_halo_kernel(SdmiGemmArgs p, int 
     const int pix0 = tile_pix0(live ? m0 : 0, mask);
 #pragma unroll
     for (int t = 0; t < ATAPS; ++t) a_cur[t] = (!live || (a_vo[t] & mask)) ? OOB : (a_vo[t] & ~15u);
-    a_so = (unsigned)pix0 * (unsigned)p.lda * 2u;
+    a_so = (unsigned)pix0 * (unsigned)p.lda * (unsigned)ELT;
   };
   auto issue_a = [&](int t) __attribute__((always_inline)) {        // piece 8 t + w of chunk (a_ti, a_c) -> buffer a_buf
     if (8 * t + w < NPIECE)
@@ -123,12 +128,12 @@ __global__ __launch_bounds__(512, 2) void igemm_halo_kernel(SdmiGemmArgs p, int 
       const int row = (w + 8 * j) * 8 + (l >> 3);
       const int kc = (l & 7) ^ ((4 * (w & 1) + (l >> 4)) & 7);
       const int n = min(n0 + row, p.N - 1);
-      b_vo[j] = ((unsigned)n * (unsigned)p.ldw + kc * 8) * 2u;
+      b_vo[j] = (unsigned)n * (unsigned)p.ldw * (unsigned)ELT + (unsigned)kc * 16u;
     }
   };
   auto issue_b = [&](int j) __attribute__((always_inline)) {        // piece w + 8 j of step (b_ti, b_c, b_t) -> stage b_stage
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_void*)(Bst + b_stage * BSTAGE + (w + 8 * j) * 1024), 16, (int)b_vo[j],
-                                             (int)((unsigned)(b_t * p.Cin + b_c * 64) * 2u), 0, 0);
+                                             (int)((unsigned)(b_t * p.Cin + b_c * CPC) * (unsigned)ELT), 0, 0);
   };
   auto b_advance = [&]() __attribute__((always_inline)) {
     if (++b_stage == NBST) b_stage = 0;
@@ -155,8 +160,21 @@ __global__ __launch_bounds__(512, 2) void igemm_halo_kernel(SdmiGemmArgs p, int 
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) swz[ks] = ((2 * ks + hsel) ^ ((R >> 1) & 7)) * 16;
   const int b_off = (wn * 32 * NJ + R) * 128;
-  u32x4 fa[KSEG][2], fb[KSEG][NJ];                     // [k-step of the segment][row / column block]
+  // fragments: bf16 -- one 16-byte k-step per register quad; fp8 -- the two k-steps of a 32x32x64 MFMA side by side in
+  // one 8-register tuple, assembled when they are READ (assembling them in front of the MFMAs made the register
+  // allocator spill the fragments across the barrier between the two segments)
+  constexpr int FV = ELT == 2 ? 1 : 2, NF = KSEG / FV;        // k-steps per fragment tuple, tuples per segment
+  typedef unsigned int frag_t __attribute__((ext_vector_type(4 * FV)));
+  frag_t fa[NF][2], fb[NF][NJ];                        // [tuple of the segment][row / column block]
   f32x16 acc[2][NJ];
+  auto ld_frag = [&](const char* q0, const char* q1) __attribute__((always_inline)) {
+    if constexpr (FV == 1) {
+      return *reinterpret_cast<const frag_t*>(q0);
+    } else {
+      const u32x4 lo = *reinterpret_cast<const u32x4*>(q0), hi = *reinterpret_cast<const u32x4*>(q1);
+      return frag_t{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    }
+  };
   auto read_seg = [&](const char* Ab, const char* Bb, int dq, int h) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -164,23 +182,37 @@ __global__ __launch_bounds__(512, 2) void igemm_halo_kernel(SdmiGemmArgs p, int 
       const int key = (q >> 1) & 7;
       const char* row = Ab + q * 128;
 #pragma unroll
-      for (int s = 0; s < KSEG; ++s) fa[s][i] = *reinterpret_cast<const u32x4*>(row + (((2 * (KSEG * h + s) + hsel) ^ key) << 4));
+      for (int f = 0; f < NF; ++f) {
+        const int s0 = KSEG * h + f * FV;
+        fa[f][i] = ld_frag(row + (((2 * s0 + hsel) ^ key) << 4), row + (((2 * (s0 + FV - 1) + hsel) ^ key) << 4));
+      }
     }
 #pragma unroll
-    for (int s = 0; s < KSEG; ++s)
+    for (int f = 0; f < NF; ++f)
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) fb[s][j] = *reinterpret_cast<const u32x4*>(Bb + b_off + j * 4096 + swz[KSEG * h + s]);
+      for (int j = 0; j < NJ; ++j) {
+        const int s0 = KSEG * h + f * FV;
+        fb[f][j] = ld_frag(Bb + b_off + j * 4096 + swz[s0], Bb + b_off + j * 4096 + swz[s0 + FV - 1]);
+      }
   };
   auto mfma_seg = [&]() __attribute__((always_inline)) {
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int s = 0; s < KSEG; ++s)
+    for (int f = 0; f < NF; ++f)
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < NJ; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fb[s][j]),
-                                                              __builtin_bit_cast(bf16x8, fa[s][i]), acc[i][j], 0, 0, 0);
+        for (int j = 0; j < NJ; ++j) {
+          if constexpr (ELT == 2) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fb[f][j]),
+                                                                __builtin_bit_cast(bf16x8, fa[f][i]), acc[i][j], 0, 0, 0);
+          } else {
+            typedef int i32x8 __attribute__((ext_vector_type(8)));
+            acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(__builtin_bit_cast(i32x8, fb[f][j]),
+                                                                        __builtin_bit_cast(i32x8, fa[f][i]), acc[i][j],
+                                                                        0, 0, 0, 127, 0, 127);
+          }
+        }
     __builtin_amdgcn_s_setprio(0);
   };
 #define HALO_BARRIER()                       \
@@ -223,7 +255,14 @@ __global__ __launch_bounds__(512, 2) void igemm_halo_kernel(SdmiGemmArgs p, int 
       for (int t = 0; t < 9; ++t) {
         const char* Bb = Bst + c_stage * BSTAGE;
         if (++c_stage == NBST) c_stage = 0;
-        const int dq = (t / 3) * PW + (t % 3);
+        // dq is a compile-time constant per unrolled tap: hipcc hoists the fragment addresses of all nine taps out of the
+        // chunk loop (256 VGPRs; 17 - 27 spilled registers in the W = 16 / 64 instantiations, none in the K loop).  Hiding
+        // the shift from the optimiser (-DSDMI_HALO_NO_HOIST: 199 VGPRs, no scratch, five VALU per tap and segment in the
+        // LOAD segments) measured SLOWER: 71.1 vs 67.0 us (256 -> 256 @32^2), 76.2 vs 67.5 (256 -> 256 @16^2, B = 256).
+        int dq = (t / 3) * PW + (t % 3);
+#ifdef SDMI_HALO_NO_HOIST
+        asm volatile("" : "+s"(dq));
+#endif
         const bool has_a = t < ATAPS && 8 * t + w < NPIECE;        // wave-uniform
 #pragma unroll
         for (int h = 0; h < NSEG; ++h) {
@@ -278,11 +317,11 @@ __global__ __launch_bounds__(512, 2) void igemm_halo_kernel(SdmiGemmArgs p, int 
 #undef HALO_BARRIER
 }
 
-template <int LOGW, int NJ>
+template <int LOGW, int NJ, typename T = bf16_t>
 int launch_halo(const SdmiGemmArgs& p, int hw_shift, hipStream_t st, int n_cu) {
   constexpr int W = 1 << LOGW, Q = (256 / W + 2) * (W + 2);
   constexpr int smem = 2 * ((Q + 7) / 8) * 1024 + 3 * 64 * NJ * 128;
-  auto kern = igemm_halo_kernel<LOGW, NJ>;
+  auto kern = igemm_halo_kernel<LOGW, NJ, T>;
   SDMI_OPTIN_LDS(kern, smem, "igemm (3x3 halo ping-pong)");
   SdmiGemmArgs q = p;
   q.split_k = 1;
