@@ -127,6 +127,11 @@ typedef struct {
    * nsplit = Ho*Wo/32: the GroupNorm behind the convolution (unet.py:243-250) needs no statistics pass. */
   float* gn_part;
   int gn_groups;
+  /* alpha_dev != NULL (fp8 operands only): the effective alpha is alpha * (*alpha_dev), read on the device when the
+   * kernel starts -- the 1 / scale of an operand that sdmi_fp8_quant_group quantised with a scale it derived from the
+   * tensor's own amax in the same stream, so that a captured train step re-derives it at every replay (BASELINE
+   * configs[4] "fp8 MFMA UNet": unet.py:271-285 with e4m3fn operands). */
+  const float* alpha_dev;
 } SdmiGemmArgs;
 int sdmi_igemm(const SdmiGemmArgs* a, void* stream);
 /* Host-side query, no launch (stream ignored): the number of K slices sdmi_igemm would use for these
@@ -421,6 +426,19 @@ typedef struct {
   const void* src; void* dst; int src_dtype; long long rows; int cols, lds, ldd; float scale;
 } SdmiQuantFp8Args;
 int sdmi_quant_fp8(const SdmiQuantFp8Args* a, void* stream);
+/* Per-tensor e4m3fn quantisation of a whole TABLE of tensors with scales derived on the device (no read-back):
+ * for every descriptor d, amax_d = max |src_d|, scale_d = 448 / max(amax_d, 1e-12), dst_d = e4m3fn(src_d * scale_d),
+ * inv_scale[d] = max(amax_d, 1e-12) / 448 (= SdmiGemmArgs.alpha_dev of the GEMMs that read dst_d).  One memset +
+ * two launches for the table: the weights of the fp8 configuration are re-quantised after every optimiser step inside
+ * the captured train step.  `descs` is a device array; workgroup b serves the descriptor with
+ * block_begin <= b < next block_begin, a tensor takes ceil(n / 4096) workgroups; n is a multiple of 16. */
+typedef struct { const void* src; void* dst; long long n; int block_begin; int pad_; } SdmiFp8Desc;
+typedef struct {
+  const void* descs; int n_desc; int src_dtype; int total_blocks;
+  unsigned* amax_bits;   /* [n_desc] workspace (zeroed by the call): max |x| as fp32 bits */
+  float* inv_scale;      /* [n_desc] out */
+} SdmiFp8GroupArgs;
+int sdmi_fp8_quant_group(const SdmiFp8GroupArgs* a, void* stream);
 /* ------------------------------------------------------------------------------------------
  * Fused SpatialTransformer block (bf16 inference): GroupNorm -> proj_in -> [LayerNorm -> self-attention ->
  * + ; LayerNorm -> slot cross-attention -> + ; LayerNorm -> GEGLU feed-forward -> +] -> proj_out -> + x in TWO

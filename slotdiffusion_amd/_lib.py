@@ -14,7 +14,7 @@ LIBPATH = os.environ.get('SDMI_LIBPATH') or os.path.join(_HERE, 'libsdmi.so')   
 
 _CT = {
     'int': ctypes.c_int, 'float': ctypes.c_float, 'long long': ctypes.c_longlong,
-    'double': ctypes.c_double,
+    'double': ctypes.c_double, 'unsigned': ctypes.c_uint,
 }
 
 
@@ -32,7 +32,7 @@ def parse_header(path=HEADER):
             decl = ' '.join(decl.split())
             if not decl:
                 continue
-            m = re.match(r'^(const\s+)?(void|float|double|int|long long)\s*(.*)$', decl)
+            m = re.match(r'^(const\s+)?(void|float|double|int|long long|unsigned)\s*(.*)$', decl)
             assert m, f'cannot parse field declaration {decl!r} in {name}'
             base, rest = m.group(2), m.group(3)
             for item in rest.split(','):

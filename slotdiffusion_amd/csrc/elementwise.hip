@@ -104,6 +104,66 @@ __global__ void quant_fp8_kernel(SdmiQuantFp8Args p) {
   }
 }
 
+// grouped per-tensor fp8 quantisation with device-side scales (sdmi.h: sdmi_fp8_quant_group): a workgroup serves
+// 4096 consecutive elements of one tensor of the table; pass 1 folds max |x| into amax_bits[d] (non-negative floats
+// order like their bit patterns: atomicMax on the bits), pass 2 derives the scale from it
+__device__ __forceinline__ int fp8_desc_of(const SdmiFp8Desc* descs, int n_desc, int b) {
+  int lo = 0, hi = n_desc - 1;            // last descriptor with block_begin <= b
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (descs[mid].block_begin <= b) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+template <typename S>
+__device__ __forceinline__ void fp8_load16(const S* src, float* f) {
+#pragma unroll
+  for (int q = 0; q < 16 / Elem<S>::VEC; ++q)
+    unpack16<S>(*reinterpret_cast<const uint4*>(src + q * Elem<S>::VEC), f + q * Elem<S>::VEC);
+}
+template <typename S>
+__global__ __launch_bounds__(256) void fp8_group_amax_kernel(SdmiFp8GroupArgs p) {
+  const SdmiFp8Desc* descs = (const SdmiFp8Desc*)p.descs;
+  const int di = fp8_desc_of(descs, p.n_desc, (int)blockIdx.x);
+  const SdmiFp8Desc d = descs[di];
+  const long long i0 = ((long long)((int)blockIdx.x - d.block_begin) * 256 + threadIdx.x) * 16;
+  float m = 0.f;
+  if (i0 < d.n) {
+    float f[16];
+    fp8_load16<S>((const S*)d.src + i0, f);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) m = fmaxf(m, fabsf(f[j]));
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  __shared__ float wm[4];
+  if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+    atomicMax(p.amax_bits + di, __float_as_uint(m));
+  }
+}
+template <typename S>
+__global__ __launch_bounds__(256) void fp8_group_quant_kernel(SdmiFp8GroupArgs p) {
+  const SdmiFp8Desc* descs = (const SdmiFp8Desc*)p.descs;
+  const int di = fp8_desc_of(descs, p.n_desc, (int)blockIdx.x);
+  const SdmiFp8Desc d = descs[di];
+  const float amax = fmaxf(__uint_as_float(p.amax_bits[di]), 1e-12f);
+  const float scale = 448.f / amax;
+  if ((int)blockIdx.x == d.block_begin && threadIdx.x == 0) p.inv_scale[di] = amax / 448.f;
+  const long long i0 = ((long long)((int)blockIdx.x - d.block_begin) * 256 + threadIdx.x) * 16;
+  if (i0 >= d.n) return;
+  float f[16];
+  fp8_load16<S>((const S*)d.src + i0, f);
+  uint4 o;
+  o.x = f32x4_to_fp8x4(f[0] * scale, f[1] * scale, f[2] * scale, f[3] * scale);
+  o.y = f32x4_to_fp8x4(f[4] * scale, f[5] * scale, f[6] * scale, f[7] * scale);
+  o.z = f32x4_to_fp8x4(f[8] * scale, f[9] * scale, f[10] * scale, f[11] * scale);
+  o.w = f32x4_to_fp8x4(f[12] * scale, f[13] * scale, f[14] * scale, f[15] * scale);
+  *reinterpret_cast<uint4*>((fp8_t*)d.dst + i0) = o;
+}
+
 template <typename T>
 __global__ void expand_heads_kernel(SdmiExpandHeadsArgs p) {
   const int gw = p.gw == 16 ? 16 : 8;
@@ -451,6 +511,22 @@ extern "C" int sdmi_quant_fp8(const SdmiQuantFp8Args* a, void* stream) {
   if (a->src_dtype == SDMI_BF16) hipLaunchKernelGGL(quant_fp8_kernel<bf16_t>, dim3(g), dim3(EW_THREADS), 0, ST, *a);
   else hipLaunchKernelGGL(quant_fp8_kernel<float>, dim3(g), dim3(EW_THREADS), 0, ST, *a);
   return sdmi_check_launch("quant_fp8");
+}
+extern "C" int sdmi_fp8_quant_group(const SdmiFp8GroupArgs* a, void* stream) {
+  SDMI_REQUIRE(a && a->descs && a->amax_bits && a->inv_scale && a->n_desc >= 1 && a->total_blocks >= 1, "bad args");
+  SDMI_REQUIRE(a->src_dtype == SDMI_F32 || a->src_dtype == SDMI_BF16, "bad src_dtype");
+  if (hipMemsetAsync(a->amax_bits, 0, sizeof(unsigned) * (size_t)a->n_desc, ST) != hipSuccess) {
+    sdmi_set_error("fp8_quant_group: hipMemsetAsync failed");
+    return SDMI_ELAUNCH;
+  }
+  if (a->src_dtype == SDMI_BF16) {
+    hipLaunchKernelGGL(fp8_group_amax_kernel<bf16_t>, dim3(a->total_blocks), dim3(256), 0, ST, *a);
+    hipLaunchKernelGGL(fp8_group_quant_kernel<bf16_t>, dim3(a->total_blocks), dim3(256), 0, ST, *a);
+  } else {
+    hipLaunchKernelGGL(fp8_group_amax_kernel<float>, dim3(a->total_blocks), dim3(256), 0, ST, *a);
+    hipLaunchKernelGGL(fp8_group_quant_kernel<float>, dim3(a->total_blocks), dim3(256), 0, ST, *a);
+  }
+  return sdmi_check_launch("fp8_quant_group");
 }
 extern "C" int sdmi_memset0(const SdmiMemsetArgs* a, void* stream) {
   SDMI_REQUIRE(a && a->ptr && a->bytes >= 0, "bad args");

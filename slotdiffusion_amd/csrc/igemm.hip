@@ -495,12 +495,18 @@ __global__ __launch_bounds__(256) void conv3x3_c64_kernel(SdmiGemmArgs p, int hw
 template <typename T, int BM, int BN, int BKB, int MODE, int EPI = 0, bool XS = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void igemm_kernel(
     SdmiGemmArgs p, int tiles_m, int tiles_n, int kt_per_split, int hw_shift) {
+  if constexpr (sizeof(T) == 1) {          // fp8 operands: the device-side half of the scale (sdmi.h: alpha_dev)
+    if (p.alpha_dev) p.alpha *= *p.alpha_dev;
+  }
   igemm_body<T, BM, BN, BKB, MODE, EPI, XS>(p, tiles_m, tiles_n, kt_per_split, hw_shift, (int)blockIdx.x,
                                             (int)gridDim.x, (int)blockIdx.y);
 }
 template <typename T, int BM, int BN, int BKB, int MODE>
 __global__ __launch_bounds__(512) void igemm_kernel_tall(SdmiGemmArgs p, int tiles_m, int tiles_n,
                                                          int kt_per_split, int hw_shift) {
+  if constexpr (sizeof(T) == 1) {
+    if (p.alpha_dev) p.alpha *= *p.alpha_dev;
+  }
   igemm_body<T, BM, BN, BKB, MODE>(p, tiles_m, tiles_n, kt_per_split, hw_shift, (int)blockIdx.x, (int)gridDim.x,
                                    (int)blockIdx.y);
 }
@@ -509,6 +515,7 @@ __global__ __launch_bounds__(512) void igemm_kernel_tall(SdmiGemmArgs p, int til
 __global__ __launch_bounds__(256) void splitk_epilogue_kernel(SdmiGemmArgs p, int hw_shift) {
   const long long total = (long long)p.M * p.N;
   const int HoWo = p.Ho * p.Wo;
+  if (p.alpha_dev) p.alpha *= *p.alpha_dev;
   for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total;
        idx += (long long)gridDim.x * 256) {
     const int m = (int)(idx / p.N);
@@ -1035,6 +1042,7 @@ extern "C" int sdmi_igemm(const SdmiGemmArgs* a, void* stream) {
   SDMI_REQUIRE(a->dtype == SDMI_F32 || a->dtype == SDMI_BF16 || a->dtype == SDMI_FP8, "bad dtype");
   SDMI_REQUIRE(a->out_dtype == SDMI_F32 || a->out_dtype == SDMI_BF16, "bad out_dtype");
   const int vec = a->dtype == SDMI_FP8 ? 16 : (a->dtype == SDMI_BF16 ? 8 : 4);
+  SDMI_REQUIRE(!a->alpha_dev || (a->dtype == SDMI_FP8 && !a->defer_epilogue), "alpha_dev goes with fp8 operands (no deferred epilogue)");
   SDMI_REQUIRE(a->dtype != SDMI_FP8 || (!(a->batch > 1) && !a->ups && a->zins <= 1),
                "fp8 operands: plain convolution / linear only (no batch, upsample fold)");
   SDMI_REQUIRE(a->M > 0 && a->N > 0 && a->K > 0, "empty problem");

@@ -256,6 +256,10 @@ class WeightBank:
         self._side_dst = {}
         # dgrad operands: key -> [buffer, epoch, (stable source view | None, geometry)]
         self._wd, self._wd_epoch, self._wd_stale, self._wd_table = {}, 0, False, None
+        # e4m3fn operands with device-side scales (training in the fp8 configuration): name -> [bytes, inv view, epoch,
+        # source view]; one slot of _w8_amax / _w8_inv per operand, in registration order
+        self._w8, self._w8_epoch, self._w8_stale, self._w8_table = {}, 0, False, None
+        self._w8_amax = self._w8_inv = None
 
     def anchor_for(self, names):
         n = names if isinstance(names, str) else names[0]
@@ -509,6 +513,7 @@ class WeightBank:
                 keep[key] = val
         self.cache = keep
         self._wd_stale = True
+        self._w8_stale = True
 
     def _frozen_names(self):
         fz = getattr(self, '_fz', None)
@@ -610,6 +615,79 @@ class WeightBank:
             scale = 448.0 / max(amax, 1e-12)
             self.cache[key] = (ops.quant_fp8(flat.float().contiguous(), scale), 1.0 / scale)
         return self.cache[key]
+
+    W8_SLOTS = 1024
+
+    def w8_dev(self, name):
+        """e4m3fn operand of a TRAINABLE conv / linear weight with a scale the device derives from the tensor's own
+        amax: (bytes [N][K], inv = one-element fp32 view holding amax / 448 -- SdmiGemmArgs.alpha_dev).  The operands
+        live in persistent buffers; after an optimiser step (invalidate()) the first request re-quantises ALL of
+        them from the fp32 master arena with one sdmi_fp8_quant_group call (memset + amax launch + quantise launch,
+        descriptor table on the device, no read-back) -- part of the captured train step, so every replay
+        quantises the weights it multiplies with."""
+        if self._w8_stale:
+            self._requant_all()
+        ent = self._w8.get(name)
+        if ent is not None and ent[2] == self._w8_epoch:
+            return ent[0], ent[1]
+        flat = self._flat(name, torch.float32)
+        if flat is None or flat.numel() % 16:
+            raise _lib.SdmiError(f'{name}: fp8 operands need 16-byte input-channel rows')
+        if self._w8_amax is None:
+            self._w8_amax = torch.zeros(self.W8_SLOTS, dtype=torch.int32, device=flat.device)
+            self._w8_inv = torch.zeros(self.W8_SLOTS, dtype=torch.float32, device=flat.device)
+        if ent is None:
+            idx = len(self._w8)
+            if idx >= self.W8_SLOTS:
+                raise _lib.SdmiError('fp8 operand table full')
+            ent = [torch.empty(flat.shape, dtype=torch.uint8, device=flat.device), self._w8_inv[idx:idx + 1],
+                   self._w8_epoch, flat, idx]
+            self._w8[name] = ent
+            self._w8_table = None             # new member: rebuild the descriptor table at the next re-quantisation
+        # (first use: a one-entry table -- eager only, it copies the table to the device)
+        Desc = _lib.CSTRUCT['SdmiFp8Desc']
+        arr = (Desc * 1)()
+        blocks = self._fill_desc8(arr[0], ent, 0)
+        dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(flat.device)
+        idx = ent[4]
+        call('sdmi_fp8_quant_group', _st(), descs=_p(dev), n_desc=1, src_dtype=_lib.F32, total_blocks=blocks,
+             amax_bits=_p(self._w8_amax[idx:]), inv_scale=_p(self._w8_inv[idx:]))
+        ent[2] = self._w8_epoch
+        return ent[0], ent[1]
+
+    @staticmethod
+    def _fill_desc8(d, e, blk):
+        d.src, d.dst, d.n, d.block_begin = e[3].data_ptr(), e[0].data_ptr(), e[3].numel(), blk
+        return blk + (e[3].numel() + 4095) // 4096
+
+    def _requant_all(self):
+        self._w8_stale = False
+        if not self._w8:
+            return
+        self._w8_epoch += 1
+        items = sorted(self._w8.values(), key=lambda e: e[4])         # slot order = descriptor order
+        if self._w8_table is None:
+            Desc = _lib.CSTRUCT['SdmiFp8Desc']
+            arr = (Desc * len(items))()
+            blk = 0
+            for d, e in zip(arr, items):
+                blk = self._fill_desc8(d, e, blk)
+            dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(items[0][0].device)
+            self._w8_table = (dev, len(items), blk)
+        tab = self._w8_table
+        call('sdmi_fp8_quant_group', _st(), descs=_p(tab[0]), n_desc=tab[1], src_dtype=_lib.F32, total_blocks=tab[2],
+             amax_bits=_p(self._w8_amax), inv_scale=_p(self._w8_inv))
+        for e in items:
+            e[2] = self._w8_epoch
+
+    def fp8_train_ok(self, x, wnames, geom):
+        """Training forward in the fp8 configuration (models.set_compute_dtype('fp8')): the denoiser's 3x3
+        convolutions multiply e4m3fn operands -- the layers Kern.fp8_ok names at inference; the backward pass keeps
+        bf16 operands (the saved activation and the bf16 shadow weights)."""
+        kh, kw, stride, pad, ups = geom
+        return (getattr(self.model, 'fp8_unet', False) and isinstance(wnames, str) and x.dim() == 4
+                and x.dtype == torch.bfloat16 and kh * kw > 1 and not ups and x.shape[-1] % 16 == 0
+                and x.shape[-1] >= 64 and wnames.startswith(self.model.fp8_prefix))
 
     def conv_skip_weights(self, n, dtype):
         """[W_out3 (3x3, tap-major K) | W_skip (1x1)] along K and the summed bias of ResBlock `n`: its second
@@ -1234,7 +1312,15 @@ class GemmFn(torch.autograd.Function):
         kh, kw, stride, pad, ups = geom
         w = wb.w(wnames, x.dtype)
         b = wb.b(bnames)
-        if x.dim() == 4 and (kh, kw) != (0, 0):
+        if wb.fp8_train_ok(x, wnames, geom):
+            # e4m3fn operands in the forward GEMM: activations at the fixed scale of the inference path, weights at
+            # 448 / amax with amax taken on the device this step (WeightBank.w8_dev); fp32 accumulation, both scales
+            # undone in the epilogue.  x stays bf16 for the backward pass.
+            w8, inv = wb.w8_dev(wnames)
+            out = ops.conv2d(ops.quant_fp8(x, FP8_ACT_SCALE), w8, b, kh=kh, kw=kw, stride=stride, pad=pad,
+                             rowvec=rowvec, residual=residual, out_dtype=out_dtype or x.dtype, ldc=ldc,
+                             alpha=1.0 / FP8_ACT_SCALE, alpha_dev=inv)
+        elif x.dim() == 4 and (kh, kw) != (0, 0):
             out = ops.conv2d(x, w, b, kh=kh, kw=kw, stride=stride, pad=pad, ups=ups, rowvec=rowvec,
                              residual=residual, out_dtype=out_dtype, ldc=ldc)
         else:

@@ -261,8 +261,10 @@ class SlotModelBase(FlatModule):
     def dtype(self):
         return self.init_latents.dtype
 
-    # 'fp8': bf16 storage with e4m3fn operands on the denoiser's 3x3 convolutions at inference
-    # (BASELINE config 5, "fp8 MFMA UNet"; kern.Kern.conv); training keeps bf16 operands
+    # 'fp8': bf16 storage with e4m3fn operands on the denoiser's 3x3 convolutions (BASELINE config 5, "fp8 MFMA
+    # UNet"): at inference kern.Kern.conv (weight scales taken once, on the host), in training the FORWARD GEMM of
+    # those layers (kern.GemmFn.forward: weights re-quantised on the device every step, WeightBank.w8_dev); the
+    # backward pass keeps bf16 operands
     fp8_unet = False
     fp8_prefix = 'dm_decoder.model.'
 

@@ -141,10 +141,11 @@ def quant_fp8(x, scale, out=None):
 
 def conv2d(x, w, bias=None, *, kh=3, kw=3, stride=1, pad=(1, 1, 1, 1), ups=False, cout=None,
            rowvec=None, residual=None, act=None, out=None, out_dtype=None, ldc=None,
-           split_k=0, alpha=1.0, x2=None, x3=None, sub=None, zero_pad=True):
+           split_k=0, alpha=1.0, x2=None, x3=None, sub=None, zero_pad=True, alpha_dev=None):
     """x [B,H,W,Cin] NHWC; w [Cout][kh][kw][Cin] (flat or 4-D channels_last view).
     pad = (top, bottom, left, right).  Returns [B,Ho,Wo,ldc or Cout].
-    uint8 x / w = e4m3fn operands (quant_fp8): out_dtype is required, alpha undoes the scales.
+    uint8 x / w = e4m3fn operands (quant_fp8): out_dtype is required, alpha undoes the scales; alpha_dev = a
+    one-element fp32 tensor multiplied into alpha on the device (a scale sdmi_fp8_quant_group derived there).
     sub = (sy, sx, oy, ox) with `out` [B, sy*Ho, sx*Wo, ldc]: output pixel (y, x) is stored at (sy*y + oy, sx*x + ox)
     (sdmi.h: osy / osx / ooy / oox; bias-only epilogue, no split-K)."""
     _need_gpu(x, w)
@@ -185,12 +186,12 @@ def conv2d(x, w, bias=None, *, kh=3, kw=3, stride=1, pad=(1, 1, 1, 1), ups=False
         B=B, H=H, W=W, Cin=Cin, Ho=Ho, Wo=Wo, KH=kh, KW=kw, stride=stride, pad_t=pad[0],
         pad_l=pad[2], ups=int(ups), act=ACT[act], alpha=float(alpha), bias_m=0,
         ldrv=(rowvec.stride(0) if rowvec is not None else 0),
-        split_k=(split_k if ws is not None or split_k == 1 else 1), batch=1)
+        split_k=(split_k if ws is not None or split_k == 1 else 1), batch=1, alpha_dev=_p(alpha_dev))
     if sub is not None:
         assert split_k == 1 and rowvec is None and residual is None and act is None and x2 is None
         assert tuple(out.shape[:3]) == (B, sub[0] * Ho, sub[1] * Wo) and out.is_contiguous()
         kwargs.update(oH=sub[0] * Ho, oW=sub[1] * Wo, osy=sub[0], osx=sub[1], ooy=sub[2], oox=sub[3])
-    if _DEFER[0] and ws is not None and split_k == 0 and act is None and ldc == N and N > 64 and N % 8 == 0 and \
+    if _DEFER[0] and alpha_dev is None and ws is not None and split_k == 0 and act is None and ldc == N and N > 64 and N % 8 == 0 and \
             odt == torch.bfloat16 and (residual is None or (residual.is_contiguous() and residual.shape[-1] == N)):
         splits = _lib.query('sdmi_igemm_split_plan', **kwargs)
         if splits > 1:

@@ -824,3 +824,45 @@ def test_cross_fold_one_launch(B, HW, C, slots, padded):
     print(f'cross_fold C={C} HW={HW}: one launch {e1:.2e}, two launches {e2:.2e} (rel-L2 vs torch fp32)')
     assert e1 < 6e-3 and e1 < 2 * e2 + 1e-3
     assert torch.equal(packed, out)                       # fragment-order operands: the same arithmetic
+
+
+def test_fp8_quant_group_device_scales():
+    """sdmi_fp8_quant_group: a table of tensors quantised to e4m3fn with scale = 448 / amax taken on the device (no
+    read-back), against sdmi_quant_fp8 with the same scale computed from torch's amax; the reciprocal scale lands
+    in the tensor's slot (SdmiGemmArgs.alpha_dev).  Sizes: several workgroups, one partial workgroup, 16 elements;
+    an all-zero tensor takes the 1e-12 floor."""
+    from slotdiffusion_amd import _lib, ops
+    g = torch.Generator(device=DEV).manual_seed(5)
+    srcs = [torch.randn(9 * 4096 + 1600, device=DEV, generator=g) * 0.03,
+            torch.randn(48, device=DEV, generator=g) * 7.0,
+            torch.zeros(4096, device=DEV),
+            torch.randn(16, device=DEV, generator=g) * 1e-3,
+            torch.randn(3 * 4096, device=DEV, generator=g) * 300.0]
+    Desc = _lib.CSTRUCT['SdmiFp8Desc']
+    for sdt in (torch.float32, torch.bfloat16):
+        xs = [s.to(sdt) for s in srcs]
+        dsts = [torch.full((x.numel(),), 0x55, dtype=torch.uint8, device=DEV) for x in xs]
+        arr = (Desc * len(xs))()
+        blk = 0
+        for d, x, o in zip(arr, xs, dsts):
+            d.src, d.dst, d.n, d.block_begin = x.data_ptr(), o.data_ptr(), x.numel(), blk
+            blk += (x.numel() + 4095) // 4096
+        tab = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(DEV)
+        amax = torch.full((len(xs),), 123, dtype=torch.int32, device=DEV)       # garbage: the call zeroes it
+        inv = torch.zeros(len(xs), device=DEV)
+        for _ in range(2):       # a second call on the same workspace gives the same result
+            _lib.call('sdmi_fp8_quant_group', None, descs=tab.data_ptr(), n_desc=len(xs), src_dtype=ops._DT[sdt],
+                      total_blocks=blk, amax_bits=amax.data_ptr(), inv_scale=inv.data_ptr())
+        torch.cuda.synchronize()
+        for i, (x, o) in enumerate(zip(xs, dsts)):
+            am = max(float(x.float().abs().max()), 1e-12)
+            am32 = torch.tensor(am, dtype=torch.float32)
+            assert float(amax.view(torch.float32)[i]) == float(x.float().abs().max())
+            assert abs(float(inv[i]) - float(am32 / 448.0)) <= 1e-7 * float(am32 / 448.0) + 1e-30
+            ref = ops.quant_fp8(x.view(1, -1), float(torch.tensor(448.0) / am32)).view(-1)
+            mism = float((ref != o).float().mean())
+            assert mism <= 1e-4, (sdt, i, mism)            # (a one-ulp difference of the scale may flip a rounding tie)
+            # the bytes decode to x / inv within the format's resolution (2^-4 relative for normals)
+            if am > 1e-12:
+                dec = o.view(torch.float8_e4m3fn).float() * inv[i]
+                assert float((dec - x.float()).abs().max()) <= am * 2 ** -4
