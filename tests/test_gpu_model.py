@@ -9,6 +9,7 @@ import os
 
 import pytest
 import torch
+import torch.nn.functional as F
 
 from tests import common as C
 from tests.detfill import det_fill_, is_buffer_name
@@ -757,3 +758,51 @@ def test_fp8_unet_coco_config_deviation():
     assert R['fp8_igemm_launches'] >= 40 and R['fp8_quant_launches'] <= 8
     assert R['bf16_eps_rel_l2'] < 0.03
     assert R['fp8_eps_rel_l2'] < 0.10
+
+
+
+def test_fp8_coco_config_train_step_deviation():
+    """`--config coco224 --dtype fp8 --mode train` (BASELINE configs[4]): one train step of the
+    COCO-224 DINO model with e4m3fn operands in the forward 3x3 convolutions of the denoiser (weights quantised on
+    the device at 448 / amax, kern.WeightBank.w8_dev) against the reference run in sadiff_dino_b1.npz and the bf16
+    step: loss within 5 %, eps of the training provider within 10 % rel-L2, gradient direction kept."""
+    from slotdiffusion_amd.models import SADiffusion
+    from slotdiffusion_amd import ops, _lib
+    cfg = C.dino_coco_cfg()
+    G = C.load_golden('sadiff_dino_b1.npz')
+    img, noise = C.dino_inputs()
+    img = img.cuda()
+    R, grads = {}, {}
+    for mode in ('bf16', 'fp8'):
+        m = SADiffusion(cfg['resolution'], cfg['slot_dict'], cfg['enc_dict'], cfg['dec_dict'],
+                        cfg['loss_dict'], compute_dtype=torch.bfloat16)
+        det_fill_(m.state_dict().items(), skip=is_buffer_name)
+        m.train_dropout = 0.0
+        m = m.cuda()
+        m.set_compute_dtype(mode)
+        m.use_graph = False
+        m.train()
+        m.grad_arena().zero_()
+        with _lib.KernelTimer() as kt:
+            out = m(dict(img=img))
+            loss = m.calc_train_loss(dict(img=img, t=G['t'].cuda(), noise=noise.cuda()), out)['denoise_loss']
+            loss.backward()
+        torch.cuda.synchronize()
+        R[mode + '_loss'] = float(loss)
+        grads[mode] = m.grad_arena().float().clone()
+        n8 = sum(1 for r in kt.records if r[0] == 'sdmi_igemm' and r[3].get('fp8'))
+        assert (n8 >= 30) if mode == 'fp8' else (n8 == 0)
+        xt = m._latent_nhwc(C_xt(G, None, noise).cuda())
+        with torch.enable_grad():
+            e = m._unet_eps(xt, G['t'].float().cuda(), G['slots'].cuda().requires_grad_(True), m.KG())
+        eps = ops.nhwc_to_nchw(e.detach(), 3).float().cpu()
+        m.bank().join()
+        R[mode + '_eps_rel_l2'] = float((eps - G['eps_pred']).norm() / G['eps_pred'].norm())
+    R['loss_ref'] = float(G['train_loss'])
+    R['fp8_grad_cosine_vs_bf16'] = float(F.cosine_similarity(grads['fp8'], grads['bf16'], dim=0))
+    REPORT['fp8_coco224_train'] = R
+    _dump()
+    assert abs(R['fp8_loss'] - R['loss_ref']) / R['loss_ref'] < 0.05
+    assert abs(R['fp8_loss'] - R['bf16_loss']) / R['bf16_loss'] < 0.05
+    assert R['fp8_eps_rel_l2'] < 0.10 and R['bf16_eps_rel_l2'] < 0.03
+    assert R['fp8_grad_cosine_vs_bf16'] > 0.95
