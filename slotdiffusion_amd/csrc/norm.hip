@@ -177,8 +177,12 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(SdmiGroupNormArgs p, int 
       for (int j = 0; j < VEC; ++j) f[j] = act_apply<sizeof(T) == 2>(f[j] * sc[j] + sh[j], p.act);
     }
     if (drop) sdmi_drop_apply<VEC>(f, dseed, (base + o) / VEC, thr16, dinv);
-    if constexpr (F8) gn_store_fp8(p, base + o, f);
-    else *reinterpret_cast<uint4*>(yb + o) = pack16<T>(f);
+    if constexpr (F8) {          // e4m3fn operand of the convolution behind the norm, and the bf16 copy when it has a reader (training)
+      gn_store_fp8(p, base + o, f);
+      if (p.y) *reinterpret_cast<uint4*>(yb + o) = pack16<T>(f);
+    } else {
+      *reinterpret_cast<uint4*>(yb + o) = pack16<T>(f);
+    }
   }
 }
 
@@ -323,8 +327,12 @@ __global__ __launch_bounds__(THREADS) void gn_fused_kernel(SdmiGroupNormArgs p) 
       if (drop) sdmi_drop_apply<VEC>(f, dseed, (base + o) / VEC, thr16, dinv);
       // (the e4m3fn output is its own instantiation: as a run-time branch it pushed the 16-vector
       // variants of the plain kernel into scratch)
-      if constexpr (F8) gn_store_fp8(p, base + o, f);
-      else *reinterpret_cast<uint4*>(yb + o) = pack16<T>(f);
+      if constexpr (F8) {          // e4m3fn operand of the convolution behind the norm, and the bf16 copy when it has a reader (training)
+        gn_store_fp8(p, base + o, f);
+        if (p.y) *reinterpret_cast<uint4*>(yb + o) = pack16<T>(f);
+      } else {
+        *reinterpret_cast<uint4*>(yb + o) = pack16<T>(f);
+      }
     }
   }
 }
@@ -534,8 +542,12 @@ __global__ __launch_bounds__(THREADS) void gn_fused2_kernel(SdmiGroupNormArgs p)
           for (int j = 0; j < VEC; ++j) f[j] = act_apply<sizeof(T) == 2>(fmaf(f[j], sc[j], sh[j]), ACT);
         }
         if (drop) sdmi_drop_apply<VEC>(f, dseed, (base + o) / VEC, thr16, dinv);
-        if constexpr (F8) gn_store_fp8(p, base + o, f);
-        else *reinterpret_cast<uint4*>(yb + o) = pack16<T>(f);
+        if constexpr (F8) {          // e4m3fn operand of the convolution behind the norm, and the bf16 copy when it has a reader (training)
+          gn_store_fp8(p, base + o, f);
+          if (p.y) *reinterpret_cast<uint4*>(yb + o) = pack16<T>(f);
+        } else {
+          *reinterpret_cast<uint4*>(yb + o) = pack16<T>(f);
+        }
       }
     }
   };

@@ -1317,7 +1317,10 @@ class GemmFn(torch.autograd.Function):
             # 448 / amax with amax taken on the device this step (WeightBank.w8_dev); fp32 accumulation, both scales
             # undone in the epilogue.  x stays bf16 for the backward pass.
             w8, inv = wb.w8_dev(wnames)
-            out = ops.conv2d(ops.quant_fp8(x, FP8_ACT_SCALE), w8, b, kh=kh, kw=kw, stride=stride, pad=pad,
+            x8 = getattr(x, '_sdmi_fp8', None)       # written by the GroupNorm in front (KernGrad.gn), else quantised here
+            if x8 is None or x8.shape != x.shape:
+                x8 = ops.quant_fp8(x, FP8_ACT_SCALE)
+            out = ops.conv2d(x8, w8, b, kh=kh, kw=kw, stride=stride, pad=pad,
                              rowvec=rowvec, residual=residual, out_dtype=out_dtype or x.dtype, ldc=ldc,
                              alpha=1.0 / FP8_ACT_SCALE, alpha_dev=inv)
         elif x.dim() == 4 and (kh, kw) != (0, 0):
@@ -1651,7 +1654,7 @@ class MultiLinearFn(torch.autograd.Function):
 
 class GroupNormFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, residual, anchor, wb, name, eps, act, n_alias=0, drop=None, rsink=None):
+    def forward(ctx, x, residual, anchor, wb, name, eps, act, n_alias=0, drop=None, rsink=None, f8=None):
         """rsink = (sink, offset): x = conv(.) + a per-image row vector whose gradient -- the pixel sums
         of this norm's dx -- goes into that slice of the shared row-vector gradient matrix (written
         by the backward kernel itself: no separate reduction launch).
@@ -1659,10 +1662,13 @@ class GroupNormFn(torch.autograd.Function):
         from the seed in backward).  n_alias aliases of x are returned next to y for x's other consumers (ResBlock skip,
         UNet skip-concat, SpatialTransformer residual): their gradients come back into this
         backward and are summed by the GroupNorm backward kernel (dextra0/1) -- no separate
-        accumulation kernels."""
+        accumulation kernels.
+        f8 = [scale]: the fp8 configuration -- the launch also writes the e4m3fn operand of the convolution behind
+        the norm (appended to the list; KernGrad.gn hands it to GemmFn.forward on the output tensor)."""
         gamma, beta = wb.f(name + '.weight'), wb.f(name + '.bias')
         y, stats = ops.group_norm(x, gamma, beta, eps=eps, act=act, residual=residual,
-                                  return_stats=True, drop=drop)
+                                  return_stats=True, drop=drop, fp8_scale=(f8[0] if f8 else None),
+                                  fp8_also=(f8 if f8 else None))
         ctx.save_for_backward(x, stats, residual)
         ctx.cfg = (wb, name, act)
         ctx.drop = drop if (drop is not None and drop[0] > 0.0) else None
@@ -1682,7 +1688,7 @@ class GroupNormFn(torch.autograd.Function):
             dx = extras[0]
             for e in extras[1:]:
                 dx = AddFn.apply(dx, e)
-            return dx, None, None, None, None, None, None, None, None, None
+            return dx, None, None, None, None, None, None, None, None, None, None
         dy = dy.contiguous()
         B, C = x.shape[0], x.shape[-1]
         HW = x.numel() // (B * C)
@@ -1717,7 +1723,7 @@ class GroupNormFn(torch.autograd.Function):
                      rows_per=HW, N=C, ldx=C, ldo=rs_view.stride(0))
             ctx.rsink[0].filled.add(ctx.rsink[1])
         _dbg(f'gn {name}', dy=dy, dx=dx, dres=dres)
-        return dx, dres, None, None, None, None, None, None, None, None
+        return dx, dres, None, None, None, None, None, None, None, None, None
 
 
 class LayerNormFn(torch.autograd.Function):
@@ -2332,8 +2338,17 @@ class KernGrad(Kern):
             if p > 0.0:          # fused behind the activation: same seed scheme as DropoutFn
                 self._drop_ctr += 1
                 drop = (p, (self.seed << 20) + self._drop_ctr, getattr(self.wb.model, 'step_seed', None))
-        return GroupNormFn.apply(x, residual, self.wb.anchor_for(name), self.wb, name, eps, act, 0, drop,
-                                 getattr(rowsum_of, '_sdmi_sink', None))
+        f8 = self._f8_for(x, for_conv)
+        y = GroupNormFn.apply(x, residual, self.wb.anchor_for(name), self.wb, name, eps, act, 0, drop,
+                              getattr(rowsum_of, '_sdmi_sink', None), f8)
+        if f8 is not None and len(f8) > 1:
+            y._sdmi_fp8 = f8[1]
+        return y
+
+    def _f8_for(self, x, for_conv):
+        """[scale] when the norm's only reader is a convolution that multiplies e4m3fn operands (fp8 configuration):
+        the norm writes that operand next to its bf16 output -- no quantisation launch in front of the GEMM."""
+        return [FP8_ACT_SCALE] if (for_conv and self.fp8_ok(x, for_conv, 9, False)) else None
 
     def ff_out_proj(self, g, tres, xres, t, n):
         tok = self.linear(g, t + '.ff.net.2.weight', t + '.ff.net.2.bias', residual=tres)
@@ -2355,7 +2370,11 @@ class KernGrad(Kern):
         return list(outs)
 
     def gn_fan(self, x, name, *, eps, act=None, residual=None, n_alias=1, for_conv=None):
-        return GroupNormFn.apply(x, residual, self.wb.anchor_for(name), self.wb, name, eps, act, n_alias)
+        f8 = self._f8_for(x, for_conv)
+        outs = GroupNormFn.apply(x, residual, self.wb.anchor_for(name), self.wb, name, eps, act, n_alias, None, None, f8)
+        if f8 is not None and len(f8) > 1:
+            outs[0]._sdmi_fp8 = f8[1]
+        return outs
 
     def linear_fan(self, x, wnames, bnames=None):
         return GemmFn.apply(x, None, None, self.wb.anchor_for(wnames), self.wb, wnames, bnames,

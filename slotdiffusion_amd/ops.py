@@ -323,10 +323,12 @@ def cross_fold(tok, wq, colsum, biasq, w2, bias, eps, slots=7, packed=False):
 # normalisation
 # ------------------------------------------------------------------------------------------
 def group_norm(x, gamma, beta, *, eps, act=None, groups=32, residual=None, out=None,
-               return_stats=False, drop=None, fp8_scale=None, x2=None):
+               return_stats=False, drop=None, fp8_scale=None, x2=None, fp8_also=None):
     """x [B,H,W,C] (or [B,HW,C]) NHWC -> same shape; fp32 statistics.  drop = (p, seed, seed_dev):
     inverted dropout fused behind the activation (training-mode ResBlocks).  fp8_scale: the output
-    is written as e4m3fn bytes (uint8 tensor) for the fp8 convolution behind the norm."""
+    is written as e4m3fn bytes (uint8 tensor) for the fp8 convolution behind the norm.  fp8_also = a list
+    (with fp8_scale): the launch writes BOTH forms -- the returned tensor is the bf16 output (the backward pass of
+    the convolution reads it), the e4m3fn bytes are appended to the list (training in the fp8 configuration)."""
     _need_gpu(x)
     B, C = x.shape[0], x.shape[-1]
     HW = x.numel() // (B * C)
@@ -338,7 +340,12 @@ def group_norm(x, gamma, beta, *, eps, act=None, groups=32, residual=None, out=N
     partial = torch.empty((B * nsplit * groups * 2,), dtype=torch.float32, device=x.device)
     stats = torch.empty((B, groups, 2), dtype=torch.float32, device=x.device)
     oshape = x.shape[:-1] + (C,)
-    if fp8_scale is not None:
+    if fp8_scale is not None and fp8_also is not None:
+        out = torch.empty(oshape, dtype=x.dtype, device=x.device)
+        out8 = torch.empty(oshape, dtype=torch.uint8, device=x.device)
+        fp8_also.append(out8)
+        kw = dict(y=_p(out), y8=_p(out8), y8_scale=float(fp8_scale))
+    elif fp8_scale is not None:
         out = torch.empty(oshape, dtype=torch.uint8, device=x.device)
         kw = dict(y=0, y8=_p(out), y8_scale=float(fp8_scale))
     else:

@@ -866,3 +866,22 @@ def test_fp8_quant_group_device_scales():
             if am > 1e-12:
                 dec = o.view(torch.float8_e4m3fn).float() * inv[i]
                 assert float((dec - x.float()).abs().max()) <= am * 2 ** -4
+
+
+@pytest.mark.parametrize('B,HW,C', [(2, 1024, 128), (3, 256, 256), (2, 64, 384), (1, 16384, 64), (2, 4096, 128)])
+def test_groupnorm_writes_both_forms(B, HW, C):
+    """fp8 configuration, training: one GroupNorm launch writes the bf16 output (the backward pass of the convolution
+    behind it reads that) AND its e4m3fn copy (the forward GEMM's operand) -- both bit-identical to the launches that
+    write one form each, with the fused dropout on (the same mask in both forms)."""
+    from slotdiffusion_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(B + HW + C)
+    x = torch.randn(B, HW, C, device=DEV, generator=g).bfloat16()
+    gamma, beta = torch.randn(C, device=DEV, generator=g), torch.randn(C, device=DEV, generator=g)
+    seed_dev = torch.zeros(1, dtype=torch.int64, device=DEV)
+    for drop in (None, (0.1, 1234, seed_dev)):
+        y = ops.group_norm(x, gamma, beta, eps=1e-5, act='silu', drop=drop)
+        y8 = ops.group_norm(x, gamma, beta, eps=1e-5, act='silu', drop=drop, fp8_scale=8.0)
+        also = []
+        yb = ops.group_norm(x, gamma, beta, eps=1e-5, act='silu', drop=drop, fp8_scale=8.0, fp8_also=also)
+        assert yb.dtype == torch.bfloat16 and len(also) == 1 and also[0].dtype == torch.uint8
+        assert torch.equal(yb, y) and torch.equal(also[0], y8)
