@@ -154,6 +154,23 @@ class FusedAdam:
 CAPTURE_MODE = 'thread_local'
 
 
+def split_runs(model):
+    """-> (denoiser runs, encoder runs) of the flat gradient arena: lr group 1 = dm_decoder (97 % of the bytes, reduced
+    while the slot encoder's backward runs), everything else follows."""
+    runs = model.lr_runs()
+    return [(lo, hi) for lo, hi, grp in runs if grp == 1], [(lo, hi) for lo, hi, grp in runs if grp != 1]
+
+
+def start_reduce_runs(reducer, runs):
+    """Start the bucketed all-reduce of the arena ranges `runs` on a parallel.GradReducer -> work handles."""
+    works = []
+    for lo, hi in runs:
+        # >= 4 buckets over the denoiser's range (135 M floats: ~70 MB each on a bf16 wire), one for small runs:
+        # the ring of the first bucket is busy while the next one is still being converted
+        works += reducer.start(lo, hi, n_buckets=(4 if hi - lo > (16 << 20) else 1))
+    return works
+
+
 class GraphedTrainStep:
     """zero-grad -> forward -> loss -> backward -> clip+Adam captured once into HIP graphs and
     replayed per step (about 1.5k kernel launches per replay instead of as many host launches).
@@ -189,9 +206,7 @@ class GraphedTrainStep:
             from . import parallel
             self.reducer = parallel.GradReducer(model.grad_arena(), self.world, wire)
         # overlap mode needs the denoiser / encoder split of the arena (lr group 1 = dm_decoder)
-        runs = model.lr_runs()
-        self.dec_runs = [(lo, hi) for lo, hi, grp in runs if grp == 1]
-        self.enc_runs = [(lo, hi) for lo, hi, grp in runs if grp != 1]
+        self.dec_runs, self.enc_runs = split_runs(model)
         self.overlap = allreduce is True and len(self.dec_runs) > 0 and len(self.enc_runs) > 0
         if allreduce is True and not self.overlap:        # no denoiser range to split at: one exchange of the arena
             self.allreduce = allreduce = lambda g: self.reducer.reduce_all(4)
@@ -273,12 +288,7 @@ class GraphedTrainStep:
         self._slots = self._dslots = None
 
     def _start_reduce(self, runs):
-        works = []
-        for lo, hi in runs:
-            # >= 4 buckets over the denoiser's range (135 M floats: ~70 MB each on a bf16 wire), one for small runs:
-            # the ring of the first bucket is busy while the next one is still being converted
-            works += self.reducer.start(lo, hi, n_buckets=(4 if hi - lo > (16 << 20) else 1))
-        return works
+        return start_reduce_runs(self.reducer, runs)
 
     def _finish_reduce(self, works):
         self.reducer.finish(works)          # (no pass over the arena: 1 / world and the wire dtype ride in _update)

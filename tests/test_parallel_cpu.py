@@ -138,3 +138,59 @@ def test_bench_refuses_more_gpus_than_present():
                        capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode != 0
     assert '--gpus 2' in (r.stderr + r.stdout) and 'visible' in (r.stderr + r.stdout)
+
+
+def _video_worker(rank, world, port, ret):
+    """One rank of `bench.py --gpus 2 --config movie15x6` without the kernels: the model's flat arenas on the CPU, the
+    clip shard of the rank, and the exchange of the train step -- the denoiser's range in four buckets, then the
+    slot encoder's / predictor's ranges (optim.split_runs / start_reduce_runs: the code GraphedTrainStep runs)."""
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import bench
+        from slotdiffusion_amd import configs, optim
+        torch.set_num_threads(4)
+        model, cfg, frames = bench.build_model(torch.float32, config='movie15x6')
+        bc = configs.BENCH_CONFIGS['movie15x6']
+        clips = bc['batch']
+        lo, hi = parallel.shard_range(clips * world, rank, world)          # weak scaling: `batch` clips per rank
+        dec, enc = optim.split_runs(model)
+        g = model.grad_arena()
+        n = g.numel()
+        covered = sorted(dec + enc)
+        ok = covered[0][0] == 0 and covered[-1][1] == n and all(a[1] == b[0] for a, b in zip(covered, covered[1:]))
+        ok = ok and sum(h - l for l, h in dec) > 0.9 * n and cfg['slot_dict']['num_slots'] == 15 and frames == 6
+        base = torch.randn(n, generator=torch.Generator().manual_seed(7))
+        out = {}
+        for wire in ('fp32', 'bf16'):
+            g.copy_(base).mul_(rank + 1.0)                                 # average over two ranks = 1.5 * base
+            red = parallel.GradReducer(g, world, wire)
+            works = optim.start_reduce_runs(red, dec)
+            works += optim.start_reduce_runs(red, enc)
+            red.finish(works)
+            avg = red.grad_src.float() * red.grad_scale
+            out[wire] = float((avg - 1.5 * base).norm() / (1.5 * base).norm())
+            del red, avg
+        parallel.broadcast_parameters(model.arena(), src=0)
+        ret[rank] = (ok, hi - lo, lo, out['fp32'], out['bf16'])
+    finally:
+        dist.destroy_process_group()
+
+
+def test_video_config_two_rank_dry_path_gloo():
+    """the N-rank half of BASELINE configs[3] (movie15x6: 15 slots, 6-frame clips) on two gloo
+    ranks -- shard of the clips, the gradient ranges the split backward exchanges (together they cover the arena of
+    138 M floats), the bucketed reduction on both wires."""
+    world = 2
+    port = _free_port()
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_video_worker, args=(world, port, ret), nprocs=world, join=True)
+        r = dict(ret)
+    from slotdiffusion_amd import configs
+    clips = configs.BENCH_CONFIGS['movie15x6']['batch']
+    for rank in range(world):
+        ok, mine, lo, e32, e16 = r[rank]
+        assert ok and mine == clips and lo == rank * clips
+        assert e32 < 1e-6 and 0 < e16 < 2.0 ** -8
