@@ -1312,14 +1312,14 @@ class GemmFn(torch.autograd.Function):
         kh, kw, stride, pad, ups = geom
         w = wb.w(wnames, x.dtype)
         b = wb.b(bnames)
-        if wb.fp8_train_ok(x, wnames, geom):
-            # e4m3fn operands in the forward GEMM: activations at the fixed scale of the inference path, weights at
-            # 448 / amax with amax taken on the device this step (WeightBank.w8_dev); fp32 accumulation, both scales
-            # undone in the epilogue.  x stays bf16 for the backward pass.
+        x8 = getattr(x, '_sdmi_fp8', None)           # e4m3fn copy written by the GroupNorm in front (KernGrad.gn)
+        if x8 is not None and x8.shape == x.shape and wb.fp8_train_ok(x, wnames, geom):
+            # e4m3fn operands in the forward GEMM: activations at the fixed scale of the inference path -- only where a
+            # GroupNorm (+ SiLU) bounds them and wrote the operand itself: the stride-2 downsample convolutions read
+            # the raw residual stream and keep bf16 in training -- weights at 448 / amax with amax taken on the device
+            # this step (WeightBank.w8_dev); fp32 accumulation, both scales undone in the epilogue.  x stays bf16 for
+            # the backward pass.
             w8, inv = wb.w8_dev(wnames)
-            x8 = getattr(x, '_sdmi_fp8', None)       # written by the GroupNorm in front (KernGrad.gn), else quantised here
-            if x8 is None or x8.shape != x.shape:
-                x8 = ops.quant_fp8(x, FP8_ACT_SCALE)
             out = ops.conv2d(x8, w8, b, kh=kh, kw=kw, stride=stride, pad=pad,
                              rowvec=rowvec, residual=residual, out_dtype=out_dtype or x.dtype, ldc=ldc,
                              alpha=1.0 / FP8_ACT_SCALE, alpha_dev=inv)
