@@ -83,6 +83,12 @@ _WGRAD_HALO = os.environ.get('SDMI_WGRAD_HALO', '1') != '0'    # direct 3x3 weig
 # folded slot cross-attention as ONE launch (sdmi_cross_fold) up to this many tokens per image (0 = off)
 _CROSS_ONE = int(os.environ.get('SDMI_CROSS_ONE', '64'))
 _UPS_PARITY = os.environ.get('SDMI_UPS_PARITY', '1') != '0'   # upsample convolutions as four 2x2 parity convolutions
+# ... launched concurrently (one on the current stream, three on side streams) when the input has at most this many
+# pixels over the batch.  Off (0): measured SLOWER inside the replayed sampler -- rotated same-box A/B, ms per 20-NFE
+# pass: 76.53 / 76.36 / 76.29 one after the other, 77.70 / 78.22 / 77.66 forked at all three levels, 78.30 / 78.34 /
+# 77.97 forked at 4^2 -> 8^2 only: a fork / join pair in the graph costs ~20 us, more than the 128-workgroup launches
+# lose by running alone (profiles/r05_pp_ablation.txt)
+_UPS_FORK = int(os.environ.get('SDMI_UPS_FORK', '0'))
 # ... only when its grid (one workgroup per 64 token rows) fills a good part of the chip: at B = 64 the 8^2 level gives 64
 # workgroups that each stream the block's 4 MB of weights -- 119 us against 108 us for the per-layer launches
 _ST_MIN_WGS = int(os.environ.get('SDMI_ST_MIN_WGS', '128'))
@@ -952,8 +958,28 @@ class Kern:
             B, H, W_, _ = x.shape
             ws = self.wb.ups_parity_weights(wname, x.dtype)
             out = torch.empty((B, 2 * H, 2 * W_, ws[0, 0].shape[0]), dtype=x.dtype, device=x.device)
+            bias = self.wb.b(bname)
+            if _UPS_FORK and B * H * W_ <= _UPS_FORK:
+                # the four parity launches are independent and small (128 workgroups each at 4^2 -> 8^2, B = 64): three
+                # of them run on side streams next to the first -- fork / join by events, capturable -- so the chip
+                # sees 4x the workgroups instead of four dependent-looking launches of 14 - 20 us
+                cur = torch.cuda.current_stream()
+                if not hasattr(self, '_ups_sides'):
+                    self._ups_sides = [torch.cuda.Stream() for _ in range(3)]
+                ev = torch.cuda.Event()
+                ev.record(cur)
+                for i, ((py, px), w) in enumerate(ws.items()):
+                    st = cur if i == 0 else self._ups_sides[i - 1]
+                    if i:
+                        st.wait_event(ev)
+                    with torch.cuda.stream(st):
+                        ops.conv2d(x, w, bias, kh=2, kw=2, pad=(1 - py, py, 1 - px, px), out=out, split_k=1,
+                                   sub=(2, 2, py, px))
+                for st in self._ups_sides:
+                    cur.wait_stream(st)
+                return out
             for (py, px), w in ws.items():
-                ops.conv2d(x, w, self.wb.b(bname), kh=2, kw=2, pad=(1 - py, py, 1 - px, px), out=out,
+                ops.conv2d(x, w, bias, kh=2, kw=2, pad=(1 - py, py, 1 - px, px), out=out,
                            split_k=1, sub=(2, 2, py, px))
             return out
         if x.dtype == torch.uint8 or self.fp8_ok(x, wname, kh * kw, ups):
