@@ -132,6 +132,12 @@ typedef struct {
    * tensor's own amax in the same stream, so that a captured train step re-derives it at every replay (BASELINE
    * configs[4] "fp8 MFMA UNet": unet.py:271-285 with e4m3fn operands). */
   const float* alpha_dev;
+  /* parity4 != 0 (batch = 4, KH = KW = 2, stride 1, osy = osx = 2, sa = sc = 0): the four parity convolutions of a
+   * nearest-2x upsample + 3x3 convolution (unet.py:108-121 as 2x2 convolutions of the low-resolution input, one per
+   * output parity) in ONE launch -- batch index z = 2 py + px selects the filter (w + z * sw), the padding
+   * (pad_t = 1 - py, pad_l = 1 - px) and the placement (ooy = py, oox = px); the caller's pad_t / pad_l / ooy / oox are
+   * ignored.  Bias-only epilogue like every sub-sampled output. */
+  int parity4;
 } SdmiGemmArgs;
 int sdmi_igemm(const SdmiGemmArgs* a, void* stream);
 /* Host-side query, no launch (stream ignored): the number of K slices sdmi_igemm would use for these

@@ -39,6 +39,19 @@ int sdmi_launch_halo(const SdmiGemmArgs& p, int logw, int nj, int hw_shift, hipS
 
 namespace {
 
+// sdmi.h parity4: batch index z = 2 py + px of the four parity convolutions of an upsample layer selects padding and
+// output placement (the filter advances by z * sw like any batch); wave-uniform scalar arithmetic on the by-value args
+__device__ __forceinline__ void parity_select(SdmiGemmArgs& p, int by) {
+  if (p.parity4) {
+    const int z = by / (p.split_k > 0 ? p.split_k : 1);
+    p.pad_t = 1 - (z >> 1);
+    p.pad_l = 1 - (z & 1);
+    p.ooy = z >> 1;
+    p.oox = z & 1;
+  }
+}
+
+
 // ------------------------------------------------------------------------------------------
 // LDS-DMA variant (MODE 1 = 1x1 / linear, MODE 2 = plain convolution with Cin % BK == 0; K tile =
 // 128 bytes of K per row).  Measured on MI355X (tools/probes/ldsdma.hip): VALU instructions of a
@@ -69,6 +82,7 @@ namespace {
 template <typename T, int BM, int BN, int NSTAGE, int MODE, int LW = 4, bool XS = false, int EPI = 0>
 __global__ __launch_bounds__(256 + 64 * LW, (BM * BN <= 64 * 64 ? 4 : 0)) void igemm_dma_kernel(
     SdmiGemmArgs p, int tiles_m, int tiles_n, int kt_per_split, int hw_shift) {
+  if constexpr (MODE == 2 && EPI == 0 && !XS) parity_select(p, (int)blockIdx.y);
   constexpr int VEC = 16 / sizeof(T);
   constexpr int BK = 128 / sizeof(T);
   constexpr int WM = BM / 2, WN = BN / 2;            // wave tile
@@ -498,6 +512,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   if constexpr (sizeof(T) == 1) {          // fp8 operands: the device-side half of the scale (sdmi.h: alpha_dev)
     if (p.alpha_dev) p.alpha *= *p.alpha_dev;
   }
+  if constexpr (MODE != 1 && EPI == 0 && !XS) parity_select(p, (int)blockIdx.y);
   igemm_body<T, BM, BN, BKB, MODE, EPI, XS>(p, tiles_m, tiles_n, kt_per_split, hw_shift, (int)blockIdx.x,
                                             (int)gridDim.x, (int)blockIdx.y);
 }
@@ -507,6 +522,7 @@ __global__ __launch_bounds__(512) void igemm_kernel_tall(SdmiGemmArgs p, int til
   if constexpr (sizeof(T) == 1) {
     if (p.alpha_dev) p.alpha *= *p.alpha_dev;
   }
+  if constexpr (MODE != 1) parity_select(p, (int)blockIdx.y);
   igemm_body<T, BM, BN, BKB, MODE>(p, tiles_m, tiles_n, kt_per_split, hw_shift, (int)blockIdx.x, (int)gridDim.x,
                                    (int)blockIdx.y);
 }
@@ -666,7 +682,8 @@ int dispatch(const SdmiGemmArgs& p, hipStream_t st, bool plan_only = false) {
   }
   const int batch = p.batch > 0 ? p.batch : 1;
   const long long tm128 = (p.M + 127) / 128;
-  const long long t128 = tm128 * ((p.N + 127) / 128) * batch;
+  // (parity4: the tile shape of ONE parity convolution -- the launch is four of those side by side)
+  const long long t128 = tm128 * ((p.N + 127) / 128) * (p.parity4 ? 1 : batch);
   // tile shape: 128x128 when that still gives >= 192 workgroups; narrow outputs (N <= 64: the
   // 64-channel encoder convs at 128x128 pixels) 128x64; everything else 64x64 (+ split-K)
   enum { T128x128, T128x64, T64x64 } shape = T64x64;
@@ -1015,7 +1032,7 @@ int dispatch(const SdmiGemmArgs& p, hipStream_t st, bool plan_only = false) {
       }
     }
     const int dma64 = dma64_min();
-    if (dma64 && shape == T64x64 && !p.a2 && kbytes >= dma64 && fits31 && batch == 1) {
+    if (dma64 && shape == T64x64 && !p.a2 && kbytes >= dma64 && fits31 && (batch == 1 || p.parity4)) {
       if (is1x1) return launch_dma<T, 64, 64, 4, 1, 4>(p, hw_shift, st, split_k);
       if (plain && p.KH * p.KW <= 32 && p.Cin % 64 == 0) return launch_dma<T, 64, 64, 4, 2, 4>(p, hw_shift, st, split_k);
     }
@@ -1053,11 +1070,16 @@ extern "C" int sdmi_igemm(const SdmiGemmArgs* a, void* stream) {
   SDMI_REQUIRE(((uintptr_t)a->a & 15) == 0 && ((uintptr_t)a->w & 15) == 0, "unaligned operand");
   SDMI_REQUIRE(a->M == a->B * a->Ho * a->Wo, "M != B*Ho*Wo");
   SDMI_REQUIRE(!(a->zins > 1 && (a->ups || a->stride != 1)), "zins excludes ups / stride");
-  SDMI_REQUIRE(!(a->batch > 1) || (a->KH == 1 && a->KW == 1), "batched mode is 1x1 only");
+  SDMI_REQUIRE(!a->parity4 || (a->batch == 4 && a->KH == 2 && a->KW == 2 && a->stride == 1 && a->osy == 2 && a->osx == 2 &&
+                               a->sa == 0 && a->sc == 0 && a->sw > 0 && !a->a2 && !a->ups && a->zins <= 1 && a->split_k <= 1 &&
+                               !a->residual && !a->ln_colsum && !a->geglu && !a->softmax8 && !a->gn_part &&
+                               !a->defer_epilogue && a->dtype != SDMI_FP8),
+               "parity4: four 2x2 parity convolutions (batch 4, osy = osx = 2, shared input and output)");
+  SDMI_REQUIRE(!(a->batch > 1) || a->parity4 || (a->KH == 1 && a->KW == 1), "batched mode is 1x1 only");
   SDMI_REQUIRE(!(a->batch > 1 && a->split_k > 1), "batched split-K unsupported");
   SDMI_REQUIRE(a->sa % vec == 0 && a->sw % vec == 0, "batch strides must keep 16-byte alignment");
   SDMI_REQUIRE(a->osy == 0 || (a->osy > 0 && a->osx > 0 && a->oH > 0 && a->oW > 0 &&
-                               a->split_k <= 1 && !(a->batch > 1)),
+                               a->split_k <= 1 && (!(a->batch > 1) || a->parity4)),
                "sub-sampled output: needs osy/osx/oH/oW > 0, no split-K / batch");
   SDMI_REQUIRE(a->osy == 0 || !a->residual || a->ldr == a->ldc,
                "sub-sampled output: the residual shares the output's layout");

@@ -89,6 +89,7 @@ _UPS_PARITY = os.environ.get('SDMI_UPS_PARITY', '1') != '0'   # upsample convolu
 # 77.97 forked at 4^2 -> 8^2 only: a fork / join pair in the graph costs ~20 us, more than the 128-workgroup launches
 # lose by running alone (profiles/r05_pp_ablation.txt)
 _UPS_FORK = int(os.environ.get('SDMI_UPS_FORK', '0'))
+_UPS_ONE = os.environ.get('SDMI_UPS_ONE', '1') != '0'         # ... or as ONE launch over the parity index (sdmi.h: parity4)
 # ... only when its grid (one workgroup per 64 token rows) fills a good part of the chip: at B = 64 the 8^2 level gives 64
 # workgroups that each stream the block's 4 MB of weights -- 119 us against 108 us for the per-layer launches
 _ST_MIN_WGS = int(os.environ.get('SDMI_ST_MIN_WGS', '128'))
@@ -713,8 +714,9 @@ class WeightBank:
         key = ('upsparity', wname, dtype)
         if key not in self.cache:
             with torch.no_grad():
-                self.cache[key] = {k: v.to(dtype).contiguous()
-                                   for k, v in ups_parity_split(self.t[wname].float()).items()}
+                parts = ups_parity_split(self.t[wname].float())
+                w4 = torch.stack([parts[py, px] for py in (0, 1) for px in (0, 1)]).to(dtype).contiguous()
+                self.cache[key] = {(z >> 1, z & 1): w4[z] for z in range(4)}       # views of one [4][Cout][4 Cin] tensor
         return self.cache[key]
 
     def ffout_proj_weights(self, t, n, dtype):
@@ -959,6 +961,9 @@ class Kern:
             ws = self.wb.ups_parity_weights(wname, x.dtype)
             out = torch.empty((B, 2 * H, 2 * W_, ws[0, 0].shape[0]), dtype=x.dtype, device=x.device)
             bias = self.wb.b(bname)
+            if _UPS_ONE:          # all four parities in one launch (sdmi.h: parity4; the filters are one [4][N][4 Cin] tensor)
+                w4 = next(iter(ws.values()))._base
+                return ops.conv2d(x, w4, bias, kh=2, kw=2, out=out, parity4=True)
             if _UPS_FORK and B * H * W_ <= _UPS_FORK:
                 # the four parity launches are independent and small (128 workgroups each at 4^2 -> 8^2, B = 64): three
                 # of them run on side streams next to the first -- fork / join by events, capturable -- so the chip

@@ -141,13 +141,15 @@ def quant_fp8(x, scale, out=None):
 
 def conv2d(x, w, bias=None, *, kh=3, kw=3, stride=1, pad=(1, 1, 1, 1), ups=False, cout=None,
            rowvec=None, residual=None, act=None, out=None, out_dtype=None, ldc=None,
-           split_k=0, alpha=1.0, x2=None, x3=None, sub=None, zero_pad=True, alpha_dev=None):
+           split_k=0, alpha=1.0, x2=None, x3=None, sub=None, zero_pad=True, alpha_dev=None, parity4=False):
     """x [B,H,W,Cin] NHWC; w [Cout][kh][kw][Cin] (flat or 4-D channels_last view).
     pad = (top, bottom, left, right).  Returns [B,Ho,Wo,ldc or Cout].
     uint8 x / w = e4m3fn operands (quant_fp8): out_dtype is required, alpha undoes the scales; alpha_dev = a
     one-element fp32 tensor multiplied into alpha on the device (a scale sdmi_fp8_quant_group derived there).
     sub = (sy, sx, oy, ox) with `out` [B, sy*Ho, sx*Wo, ldc]: output pixel (y, x) is stored at (sy*y + oy, sx*x + ox)
-    (sdmi.h: osy / osx / ooy / oox; bias-only epilogue, no split-K)."""
+    (sdmi.h: osy / osx / ooy / oox; bias-only epilogue, no split-K).
+    parity4: w [4][Cout][2*2*Cin] = the four parity filters of an upsample convolution (kern.ups_parity_split, z = 2 py +
+    px), out [B, 2H, 2W, ldc]: all four 2x2 parity convolutions in ONE launch (sdmi.h: parity4)."""
     _need_gpu(x, w)
     B, H, W, Cin = x.shape
     assert x.is_contiguous()
@@ -164,8 +166,13 @@ def conv2d(x, w, bias=None, *, kh=3, kw=3, stride=1, pad=(1, 1, 1, 1), ups=False
     Ho = (Hs + pad[0] + pad[1] - kh) // stride + 1
     Wo = (Ws + pad[2] + pad[3] - kw) // stride + 1
     K = kh * kw * Cin + extra
+    if parity4:
+        assert (kh, kw) == (2, 2) and stride == 1 and not ups and x2 is None and out is not None and rowvec is None and \
+            residual is None and act is None and w.dim() == 3 and w.shape[0] == 4 and w.is_contiguous()
+        pad, sub, split_k, cout = (1, 0, 1, 0), (2, 2, 0, 0), 1, w.shape[1]
+        Ho, Wo = H, W
     N = cout if cout is not None else w.numel() // K
-    assert w.numel() == N * K, (w.shape, N, K)
+    assert w.numel() == N * K * (4 if parity4 else 1), (w.shape, N, K)
     odt = out_dtype or x.dtype
     ldc = ldc or N
     if out is None:
@@ -191,6 +198,8 @@ def conv2d(x, w, bias=None, *, kh=3, kw=3, stride=1, pad=(1, 1, 1, 1), ups=False
         assert split_k == 1 and rowvec is None and residual is None and act is None and x2 is None
         assert tuple(out.shape[:3]) == (B, sub[0] * Ho, sub[1] * Wo) and out.is_contiguous()
         kwargs.update(oH=sub[0] * Ho, oW=sub[1] * Wo, osy=sub[0], osx=sub[1], ooy=sub[2], oox=sub[3])
+        if parity4:
+            kwargs.update(parity4=1, batch=4, sw=N * K)
     if _DEFER[0] and alpha_dev is None and ws is not None and split_k == 0 and act is None and ldc == N and N > 64 and N % 8 == 0 and \
             odt == torch.bfloat16 and (residual is None or (residual.is_contiguous() and residual.shape[-1] == N)):
         splits = _lib.query('sdmi_igemm_split_plan', **kwargs)

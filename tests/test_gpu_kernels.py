@@ -759,7 +759,8 @@ def test_softmax_rows(shape, dtype):
     assert float((y.float().cpu().sum(-1) - 1).abs().max()) <= (1e-5 if dtype == torch.float32 else 2e-2)
 
 
-@pytest.mark.parametrize('B,H,ci,co', [(3, 8, 256, 256), (2, 4, 512, 512), (2, 16, 128, 192)])
+@pytest.mark.parametrize('B,H,ci,co', [(3, 8, 256, 256), (2, 4, 512, 512), (2, 16, 128, 192),
+                                        (64, 4, 512, 512), (64, 8, 384, 384), (64, 16, 256, 256)])   # the sampler's three at B = 64
 def test_upsample_conv_as_four_parity_convs(B, H, ci, co):
     """nearest-2x + 3x3 convolution (unet.py:108-121) as four 2x2 convolutions of the low-resolution input
     (kern.ups_parity_split, sdmi.h: osy / osx) against torch fp32 and against the in-gather form it replaces."""
@@ -783,6 +784,12 @@ def test_upsample_conv_as_four_parity_convs(B, H, ci, co):
     e_old = float((old.float().cpu() - ref).norm() / ref.norm())
     print(f'ups conv {ci}->{co} @{H}: parity form {e_new:.2e}, in-gather form {e_old:.2e} (rel-L2 vs torch fp32)')
     assert e_new < 6e-3 and e_old < 6e-3                  # bf16 operands, fp32 accumulation, bf16 output
+    # ... and all four parities in ONE launch (sdmi.h: parity4): bit-identical to the four launches
+    parts = kern.ups_parity_split(w)
+    w4 = torch.stack([parts[py, px] for py in (0, 1) for px in (0, 1)]).bfloat16().to(DEV).contiguous()
+    one = torch.full((B, 2 * H, 2 * H, co), float('nan'), dtype=torch.bfloat16, device=DEV)
+    ops.conv2d(xd, w4, b.to(DEV), kh=2, kw=2, out=one, parity4=True)
+    assert torch.equal(one, out)
 
 
 @pytest.mark.parametrize('B,HW,C,slots,padded', [(64, 16, 512, 7, False), (5, 64, 384, 7, True), (3, 16, 256, 5, True),
