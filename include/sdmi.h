@@ -177,7 +177,10 @@ int sdmi_wgrad(const SdmiWgradArgs* a, void* stream);
  * tiles to fill 256 CUs and would pay an M-split + fold launch pair; together their tiles fill the
  * chip.  `problems` is a HOST array of n SdmiWgradArgs (each with its own splits / workspace as for
  * sdmi_wgrad; bf16, KH = KW = 1, N > 64, K > 64); problems with splits > 1 are folded by one shared
- * second launch.  Results equal n sdmi_wgrad calls bit for bit. */
+ * second launch.  Results equal n sdmi_wgrad calls bit for bit.
+ * A group may instead hold fp32 problems (all of them; any N, K; 64 x 64 tiles of the exact-fp32 kernel): the Slot
+ * Attention / predictor layers (slot_attention.py:57-106: M = images x slots rows) are 9 - 36 workgroups and ~20 us of
+ * latency each when launched alone. */
 typedef struct { const void* problems; int n; } SdmiWgradGroupArgs;
 int sdmi_wgrad_group(const SdmiWgradGroupArgs* a, void* stream);
 int sdmi_wgrad_fold_group(const SdmiWgradGroupArgs* a, void* stream);

@@ -48,9 +48,10 @@ __device__ __forceinline__ void transpose_block(const u32x4 (&r)[4], u32x4 (&c)[
     for (int e = 0; e < 4; ++e) c[n][e] = r[e][n];
 }
 
+// (body of wgrad_kernel: `tile` / `split` are the launch's block indices, or a slice of a grouped grid)
 template <typename T, int TN, int TK, bool IS1X1>
-__global__ __launch_bounds__(512) void wgrad_kernel(SdmiWgradArgs p, int tiles_n, int tiles_k,
-                                                    int m_per_split) {
+__device__ __forceinline__ void wgrad_std_body(const SdmiWgradArgs& p, int tiles_n, int tiles_k, int m_per_split,
+                                               const int tile, const int split, char* smem) {
   constexpr int VEC = 16 / sizeof(T);
   constexpr int MTB = WCfg<T>::MTB;
   constexpr int MT = MTB / sizeof(T);        // m rows per step
@@ -65,15 +66,11 @@ __global__ __launch_bounds__(512) void wgrad_kernel(SdmiWgradArgs p, int tiles_n
   constexpr int FN = WTN / 32, FK = WTK / 32;
   constexpr int BUFB = (TN + TK) * ROWB;     // one LDS stage: Ys [TN][ROWB] | As [TK][ROWB]
 
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-
-  const int tile = blockIdx.x;
   if (tile >= tiles_n * tiles_k) {   // trailing workgroups: bias gradient (column sums of dY)
-    bias_tile<T, TN>(p, tile - tiles_n * tiles_k, blockIdx.y, m_per_split, smem);
+    bias_tile<T, TN>(p, tile - tiles_n * tiles_k, split, m_per_split, smem);
     return;
   }
   const int tile_n = tile / tiles_k, tile_k = tile - tile_n * tiles_k;
-  const int split = blockIdx.y;
   const int n0 = tile_n * TN, k0 = tile_k * TK;
   const int m_begin = split * m_per_split;
   int m_end = m_begin + m_per_split;
@@ -304,6 +301,13 @@ __global__ __launch_bounds__(512) void wgrad_kernel(SdmiWgradArgs p, int tiles_n
   }
 }
 
+template <typename T, int TN, int TK, bool IS1X1>
+__global__ __launch_bounds__(512) void wgrad_kernel(SdmiWgradArgs p, int tiles_n, int tiles_k,
+                                                    int m_per_split) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  wgrad_std_body<T, TN, TK, IS1X1>(p, tiles_n, tiles_k, m_per_split, (int)blockIdx.x, (int)blockIdx.y, smem);
+}
+
 template <int TN, int TK, int MODE>
 __global__ __launch_bounds__(512) void wgrad_tr_kernel(SdmiWgradArgs p, int tiles_n, int tiles_k,
                                                        int m_per_split) {
@@ -341,6 +345,19 @@ __global__ __launch_bounds__(512) void wgrad_group_kernel(WgradGroup g) {
   const int split = local / g.per_split[i];
   const int tile = local - split * g.per_split[i];
   wgrad_tr_body<128, 128, 1>(g.p[i], g.tiles_n[i], g.tiles_k[i], g.mps[i], tile, split);
+}
+
+// fp32 form: the exact-fp32 64 x 64 tiles of the Slot Attention / predictor layers (M = images x slots rows: each of
+// these problems alone is 9 - 36 workgroups and ~20 us of latency; dispatch_wgrad_f32)
+__global__ __launch_bounds__(512) void wgrad_group_f32_kernel(WgradGroup g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int bid = blockIdx.x;
+  int i = 0;
+  while (i + 1 < g.n && bid >= g.item_begin[i + 1]) ++i;
+  const int local = bid - g.item_begin[i];
+  const int split = local / g.per_split[i];
+  const int tile = local - split * g.per_split[i];
+  wgrad_std_body<float, 64, 64, true>(g.p[i], g.tiles_n[i], g.tiles_k[i], g.mps[i], tile, split, smem);
 }
 
 __global__ __launch_bounds__(256) void wgrad_group_reduce_kernel(WgradGroup g) {
@@ -820,6 +837,38 @@ extern "C" int sdmi_wgrad_group(const SdmiWgradGroupArgs* ga, void* stream) {
   WgradGroup g;
   g.n = ga->n;
   int items = 0, red = 0;
+  if (ps[0].dtype == SDMI_F32) {          // exact-fp32 problems on 64 x 64 tiles (any N, K)
+    constexpr int MT = WCfg<float>::MTB / 4;
+    for (int i = 0; i < ga->n; ++i) {
+      const SdmiWgradArgs& a = ps[i];
+      SDMI_REQUIRE(a.a && a.dy && a.dw, "null pointer");
+      SDMI_REQUIRE(a.dtype == SDMI_F32 && wgrad_is1x1(a), "grouped wgrad: one dtype per group, 1x1 / linear problems");
+      SDMI_REQUIRE(a.K == a.Cin && a.Cin % 4 == 0 && a.lda % 4 == 0 && a.ldy % 4 == 0 && a.M == a.B * a.Ho * a.Wo,
+                   "bad geometry");
+      SDMI_REQUIRE(a.splits >= 1 && (a.splits == 1 || a.workspace), "splits / workspace");
+      g.p[i] = a;
+      g.tiles_n[i] = (a.N + 63) / 64;
+      g.tiles_k[i] = (a.K + 63) / 64;
+      g.per_split[i] = g.tiles_n[i] * g.tiles_k[i] + (a.dbias ? g.tiles_n[i] : 0);
+      const int mps = (a.M + a.splits - 1) / a.splits;
+      g.mps[i] = (mps + MT - 1) / MT * MT;
+      g.item_begin[i] = items;
+      items += g.per_split[i] * a.splits;
+      g.red_begin[i] = red;
+      if (a.splits > 1) {
+        long long blocks = wgrad_fold_blocks(a);
+        red += (int)(blocks > 512 ? 512 : blocks);
+      }
+    }
+    for (int i = ga->n; i <= WG_MAX; ++i) { g.item_begin[i] = items; g.red_begin[i] = red; }
+    constexpr int smem32 = 2 * (64 + 64) * (WCfg<float>::MTB + 16);
+    SDMI_OPTIN_LDS(wgrad_group_f32_kernel, smem32, "wgrad group (fp32)");
+    hipLaunchKernelGGL(wgrad_group_f32_kernel, dim3(items), dim3(512), smem32, st, g);
+    int rc = sdmi_check_launch("wgrad group (fp32)");
+    if (rc || red == 0) return rc;
+    hipLaunchKernelGGL(wgrad_group_reduce_kernel, dim3(red), dim3(256), 0, st, g);
+    return sdmi_check_launch("wgrad group reduce");
+  }
   for (int i = 0; i < ga->n; ++i) {
     const SdmiWgradArgs& a = ps[i];
     SDMI_REQUIRE(a.a && a.dy && a.dw, "null pointer");

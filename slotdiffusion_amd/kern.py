@@ -244,6 +244,14 @@ class WeightBank:
         # (sdmi_wgrad_group) once their tiles can fill the chip -- see queue_wgrad()
         self.group_wgrad = os.environ.get('SDMI_WGRAD_GROUP', '0') != '0'
         self._wq, self._wq_keep, self._wq_items, self._wq_bytes = [], [], 0, 0
+        # ... and the exact-fp32 problems of the Slot Attention / predictor layers (M = images x slots rows: 9 - 36
+        # workgroups and ~20 us each, ~25 of them per step, every one behind its own cross-stream edge): queued and
+        # launched 16 at a time (queue_wgrad32).  Off: the region of the step it shortens (Slot Attention backward:
+        # 930 -> 707 us of wall time in the launch list) is not what bounds the step -- the side streams' backlog of
+        # large weight gradients fills the idle CUs of that region either way -- rotated same-box A/B 26.63 / 26.87 /
+        # 26.75 ms off, 26.73 / 26.95 / 26.91 on (profiles/r05_pp_ablation.txt)
+        self.group_wgrad32 = os.environ.get('SDMI_WGRAD_GROUP32', '0') != '0'
+        self._wq32, self._wq32_keep = [], []
         self.defer_colsum = os.environ.get('SDMI_DEFER_COLSUM', '1') != '0'
         # data gradient + weight gradient of a layer in ONE launch on the main stream (sdmi_bwd_pair):
         # no side-stream fork / join per layer, the M-split partials of a layer are folded by extra
@@ -317,6 +325,53 @@ class WeightBank:
         self.ensure_join()
         if len(self._wq) >= self.WQ_MAX or self._wq_items >= self.WQ_ITEMS or self._wq_bytes >= self.WQ_BYTES:
             self.flush_wgrad()
+
+    def queue_wgrad32(self, kw, keep):
+        """Queue one small fp32 1x1 / linear problem (kw = sdmi_wgrad fields, splits = 1: written straight into dw).
+        Launched when 16 are queued, when a parameter comes again (Slot Attention iterations: accumulation order) and
+        at the end of the backward pass (join) -- all on ONE side stream, so that groups touching the same parameter
+        stay ordered."""
+        if any(q['dw'] == kw['dw'] for q in self._wq32):
+            self.flush_wgrad32()
+        self._wq32.append(kw)
+        self._wq32_keep.extend(keep)
+        self.ensure_join()
+        if len(self._wq32) >= self.WQ_MAX:
+            self.flush_wgrad32()
+
+    def flush_wgrad32(self):
+        if not self._wq32:
+            return
+        q, keep = self._wq32, self._wq32_keep
+        self._wq32, self._wq32_keep = [], []
+        import ctypes
+        arr = (_lib.CSTRUCT['SdmiWgradArgs'] * len(q))()
+        flops = 0.0
+        for a, kw in zip(arr, q):
+            for k, v in kw.items():
+                setattr(a, k, v)
+            a.splits = 1
+            flops += 2.0 * kw['M'] * kw['N'] * kw['K']
+        side = self.side_stream('wgrad-group-f32')
+        if side is not None:
+            ev = torch.cuda.Event()
+            ev.record()
+            side.wait_event(ev)
+            for kw in q:             # an earlier launch into one of these destinations on ANOTHER side stream goes first
+                for d in (kw['dw'], kw.get('dbias')):
+                    prev = self._side_dst.get(d) if d else None
+                    if prev is not None and prev is not side:
+                        side.wait_stream(prev)
+        else:
+            self._after_side_writers(*[kw['dw'] for kw in q], *[kw['dbias'] for kw in q if kw.get('dbias')])
+        with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+            call('sdmi_wgrad_group', _st(), problems=ctypes.addressof(arr), n=len(q), _meta=dict(flops=flops))
+        if side is not None:
+            for kw in q:
+                self._side_dst[kw['dw']] = side
+                if kw.get('dbias'):
+                    self._side_dst[kw['dbias']] = side
+        self._pending.append(tuple(keep))
 
     def flush_wgrad(self):
         if not self._wq:
@@ -500,6 +555,7 @@ class WeightBank:
     def join(self):
         self.flush_pending_fold()
         self.flush_wgrad()
+        self.flush_wgrad32()
         self.flush_colsum()
         for side in self._sides:
             torch.cuda.current_stream().wait_stream(side)
@@ -1453,7 +1509,15 @@ class GemmFn(torch.autograd.Function):
                 splits = halo_splits
         bdst = _grads_of(wb, bnames) if bnames is not None else None
         lda = Cin if is_conv else x.stride(-2)
-        if (wb.group_wgrad and dt == torch.bfloat16 and kh == 1 and kw == 1 and stride == 1 and not ups
+        if (wb.group_wgrad32 and dt == torch.float32 and kh == 1 and kw == 1 and stride == 1 and not ups
+                and pad[0] == 0 and pad[2] == 0 and direct and (bnames is None or bdst is not None) and M <= 16 * mt
+                and Cin % 4 == 0 and lda % 4 == 0 and ldy % 4 == 0 and ((N + 63) // 64) * ((K + 63) // 64) <= 64):
+            # small exact-fp32 problem (Slot Attention, predictor): queued for a grouped launch
+            wb.flush_pending_fold((_p(dst), _p(bdst)))
+            wb.queue_wgrad32(dict(a=_p(x), dy=_p(dy), dw=_p(dst), dbias=_p(bdst), dtype=_DT[dt], M=M, N=N, K=K, lda=lda,
+                                  ldy=ldy, B=B, H=H, W=W_, Cin=Cin, Ho=Ho, Wo=Wo, KH=1, KW=1, stride=1, pad_t=0,
+                                  pad_l=0, ups=0, accumulate=1), (x, dy))
+        elif (wb.group_wgrad and dt == torch.bfloat16 and kh == 1 and kw == 1 and stride == 1 and not ups
                 and pad[0] == 0 and pad[2] == 0 and N > 64 and K > 64 and direct
                 and (bnames is None or bdst is not None) and (M + 128) * max(lda, ldy) * 2 < (1 << 31)):
             # 1x1 / linear: queued for a grouped launch with the block's other weight gradients

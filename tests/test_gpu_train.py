@@ -713,6 +713,51 @@ def test_wgrad_group_matches_single_launches():
         _lib.call('sdmi_wgrad_group', st, problems=ctypes.addressof(bad), n=1)
 
 
+def test_wgrad_group_fp32_matches_single_launches():
+    """sdmi_wgrad_group with exact-fp32 problems (the Slot Attention / predictor layers: M = images x slots rows, any
+    N / K, with and without bias, one with M-splits): one launch equals the single-problem launches bit for bit and
+    torch's fp32 result to 1e-5; mixing dtypes in a group is refused."""
+    import ctypes
+    from slotdiffusion_amd import _lib
+    g = torch.Generator().manual_seed(12)
+    shapes = [(448, 192, 192, True, 1), (448, 576, 192, True, 1), (448, 192, 384, False, 1), (448, 384, 192, True, 1),
+              (240, 768, 192, True, 1), (100, 64, 72, False, 1), (1000, 200, 136, True, 2), (448, 1024, 192, True, 1)]
+    st = torch.cuda.current_stream().cuda_stream
+    probs, refs, keep = [], [], []
+    for M, N, K, bias, splits in shapes:
+        x = torch.randn(M, K, generator=g).cuda()
+        dy = (torch.randn(M, N, generator=g) / 8).cuda()
+        init = torch.randn(N, K, generator=g).cuda()
+        binit = torch.randn(N, generator=g).cuda()
+        ws = torch.empty(splits * (N * K + N), device='cuda')
+        kw = dict(a=x.data_ptr(), dy=dy.data_ptr(), dtype=_lib.F32, M=M, N=N, K=K, lda=K, ldy=N, B=M, H=1,
+                  W=1, Cin=K, Ho=1, Wo=1, KH=1, KW=1, stride=1, pad_t=0, pad_l=0, ups=0, splits=splits,
+                  accumulate=1, workspace=ws.data_ptr())
+        outs = [(init.clone(), binit.clone()) for _ in range(2)]           # [0]: single launches, [1]: grouped
+        _lib.call('sdmi_wgrad', st, dw=outs[0][0].data_ptr(), dbias=(outs[0][1].data_ptr() if bias else 0), **kw)
+        probs.append(dict(kw, dw=outs[1][0].data_ptr(), dbias=(outs[1][1].data_ptr() if bias else 0)))
+        refs.append((init.cpu() + dy.cpu().t() @ x.cpu(), binit.cpu() + dy.cpu().sum(0), outs, bias))
+        keep += [x, dy, ws]
+    arr = (_lib.CSTRUCT['SdmiWgradArgs'] * len(probs))()
+    for a, kw in zip(arr, probs):
+        for k, v in kw.items():
+            setattr(a, k, v)
+    _lib.call('sdmi_wgrad_group', st, problems=ctypes.addressof(arr), n=len(probs))
+    torch.cuda.synchronize()
+    for (rw, rb, outs, bias), sh in zip(refs, shapes):
+        assert torch.equal(outs[0][0], outs[1][0]), sh
+        assert float((outs[1][0].cpu() - rw).norm() / rw.norm()) < 1e-5, sh
+        if bias:
+            assert torch.equal(outs[0][1], outs[1][1]), sh
+            assert float((outs[1][1].cpu() - rb).norm() / rb.norm()) < 1e-5, sh
+    mixed = (_lib.CSTRUCT['SdmiWgradArgs'] * 2)()
+    for a, kw in zip(mixed, [probs[0], dict(probs[1], dtype=_lib.BF16)]):
+        for k, v in kw.items():
+            setattr(a, k, v)
+    with pytest.raises(_lib.SdmiError):
+        _lib.call('sdmi_wgrad_group', st, problems=ctypes.addressof(mixed), n=2)
+
+
 @pytest.mark.parametrize('case', [
     # (B, H, Cin, Cout, k, bias, residual, splits)   H = 0: linear with B rows
     (1024, 0, 512, 512, 1, True, False, 1), (1000, 0, 384, 1536, 1, False, True, 3),
