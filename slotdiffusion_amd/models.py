@@ -135,6 +135,14 @@ class LDM(_Owned):
                   n=hi - lo, one_minus_decay=float(np.float32(1.0) - decay))
 
     # -- a7/a8 ---------------------------------------------------------------------------
+    x0_prefetched = None
+
+    def encode_x0(self, img):
+        """Frozen VQ-VAE encode of a batch of images -> x0 [B,h,w,4] fp32 (ldm.py:61-63, under no_grad)."""
+        r = self.root
+        with torch.no_grad():
+            return engine.vae_encode(r.K(), r._to_nhwc(img), r.ed, scale_factor=r.z_scale)
+
     def loss_function(self, data_dict, t=None, noise=None):
         """ldm.py:59-83; t / noise may be supplied (fixtures) or are drawn like the reference.
         Records the autograd graph (HIP backward kernels) when `slots` requires grad."""
@@ -143,7 +151,9 @@ class LDM(_Owned):
         B = img.shape[0]
         train_draw = bool(r.training and torch.is_grad_enabled())    # (read before the no_grad block below)
         with torch.no_grad():
-            x0 = engine.vae_encode(r.K(), r._to_nhwc(img), r.ed, scale_factor=r.z_scale)
+            # (optim.GraphedTrainStep(prefetch=True) encodes the batch ahead of the step -- the VQ-VAE is frozen, the
+            #  latents depend on the images alone -- and hands them over here)
+            x0 = self.x0_prefetched if self.x0_prefetched is not None else self.encode_x0(img)
             tf = None
             if t is None and noise is None:
                 # the reference's two draws (ldm.py:65-69) + the schedule gathers in ONE launch of
@@ -599,6 +609,11 @@ class SADiffusion(SlotModelBase):
         slots, masks = self.encode(data_dict['img'])
         return {'masks': masks, 'slots': slots}
 
+    def prefetch_latents(self, data_dict):
+        """x0 of the batch's images, as calc_train_loss would encode them (frozen VQ-VAE: a function of the images
+        alone, so a training loop may compute it ahead of the step)."""
+        return self.dm_decoder.encode_x0(data_dict['img'])
+
     def calc_train_loss(self, data_dict, out_dict):
         """sa_diffusion.py:206-213."""
         ddpm_dict = {'img': data_dict['img'], 'slots': out_dict['slots']}
@@ -683,6 +698,9 @@ class SAViDiffusion(SADiffusion):
     def encode(self, img, prev_slots=None):
         """savi_diffusion.py:169-216: img [B,T,3,H,W] -> slots [B,T,N,D], masks [B,T,N,*,*]."""
         return _encode_clip(self, img, prev_slots)
+
+    def prefetch_latents(self, data_dict):
+        return self.dm_decoder.encode_x0(data_dict['img'].flatten(0, 1))
 
     def calc_train_loss(self, data_dict, out_dict):
         """savi_diffusion.py:252-264: the LDM sees the B*T frames as independent images."""

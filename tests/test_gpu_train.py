@@ -186,16 +186,19 @@ def test_graphed_train_step_matches_eager():
     img = C.make_inputs(2)[0].cuda()
     batch = dict(img=img, t=G['t'].cuda(), noise=G['noise'].cuda())
     finals, losses = [], []
-    for graphed in (False, True):
+    for graphed in (False, True, 'prefetch'):
         m = _model(torch.float32)
         m.train()
         opt = FusedAdam(m, lr=1e-4, dec_lr=2e-4, clip_grad=1.0, total_steps=50, warmup_pct=0.2)
         ls = []
         if graphed:
-            gs = GraphedTrainStep(m, opt, batch)       # (its warm-up passes are rolled back)
+            # 'prefetch': the frozen VQ-VAE encode of the next batch runs under this step's update graph; the third
+            # call passes no next batch, so the fourth encodes in line -- the trajectory is the same either way
+            gs = GraphedTrainStep(m, opt, batch, prefetch=(graphed == 'prefetch'))       # (its warm-up passes are rolled back)
             assert opt.step_count == 0 and int(opt.step_dev) == 0
-            for _ in range(4):
-                ls.append(float(gs(batch)))
+            assert gs.prefetch == (graphed == 'prefetch') and m.dm_decoder.x0_prefetched is None
+            for i in range(4):
+                ls.append(float(gs(batch, next_batch=(batch if (graphed == 'prefetch' and i != 2) else None))))
         else:
             for _ in range(4):
                 opt.zero_grad()
@@ -213,6 +216,7 @@ def test_graphed_train_step_matches_eager():
     _dump()
     assert diff == 0.0
     assert losses[0] == losses[1]
+    assert float((finals[0] - finals[2]).abs().max()) == 0.0 and losses[0] == losses[2]
     # dropout on: the in-graph seed word advances, so replays differ
     m = _model(torch.float32)
     m.train_dropout = 0.1
