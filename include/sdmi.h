@@ -479,6 +479,62 @@ typedef struct {
 } SdmiStBlockArgs;
 int sdmi_st_block(const SdmiStBlockArgs* a, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Training twin of the fused SpatialTransformer block (bf16): the forward pass of
+ * SpatialTransformer.forward / BasicTransformerBlock._forward / CrossAttention.forward / FeedForward
+ * (video_based/models/unet/attention.py:297-308, 247-251, 182-206, 44-65) in TWO launches that also store
+ * what the backward pass reads -- instead of ~14 launches of sdmi_groupnorm / sdmi_igemm / sdmi_layernorm /
+ * sdmi_attention per block.  Differences to sdmi_st_block (inference): plain weights (no LayerNorm fold, no
+ * ff.net.2 / proj_out merge: the weights change every step), LayerNorm computed explicitly on the fp32
+ * residual stream, slot cross-attention explicit (q projection, softmax over the slots per head, output
+ * projection: gradients reach the slot keys / values).
+ *   x [B][S][C] block input; out [B][S][C] block output.
+ *   saved for backward (all bf16 [B][S][.] unless noted):
+ *     hgn  = GroupNorm(x)                          gn_stats [B][32][2] fp32 (mean, rstd)
+ *     tok  = proj_in(hgn)            n1 = LN1(tok)  st1 [B*S][2] fp32 (mean, rstd)
+ *     qkv  [B][S][3C] = n1 Wqkv^T    a1 = self-attention output, lse1 [B][heads][S] fp32
+ *     x1   = a1 Wo^T + bo + tok      n2 = LN2(x1)   st2
+ *     q2   = n2 Wq2^T                a2 = slot cross-attention output, lse2 [B][heads][S] fp32
+ *     x2   = a2 Wo2^T + bo2 + x1     n3 = LN3(x2)   st3
+ *     h    [B][S][8C] = n3 W1^T + b1 (value | gate) g [B][S][4C] = value * gelu(gate)
+ *     x3   = g Wff2^T + bff2 + x2    out = x3 Wpo^T + bpo + x
+ *   kv2 [B][slots][ldkv] bf16: slot keys in columns [0, C), values in [C, 2C) (attn2.to_k / to_v of the context).
+ *   wstream_a / wstream_b: the block's bf16 weights as per-wave unit streams (sdmi_st_pack, re-packed after
+ *     every optimiser step): A = [proj_in | to_q | to_k | to_v], B = [attn1.to_out | attn2.to_q | attn2.to_out |
+ *     per hidden chunk of 128: ff.net.0.proj value rows, gate rows, ff.net.2 k-chunk | proj_out].
+ *   fp32 vectors straight from the parameter arena: gn_gamma / gn_beta, b_in, ln{1,2,3}_g / _b, b_o, b_o2,
+ *     b_ff1 [8C], b_ff2, b_po.
+ *   C = 256 or 384; S a multiple of `rows` (64 or 32), <= 256; slots <= 16; phase 0 = both, 1 = A, 2 = B.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  const void* x; void* out;
+  void* hgn; float* gn_stats;
+  void* tok; void* n1; float* st1; void* qkv;
+  void* a1; float* lse1;
+  void* x1; void* n2; float* st2;
+  void* q2; void* a2; float* lse2;
+  void* x2; void* n3; float* st3;
+  void* h; void* g; void* x3;
+  const void* kv2; int ldkv;
+  const void* wstream_a; const void* wstream_b;
+  const float* gn_gamma; const float* gn_beta; const float* b_in;
+  const float* ln1_g; const float* ln1_b; const float* b_o;
+  const float* ln2_g; const float* ln2_b; const float* b_o2;
+  const float* ln3_g; const float* ln3_b; const float* b_ff1; const float* b_ff2; const float* b_po;
+  int B, S, C, slots, phase, rows;
+  float gn_eps, ln_eps, attn_scale;
+} SdmiStTrainArgs;
+int sdmi_st_train_fwd(const SdmiStTrainArgs* a, void* stream);
+
+/* Weight units of the fused SpatialTransformer kernels from the (bf16) parameter arena: unit u = the XOR-swizzled
+ * LDS image of 16 rows x 64 k of a matrix (physical 16-byte chunk p of row r holds logical chunk p ^ ((r >> 1) & 7)),
+ * element (r, k) read at src + 2 * (r * rs + k * cs) bytes -- cs = 1: a row-major weight; rs = 1: its transpose (the
+ * data-gradient streams).  `descs`: DEVICE array of n_units descriptors; one launch re-packs every stream of a model
+ * after an optimiser step (inside the captured train step). */
+typedef struct { const void* src; void* dst; int rs; int cs; } SdmiStPackDesc;
+typedef struct { const void* descs; int n_units; } SdmiStPackArgs;
+int sdmi_st_pack(const SdmiStPackArgs* a, void* stream);
+
 /* Folded slot cross-attention of one transformer block in ONE launch (bf16 inference; attention.py:182-206,
  * 247-251: norm2 -> CrossAttention(slots) -> to_out + residual), per image b with the operands of
  * kern.Kern.cross_prepare (the slot keys folded into the query projection, the values into the output projection):

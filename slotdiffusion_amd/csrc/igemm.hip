@@ -977,7 +977,7 @@ int dispatch(const SdmiGemmArgs& p, hipStream_t st, bool plan_only = false) {
       const char* e = getenv("SDMI_IGEMM_DMA");
       dma_env = e ? atoi(e) : SDMI_IGEMM_DMA;
     }
-    const bool dma_ok = sizeof(T) != 1 && !p.a2 && dma_env && wide && kbytes >= 8 * 128 && split_k == 1 && p.N > 64 && fits31 &&
+    const bool dma_ok = sizeof(T) != 1 && !p.a2 && !p.parity4 && dma_env && wide && kbytes >= 8 * 128 && split_k == 1 && p.N > 64 && fits31 &&
                         (is1x1 || (plain && p.Cin % (128 / (int)sizeof(T)) == 0)) && p.KH * p.KW <= 32;
     if (dma_ok && dma_env == 3) {
       // default: the 4-stage 128 x 128 LDS-DMA kernel where it measured faster in dependent chains on MI355X

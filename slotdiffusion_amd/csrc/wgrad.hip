@@ -805,7 +805,9 @@ int dispatch_wgrad_bf16(const SdmiWgradArgs& a, hipStream_t st) {
       return launch_wgrad3x3_c64(a, st);
   }
   // ... and for every other 3x3 stride-1 layer on 16 / 32 / 64-column power-of-two images (pairs of 64 output x 64
-  // input channels; the caller sizes `splits` so that pairs x splits fills the chip: kern.py)
+  // input channels; the caller sizes `splits` so that pairs x splits fills the chip: kern.py).  The kernel always
+  // writes M-split partials for the fold behind it, so -- like the 64-channel kernel above -- it takes splits >= 2 only:
+  // splits == 1 means "written straight into dw" at the C ABI and goes to the implicit-GEMM kernel below.
   {
     static int halo = -1;
     if (halo < 0) {
@@ -816,7 +818,7 @@ int dispatch_wgrad_bf16(const SdmiWgradArgs& a, hipStream_t st) {
     const long long hw = (long long)a.H * a.W;
     if (halo && logw && a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad_t == 1 && a.pad_l == 1 && !a.ups && a.H == a.Ho &&
         a.W == a.Wo && a.Cin % 64 == 0 && a.N % 64 == 0 && a.K == 9 * a.Cin && hw % 256 == 0 && (hw & (hw - 1)) == 0 &&
-        a.splits >= 1 && a.M / 256 >= a.splits && (a.N / 64) * (a.Cin / 64) * a.splits >= 128 &&
+        a.splits >= 2 && a.M / 256 >= a.splits && (a.N / 64) * (a.Cin / 64) * a.splits >= 128 &&
         (long long)a.M * (a.lda > a.ldy ? a.lda : a.ldy) < (1ll << 40))
       return logw == 4 ? launch_wgrad3x3_halo<4>(a, st) : (logw == 5 ? launch_wgrad3x3_halo<5>(a, st) : launch_wgrad3x3_halo<6>(a, st));
   }

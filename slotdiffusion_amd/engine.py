@@ -208,6 +208,10 @@ class UNetRunner:
             out = K.st_fused(x, n, heads, kv)
             if out is not None:
                 return out
+        if K.training and hasattr(K, 'st_train'):         # bf16 training: fused forward that keeps what backward reads
+            out = K.st_train(x, n, heads, kv)
+            if out is not None:
+                return out
         # (every residual branch takes an alias of the normalised tensor: its gradient is summed
         # inside the norm's backward kernel)
         h, xres = K.gn_fan(x, n + '.norm', eps=1e-6)

@@ -189,6 +189,28 @@ def st_index_img(C):
     return _st_unit_index(ent)
 
 
+def st_train_units(C):
+    """Unit order of the training kernels' weight streams (csrc/st_train.hip), per wave: lists of
+    (matrix key, first row, first k).  Forward: A = [proj_in | q | k | v], B = [to_out | q2 | to_out2 | per hidden
+    chunk: ff1 value rows, ff1 gate rows, ff2 k-chunk | proj_out]."""
+    NSL, KT, NHC = C // 128, C // 64, C // 32
+    A, Bs = [], []
+    for w in range(8):
+        a = [(m, (w * NSL + s_) * 16, kt * 64) for m in ('in', 'q', 'k', 'v') for kt in range(KT) for s_ in range(NSL)]
+        b = [(m, (w * NSL + s_) * 16, kt * 64) for m in ('o', 'q2', 'o2') for kt in range(KT) for s_ in range(NSL)]
+        for hc in range(NHC):
+            for kt in range(KT):
+                b.append(('ff1', hc * 128 + w * 16, kt * 64))
+                b.append(('ff1', 4 * C + hc * 128 + w * 16, kt * 64))
+            for k2 in range(2):
+                for s_ in range(NSL):
+                    b.append(('ff2', (w * NSL + s_) * 16, hc * 128 + k2 * 64))
+        b += [('po', (w * NSL + s_) * 16, kt * 64) for kt in range(KT) for s_ in range(NSL)]
+        A.append(a)
+        Bs.append(b)
+    return A, Bs
+
+
 def ups_parity_split(w):
     """Nearest-2x upsampling followed by a 3x3 convolution (unet.py:108-121) reads only 2 x 2 DISTINCT input pixels
     per output pixel: output parity (py, px) is a 2 x 2 convolution of the low-resolution input whose taps are sums
@@ -275,6 +297,8 @@ class WeightBank:
         # source view]; one slot of _w8_amax / _w8_inv per operand, in registration order
         self._w8, self._w8_epoch, self._w8_stale, self._w8_table = {}, 0, False, None
         self._w8_amax = self._w8_inv = None
+        # unit streams of the fused SpatialTransformer training kernels: block -> dict(wa, wb, descs, epoch)
+        self._stp, self._stp_epoch, self._stp_stale, self._stp_table = {}, 0, False, None
 
     def anchor_for(self, names):
         n = names if isinstance(names, str) else names[0]
@@ -577,6 +601,7 @@ class WeightBank:
         self.cache = keep
         self._wd_stale = True
         self._w8_stale = True
+        self._stp_stale = True
 
     def _frozen_names(self):
         fz = getattr(self, '_fz', None)
@@ -708,6 +733,9 @@ class WeightBank:
             self._w8[name] = ent
             self._w8_table = None             # new member: rebuild the descriptor table at the next re-quantisation
         # (first use: a one-entry table -- eager only, it copies the table to the device)
+        if torch.cuda.is_current_stream_capturing():
+            raise _lib.SdmiError(f'{name}: first fp8 use of a weight inside a graph capture (its descriptor table is '
+                                 'a host-to-device copy): run the warm-up passes before capturing')
         Desc = _lib.CSTRUCT['SdmiFp8Desc']
         arr = (Desc * 1)()
         blocks = self._fill_desc8(arr[0], ent, 0)
@@ -730,6 +758,9 @@ class WeightBank:
         self._w8_epoch += 1
         items = sorted(self._w8.values(), key=lambda e: e[4])         # slot order = descriptor order
         if self._w8_table is None:
+            if torch.cuda.is_current_stream_capturing():
+                raise _lib.SdmiError('fp8 descriptor table rebuilt inside a graph capture (a new fp8 operand was '
+                                     'registered after the warm-up passes)')
             Desc = _lib.CSTRUCT['SdmiFp8Desc']
             arr = (Desc * len(items))()
             blk = 0
@@ -866,6 +897,79 @@ class WeightBank:
                 vec_b = torch.cat([bo, bo2, w1_p.float().sum(1), w1 @ b3 + bb1, wpo @ bff + bpo]).contiguous()
                 self.cache[key] = dict(wa=wa, va=vec_a, wb=wbs, vb=vec_b, C=C)
         return self.cache[key]
+
+    # ---- weight streams of the fused SpatialTransformer TRAINING kernels (sdmi.h: sdmi_st_train_fwd, sdmi_st_pack)
+    def st_train_mats(self, n):
+        """{key: (bf16 operand view [N][K], K)} of block `n` straight out of the shadow arena."""
+        t = n + '.transformer_blocks.0'
+        names = {'in': n + '.proj_in.weight', 'q': t + '.attn1.to_q.weight', 'k': t + '.attn1.to_k.weight',
+                 'v': t + '.attn1.to_v.weight', 'o': t + '.attn1.to_out.0.weight', 'q2': t + '.attn2.to_q.weight',
+                 'o2': t + '.attn2.to_out.0.weight', 'ff1': t + '.ff.net.0.proj.weight', 'ff2': t + '.ff.net.2.weight',
+                 'po': n + '.proj_out.weight'}
+        out = {}
+        for k, nm in names.items():
+            v = self._flat(nm, torch.bfloat16)
+            assert v is not None and v.is_contiguous()
+            out[k] = v
+        return out
+
+    def _st_descs(self, units, mats, dst):
+        """numpy descriptor table (SdmiStPackDesc) of one stream: `units` per wave, destination tensor `dst`."""
+        import numpy as np
+        flat = [u for wave in units for u in wave]
+        arr = np.zeros(len(flat), dtype=np.dtype([('src', '<u8'), ('dst', '<u8'), ('rs', '<i4'), ('cs', '<i4')]))
+        base = dst.data_ptr()
+        for i, (key, r0, k0) in enumerate(flat):
+            m = mats[key]
+            ld = m.shape[1]
+            arr[i] = (m.data_ptr() + 2 * (r0 * ld + k0), base + i * 2048, ld, 1)
+        return arr
+
+    def st_train_streams(self, n):
+        """dict(wa, wb) -- bf16 unit streams of block `n` for sdmi_st_train_fwd.  The streams live in persistent buffers;
+        after an optimiser step (invalidate()) the first request re-packs the streams of ALL registered blocks with
+        one sdmi_st_pack launch (descriptor table on the device: part of the captured train step)."""
+        if self._stp_stale:
+            self._st_pack_all()
+        ent = self._stp.get(n)
+        if ent is not None and ent['epoch'] == self._stp_epoch and ent['shadow'] == self.model.shadow_arena().data_ptr():
+            return ent
+        if torch.cuda.is_current_stream_capturing():
+            raise _lib.SdmiError(f'{n}: first use of a fused training block inside a graph capture (its descriptor '
+                                 'table is a host-to-device copy): run the warm-up passes before capturing')
+        import numpy as np
+        mats = self.st_train_mats(n)
+        C = mats['in'].shape[0]
+        dev = mats['in'].device
+        ua, ub = st_train_units(C)
+        na, nb = sum(len(w) for w in ua), sum(len(w) for w in ub)
+        if ent is None:
+            ent = dict(wa=torch.empty((na * 1024,), dtype=torch.bfloat16, device=dev),
+                       wb=torch.empty((nb * 1024,), dtype=torch.bfloat16, device=dev))
+        ent['descs'] = np.concatenate([self._st_descs(ua, mats, ent['wa']), self._st_descs(ub, mats, ent['wb'])])
+        ent['epoch'], ent['shadow'], ent['C'] = self._stp_epoch, self.model.shadow_arena().data_ptr(), C
+        self._stp[n] = ent
+        self._stp_table = None                      # new member: rebuild the device table at the next re-pack
+        tab = torch.from_numpy(ent['descs'].view(np.uint8).copy()).to(dev)
+        call('sdmi_st_pack', _st(), descs=_p(tab), n_units=len(ent['descs']))
+        ent['_tab'] = tab                            # (kept alive past the launch)
+        return ent
+
+    def _st_pack_all(self):
+        self._stp_stale = False
+        if not self._stp:
+            return
+        self._stp_epoch += 1
+        if self._stp_table is None:
+            if torch.cuda.is_current_stream_capturing():
+                raise _lib.SdmiError('stream descriptor table rebuilt inside a graph capture')
+            import numpy as np
+            arr = np.concatenate([e['descs'] for e in self._stp.values()])
+            dev = next(iter(self._stp.values()))['wa'].device
+            self._stp_table = (torch.from_numpy(arr.view(np.uint8).copy()).to(dev), len(arr))
+        call('sdmi_st_pack', _st(), descs=_p(self._stp_table[0]), n_units=self._stp_table[1])
+        for e in self._stp.values():
+            e['epoch'] = self._stp_epoch
 
     def b(self, names):
         """fp32 bias vector, fused across names (view when adjacent)."""
@@ -1504,8 +1608,8 @@ class GemmFn(torch.autograd.Function):
             # the direct 3x3 kernel on (64 output x 64 input channel) pairs (wgrad.hip: wgrad3x3_halo_kernel): one
             # persistent workgroup per CU -- slots x pairs fills the chip
             pairs = (N // 64) * (Cin // 64)
-            halo_splits = max(1, min(_n_cus(x.device) // pairs, M // 256))
-            if pairs * halo_splits >= 128:
+            halo_splits = min(_n_cus(x.device) // pairs, M // 256)
+            if halo_splits >= 2 and pairs * halo_splits >= 128:        # (the kernel writes partials: never one split)
                 splits = halo_splits
         bdst = _grads_of(wb, bnames) if bnames is not None else None
         lda = Cin if is_conv else x.stride(-2)
@@ -1842,7 +1946,12 @@ class LayerNormFn(torch.autograd.Function):
             dalias = dalias.contiguous()
         if dy is None:
             return dalias, None, None, None, None
-        dy = dy.contiguous()
+        return LayerNormFn.bwd_core(wb, name, x, stats, dy.contiguous(), dalias), None, None, None, None
+
+    @staticmethod
+    def bwd_core(wb, name, x, stats, dy, dalias=None):
+        """dx of y = LayerNorm(x) (+ dalias: the gradient of x's other consumer, summed in the kernel); dgamma / dbeta
+        into the gradient arena (deferred column sums)."""
         C = x.shape[-1]
         rows = x.numel() // C
         nblk = max(1, min(512, rows // 16))
@@ -1857,7 +1966,7 @@ class LayerNormFn(torch.autograd.Function):
              partial=_p(partial), dtype=_DT[x.dtype], rows=rows, C=C, nblk=nblk, accumulate=1,
              dextra=_p(dalias), defer_colsum=int(defer))
         _dbg(f'ln {name}', dy=dy, dx=dx)
-        return dx, None, None, None, None
+        return dx
 
 
 class AttnFn(torch.autograd.Function):
@@ -1880,9 +1989,13 @@ class AttnFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         a, kv, out, lse = ctx.saved_tensors
-        heads, hd = ctx.heads, ctx.hd
+        da, dkv = AttnFn.bwd_core(a, kv, out, lse, dout.contiguous(), ctx.heads, ctx.hd)
+        return da, dkv, None, None
+
+    @staticmethod
+    def bwd_core(a, kv, out, lse, dout, heads, hd=32):
+        """(d q|k|v, None) of self-attention over the fused a = q|k|v, or (dq, d k|v) of cross-attention."""
         C = heads * hd
-        dout = dout.contiguous()
         da = torch.empty_like(a)
         dkv = torch.empty_like(kv) if kv is not None else None
         if kv is None:
@@ -1897,7 +2010,7 @@ class AttnFn(torch.autograd.Function):
              Sq=Sq, Skv=Skv, ldq=q.stride(1), ldk=k.stride(1), ldv=v.stride(1), ldo=out.stride(1),
              scale=hd ** -0.5, head_dim=hd)
         _dbg(f'attn Sq={Sq} Skv={Skv}', dout=dout, da=da, dkv=dkv)
-        return da, dkv, None, None
+        return da, dkv
 
 
 class LongAttnFn(torch.autograd.Function):
@@ -1978,6 +2091,110 @@ class GegluLinearFn(torch.autograd.Function):
              rows=h.numel() // (2 * C), C=C)
         dx = GemmFn.core(wb, x, dh, wname, bname, (0, 0, 1, (0, 0, 0, 0), False), ctx.needs_input_grad[0])[0]
         return dx, None, None, None, None
+
+
+def _gn_bwd_plain(wb, name, x, stats, dy, extras=()):
+    """dx of y = GroupNorm(x) (no activation / residual / dropout) + the gradients of x's other consumers."""
+    B, C = x.shape[0], x.shape[-1]
+    HW = x.numel() // (B * C)
+    G = 32
+    nsplit = max(1, min(16, HW // 64))
+    partial = torch.empty((B * nsplit * C * 2 + B * G * 2,), dtype=torch.float32, device=x.device)
+    dx = torch.empty_like(x)
+    dg, db = _grads_of(wb, name + '.weight'), _grads_of(wb, name + '.bias')
+    geo = dict(dtype=_DT[x.dtype], B=B, HW=HW, C=C, groups=G, nsplit=nsplit)
+    defer = wb.defer_colsum
+    if defer:
+        wb.queue_colsum(partial, _lib.query('sdmi_groupnorm_bwd_entries', **geo), C, db, dg)
+    call('sdmi_groupnorm_bwd', _st(), x=_p(x), dy=_p(dy), dx=_p(dx), gamma=_p(wb.f(name + '.weight')),
+         beta=_p(wb.f(name + '.bias')), stats=_p(stats), dgamma=_p(dg), dbeta=_p(db), partial=_p(partial),
+         defer_colsum=int(defer), **geo, act=0, residual=0, dresidual=0, accumulate=1,
+         dextra0=(_p(extras[0]) if extras else 0), dextra1=(_p(extras[1]) if len(extras) > 1 else 0))
+    return dx
+
+
+_ST_TRAIN = os.environ.get('SDMI_ST_TRAIN', '1') != '0'        # fused training form of the SpatialTransformer block
+_ST_TRAIN_MIN_WGS = int(os.environ.get('SDMI_ST_TRAIN_MIN_WGS', '96'))
+
+
+class StBlockFn(torch.autograd.Function):
+    """A whole SpatialTransformer block of the denoiser in training (attention.py:297-308, 247-251, 182-206, 44-65):
+    forward = TWO launches (sdmi.h: sdmi_st_train_fwd) that also store what the backward pass reads.
+    x [B,H,W,C] bf16, kv [B,N,2C] bf16 (attn2.to_k | to_v of the slots) -> out [B,H,W,C]."""
+
+    SAVED = ('hgn', 'gn_stats', 'tok', 'n1', 'st1', 'qkv', 'a1', 'lse1', 'x1', 'n2', 'st2', 'q2', 'a2', 'lse2', 'x2', 'n3',
+             'st3', 'h', 'g', 'x3')
+
+    @staticmethod
+    def run_forward(wb, x, kv, n, heads, rows):
+        """-> (out, {saved tensors}).  Plain launch (also what the tests drive)."""
+        B, H, W, C = x.shape
+        S = H * W
+        dev, bf, f32 = x.device, torch.bfloat16, torch.float32
+        e = lambda *sh: torch.empty(sh, dtype=bf, device=dev)
+        f = lambda *sh: torch.empty(sh, dtype=f32, device=dev)
+        sv = dict(hgn=e(B, S, C), gn_stats=f(B, 32, 2), tok=e(B, S, C), n1=e(B, S, C), st1=f(B * S, 2), qkv=e(B, S, 3 * C),
+                  a1=e(B, S, C), lse1=f(B, heads, S), x1=e(B, S, C), n2=e(B, S, C), st2=f(B * S, 2), q2=e(B, S, C),
+                  a2=e(B, S, C), lse2=f(B, heads, S), x2=e(B, S, C), n3=e(B, S, C), st3=f(B * S, 2), h=e(B, S, 8 * C),
+                  g=e(B, S, 4 * C), x3=e(B, S, C))
+        out = torch.empty_like(x)
+        st = wb.st_train_streams(n)
+        t = n + '.transformer_blocks.0'
+        F_ = lambda k: _p(wb.f(k))
+        flops = 2.0 * B * S * C * C * 20 + 4.0 * B * S * S * C + 4.0 * B * S * kv.shape[1] * C
+        call('sdmi_st_train_fwd', _st(), x=_p(x), out=_p(out), **{k: _p(v) for k, v in sv.items()},
+             kv2=_p(kv), ldkv=kv.stride(1), wstream_a=_p(st['wa']), wstream_b=_p(st['wb']),
+             gn_gamma=F_(n + '.norm.weight'), gn_beta=F_(n + '.norm.bias'), b_in=F_(n + '.proj_in.bias'),
+             ln1_g=F_(t + '.norm1.weight'), ln1_b=F_(t + '.norm1.bias'), b_o=F_(t + '.attn1.to_out.0.bias'),
+             ln2_g=F_(t + '.norm2.weight'), ln2_b=F_(t + '.norm2.bias'), b_o2=F_(t + '.attn2.to_out.0.bias'),
+             ln3_g=F_(t + '.norm3.weight'), ln3_b=F_(t + '.norm3.bias'), b_ff1=F_(t + '.ff.net.0.proj.bias'),
+             b_ff2=F_(t + '.ff.net.2.bias'), b_po=F_(n + '.proj_out.bias'), B=B, S=S, C=C, slots=kv.shape[1], phase=0,
+             rows=rows, gn_eps=1e-6, ln_eps=1e-5, attn_scale=32.0 ** -0.5,
+             _meta=dict(flops=flops, bytes=2.0 * B * S * C * 23 + 2.0 * 36.5 * C * C))
+        return out, sv
+
+    @staticmethod
+    def forward(ctx, x, kv, anchor, wb, n, heads, rows):
+        out, sv = StBlockFn.run_forward(wb, x, kv, n, heads, rows)
+        ctx.save_for_backward(x, kv, *[sv[k] for k in StBlockFn.SAVED])
+        ctx.cfg = (wb, n, heads, rows)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, kv = ctx.saved_tensors[:2]
+        sv = dict(zip(StBlockFn.SAVED, ctx.saved_tensors[2:]))
+        wb, n, heads, rows = ctx.cfg
+        dx, dkv = StBlockFn.backward_layers(wb, n, heads, x, kv, sv, dout.contiguous())
+        return dx, dkv, None, None, None, None, None
+
+    @staticmethod
+    def backward_layers(wb, n, heads, x, kv, sv, dout):
+        """The block's backward pass as per-layer launches (pair launches of the linear layers, LayerNorm / attention /
+        GEGLU / GroupNorm backward kernels) on the tensors the fused forward stored."""
+        t = n + '.transformer_blocks.0'
+        lin = (0, 0, 1, (0, 0, 0, 0), False)
+        B, S, C = sv['tok'].shape
+        do = dout.view(B, S, C)
+        core = lambda a, dy, wn, bn, dal=None: GemmFn.core(wb, a, dy, wn, bn, lin, True, dal)[0]
+        dx3 = core(sv['x3'], do, n + '.proj_out.weight', n + '.proj_out.bias')
+        dg = core(sv['g'], dx3, t + '.ff.net.2.weight', t + '.ff.net.2.bias')
+        h = sv['h']
+        dh = torch.empty_like(h)
+        call('sdmi_geglu_bwd', _st(), h=_p(h), dy=_p(dg), dh=_p(dh), dtype=_DT[h.dtype], rows=B * S, C=4 * C)
+        dn3 = core(sv['n3'], dh, t + '.ff.net.0.proj.weight', t + '.ff.net.0.proj.bias')
+        dx2 = LayerNormFn.bwd_core(wb, t + '.norm3', sv['x2'], sv['st3'], dn3, dx3)
+        da2 = core(sv['a2'], dx2, t + '.attn2.to_out.0.weight', t + '.attn2.to_out.0.bias')
+        dq2, dkv = AttnFn.bwd_core(sv['q2'], kv, sv['a2'], sv['lse2'], da2, heads)
+        dn2 = core(sv['n2'], dq2, t + '.attn2.to_q.weight', None)
+        dx1 = LayerNormFn.bwd_core(wb, t + '.norm2', sv['x1'], sv['st2'], dn2, dx2)
+        da1 = core(sv['a1'], dx1, t + '.attn1.to_out.0.weight', t + '.attn1.to_out.0.bias')
+        dqkv, _ = AttnFn.bwd_core(sv['qkv'], None, sv['a1'], sv['lse1'], da1, heads)
+        dn1 = core(sv['n1'], dqkv, (t + '.attn1.to_q.weight', t + '.attn1.to_k.weight', t + '.attn1.to_v.weight'), None)
+        dtok = LayerNormFn.bwd_core(wb, t + '.norm1', sv['tok'], sv['st1'], dn1, dx1)
+        dhgn = core(sv['hgn'], dtok, n + '.proj_in.weight', n + '.proj_in.bias')
+        dx = _gn_bwd_plain(wb, n + '.norm', x.view(B, S, C), sv['gn_stats'], dhgn, (do,))
+        return dx.view_as(x), dkv
 
 
 class ActFn(torch.autograd.Function):
@@ -2444,6 +2661,21 @@ class KernGrad(Kern):
         """[scale] when the norm's only reader is a convolution that multiplies e4m3fn operands (fp8 configuration):
         the norm writes that operand next to its bf16 output -- no quantisation launch in front of the GEMM."""
         return [FP8_ACT_SCALE] if (for_conv and self.fp8_ok(x, for_conv, 9, False)) else None
+
+    def st_train(self, x, n, heads, kv):
+        """The SpatialTransformer block `n` through the fused training kernels (StBlockFn), or None when the block
+        does not qualify (the caller runs the per-layer launches): bf16, C = 256 / 384, 32 | tokens per image <= 256,
+        <= 16 slots, a grid that fills a good part of the chip."""
+        B, H, W, C = x.shape
+        S = H * W
+        if not (_ST_TRAIN and torch.is_tensor(kv) and x.dtype == torch.bfloat16 and kv.dtype == torch.bfloat16 and
+                C in (256, 384) and heads * 32 == C and S % 32 == 0 and S <= 256 and kv.shape[1] <= 16 and
+                kv.shape[-1] == 2 * C and kv.stride(-1) == 1 and x.is_contiguous()):
+            return None
+        rows = _ST_ROWS or (64 if (S % 64 == 0 and B * S // 64 >= 192) else 32)
+        if S % rows or B * S // rows < _ST_TRAIN_MIN_WGS:
+            return None
+        return StBlockFn.apply(x, kv, self.wb.anchor_for(n), self.wb, n, heads, rows)
 
     def ff_out_proj(self, g, tres, xres, t, n):
         tok = self.linear(g, t + '.ff.net.2.weight', t + '.ff.net.2.bias', residual=tres)

@@ -99,8 +99,10 @@ class FusedAdam:
         self.set_lr_for_next_step()
 
     def grad_norm(self):
-        """Global L2 norm of the last step's gradients (syncs; diagnostics only)."""
-        return float(self.partial.double().sum().sqrt())
+        """Global L2 norm of the last step's gradients (syncs; diagnostics only).  Under data parallel `partial` holds
+        the squared norm of the SUM over ranks (1 / world is applied inside the kernels): scaled back here, so the value
+        is the averaged gradient's norm on every world size."""
+        return float(self.partial.double().sum().sqrt()) * getattr(self, '_last_gscale', 1.0)
 
     def set_lr_for_next_step(self):
         """Host side of the schedule: refresh the device lr scalars (outside any graph)."""
@@ -122,6 +124,7 @@ class FusedAdam:
         grad_src / grad_scale (data parallel, parallel.GradReducer): the gradients are read from `grad_src` (the
         fp32 arena, or the bf16 wire buffer with the same offsets) as the all-reduce left them -- the SUM over ranks --
         and multiplied by `grad_scale` = 1 / world inside the kernels; the clip sees the norm of the scaled gradients."""
+        self._last_gscale = float(grad_scale)
         m = self.model
         g = m.grad_arena() if grad_src is None else grad_src
         assert g.numel() >= self.n_train and g.dtype in (torch.float32, torch.bfloat16)

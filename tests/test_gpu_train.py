@@ -513,6 +513,33 @@ def test_wgrad3x3_halo_kernel(case):
     assert torch.equal(run(splits)[0], dw)          # deterministic fold
 
 
+def test_wgrad3x3_one_split_writes_the_gradient():
+    """splits = 1 means 'written straight into dw' at the C ABI.  The direct channel-pair kernel always leaves M-split
+    partials for a fold, so a one-split problem with >= 128 channel pairs (512 -> 1024 channels: 128 pairs) must NOT
+    reach it (weight and bias gradients were silently lost on exactly this shape)."""
+    from slotdiffusion_amd import _lib
+    from slotdiffusion_amd.kern import _DT
+    B, Cin, Cout, H = 1, 512, 1024, 16
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(B, H, H, Cin, generator=g).to(dtype)
+    dy = torch.randn(B, H, H, Cout, generator=g).to(dtype)
+    xd, dyd = x.cuda(), dy.cuda()
+    M, K = B * H * H, 9 * Cin
+    assert (Cout // 64) * (Cin // 64) >= 128 and M // 256 >= 1
+    dw = torch.full((Cout, K), 7.0, device='cuda')
+    db = torch.full((Cout,), 7.0, device='cuda')
+    _lib.call('sdmi_wgrad', torch.cuda.current_stream().cuda_stream, a=xd.data_ptr(), dy=dyd.data_ptr(),
+              dw=dw.data_ptr(), dbias=db.data_ptr(), workspace=0, dtype=_DT[dtype], M=M, N=Cout, K=K, lda=Cin, ldy=Cout,
+              B=B, H=H, W=H, Cin=Cin, Ho=H, Wo=H, KH=3, KW=3, stride=1, pad_t=1, pad_l=1, ups=0, splits=1, accumulate=0)
+    xp = F.pad(x.float().permute(0, 3, 1, 2), (1, 1, 1, 1))
+    cols = F.unfold(xp, 3).view(B, Cin, 9, H * H)                          # [B, Cin, tap, pixel]
+    ref = torch.einsum('bpn,bctp->ntc', dy.float().view(B, H * H, Cout), cols).reshape(Cout, K)
+    assert float((dw.cpu() - ref).norm() / ref.norm()) <= 2e-3
+    ref_db = dy.float().sum((0, 1, 2))
+    assert float((db.cpu() - ref_db).norm() / ref_db.norm()) <= 1e-4
+
+
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize('rows,C', [(100, 192), (1000, 256), (333, 384), (64, 512), (50, 1024),
                                     (7, 64)])
