@@ -529,8 +529,9 @@ def test_wgrad3x3_one_split_writes_the_gradient():
     assert (Cout // 64) * (Cin // 64) >= 128 and M // 256 >= 1
     dw = torch.full((Cout, K), 7.0, device='cuda')
     db = torch.full((Cout,), 7.0, device='cuda')
+    ws = torch.empty(Cout * K + Cout, device='cuda')          # (one slot: the entry point wants a workspace pointer)
     _lib.call('sdmi_wgrad', torch.cuda.current_stream().cuda_stream, a=xd.data_ptr(), dy=dyd.data_ptr(),
-              dw=dw.data_ptr(), dbias=db.data_ptr(), workspace=0, dtype=_DT[dtype], M=M, N=Cout, K=K, lda=Cin, ldy=Cout,
+              dw=dw.data_ptr(), dbias=db.data_ptr(), workspace=ws.data_ptr(), dtype=_DT[dtype], M=M, N=Cout, K=K, lda=Cin, ldy=Cout,
               B=B, H=H, W=H, Cin=Cin, Ho=H, Wo=H, KH=3, KW=3, stride=1, pad_t=1, pad_l=1, ups=0, splits=1, accumulate=0)
     xp = F.pad(x.float().permute(0, 3, 1, 2), (1, 1, 1, 1))
     cols = F.unfold(xp, 3).view(B, Cin, 9, H * H)                          # [B, Cin, tap, pixel]
