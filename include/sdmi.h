@@ -526,6 +526,29 @@ typedef struct {
 } SdmiStTrainArgs;
 int sdmi_st_train_fwd(const SdmiStTrainArgs* a, void* stream);
 
+/* Backward data path of the block above in three launches (the two attention backward passes run between them as
+ * sdmi_attention_bwd; weight / bias gradients are sdmi_wgrad launches on the tensors stored here):
+ *   phase 1 (B1): dout -> proj_out' -> dx3 ; ff.net.2' -> GEGLU' (h) -> dh ; ff.net.0.proj' -> LN3' (x2, st3) + dx3 -> dx2 ;
+ *                 attn2.to_out' -> da2
+ *   phase 2 (B2): dq2 -> attn2.to_q' -> LN2' (x1, st2) + dx2 -> dx1 ; attn1.to_out' -> da1
+ *   phase 3 (A) : dqkv -> to_q|k|v' -> LN1' (tok, st1) + dx1 -> dtok ; proj_in' -> dhgn   (GroupNorm' = sdmi_groupnorm_bwd)
+ * All row tensors bf16 [B][S][C] (dh [B][S][8C], dqkv [B][S][3C]); ln{1,2,3}_part: [B*S/rows][C] float2 partial column
+ * sums (sum_rows dn * xhat, sum_rows dn) of this launch's workgroups for sdmi_colsum_group (dgamma, dbeta).
+ * wstream_b1 / _b2 / _a: the TRANSPOSED weights as unit streams (sdmi_st_pack with rs = 1):
+ *   b1 = [proj_out^T | per hidden chunk: ff.net.2^T rows, ff.net.0.proj^T value k-chunk, gate k-chunk | attn2.to_out^T],
+ *   b2 = [attn2.to_q^T | attn1.to_out^T],  a = [to_q^T | to_k^T | to_v^T | proj_in^T]. */
+typedef struct {
+  const void* dout; const void* h; const void* x2; const float* st3; const float* ln3_g;
+  void* dx3; void* dh; void* dx2; void* da2; float* ln3_part;
+  const void* dq2; const void* x1; const float* st2; const float* ln2_g;
+  void* dx1; void* da1; float* ln2_part;
+  const void* dqkv; const void* tok; const float* st1; const float* ln1_g;
+  void* dtok; void* dhgn; float* ln1_part;
+  const void* wstream_b1; const void* wstream_b2; const void* wstream_a;
+  int B, S, C, phase, rows;
+} SdmiStTrainBwdArgs;
+int sdmi_st_train_bwd(const SdmiStTrainBwdArgs* a, void* stream);
+
 /* Weight units of the fused SpatialTransformer kernels from the (bf16) parameter arena: unit u = the XOR-swizzled
  * LDS image of 16 rows x 64 k of a matrix (physical 16-byte chunk p of row r holds logical chunk p ^ ((r >> 1) & 7)),
  * element (r, k) read at src + 2 * (r * rs + k * cs) bytes -- cs = 1: a row-major weight; rs = 1: its transpose (the

@@ -719,6 +719,356 @@ __global__ __launch_bounds__(256) void st_pack_kernel(const SdmiStPackDesc* __re
   *reinterpret_cast<uint4*>((char*)d.dst + ch * 16) = v;
 }
 
+// =========================================================================================================
+// backward data path (sdmi_st_train_bwd): three launches around the two attention backward passes
+// =========================================================================================================
+template <int C, int TT>
+struct StTrBwdGeom {
+  static constexpr int ROWS = 16 * TT, NSL = C / 128, KT = C / 64, NHC = C / 32, PITCH = C * 2;
+  static constexpr int Y_BYTES = ROWS * PITCH, G_BYTES = ROWS * 256, RED_BYTES = 8 * ROWS * 8;
+  // phase B1: operand buffer | value-gradient chunk | gate-gradient chunk | LayerNorm partials | rings
+  static constexpr int GV_OFF = Y_BYTES, GG_OFF = GV_OFF + G_BYTES, RED1_OFF = GG_OFF + G_BYTES, RING1_OFF = RED1_OFF + RED_BYTES;
+  static constexpr int D1F = (160 * 1024 - RING1_OFF) / (8 * ST_UNIT);
+  static constexpr int D1 = D1F >= 8 ? 8 : D1F;
+  static_assert(D1 >= 4 && D1 >= NSL + 1, "ring too shallow");
+  static constexpr int SMEM1 = RING1_OFF + 8 * D1 * ST_UNIT;
+  // phases B2 / A: operand buffer | LayerNorm partials | rings
+  static constexpr int RED2_OFF = Y_BYTES, RING2_OFF = RED2_OFF + RED_BYTES;
+  static constexpr int D2F = (160 * 1024 - RING2_OFF) / (8 * ST_UNIT);
+  static constexpr int D2 = D2F >= 8 ? 8 : D2F;
+  static constexpr int SMEM2 = RING2_OFF + 8 * D2 * ST_UNIT;
+  static constexpr int UB1 = 2 * KT * NSL + NHC * (KT + 4 * NSL);      // proj_out^T, chunks (ff2^T, ff1^T value | gate), to_out2^T
+  static constexpr int UB2 = 2 * KT * NSL;                             // to_q2^T, to_out^T
+  static constexpr int UA = 4 * KT * NSL;                              // q^T, k^T, v^T, proj_in^T
+};
+
+// ROWS x C bf16 rows from global memory into the swizzled operand buffer (all 512 threads, 16-byte vectors)
+template <int C, int TT>
+__device__ __forceinline__ void st_rows_global_to_y(const bf16_t* src, int ld, lds_char* Y, int tid) {
+  constexpr int ROWS = 16 * TT, VPR = C / 8, PITCH = 2 * C;
+  static_assert((ROWS * VPR) % 512 == 0, "whole passes");
+  u32x4 v[ROWS * VPR / 512];
+#pragma unroll
+  for (int it = 0; it < ROWS * VPR / 512; ++it) {
+    const int i = tid + it * 512, r = i / VPR, vc = i - r * VPR;
+    v[it] = *reinterpret_cast<const u32x4*>(src + (long long)r * ld + vc * 8);
+  }
+#pragma unroll
+  for (int it = 0; it < ROWS * VPR / 512; ++it) {
+    const int i = tid + it * 512, r = i / VPR, vc = i - r * VPR;
+    const int phys = (vc & ~15) | ((vc ^ r) & 15);
+    *reinterpret_cast<__attribute__((address_space(3))) u32x4*>(Y + r * PITCH + phys * 16) = v[it];
+  }
+}
+
+// LayerNorm backward on rows held across the workgroup: dn (gradient of the normalised rows, fp32) ->
+//   dx = rstd (g - mean_k g - xhat mean_k (g xhat)) + residual gradient,   g = dn gamma, xhat = (x - mean) rstd
+// written back into dn; per-workgroup column sums (sum_rows dn xhat, sum_rows dn) -> colpart [C] float2.
+// x rows / statistics / the bf16 residual gradient come from global memory; RES_REG: the residual gradient is `resreg`.
+// One workgroup barrier (also: every wave is done reading the operand buffer of the GEMM in front).
+template <int C, int TT, int NSL, bool RES_REG>
+__device__ __forceinline__ void st_ln_bwd_rows(f32x4 (&dn)[NSL][TT], const bf16_t* xrows, const float* strows,
+                                               const float* gamma, const bf16_t* resrows, const f32x4 (&resreg)[NSL][TT],
+                                               float* red, float* colpart, int w, int l15, int lg) {
+  constexpr int ROWS = 16 * TT;
+  uint2 xv[NSL][TT], rv[NSL][TT];
+  float2 ms[TT];
+  f32x4 gm[NSL];
+#pragma unroll
+  for (int s = 0; s < NSL; ++s) {
+    const int n0 = (w * NSL + s) * 16 + 4 * lg;
+    gm[s] = *reinterpret_cast<const f32x4*>(gamma + n0);
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt) {
+      xv[s][tt] = *reinterpret_cast<const uint2*>(xrows + (long long)(tt * 16 + l15) * C + n0);
+      if constexpr (!RES_REG) rv[s][tt] = *reinterpret_cast<const uint2*>(resrows + (long long)(tt * 16 + l15) * C + n0);
+    }
+  }
+#pragma unroll
+  for (int tt = 0; tt < TT; ++tt) ms[tt] = *reinterpret_cast<const float2*>(strows + (long long)(tt * 16 + l15) * 2);
+  float xh[NSL][TT][4];
+  float cg[NSL][4], cb[NSL][4];
+#pragma unroll
+  for (int s = 0; s < NSL; ++s)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) cg[s][j] = cb[s][j] = 0.f;
+#pragma unroll
+  for (int tt = 0; tt < TT; ++tt) {
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int s = 0; s < NSL; ++s) {
+      const uint2 t2 = xv[s][tt];
+      const float xf[4] = {__uint_as_float(t2.x << 16), __uint_as_float(t2.x & 0xffff0000u), __uint_as_float(t2.y << 16),
+                           __uint_as_float(t2.y & 0xffff0000u)};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float h_ = (xf[j] - ms[tt].x) * ms[tt].y;
+        xh[s][tt][j] = h_;
+        const float g = dn[s][tt][j] * gm[s][j];
+        a += g;
+        b += g * h_;
+        cg[s][j] += dn[s][tt][j] * h_;
+        cb[s][j] += dn[s][tt][j];
+      }
+    }
+    a += __shfl_xor(a, 16, 64);
+    b += __shfl_xor(b, 16, 64);
+    a += __shfl_xor(a, 32, 64);
+    b += __shfl_xor(b, 32, 64);
+    if (lg == 0) *reinterpret_cast<float2*>(red + (w * ROWS + tt * 16 + l15) * 2) = make_float2(a, b);
+  }
+  // column sums over this workgroup's rows: the 16 row lanes of a column group, then one lane writes
+#pragma unroll
+  for (int s = 0; s < NSL; ++s)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float a = cg[s][j], b = cb[s][j];
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) {
+        a += __shfl_xor(a, o, 64);
+        b += __shfl_xor(b, o, 64);
+      }
+      if (l15 == 0) *reinterpret_cast<float2*>(colpart + (long long)((w * NSL + s) * 16 + 4 * lg + j) * 2) = make_float2(a, b);
+    }
+  ST_BARRIER();
+#pragma unroll
+  for (int tt = 0; tt < TT; ++tt) {
+    const int r = tt * 16 + l15;
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int ww = 0; ww < 8; ++ww) {
+      const float2 v = *reinterpret_cast<const float2*>(red + (ww * ROWS + r) * 2);
+      a += v.x;
+      b += v.y;
+    }
+    const float c1 = a * (1.f / (float)C), c2 = b * (1.f / (float)C), rstd = ms[tt].y;
+#pragma unroll
+    for (int s = 0; s < NSL; ++s) {
+      float rr[4];
+      if constexpr (RES_REG) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) rr[j] = resreg[s][tt][j];
+      } else {
+        const uint2 t2 = rv[s][tt];
+        rr[0] = __uint_as_float(t2.x << 16);
+        rr[1] = __uint_as_float(t2.x & 0xffff0000u);
+        rr[2] = __uint_as_float(t2.y << 16);
+        rr[3] = __uint_as_float(t2.y & 0xffff0000u);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        dn[s][tt][j] = rstd * (dn[s][tt][j] * gm[s][j] - c1 - xh[s][tt][j] * c2) + rr[j];
+    }
+  }
+}
+
+#define ST_BWD_PROLOGUE(GEOM)                                                                         \
+  extern __shared__ __attribute__((aligned(16))) char smem_[];                                        \
+  lds_char* const smem = (lds_char*)smem_;                                                            \
+  lds_char* const Y = smem;                                                                           \
+  const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, lg = lane >> 4;                      \
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);                                             \
+  const int vid = st_xcd_id((int)blockIdx.x, (int)gridDim.x);                                         \
+  const long long row0 = (long long)vid * GEOM::ROWS;                                                 \
+  int yaddr[4], gaddr[4], woff[2];                                                                    \
+  _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                     \
+    const int sw = (((4 * j + lg) ^ l15) & 15) * 16;                                                  \
+    yaddr[j] = l15 * GEOM::PITCH + sw;                                                                \
+    gaddr[j] = l15 * 256 + sw;                                                                        \
+  }                                                                                                   \
+  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) woff[ks] = l15 * 128 + (((4 * ks + lg) ^ ((l15 >> 1) & 7)) * 16); \
+  float sx[TT], sxx[TT];                                                                              \
+  _Pragma("unroll") for (int tt = 0; tt < TT; ++tt) sx[tt] = sxx[tt] = 0.f;                           \
+  (void)gaddr
+
+// ---- phase B1: dout -> dx3 -> (dh) -> dn3 -> dx2 -> da2
+template <int C, int TT>
+__global__ __launch_bounds__(512) void st_train_bwd_b1_kernel(SdmiStTrainBwdArgs p) {
+  typedef StTrBwdGeom<C, TT> G;
+  constexpr int NSL = G::NSL, KT = G::KT, D = G::D1, PITCH = G::PITCH;
+  ST_BWD_PROLOGUE(G);
+  lds_char* const Gv = smem + G::GV_OFF;
+  lds_char* const Gg = smem + G::GG_OFF;
+  float* const red = (float*)(smem_ + G::RED1_OFF);
+  StRing<D> rg;
+  st_ring_init<D>(rg, p.wstream_b1, G::UB1, smem + G::RING1_OFF, lane, w);
+  st_rows_global_to_y<C, TT>((const bf16_t*)p.dout + row0 * C, C, Y, tid);
+  ST_BARRIER();
+  f32x4 res[NSL][TT], acc[NSL][TT];
+  auto zero_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int s = 0; s < NSL; ++s)
+#pragma unroll
+      for (int tt = 0; tt < TT; ++tt) acc[s][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+  // ---- dx3 = dout Wpo
+  zero_acc();
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt) st_gemm_step<D, NSL, false, 0, TT>(rg, Y, yaddr, kt, 16 * PITCH, woff, acc, sx, sxx);
+#pragma unroll
+  for (int s = 0; s < NSL; ++s)
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt) res[s][tt] = acc[s][tt];
+  ST_BARRIER();
+  st_rows_to_y<C, TT, NSL, true>(res, Y, (bf16_t*)p.dx3 + row0 * C, w, l15, lg);
+  ST_BARRIER();
+  // ---- feed-forward backward, hidden chunk by hidden chunk: dg = dx3 Wff2 ; GEGLU' ; dn3 += [dval | dgate] W1
+  zero_acc();
+  const bf16_t* hrow = (const bf16_t*)p.h + row0 * 8 * C;
+  bf16_t* dhrow = (bf16_t*)p.dh + row0 * 8 * C;
+#pragma unroll 1
+  for (int hc = 0; hc < G::NHC; ++hc) {
+    const int n0 = hc * 128 + w * 16 + 4 * lg;
+    uint2 hv[TT], hg[TT];
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt) {
+      hv[tt] = *reinterpret_cast<const uint2*>(hrow + (long long)(tt * 16 + l15) * 8 * C + n0);
+      hg[tt] = *reinterpret_cast<const uint2*>(hrow + (long long)(tt * 16 + l15) * 8 * C + 4 * C + n0);
+    }
+    f32x4 dg[1][TT];
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt) dg[0][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) st_gemm_step<D, 1, false, 0, TT>(rg, Y, yaddr, kt, 16 * PITCH, woff, dg, sx, sxx);
+    ST_BARRIER();                                       // the previous chunk's readers are done with Gv / Gg
+    {
+      const int c = (w * 16 + 4 * lg) >> 3;
+#pragma unroll
+      for (int tt = 0; tt < TT; ++tt) {
+        const int r = tt * 16 + l15;
+        const float v[4] = {__uint_as_float(hv[tt].x << 16), __uint_as_float(hv[tt].x & 0xffff0000u),
+                            __uint_as_float(hv[tt].y << 16), __uint_as_float(hv[tt].y & 0xffff0000u)};
+        const float gt[4] = {__uint_as_float(hg[tt].x << 16), __uint_as_float(hg[tt].x & 0xffff0000u),
+                             __uint_as_float(hg[tt].y << 16), __uint_as_float(hg[tt].y & 0xffff0000u)};
+        float dv[4], dgt[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          dv[j] = dg[0][tt][j] * act_apply<true>(gt[j], SDMI_ACT_GELU);
+          dgt[j] = dg[0][tt][j] * v[j] * act_grad<true>(gt[j], SDMI_ACT_GELU);
+        }
+        uint2 ov, og;
+        ov.x = st_pack2(dv[0], dv[1]);
+        ov.y = st_pack2(dv[2], dv[3]);
+        og.x = st_pack2(dgt[0], dgt[1]);
+        og.y = st_pack2(dgt[2], dgt[3]);
+        *reinterpret_cast<uint2*>(dhrow + (long long)r * 8 * C + n0) = ov;
+        *reinterpret_cast<uint2*>(dhrow + (long long)r * 8 * C + 4 * C + n0) = og;
+        const int phys = (c & ~15) | ((c ^ r) & 15);
+        *reinterpret_cast<__attribute__((address_space(3))) u32x2*>(Gv + r * 256 + phys * 16 + (lg & 1) * 8) = u32x2{ov.x, ov.y};
+        *reinterpret_cast<__attribute__((address_space(3))) u32x2*>(Gg + r * 256 + phys * 16 + (lg & 1) * 8) = u32x2{og.x, og.y};
+      }
+    }
+    ST_BARRIER();
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) st_gemm_step<D, NSL, false, 0, TT>(rg, Gv, gaddr, kt, 16 * 256, woff, acc, sx, sxx);
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) st_gemm_step<D, NSL, false, 0, TT>(rg, Gg, gaddr, kt, 16 * 256, woff, acc, sx, sxx);
+  }
+  // ---- LayerNorm3 backward + dx3 -> dx2
+  st_ln_bwd_rows<C, TT, NSL, true>(acc, (const bf16_t*)p.x2 + row0 * C, p.st3 + row0 * 2, p.ln3_g, nullptr, res, red,
+                                   p.ln3_part + (long long)vid * C * 2, w, l15, lg);
+  st_rows_to_y<C, TT, NSL, true>(acc, Y, (bf16_t*)p.dx2 + row0 * C, w, l15, lg);
+  ST_BARRIER();
+  // ---- da2 = dx2 Wo2
+  zero_acc();
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt) st_gemm_step<D, NSL, false, 0, TT>(rg, Y, yaddr, kt, 16 * PITCH, woff, acc, sx, sxx);
+  st_rows_store<C, TT, NSL>(acc, (bf16_t*)p.da2 + row0 * C, C, w, l15, lg);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// ---- phase B2: dq2 -> dn2 -> LN2' + dx2 -> dx1 -> da1
+template <int C, int TT>
+__global__ __launch_bounds__(512) void st_train_bwd_b2_kernel(SdmiStTrainBwdArgs p) {
+  typedef StTrBwdGeom<C, TT> G;
+  constexpr int NSL = G::NSL, KT = G::KT, D = G::D2, PITCH = G::PITCH;
+  ST_BWD_PROLOGUE(G);
+  float* const red = (float*)(smem_ + G::RED2_OFF);
+  StRing<D> rg;
+  st_ring_init<D>(rg, p.wstream_b2, G::UB2, smem + G::RING2_OFF, lane, w);
+  st_rows_global_to_y<C, TT>((const bf16_t*)p.dq2 + row0 * C, C, Y, tid);
+  ST_BARRIER();
+  f32x4 acc[NSL][TT];
+#pragma unroll
+  for (int s = 0; s < NSL; ++s)
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt) acc[s][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt) st_gemm_step<D, NSL, false, 0, TT>(rg, Y, yaddr, kt, 16 * PITCH, woff, acc, sx, sxx);
+  st_ln_bwd_rows<C, TT, NSL, false>(acc, (const bf16_t*)p.x1 + row0 * C, p.st2 + row0 * 2, p.ln2_g,
+                                    (const bf16_t*)p.dx2 + row0 * C, acc, red, p.ln2_part + (long long)vid * C * 2, w, l15, lg);
+  st_rows_to_y<C, TT, NSL, true>(acc, Y, (bf16_t*)p.dx1 + row0 * C, w, l15, lg);
+  ST_BARRIER();
+#pragma unroll
+  for (int s = 0; s < NSL; ++s)
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt) acc[s][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt) st_gemm_step<D, NSL, false, 0, TT>(rg, Y, yaddr, kt, 16 * PITCH, woff, acc, sx, sxx);
+  st_rows_store<C, TT, NSL>(acc, (bf16_t*)p.da1 + row0 * C, C, w, l15, lg);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// ---- phase A: dqkv -> dn1 -> LN1' + dx1 -> dtok -> dhgn
+template <int C, int TT>
+__global__ __launch_bounds__(512) void st_train_bwd_a_kernel(SdmiStTrainBwdArgs p) {
+  typedef StTrBwdGeom<C, TT> G;
+  constexpr int NSL = G::NSL, KT = G::KT, D = G::D2, PITCH = G::PITCH;
+  ST_BWD_PROLOGUE(G);
+  float* const red = (float*)(smem_ + G::RED2_OFF);
+  StRing<D> rg;
+  st_ring_init<D>(rg, p.wstream_a, G::UA, smem + G::RING2_OFF, lane, w);
+  const bf16_t* dqkv = (const bf16_t*)p.dqkv + row0 * 3 * C;
+  st_rows_global_to_y<C, TT>(dqkv, 3 * C, Y, tid);
+  ST_BARRIER();
+  f32x4 acc[NSL][TT];
+#pragma unroll
+  for (int s = 0; s < NSL; ++s)
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt) acc[s][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int pass = 0; pass < 3; ++pass) {
+    if (pass) {
+      ST_BARRIER();                                     // every wave is done with the previous part of dqkv
+      st_rows_global_to_y<C, TT>(dqkv + pass * C, 3 * C, Y, tid);
+      ST_BARRIER();
+    }
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) st_gemm_step<D, NSL, false, 0, TT>(rg, Y, yaddr, kt, 16 * PITCH, woff, acc, sx, sxx);
+  }
+  st_ln_bwd_rows<C, TT, NSL, false>(acc, (const bf16_t*)p.tok + row0 * C, p.st1 + row0 * 2, p.ln1_g,
+                                    (const bf16_t*)p.dx1 + row0 * C, acc, red, p.ln1_part + (long long)vid * C * 2, w, l15, lg);
+  st_rows_to_y<C, TT, NSL, true>(acc, Y, (bf16_t*)p.dtok + row0 * C, w, l15, lg);
+  ST_BARRIER();
+#pragma unroll
+  for (int s = 0; s < NSL; ++s)
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt) acc[s][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt) st_gemm_step<D, NSL, false, 0, TT>(rg, Y, yaddr, kt, 16 * PITCH, woff, acc, sx, sxx);
+  st_rows_store<C, TT, NSL>(acc, (bf16_t*)p.dhgn + row0 * C, C, w, l15, lg);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <int C, int TT>
+int st_train_bwd_launch(const SdmiStTrainBwdArgs& a, hipStream_t st) {
+  typedef StTrBwdGeom<C, TT> G;
+  const int grid = a.B * (a.S / G::ROWS);
+  if (a.phase == 1) {
+    SDMI_OPTIN_LDS((st_train_bwd_b1_kernel<C, TT>), G::SMEM1, "st_train_bwd (B1)");
+    hipLaunchKernelGGL((st_train_bwd_b1_kernel<C, TT>), dim3(grid), dim3(512), G::SMEM1, st, a);
+    return sdmi_check_launch("st_train_bwd (B1)");
+  }
+  if (a.phase == 2) {
+    SDMI_OPTIN_LDS((st_train_bwd_b2_kernel<C, TT>), G::SMEM2, "st_train_bwd (B2)");
+    hipLaunchKernelGGL((st_train_bwd_b2_kernel<C, TT>), dim3(grid), dim3(512), G::SMEM2, st, a);
+    return sdmi_check_launch("st_train_bwd (B2)");
+  }
+  SDMI_OPTIN_LDS((st_train_bwd_a_kernel<C, TT>), G::SMEM2, "st_train_bwd (A)");
+  hipLaunchKernelGGL((st_train_bwd_a_kernel<C, TT>), dim3(grid), dim3(512), G::SMEM2, st, a);
+  return sdmi_check_launch("st_train_bwd (A)");
+}
+
 template <int C, int TT, int KVS>
 int st_train_launch(const SdmiStTrainArgs& a, hipStream_t st) {
   typedef StTrGeom<C, TT, KVS> G;
@@ -770,4 +1120,24 @@ extern "C" int sdmi_st_pack(const SdmiStPackArgs* a, void* stream) {
   hipLaunchKernelGGL(st_pack_kernel, dim3((a->n_units + 1) / 2), dim3(256), 0, (hipStream_t)stream,
                      (const SdmiStPackDesc*)a->descs, a->n_units);
   return sdmi_check_launch("st_pack");
+}
+
+extern "C" int sdmi_st_train_bwd(const SdmiStTrainBwdArgs* a, void* stream) {
+  SDMI_REQUIRE(a && a->phase >= 1 && a->phase <= 3, "phase: 1 = B1, 2 = B2, 3 = A");
+  SDMI_REQUIRE(a->C == 256 || a->C == 384, "C must be 256 or 384");
+  SDMI_REQUIRE(a->rows == 0 || a->rows == 64 || a->rows == 32, "rows per workgroup: 64 (0) or 32");
+  const int rows = a->rows ? a->rows : 64;
+  SDMI_REQUIRE(a->B >= 1 && a->S >= rows && a->S % rows == 0, "S must be a multiple of the rows per workgroup");
+  if (a->phase == 1)
+    SDMI_REQUIRE(a->dout && a->h && a->x2 && a->st3 && a->ln3_g && a->dx3 && a->dh && a->dx2 && a->da2 && a->ln3_part &&
+                     a->wstream_b1, "phase B1: null pointer");
+  else if (a->phase == 2)
+    SDMI_REQUIRE(a->dq2 && a->x1 && a->st2 && a->ln2_g && a->dx2 && a->dx1 && a->da1 && a->ln2_part && a->wstream_b2,
+                 "phase B2: null pointer");
+  else
+    SDMI_REQUIRE(a->dqkv && a->tok && a->st1 && a->ln1_g && a->dx1 && a->dtok && a->dhgn && a->ln1_part && a->wstream_a,
+                 "phase A: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  if (rows == 64) return a->C == 256 ? st_train_bwd_launch<256, 4>(*a, st) : st_train_bwd_launch<384, 4>(*a, st);
+  return a->C == 256 ? st_train_bwd_launch<256, 2>(*a, st) : st_train_bwd_launch<384, 2>(*a, st);
 }

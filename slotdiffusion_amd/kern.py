@@ -191,24 +191,36 @@ def st_index_img(C):
 
 def st_train_units(C):
     """Unit order of the training kernels' weight streams (csrc/st_train.hip), per wave: lists of
-    (matrix key, first row, first k).  Forward: A = [proj_in | q | k | v], B = [to_out | q2 | to_out2 | per hidden
-    chunk: ff1 value rows, ff1 gate rows, ff2 k-chunk | proj_out]."""
+    (matrix key, first row, first k, transposed).  Forward: a = [proj_in | q | k | v], b = [to_out | q2 | to_out2 | per
+    hidden chunk: ff1 value rows, ff1 gate rows, ff2 k-chunk | proj_out].  Backward (rows / k of the TRANSPOSED
+    matrices): b1 = [proj_out^T | per hidden chunk: ff2^T rows, ff1^T value k-chunk, gate k-chunk | to_out2^T],
+    b2 = [q2^T | to_out^T], ba = [q^T | k^T | v^T | proj_in^T]."""
     NSL, KT, NHC = C // 128, C // 64, C // 32
-    A, Bs = [], []
+    out = dict(a=[], b=[], b1=[], b2=[], ba=[])
     for w in range(8):
-        a = [(m, (w * NSL + s_) * 16, kt * 64) for m in ('in', 'q', 'k', 'v') for kt in range(KT) for s_ in range(NSL)]
-        b = [(m, (w * NSL + s_) * 16, kt * 64) for m in ('o', 'q2', 'o2') for kt in range(KT) for s_ in range(NSL)]
+        full = lambda m, tr: [(m, (w * NSL + s_) * 16, kt * 64, tr) for kt in range(KT) for s_ in range(NSL)]
+        a = [u for m in ('in', 'q', 'k', 'v') for u in full(m, False)]
+        b = [u for m in ('o', 'q2', 'o2') for u in full(m, False)]
+        b1 = full('po', True)
         for hc in range(NHC):
             for kt in range(KT):
-                b.append(('ff1', hc * 128 + w * 16, kt * 64))
-                b.append(('ff1', 4 * C + hc * 128 + w * 16, kt * 64))
+                b.append(('ff1', hc * 128 + w * 16, kt * 64, False))
+                b.append(('ff1', 4 * C + hc * 128 + w * 16, kt * 64, False))
             for k2 in range(2):
                 for s_ in range(NSL):
-                    b.append(('ff2', (w * NSL + s_) * 16, hc * 128 + k2 * 64))
-        b += [('po', (w * NSL + s_) * 16, kt * 64) for kt in range(KT) for s_ in range(NSL)]
-        A.append(a)
-        Bs.append(b)
-    return A, Bs
+                    b.append(('ff2', (w * NSL + s_) * 16, hc * 128 + k2 * 64, False))
+            b1 += [('ff2', hc * 128 + w * 16, kt * 64, True) for kt in range(KT)]
+            for part in range(2):
+                b1 += [('ff1', (w * NSL + s_) * 16, part * 4 * C + hc * 128 + k2 * 64, True)
+                       for k2 in range(2) for s_ in range(NSL)]
+        b += full('po', False)
+        b1 += full('o2', True)
+        out['a'].append(a)
+        out['b'].append(b)
+        out['b1'].append(b1)
+        out['b2'].append(full('q2', True) + full('o', True))
+        out['ba'].append([u for m in ('q', 'k', 'v', 'in') for u in full(m, True)])
+    return out
 
 
 def ups_parity_split(w):
@@ -919,16 +931,21 @@ class WeightBank:
         flat = [u for wave in units for u in wave]
         arr = np.zeros(len(flat), dtype=np.dtype([('src', '<u8'), ('dst', '<u8'), ('rs', '<i4'), ('cs', '<i4')]))
         base = dst.data_ptr()
-        for i, (key, r0, k0) in enumerate(flat):
+        for i, (key, r0, k0, tr) in enumerate(flat):
             m = mats[key]
             ld = m.shape[1]
-            arr[i] = (m.data_ptr() + 2 * (r0 * ld + k0), base + i * 2048, ld, 1)
+            if tr:      # unit rows walk the matrix's columns: element (r, k) = M[k0 + k][r0 + r]
+                arr[i] = (m.data_ptr() + 2 * (k0 * ld + r0), base + i * 2048, 1, ld)
+            else:
+                arr[i] = (m.data_ptr() + 2 * (r0 * ld + k0), base + i * 2048, ld, 1)
         return arr
 
+    ST_STREAMS = ('a', 'b', 'b1', 'b2', 'ba')
+
     def st_train_streams(self, n):
-        """dict(wa, wb) -- bf16 unit streams of block `n` for sdmi_st_train_fwd.  The streams live in persistent buffers;
-        after an optimiser step (invalidate()) the first request re-packs the streams of ALL registered blocks with
-        one sdmi_st_pack launch (descriptor table on the device: part of the captured train step)."""
+        """dict(wa, wb, wb1, wb2, wba) -- bf16 unit streams of block `n` for sdmi_st_train_fwd / _bwd.  The streams live in
+        persistent buffers; after an optimiser step (invalidate()) the first request re-packs the streams of ALL
+        registered blocks with one sdmi_st_pack launch (descriptor table on the device: part of the captured train step)."""
         if self._stp_stale:
             self._st_pack_all()
         ent = self._stp.get(n)
@@ -941,12 +958,11 @@ class WeightBank:
         mats = self.st_train_mats(n)
         C = mats['in'].shape[0]
         dev = mats['in'].device
-        ua, ub = st_train_units(C)
-        na, nb = sum(len(w) for w in ua), sum(len(w) for w in ub)
+        units = st_train_units(C)
         if ent is None:
-            ent = dict(wa=torch.empty((na * 1024,), dtype=torch.bfloat16, device=dev),
-                       wb=torch.empty((nb * 1024,), dtype=torch.bfloat16, device=dev))
-        ent['descs'] = np.concatenate([self._st_descs(ua, mats, ent['wa']), self._st_descs(ub, mats, ent['wb'])])
+            ent = {'w' + k: torch.empty((sum(len(w) for w in units[k]) * 1024,), dtype=torch.bfloat16, device=dev)
+                   for k in self.ST_STREAMS}
+        ent['descs'] = np.concatenate([self._st_descs(units[k], mats, ent['w' + k]) for k in self.ST_STREAMS])
         ent['epoch'], ent['shadow'], ent['C'] = self._stp_epoch, self.model.shadow_arena().data_ptr(), C
         self._stp[n] = ent
         self._stp_table = None                      # new member: rebuild the device table at the next re-pack
@@ -2115,6 +2131,7 @@ def _gn_bwd_plain(wb, name, x, stats, dy, extras=()):
 
 _ST_TRAIN = os.environ.get('SDMI_ST_TRAIN', '1') != '0'        # fused training form of the SpatialTransformer block
 _ST_TRAIN_MIN_WGS = int(os.environ.get('SDMI_ST_TRAIN_MIN_WGS', '96'))
+_ST_TRAIN_BWD = os.environ.get('SDMI_ST_TRAIN_BWD', '1') != '0'    # ... and its backward data path (sdmi_st_train_bwd)
 
 
 class StBlockFn(torch.autograd.Function):
@@ -2122,6 +2139,7 @@ class StBlockFn(torch.autograd.Function):
     forward = TWO launches (sdmi.h: sdmi_st_train_fwd) that also store what the backward pass reads.
     x [B,H,W,C] bf16, kv [B,N,2C] bf16 (attn2.to_k | to_v of the slots) -> out [B,H,W,C]."""
 
+    capture = None          # tests set a dict here: the backward pass leaves its intermediate gradients in it
     SAVED = ('hgn', 'gn_stats', 'tok', 'n1', 'st1', 'qkv', 'a1', 'lse1', 'x1', 'n2', 'st2', 'q2', 'a2', 'lse2', 'x2', 'n3',
              'st3', 'h', 'g', 'x3')
 
@@ -2165,8 +2183,64 @@ class StBlockFn(torch.autograd.Function):
         x, kv = ctx.saved_tensors[:2]
         sv = dict(zip(StBlockFn.SAVED, ctx.saved_tensors[2:]))
         wb, n, heads, rows = ctx.cfg
-        dx, dkv = StBlockFn.backward_layers(wb, n, heads, x, kv, sv, dout.contiguous())
+        if _ST_TRAIN_BWD:
+            dx, dkv = StBlockFn.backward_fused(wb, n, heads, x, kv, sv, dout.contiguous(), rows)
+        else:
+            dx, dkv = StBlockFn.backward_layers(wb, n, heads, x, kv, sv, dout.contiguous())
         return dx, dkv, None, None, None, None, None
+
+    @staticmethod
+    def backward_fused(wb, n, heads, x, kv, sv, dout, rows):
+        """The block's backward data path as three fused launches (sdmi.h: sdmi_st_train_bwd) around the two attention
+        backward kernels and the GroupNorm backward; the weight / bias gradients of the eight linear layers are
+        stand-alone launches on side streams as their dY tensors appear; LayerNorm dgamma / dbeta from the per-workgroup
+        column sums the fused launches leave (deferred grouped fold)."""
+        t = n + '.transformer_blocks.0'
+        lin = (0, 0, 1, (0, 0, 0, 0), False)
+        B, S, C = sv['tok'].shape
+        dev = x.device
+        do = dout.view(B, S, C)
+        nwg = B * S // rows
+        st = wb.st_train_streams(n)
+        e = lambda *sh: torch.empty(sh, dtype=torch.bfloat16, device=dev)
+        part = lambda: torch.empty((nwg * C * 2,), dtype=torch.float32, device=dev)
+        wgrad = lambda a, dy, wn, bn: GemmFn.core(wb, a, dy, wn, bn, lin, False)
+        F_ = lambda k: _p(wb.f(k))
+        geo = dict(B=B, S=S, C=C, rows=rows)
+        rf = 2.0 * B * S * C * C
+        # ---- phase B1
+        dx3, dh, dx2, da2, p3 = e(B, S, C), e(B, S, 8 * C), e(B, S, C), e(B, S, C), part()
+        call('sdmi_st_train_bwd', _st(), phase=1, dout=_p(do), h=_p(sv['h']), x2=_p(sv['x2']), st3=_p(sv['st3']),
+             ln3_g=F_(t + '.norm3.weight'), dx3=_p(dx3), dh=_p(dh), dx2=_p(dx2), da2=_p(da2), ln3_part=_p(p3),
+             wstream_b1=_p(st['wb1']), **geo, _meta=dict(flops=14.0 * rf, bytes=2.0 * B * S * C * 22 + 28.0 * C * C))
+        wb.queue_colsum(p3, nwg, C, _grads_of(wb, t + '.norm3.weight'), _grads_of(wb, t + '.norm3.bias'))
+        wgrad(sv['x3'], do, n + '.proj_out.weight', n + '.proj_out.bias')
+        wgrad(sv['g'], dx3, t + '.ff.net.2.weight', t + '.ff.net.2.bias')
+        wgrad(sv['n3'], dh, t + '.ff.net.0.proj.weight', t + '.ff.net.0.proj.bias')
+        wgrad(sv['a2'], dx2, t + '.attn2.to_out.0.weight', t + '.attn2.to_out.0.bias')
+        dq2, dkv = AttnFn.bwd_core(sv['q2'], kv, sv['a2'], sv['lse2'], da2, heads)
+        # ---- phase B2
+        dx1, da1, p2 = e(B, S, C), e(B, S, C), part()
+        call('sdmi_st_train_bwd', _st(), phase=2, dq2=_p(dq2), x1=_p(sv['x1']), st2=_p(sv['st2']),
+             ln2_g=F_(t + '.norm2.weight'), dx2=_p(dx2), dx1=_p(dx1), da1=_p(da1), ln2_part=_p(p2),
+             wstream_b2=_p(st['wb2']), **geo, _meta=dict(flops=2.0 * rf, bytes=2.0 * B * S * C * 6 + 4.0 * C * C))
+        wb.queue_colsum(p2, nwg, C, _grads_of(wb, t + '.norm2.weight'), _grads_of(wb, t + '.norm2.bias'))
+        wgrad(sv['n2'], dq2, t + '.attn2.to_q.weight', None)
+        wgrad(sv['a1'], dx1, t + '.attn1.to_out.0.weight', t + '.attn1.to_out.0.bias')
+        dqkv, _ = AttnFn.bwd_core(sv['qkv'], None, sv['a1'], sv['lse1'], da1, heads)
+        # ---- phase A
+        dtok, dhgn, p1 = e(B, S, C), e(B, S, C), part()
+        call('sdmi_st_train_bwd', _st(), phase=3, dqkv=_p(dqkv), tok=_p(sv['tok']), st1=_p(sv['st1']),
+             ln1_g=F_(t + '.norm1.weight'), dx1=_p(dx1), dtok=_p(dtok), dhgn=_p(dhgn), ln1_part=_p(p1),
+             wstream_a=_p(st['wba']), **geo, _meta=dict(flops=4.0 * rf, bytes=2.0 * B * S * C * 8 + 8.0 * C * C))
+        wb.queue_colsum(p1, nwg, C, _grads_of(wb, t + '.norm1.weight'), _grads_of(wb, t + '.norm1.bias'))
+        wgrad(sv['n1'], dqkv, (t + '.attn1.to_q.weight', t + '.attn1.to_k.weight', t + '.attn1.to_v.weight'), None)
+        wgrad(sv['hgn'], dtok, n + '.proj_in.weight', n + '.proj_in.bias')
+        dx = _gn_bwd_plain(wb, n + '.norm', x.view(B, S, C), sv['gn_stats'], dhgn, (do,))
+        if StBlockFn.capture is not None:        # (tests: the intermediate gradients of this form)
+            StBlockFn.capture.update(dx3=dx3, dh=dh, dx2=dx2, da2=da2, dq2=dq2, dx1=dx1, da1=da1, dqkv=dqkv, dtok=dtok,
+                                     dhgn=dhgn)
+        return dx.view_as(x), dkv
 
     @staticmethod
     def backward_layers(wb, n, heads, x, kv, sv, dout):
@@ -2194,6 +2268,9 @@ class StBlockFn(torch.autograd.Function):
         dtok = LayerNormFn.bwd_core(wb, t + '.norm1', sv['tok'], sv['st1'], dn1, dx1)
         dhgn = core(sv['hgn'], dtok, n + '.proj_in.weight', n + '.proj_in.bias')
         dx = _gn_bwd_plain(wb, n + '.norm', x.view(B, S, C), sv['gn_stats'], dhgn, (do,))
+        if StBlockFn.capture is not None:
+            StBlockFn.capture.update(dx3=dx3, dh=dh, dx2=dx2, da2=da2, dq2=dq2, dx1=dx1, da1=da1, dqkv=dqkv, dtok=dtok,
+                                     dhgn=dhgn)
         return dx.view_as(x), dkv
 
 

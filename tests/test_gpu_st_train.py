@@ -193,3 +193,50 @@ def test_st_pack_units_are_the_swizzled_lds_image():
             for p in range(8):
                 lc = p ^ ((r >> 1) & 7)
                 assert torch.equal(got[i, r, p], src[r, lc * 8:lc * 8 + 8]), (i, r, p)
+
+
+@pytest.mark.parametrize('name,hw,B,n_slots,rows', CASES)
+def test_fused_backward_data_path_matches_the_per_layer_kernels(name, hw, B, n_slots, rows):
+    """sdmi_st_train_bwd (three launches) against the per-layer backward kernels on the SAME stored tensors: every
+    intermediate gradient, the input / slot gradients and the parameter gradients; repeatable run to run."""
+    from slotdiffusion_amd import kern
+    m = _model(seed=7)
+    u, n, heads, Cc, x, kv = _inputs(m, name, hw, B, n_slots)
+    g = torch.Generator().manual_seed(9)
+    dout = torch.randn(x.shape, generator=g).bfloat16().cuda()
+    wb = m.KG().wb
+    ga = m.grad_arena()
+    lo = min(m._offsets[k][0] for k in m._offsets if k.startswith(n + '.'))
+    hi = max(sum(m._offsets[k]) for k in m._offsets if k.startswith(n + '.'))
+    with torch.no_grad():
+        out, sv = kern.StBlockFn.run_forward(wb, x, kv, n, heads, rows)
+
+    def run(fused):
+        ga.zero_()
+        kern.StBlockFn.capture = {}
+        try:
+            with torch.no_grad():
+                wb._join_queued = True            # (outside an autograd pass: the join below is called by hand)
+                if fused:
+                    dx, dkv = kern.StBlockFn.backward_fused(wb, n, heads, x, kv, sv, dout, rows)
+                else:
+                    dx, dkv = kern.StBlockFn.backward_layers(wb, n, heads, x, kv, sv, dout)
+                wb.join()
+            torch.cuda.synchronize()
+            cap = {k: v.float().clone() for k, v in kern.StBlockFn.capture.items()}
+        finally:
+            kern.StBlockFn.capture = None
+        return dict(cap, dx=dx.float().clone(), dkv=dkv.float().clone(), params=ga[lo:hi].clone())
+    f, p = run(True), run(False)
+    errs = {k: _rel(f[k], p[k]) for k in p}
+    print(f'{name} C={Cc} S={hw * hw} B={B} slots={n_slots} rows={rows}: ' + ' '.join(f'{k}={v:.1e}' for k, v in errs.items()))
+    for k, v in errs.items():
+        assert torch.isfinite(f[k]).all(), k
+        assert v < 1.5e-2, (k, v)
+    for k in m._offsets:
+        if k.startswith(n + '.') and 'attn2.to_k' not in k and 'attn2.to_v' not in k:
+            o, cnt = m._offsets[k]
+            a, b_ = f['params'][o - lo:o - lo + cnt], p['params'][o - lo:o - lo + cnt]
+            assert float(b_.norm()) > 0 and _rel(a, b_) < 3e-2, (k, _rel(a, b_))
+    f2 = run(True)
+    assert all(torch.equal(f[k], f2[k]) for k in f), 'fused backward is not repeatable run to run'
