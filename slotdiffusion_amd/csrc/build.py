@@ -9,7 +9,9 @@ OUT = os.path.join(HERE, '..', 'libsdmi.so')
 SOURCES = ['api.cpp', 'igemm.hip', 'igemm_pp.hip', 'wgrad.hip', 'bwd_pair.hip', 'norm.hip', 'norm_bwd.hip', 'attention.hip',
            'attention_bwd.hip', 'st_fused.hip', 'st_train.hip', 'cross_fold.hip', 'slot_attn.hip', 'slot_attn_train.hip', 'bwd_misc.hip',
            'elementwise.hip', 'vq.hip', 'metrics.hip', 'vae_train.hip']
-EXTRA = {'vq.hip': ['-ffp-contract=off'], 'elementwise.hip': ['-ffp-contract=off']}
+EXTRA = {'vq.hip': ['-ffp-contract=off'], 'elementwise.hip': ['-ffp-contract=off'],
+         # no packed-fp32 VALU ops in the fused training kernels (st_train.hip's build note: not repeatable on MI355X)
+         'st_train.hip': ['-fno-slp-vectorize']}
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
 

@@ -45,6 +45,34 @@ struct StTrGeom {
   static constexpr int UB = 4 * KT * NSL + NHC * (2 * KT + 2 * NSL);        // to_out, q2, to_out2, FF chunks, proj_out
 };
 
+// Cross-lane sums without the LDS path (ds_bpermute): v_permlane16_swap / v_permlane32_swap exchange 16- / 32-lane halves
+// in the VALU, DPP row rotations sum the 16 lanes of a row (no LDS round trip next to the weight DMAs).
+//
+// BUILD NOTE: this file is compiled with -fno-slp-vectorize (csrc/build.py).  With the SLP vectoriser on, the LayerNorm
+// backward below is emitted with packed fp32 VALU ops (v_pk_add_f32 / v_pk_mul_f32 with op_sel / neg modifiers behind
+// v_lshlrev_b32 unpacks), and on MI355X those were NOT repeatable run to run: in ~1 % of the workgroups the LOW half of a
+// packed result came out wrong in lanes 48 - 63 of a wave (the raw loaded words, the MFMA accumulators and every scalar
+// form of the same arithmetic were bit-stable; tools/exp/st_bwd_repeat.py: 39 of 39 runs differed at B = 64 with the
+// packed ops, 0 of 351 without, same source).  Looks like a packed-fp32 hazard next to a draining MFMA pipeline that the
+// compiler does not cover; the scalar forms cost nothing measurable here.
+__device__ __forceinline__ float st_sum_x16(float a) {        // a(lane) + a(lane ^ 16), identical in both lanes
+  const unsigned i = __float_as_uint(a);
+  const auto r = __builtin_amdgcn_permlane16_swap(i, i, false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float st_sum_x32(float a) {        // a(lane) + a(lane ^ 32)
+  const unsigned i = __float_as_uint(a);
+  const auto r = __builtin_amdgcn_permlane32_swap(i, i, false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float st_sum_row16(float v) {      // sum over the 16 lanes of a DPP row, in every lane
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, false));   // row_ror:8
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xf, 0xf, false));   // row_ror:4
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x122, 0xf, 0xf, false));   // row_ror:2
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x121, 0xf, 0xf, false));   // row_ror:1
+  return v;
+}
+
 template <int D>
 __device__ __forceinline__ void st_ring_init(StRing<D>& rg, const void* stream, int units, lds_char* ring, int lane, int w) {
   rg.rs_sh = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)stream + (long long)w * units * ST_UNIT), 0,
@@ -76,10 +104,8 @@ __device__ __forceinline__ void st_layernorm_rows(const f32x4 (&x)[NSL][TT], con
         a += x[s][tt][j];
         b += x[s][tt][j] * x[s][tt][j];
       }
-    a += __shfl_xor(a, 16, 64);
-    b += __shfl_xor(b, 16, 64);
-    a += __shfl_xor(a, 32, 64);
-    b += __shfl_xor(b, 32, 64);
+    a = st_sum_x32(st_sum_x16(a));
+    b = st_sum_x32(st_sum_x16(b));
     if (lg == 0) *reinterpret_cast<float2*>(red + (w * ROWS + tt * 16 + l15) * 2) = make_float2(a, b);
   }
   ST_BARRIER();
@@ -811,10 +837,8 @@ __device__ __forceinline__ void st_ln_bwd_rows(f32x4 (&dn)[NSL][TT], const bf16_
         cb[s][j] += dn[s][tt][j];
       }
     }
-    a += __shfl_xor(a, 16, 64);
-    b += __shfl_xor(b, 16, 64);
-    a += __shfl_xor(a, 32, 64);
-    b += __shfl_xor(b, 32, 64);
+    a = st_sum_x32(st_sum_x16(a));
+    b = st_sum_x32(st_sum_x16(b));
     if (lg == 0) *reinterpret_cast<float2*>(red + (w * ROWS + tt * 16 + l15) * 2) = make_float2(a, b);
   }
   // column sums over this workgroup's rows: the 16 row lanes of a column group, then one lane writes
@@ -822,12 +846,7 @@ __device__ __forceinline__ void st_ln_bwd_rows(f32x4 (&dn)[NSL][TT], const bf16_
   for (int s = 0; s < NSL; ++s)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      float a = cg[s][j], b = cb[s][j];
-#pragma unroll
-      for (int o = 1; o < 16; o <<= 1) {
-        a += __shfl_xor(a, o, 64);
-        b += __shfl_xor(b, o, 64);
-      }
+      const float a = st_sum_row16(cg[s][j]), b = st_sum_row16(cb[s][j]);
       if (l15 == 0) *reinterpret_cast<float2*>(colpart + (long long)((w * NSL + s) * 16 + 4 * lg + j) * 2) = make_float2(a, b);
     }
   ST_BARRIER();

@@ -448,6 +448,7 @@ class WeightBank:
             call('sdmi_wgrad_group', _st(), problems=ctypes.addressof(arr), n=len(q),
                  _meta=dict(flops=flops))
         self._pending.append(tuple(keep) + (ws,))
+        return side
 
     # ---- deferred dgamma / dbeta folds of the normalisation backward passes ---------------------
     def queue_colsum(self, partial, nblk, C, out0, out1):
@@ -2131,7 +2132,8 @@ def _gn_bwd_plain(wb, name, x, stats, dy, extras=()):
 
 _ST_TRAIN = os.environ.get('SDMI_ST_TRAIN', '1') != '0'        # fused training form of the SpatialTransformer block
 _ST_TRAIN_MIN_WGS = int(os.environ.get('SDMI_ST_TRAIN_MIN_WGS', '96'))
-_ST_TRAIN_BWD = os.environ.get('SDMI_ST_TRAIN_BWD', '1') != '0'    # ... and its backward data path (sdmi_st_train_bwd)
+_ST_TRAIN_BWD = os.environ.get('SDMI_ST_TRAIN_BWD', '1') != '0'
+_ST_WGRAD_GROUP = os.environ.get('SDMI_ST_WGRAD_GROUP', '1') != '0'   # the block's weight gradients as two grouped launches    # ... and its backward data path (sdmi_st_train_bwd)
 
 
 class StBlockFn(torch.autograd.Function):
@@ -2204,7 +2206,36 @@ class StBlockFn(torch.autograd.Function):
         st = wb.st_train_streams(n)
         e = lambda *sh: torch.empty(sh, dtype=torch.bfloat16, device=dev)
         part = lambda: torch.empty((nwg * C * 2,), dtype=torch.float32, device=dev)
-        wgrad = lambda a, dy, wn, bn: GemmFn.core(wb, a, dy, wn, bn, lin, False)
+        grp = []                      # (weight-gradient problems of this block for ONE grouped launch)
+
+        def wgrad(a, dy, wn, bn):
+            names = (wn,) if isinstance(wn, str) else tuple(wn)
+            dst, bdst = _grads_of(wb, names), (_grads_of(wb, bn) if bn is not None else None)
+            if not _ST_WGRAD_GROUP or dst is None or (bn is not None and bdst is None):
+                GemmFn.core(wb, a, dy, wn, bn, lin, False)
+                return
+            M, K, N = a.numel() // a.shape[-1], a.shape[-1], dy.shape[-1]
+            kw = dict(a=_p(a), dy=_p(dy), dw=_p(dst), dbias=_p(bdst), dtype=_lib.BF16, M=M, N=N, K=K, lda=K, ldy=N, B=M,
+                      H=1, W=1, Cin=K, Ho=1, Wo=1, KH=1, KW=1, stride=1, pad_t=0, pad_l=0, ups=0, accumulate=1)
+            tn = (N + 127) // 128
+            grp.append((kw, tn * ((K + 127) // 128) + (tn if bn is not None else 0), (M + 63) // 64, a, dy))
+
+        def flush_group():
+            if not grp:
+                return
+            wb.flush_wgrad()                       # (nothing of another layer rides in this launch)
+            for kw, tiles, steps, a, dy in grp:
+                wb.flush_pending_fold((kw['dw'], kw['dbias']))
+                wb._after_side_writers(kw['dw'], kw['dbias'])
+                wb._wq.append((kw, tiles, steps))
+                wb._wq_keep.extend((a, dy))
+            side = wb.flush_wgrad()
+            for kw, *_ in grp:
+                for d in (kw['dw'], kw['dbias']):
+                    if d and side is not None:
+                        wb._side_dst[d] = side
+            del grp[:]
+            wb.ensure_join()
         F_ = lambda k: _p(wb.f(k))
         geo = dict(B=B, S=S, C=C, rows=rows)
         rf = 2.0 * B * S * C * C
@@ -2218,6 +2249,7 @@ class StBlockFn(torch.autograd.Function):
         wgrad(sv['g'], dx3, t + '.ff.net.2.weight', t + '.ff.net.2.bias')
         wgrad(sv['n3'], dh, t + '.ff.net.0.proj.weight', t + '.ff.net.0.proj.bias')
         wgrad(sv['a2'], dx2, t + '.attn2.to_out.0.weight', t + '.attn2.to_out.0.bias')
+        flush_group()
         dq2, dkv = AttnFn.bwd_core(sv['q2'], kv, sv['a2'], sv['lse2'], da2, heads)
         # ---- phase B2
         dx1, da1, p2 = e(B, S, C), e(B, S, C), part()
@@ -2236,6 +2268,7 @@ class StBlockFn(torch.autograd.Function):
         wb.queue_colsum(p1, nwg, C, _grads_of(wb, t + '.norm1.weight'), _grads_of(wb, t + '.norm1.bias'))
         wgrad(sv['n1'], dqkv, (t + '.attn1.to_q.weight', t + '.attn1.to_k.weight', t + '.attn1.to_v.weight'), None)
         wgrad(sv['hgn'], dtok, n + '.proj_in.weight', n + '.proj_in.bias')
+        flush_group()
         dx = _gn_bwd_plain(wb, n + '.norm', x.view(B, S, C), sv['gn_stats'], dhgn, (do,))
         if StBlockFn.capture is not None:        # (tests: the intermediate gradients of this form)
             StBlockFn.capture.update(dx3=dx3, dh=dh, dx2=dx2, da2=da2, dq2=dq2, dx1=dx1, da1=da1, dqkv=dqkv, dtok=dtok,

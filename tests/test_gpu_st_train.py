@@ -238,5 +238,12 @@ def test_fused_backward_data_path_matches_the_per_layer_kernels(name, hw, B, n_s
             o, cnt = m._offsets[k]
             a, b_ = f['params'][o - lo:o - lo + cnt], p['params'][o - lo:o - lo + cnt]
             assert float(b_.norm()) > 0 and _rel(a, b_) < 3e-2, (k, _rel(a, b_))
-    f2 = run(True)
-    assert all(torch.equal(f[k], f2[k]) for k in f), 'fused backward is not repeatable run to run'
+    bad = {}
+    for _ in range(3):
+        f2 = run(True)
+        for k in f:
+            if not torch.equal(f[k], f2[k]):
+                bad[k] = max(bad.get(k, 0.0), float((f[k] - f2[k]).abs().max()))
+    p2 = run(False)
+    badp = {k: float((p[k] - p2[k]).abs().max()) for k in p if not torch.equal(p[k], p2[k])}
+    assert not bad, f'fused backward is not repeatable run to run: {bad} (per-layer form: {badp})'
