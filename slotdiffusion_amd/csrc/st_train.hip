@@ -310,8 +310,9 @@ __global__ __launch_bounds__(512) void st_train_a_kernel(SdmiStTrainArgs p) {
     for (int s = 0; s < NSL; ++s)
 #pragma unroll
       for (int tt = 0; tt < TT; ++tt) acc[s][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    st_gemm_step<D, NSL, false, NSL * TT, TT>(rg, Y, yaddr, 0, 16 * PITCH, woff, acc, sx, sxx);   // (EXTRA: the stores / loads just issued stay outstanding)
 #pragma unroll
-    for (int kt = 0; kt < KT; ++kt) st_gemm_step<D, NSL, false, 0, TT>(rg, Y, yaddr, kt, 16 * PITCH, woff, acc, sx, sxx);
+    for (int kt = 1; kt < KT; ++kt) st_gemm_step<D, NSL, false, 0, TT>(rg, Y, yaddr, kt, 16 * PITCH, woff, acc, sx, sxx);
     st_rows_store<C, TT, NSL>(acc, (bf16_t*)p.qkv + row0 * 3 * C + pass * C, 3 * C, w, l15, lg);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no DMA may outlive the workgroup's LDS
@@ -545,8 +546,9 @@ __global__ __launch_bounds__(512) void st_train_b_kernel(SdmiStTrainArgs p) {
   // ---- slot cross-attention: q2 = n2 Wq2^T ; per (row, head): softmax over the slots ; a2
   load_vecs(p.b_o2, p.ln3_g, p.ln3_b);            // (epilogue vectors of the GEMM BEHIND the attention: fetched early)
   zero_acc();
+  st_gemm_step<D, NSL, false, NSL * TT, TT>(rg, Y, yaddr, 0, 16 * PITCH, woff, acc, sx, sxx);   // (EXTRA: the stores / loads just issued stay outstanding)
 #pragma unroll
-  for (int kt = 0; kt < KT; ++kt) st_gemm_step<D, NSL, false, 0, TT>(rg, Y, yaddr, kt, 16 * PITCH, woff, acc, sx, sxx);
+  for (int kt = 1; kt < KT; ++kt) st_gemm_step<D, NSL, false, 0, TT>(rg, Y, yaddr, kt, 16 * PITCH, woff, acc, sx, sxx);
   ST_BARRIER();                                    // every wave is done reading n2
   st_rows_to_y<C, TT, NSL, true>(acc, Y, (bf16_t*)p.q2 + row0 * C, w, l15, lg);
   ST_BARRIER();
@@ -676,8 +678,9 @@ __global__ __launch_bounds__(512) void st_train_b_kernel(SdmiStTrainArgs p) {
       }
     }
     ST_BARRIER();
+    st_gemm_step<D, NSL, false, 3 * TT, TT>(rg, gb, gaddr, 0, 16 * 256, woff, acc, sx, sxx);   // (EXTRA: the stores / loads just issued stay outstanding)
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt) st_gemm_step<D, NSL, false, 0, TT>(rg, gb, gaddr, kt, 16 * 256, woff, acc, sx, sxx);
+    for (int kt = 1; kt < 2; ++kt) st_gemm_step<D, NSL, false, 0, TT>(rg, gb, gaddr, kt, 16 * 256, woff, acc, sx, sxx);
   }
   // ---- x3 = acc + bff2 + x2 -> operand buffer ; out = x3 Wpo^T + bpo + x
 #pragma unroll
@@ -692,8 +695,9 @@ __global__ __launch_bounds__(512) void st_train_b_kernel(SdmiStTrainArgs p) {
   st_rows_to_y<C, TT, NSL, true>(res, Y, (bf16_t*)p.x3 + row0 * C, w, l15, lg);
   ST_BARRIER();
   zero_acc();
+  st_gemm_step<D, NSL, false, NSL * TT, TT>(rg, Y, yaddr, 0, 16 * PITCH, woff, acc, sx, sxx);   // (EXTRA: the stores / loads just issued stay outstanding)
 #pragma unroll
-  for (int kt = 0; kt < KT; ++kt) st_gemm_step<D, NSL, false, 0, TT>(rg, Y, yaddr, kt, 16 * PITCH, woff, acc, sx, sxx);
+  for (int kt = 1; kt < KT; ++kt) st_gemm_step<D, NSL, false, 0, TT>(rg, Y, yaddr, kt, 16 * PITCH, woff, acc, sx, sxx);
   // (only dummy re-fetches are in flight now: drain them, then ordinary loads are safe)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   {
@@ -947,8 +951,9 @@ __global__ __launch_bounds__(512) void st_train_bwd_b1_kernel(SdmiStTrainBwdArgs
     f32x4 dg[1][TT];
 #pragma unroll
     for (int tt = 0; tt < TT; ++tt) dg[0][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    st_gemm_step<D, 1, false, 2 * TT, TT>(rg, Y, yaddr, 0, 16 * PITCH, woff, dg, sx, sxx);   // (EXTRA: the stores / loads just issued stay outstanding)
 #pragma unroll
-    for (int kt = 0; kt < KT; ++kt) st_gemm_step<D, 1, false, 0, TT>(rg, Y, yaddr, kt, 16 * PITCH, woff, dg, sx, sxx);
+    for (int kt = 1; kt < KT; ++kt) st_gemm_step<D, 1, false, 0, TT>(rg, Y, yaddr, kt, 16 * PITCH, woff, dg, sx, sxx);
     ST_BARRIER();                                       // the previous chunk's readers are done with Gv / Gg
     {
       const int c = (w * 16 + 4 * lg) >> 3;
@@ -978,8 +983,9 @@ __global__ __launch_bounds__(512) void st_train_bwd_b1_kernel(SdmiStTrainBwdArgs
       }
     }
     ST_BARRIER();
+    st_gemm_step<D, NSL, false, 2 * TT, TT>(rg, Gv, gaddr, 0, 16 * 256, woff, acc, sx, sxx);   // (EXTRA: the stores / loads just issued stay outstanding)
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt) st_gemm_step<D, NSL, false, 0, TT>(rg, Gv, gaddr, kt, 16 * 256, woff, acc, sx, sxx);
+    for (int kt = 1; kt < 2; ++kt) st_gemm_step<D, NSL, false, 0, TT>(rg, Gv, gaddr, kt, 16 * 256, woff, acc, sx, sxx);
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) st_gemm_step<D, NSL, false, 0, TT>(rg, Gg, gaddr, kt, 16 * 256, woff, acc, sx, sxx);
   }
@@ -990,8 +996,9 @@ __global__ __launch_bounds__(512) void st_train_bwd_b1_kernel(SdmiStTrainBwdArgs
   ST_BARRIER();
   // ---- da2 = dx2 Wo2
   zero_acc();
+  st_gemm_step<D, NSL, false, NSL * TT, TT>(rg, Y, yaddr, 0, 16 * PITCH, woff, acc, sx, sxx);   // (EXTRA: the stores / loads just issued stay outstanding)
 #pragma unroll
-  for (int kt = 0; kt < KT; ++kt) st_gemm_step<D, NSL, false, 0, TT>(rg, Y, yaddr, kt, 16 * PITCH, woff, acc, sx, sxx);
+  for (int kt = 1; kt < KT; ++kt) st_gemm_step<D, NSL, false, 0, TT>(rg, Y, yaddr, kt, 16 * PITCH, woff, acc, sx, sxx);
   st_rows_store<C, TT, NSL>(acc, (bf16_t*)p.da2 + row0 * C, C, w, l15, lg);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
@@ -1022,8 +1029,9 @@ __global__ __launch_bounds__(512) void st_train_bwd_b2_kernel(SdmiStTrainBwdArgs
   for (int s = 0; s < NSL; ++s)
 #pragma unroll
     for (int tt = 0; tt < TT; ++tt) acc[s][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  st_gemm_step<D, NSL, false, NSL * TT, TT>(rg, Y, yaddr, 0, 16 * PITCH, woff, acc, sx, sxx);   // (EXTRA: the stores / loads just issued stay outstanding)
 #pragma unroll
-  for (int kt = 0; kt < KT; ++kt) st_gemm_step<D, NSL, false, 0, TT>(rg, Y, yaddr, kt, 16 * PITCH, woff, acc, sx, sxx);
+  for (int kt = 1; kt < KT; ++kt) st_gemm_step<D, NSL, false, 0, TT>(rg, Y, yaddr, kt, 16 * PITCH, woff, acc, sx, sxx);
   st_rows_store<C, TT, NSL>(acc, (bf16_t*)p.da1 + row0 * C, C, w, l15, lg);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
@@ -1063,8 +1071,9 @@ __global__ __launch_bounds__(512) void st_train_bwd_a_kernel(SdmiStTrainBwdArgs 
   for (int s = 0; s < NSL; ++s)
 #pragma unroll
     for (int tt = 0; tt < TT; ++tt) acc[s][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  st_gemm_step<D, NSL, false, NSL * TT, TT>(rg, Y, yaddr, 0, 16 * PITCH, woff, acc, sx, sxx);   // (EXTRA: the stores / loads just issued stay outstanding)
 #pragma unroll
-  for (int kt = 0; kt < KT; ++kt) st_gemm_step<D, NSL, false, 0, TT>(rg, Y, yaddr, kt, 16 * PITCH, woff, acc, sx, sxx);
+  for (int kt = 1; kt < KT; ++kt) st_gemm_step<D, NSL, false, 0, TT>(rg, Y, yaddr, kt, 16 * PITCH, woff, acc, sx, sxx);
   st_rows_store<C, TT, NSL>(acc, (bf16_t*)p.dhgn + row0 * C, C, w, l15, lg);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }

@@ -1,11 +1,12 @@
 cd $GRAFT_REPO_ROOT
-python -m pytest tests/test_gpu_st_train.py -x -q 2>&1 | tail -8 > gpurun_out/st_train_t6.txt
+python -m pytest tests/test_gpu_st_train.py -x -q 2>&1 | tail -4 > gpurun_out/st_train_t7.txt
+python tools/exp/st_repeat_model.py 20 2>&1 | grep -v amdgpu >> gpurun_out/st_train_t7.txt
+python tools/exp/st_bwd_repeat.py 2>&1 | grep -v amdgpu >> gpurun_out/st_train_t7.txt
 B="python bench.py --steps 20 --warmup 3 --only-train --no-cpu-baseline --no-roofline --no-pmc"
 rm -f gpurun_out/ab_st_train.txt
-for i in 1 2; do
-  for v in "0" "1"; do
-    echo "ST_WGRAD_GROUP=$v" >> gpurun_out/ab_st_train.txt
-    SDMI_ST_WGRAD_GROUP=$v $B 2>gpurun_out/ab_err.txt | grep '^{' | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['value'], d.get('loss'))" >> gpurun_out/ab_st_train.txt
-  done
+for i in 1 2 3; do
+    $B 2>gpurun_out/ab_err.txt | grep '^{' | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['value'], d.get('loss'))" >> gpurun_out/ab_st_train.txt
 done
-bash tools/exp/trace_train.sh grp
+echo baseline >> gpurun_out/ab_st_train.txt
+SDMI_ST_TRAIN=0 $B 2>gpurun_out/ab_err.txt | grep '^{' | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['value'], d.get('loss'))" >> gpurun_out/ab_st_train.txt
+bash tools/exp/trace_train.sh extra
