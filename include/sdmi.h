@@ -593,6 +593,13 @@ typedef struct {
 } SdmiExpandHeadsArgs;
 int sdmi_expand_heads(const SdmiExpandHeadsArgs* a, void* stream);
 
+/* Batched gather of 2-byte elements: dst[b][i] = src[b][idx[i]], i < n (n a multiple of 8), idx a DEVICE array of n
+ * 64-bit element offsets shared by all b; s_src / s_dst = batch pitches in elements.  Re-lays the per-image operands
+ * of the folded slot cross-attention into unit-stream / MFMA-fragment order once per sampling call
+ * (kern.Kern.cross_prepare / cross_block: replaces torch.index_select on the timed path). */
+typedef struct { const void* src; void* dst; const long long* idx; long long n, s_src, s_dst; int B; } SdmiGatherRowsArgs;
+int sdmi_gather_rows(const SdmiGatherRowsArgs* a, void* stream);
+
 /* Small stream-ordered helpers that keep the training step free of framework kernels:
  *   sdmi_memset0 ...... zero `bytes` bytes (gradient arena, padded buffers) -- a memset node in a graph
  *   sdmi_scale_dev .... y = x * s[0], s a DEVICE scalar (upstream gradient of the loss)

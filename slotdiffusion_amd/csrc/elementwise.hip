@@ -494,6 +494,25 @@ extern "C" int sdmi_cast2d(const SdmiCast2dArgs* a, void* stream) {
   else hipLaunchKernelGGL((cast2d_kernel<float, float>), dim3(g), dim3(EW_THREADS), 0, ST, *a);
   return sdmi_check_launch("cast2d");
 }
+// dst[b][i] = src[b][idx[i]] over 2-byte elements: eight gathered elements per thread, one 16-byte store
+__global__ __launch_bounds__(256) void gather_rows_kernel(SdmiGatherRowsArgs p) {
+  const long long v = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (v * 8 >= p.n) return;
+  const unsigned short* s = (const unsigned short*)p.src + (long long)blockIdx.y * p.s_src;
+  const long long* ix = p.idx + v * 8;
+  unsigned e[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) e[j] = s[ix[j]];
+  *reinterpret_cast<uint4*>((unsigned short*)p.dst + (long long)blockIdx.y * p.s_dst + v * 8) =
+      make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
+}
+extern "C" int sdmi_gather_rows(const SdmiGatherRowsArgs* a, void* stream) {
+  SDMI_REQUIRE(a && a->src && a->dst && a->idx, "null pointer");
+  SDMI_REQUIRE(a->B >= 1 && a->n >= 8 && a->n % 8 == 0 && a->s_dst % 8 == 0 && ((uintptr_t)a->dst & 15) == 0,
+               "n and the destination pitch are multiples of eight 2-byte elements");
+  hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((a->n / 8 + 255) / 256), a->B), dim3(256), 0, ST, *a);
+  return sdmi_check_launch("gather_rows");
+}
 extern "C" int sdmi_expand_heads(const SdmiExpandHeadsArgs* a, void* stream) {
   SDMI_REQUIRE(a && a->kv && a->kexp && a->vexp, "null pointer");
   SDMI_REQUIRE((a->gw == 0 || a->gw == 8 || a->gw == 16) && a->S >= 1 && a->S <= (a->gw == 16 ? 16 : 8) && a->heads > 0 &&

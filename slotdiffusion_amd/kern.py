@@ -1336,7 +1336,7 @@ class Kern:
         ops.bmm_nt(wo.view(1, C, C).expand(B, -1, -1), vexp, w2)
         fold = dict(wq=wq, colsum=colsum.squeeze(-1), biasq=biasq.squeeze(-1), w2=w2, slots=kv.shape[1])
         if fused:
-            fold['st_img'] = torch.index_select(src, 1, self.wb.st_index('img', C, kv.device))
+            fold['st_img'] = ops.gather_rows(src, self.wb.st_index('img', C, kv.device))
             fold['st_vec'] = vec
         return fold
 
@@ -1353,8 +1353,8 @@ class Kern:
                     R = fold['wq'].shape[1]
                     iq = self.wb.cf_index(R, C, tok.device)
                     i2 = self.wb.cf_index(C, R, tok.device)
-                    fold['cf_wq'] = torch.index_select(fold['wq'].reshape(B, R * C), 1, iq)
-                    fold['cf_w2'] = torch.index_select(fold['w2'].reshape(B, C * R), 1, i2)
+                    fold['cf_wq'] = ops.gather_rows(fold['wq'].reshape(B, R * C), iq)
+                    fold['cf_w2'] = ops.gather_rows(fold['w2'].reshape(B, C * R), i2)
                 return ops.cross_fold(tok, fold['cf_wq'], fold['colsum'], fold['biasq'], fold['cf_w2'],
                                       self.wb.b(t + '.attn2.to_out.0.bias'), 1e-5, fold['slots'], packed=True)
             P = ops.cross_scores(tok, fold['wq'], fold['colsum'], fold['biasq'], 1e-5, fold['slots'])
@@ -2461,6 +2461,37 @@ class AddFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         return dy, dy
+
+
+class StackTimeFn(torch.autograd.Function):
+    """out[:, t] = xs[t] -- torch.stack(xs, 1) of the per-frame slots / masks on the strided copy kernel (no framework
+    kernel on the clip encode); backward hands every frame its slice of the gradient."""
+
+    @staticmethod
+    def forward(ctx, *xs):
+        T, B = len(xs), xs[0].shape[0]
+        n = xs[0].numel() // B
+        out = torch.empty((B, T) + tuple(xs[0].shape[1:]), dtype=xs[0].dtype, device=xs[0].device)
+        es, dt = out.element_size(), _DT[out.dtype]
+        for t, x in enumerate(xs):
+            x = x.contiguous()
+            call('sdmi_cast2d', _st(), src=_p(x), dst=out.data_ptr() + t * n * es, src_dtype=dt, dst_dtype=dt, rows=B, cols=n,
+                 lds=n, ldd=T * n, zpad=0)
+        ctx.geo = (T, B, n, tuple(xs[0].shape))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        T, B, n, shape = ctx.geo
+        dout = dout.contiguous()
+        es, dt = dout.element_size(), _DT[dout.dtype]
+        outs = []
+        for t in range(T):
+            g = torch.empty(shape, dtype=dout.dtype, device=dout.device)
+            call('sdmi_cast2d', _st(), src=dout.data_ptr() + t * n * es, dst=_p(g), src_dtype=dt, dst_dtype=dt, rows=B,
+                 cols=n, lds=T * n, ldd=n, zpad=0)
+            outs.append(g)
+        return tuple(outs)
 
 
 class VaeAttnFn(torch.autograd.Function):

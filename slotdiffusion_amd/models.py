@@ -665,9 +665,9 @@ def _encode_clip(self, img, prev_slots=None):
             all_s.append(s)
             all_seg.append(seg)
             prev_slots = s
-        slots = torch.stack(all_s, 1)
+        slots = kern.StackTimeFn.apply(*all_s)
     with torch.no_grad():
-        seg = torch.stack([x.detach() for x in all_seg], 1)            # [B,T,M,N]
+        seg = kern.StackTimeFn.apply(*[x.detach() for x in all_seg])    # [B,T,M,N]
         if not self.training and (h, w) != (H, W):
             masks, _ = ops.mask_upsample_argmax(seg.flatten(0, 1).contiguous(), h, w, H, W)
             masks = masks.view(B, T, self.num_slots, H, W)

@@ -311,6 +311,16 @@ def cross_fold_pack_index(rows, cols):
     return ((t * 16 + (lane & 15)) * cols + ks * 32 + (lane >> 4) * 8 + e).reshape(-1)
 
 
+def gather_rows(src, idx):
+    """src [B, n_src] (2-byte elements, row pitch src.stride(0)), idx int64 [n] on the device -> [B, n] = src[:, idx]."""
+    _need_gpu(src, idx)
+    assert src.element_size() == 2 and src.stride(1) == 1 and idx.dtype == torch.int64 and idx.is_contiguous()
+    B, n = src.shape[0], idx.numel()
+    out = torch.empty((B, n), dtype=src.dtype, device=src.device)
+    call('sdmi_gather_rows', _stream(), src=_p(src), dst=_p(out), idx=_p(idx), n=n, s_src=src.stride(0), s_dst=n, B=B)
+    return out
+
+
 def cross_fold(tok, wq, colsum, biasq, w2, bias, eps, slots=7, packed=False):
     """The folded slot cross-attention layer in one launch (sdmi.h: sdmi_cross_fold): out = softmax_slots(LayerNorm(tok)
     wq^T + biasq) w2^T + bias + tok.  tok [B,HW,C] contiguous; wq [B,R,C], w2 [B,C,R] (row / image pitches free), or
