@@ -43,10 +43,6 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# train step: VQ-VAE encode of batch i + 1 under the update of step i (optim.GraphedTrainStep(prefetch=True)).  Off: bit-identical
-# trajectory, and SLOWER -- rotated same-box A/B 27.20 / 27.11 / 27.17 ms without, 27.44 / 27.36 / 27.44 with: the encode's
-# GroupNorm passes at 128^2 are as HBM-bound as the Adam kernel they were meant to hide under (profiles/r05_pp_ablation.txt)
-PREFETCH = os.environ.get('SDMI_PREFETCH_X0', '0') != '0'
 PEAK_TFLOPS = {'bf16': 2500.0, 'fp32': 157.3, 'fp8': 5000.0}      # MI355X dense MFMA peaks (MI355X_MICROARCH.md)
 CPU_THREADS = 64       # cpu_baseline: fixed thread count, pinned to the first cores (repeatable across boxes)
 
@@ -539,12 +535,9 @@ def main():
             from slotdiffusion_amd.optim import GraphedTrainStep
             # world > 1: backward split at the slots, denoiser gradients all-reduced under the
             # encoder's backward (optim.GraphedTrainStep)
-            # prefetch: the frozen VQ-VAE encode of the NEXT batch (here: the same synthetic batch) runs next to this
-            # step's clip + Adam tail; every step still does one encode (optim.GraphedTrainStep)
             graphed = GraphedTrainStep(model, opt, dict(img=img),
-                                       allreduce=(True if dist is not None else None), world=world, wire=wire,
-                                       prefetch=PREFETCH)
-            run_step = lambda: graphed(dict(img=img), next_batch=(dict(img=img) if PREFETCH else None))
+                                       allreduce=(True if dist is not None else None), world=world, wire=wire)
+            run_step = lambda: graphed(dict(img=img))
         dt_t = timed(run_step, args.steps, args.warmup, marked=True)
         train_rate = world * n_img * args.steps / dt_t
         # loss of the last timed step (the graphed step keeps it in a static tensor) + a finite check of the
@@ -576,9 +569,7 @@ def main():
         value, unit, ms = train_rate, 'images/s', 1e3 * dt_t / args.steps
         metric = f'train-step images/sec, {shape} {slots_n}-slot (DPM-Solver denoise-steps/sec in `denoise`)'
         work = (f'BASELINE {what}: train step = slot encoder + frozen VQ-VAE encode + q-sample + UNet eps + '
-                f'MSE, backward, clip, Adam (dropout 0.1)'
-                + ('; the VQ-VAE encode of batch i + 1 overlaps the clip + Adam tail of step i (one encode per step)'
-                   if (PREFETCH and not args.no_graph) else ''))
+                f'MSE, backward, clip, Adam (dropout 0.1)')
     else:
         value, unit, ms = denoise_rate, 'image-denoise-steps/s', 1e3 * dt_s / n_s
         metric = f'DPM-Solver denoise-steps/sec, {shape} {slots_n}-slot'

@@ -6,7 +6,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 OUT = os.path.join(HERE, '..', 'libsdmi.so')
-SOURCES = ['api.cpp', 'igemm.hip', 'igemm_pp.hip', 'wgrad.hip', 'bwd_pair.hip', 'norm.hip', 'norm_bwd.hip', 'attention.hip',
+SOURCES = ['api.cpp', 'igemm.hip', 'igemm_halo.hip', 'wgrad.hip', 'bwd_pair.hip', 'norm.hip', 'norm_bwd.hip', 'attention.hip',
            'attention_bwd.hip', 'st_fused.hip', 'st_train.hip', 'cross_fold.hip', 'slot_attn.hip', 'slot_attn_train.hip', 'bwd_misc.hip',
            'elementwise.hip', 'vq.hip', 'metrics.hip', 'vae_train.hip']
 EXTRA = {'vq.hip': ['-ffp-contract=off'], 'elementwise.hip': ['-ffp-contract=off'],

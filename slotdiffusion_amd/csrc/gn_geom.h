@@ -8,18 +8,11 @@
 // MI355X, profiles/r02_gn_geometry_sweep.txt): candidates keep row segments >= 64 bytes and >= 8 KB
 // of slab per workgroup; among them take the largest split whose slab needs <= 4 vectors per
 // thread with the narrowest workgroup that achieves it, else the fewest vectors per thread.
-// SDMI_GN_T / SDMI_GN_S override (kernel experiments).
 struct GnGeom { int T, S, need; };   // need = vectors per thread the slab takes
 // min_slab: smallest slab (bytes of 16-byte vectors) a channel chunk may shrink to -- the partials-source form of the
 // forward kernel reads 4 x splits the bytes per element and wants the read spread over more workgroups.
 static inline GnGeom gn_pick(int B, int HW, int C, int groups, int vec, int nv_of_T[3], int min_slab = 8192) {
-  static int env_T = -1, env_S = -1;
-  if (env_T < 0) {
-    const char* e = getenv("SDMI_GN_T");
-    env_T = e ? atoi(e) : 0;
-    e = getenv("SDMI_GN_S");
-    env_S = e ? atoi(e) : 0;
-  }
+  constexpr int env_T = 0, env_S = 0;       // (the sweep that set the rule below: profiles/r02_gn_geometry_sweep.txt)
   (void)B;
   const int cvt = C / vec;
   static const int Ts[3] = {256, 512, 1024};

@@ -32,8 +32,6 @@
 #include "epi_rows.h"
 #include "igemm_sym.h"
 
-// 256 x 128 ping-pong kernel: its own translation unit (igemm_pp.hip)
-int sdmi_launch_pp(const SdmiGemmArgs& p, bool is1x1, int hw_shift, hipStream_t st, int n_cu);
 // 3x3 stride-1 convolution with the activation patch staged once per 64-channel chunk (igemm_halo.h)
 int sdmi_launch_halo(const SdmiGemmArgs& p, int logw, int nj, int hw_shift, hipStream_t st, int n_cu);
 
@@ -634,25 +632,8 @@ int launch_dma(const SdmiGemmArgs& p, int hw_shift, hipStream_t st, int split_k 
   return rc;
 }
 
-// SDMI_IGEMM_DMA64: smallest K (bytes per row) that takes the 64 x 64 LDS-DMA kernel, 0 = off
-static int dma64_min() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("SDMI_IGEMM_DMA64");
-    v = e ? atoi(e) : 256;
-  }
-  return v;
-}
-
-// SDMI_IGEMM_T12864: LDS stages of the 128 x 64-tile LDS-DMA kernel (4: one workgroup per CU, 3: two), 0 = off
-static int t12864_stages() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("SDMI_IGEMM_T12864");
-    v = e ? atoi(e) : 0;      // faster per launch in isolation, slower inside the sampler and the train step (dispatch)
-  }
-  return v;
-}
+// smallest K (bytes per row) that takes the 64 x 64 LDS-DMA kernel
+static constexpr int dma64_min() { return 256; }
 
 // SDMI_IGEMM_SYM: LDS stages of the symmetric-wave kernel (2: two workgroups per CU, 3 / 4: one), 0 = off,
 // unset = by shape (see dispatch)
@@ -698,19 +679,8 @@ int dispatch(const SdmiGemmArgs& p, hipStream_t st, bool plan_only = false) {
     // shallow-K 1x1 problems (<= 512 bytes of K per row: two K tiles) on 64x64 tiles: more, shorter
     // workgroups.  Slower per launch in isolation (10.4 vs 9.7 us at 16384 x 256 x 256), faster inside
     // the sampler (same-box A/B twice: 104.2 / 104.6 vs 105.1 / 105.2 ms per 20-NFE pass); train neutral.
-    static int t64_kb = -1;
-    if (t64_kb < 0) {
-      const char* e = getenv("SDMI_IGEMM_T64_MAXKB");
-      t64_kb = e ? atoi(e) : 512;
-    }
-    if (t64_kb > 0 && is1x1 && p.K * (int)sizeof(T) <= t64_kb && shape == T128x128) shape = T64x64;
-    // experiment knob: 128x64 tiles when 128x128 gives fewer than this many workgroups
-    static int t12864 = -1;
-    if (t12864 < 0) {
-      const char* e = getenv("SDMI_IGEMM_T128X64_BELOW");
-      t12864 = e ? atoi(e) : 0;
-    }
-    if (t12864 > 0 && shape == T128x128 && t128 < t12864 && !is1x1) shape = T128x64;
+    constexpr int t64_kb = 512;
+    if (is1x1 && p.K * (int)sizeof(T) <= t64_kb && shape == T128x128) shape = T64x64;
   }
   const bool big = shape != T64x64;
   // K tile: 128 bytes of K per row when K is deep enough, else 64
@@ -734,23 +704,15 @@ int dispatch(const SdmiGemmArgs& p, hipStream_t st, bool plan_only = false) {
       const char* e = getenv("SDMI_IGEMM_HALO");
       halo_min = e ? atoi(e) : 192;
     }
-    static int halo_nj1 = -1;                // SDMI_IGEMM_HALO_NJ1=1: 256 x 64 tiles where 256 x 128 leave CUs idle
-    if (halo_nj1 < 0) {                      // (off: 26.3 vs 27.3 us at 256 -> 256 @16^2, 44.2 vs 41.4 us at 512 -> 256:
-      const char* e = getenv("SDMI_IGEMM_HALO_NJ1");   //  the narrow tile doubles the weight bytes per flop)
-      halo_nj1 = e ? atoi(e) : 0;
-    }
-    static int halo_c64 = -1;                // SDMI_IGEMM_HALO_C64=1: the 64 -> 64 channel layers through 256 x 64 halo tiles
-    if (halo_c64 < 0) {                      // (off: 135.1 vs 120.4 us at 128^2 against conv3x3_c64_kernel, whose filter stays
-      const char* e = getenv("SDMI_IGEMM_HALO_C64");   //  in LDS; train step +0.4 ms)
-      halo_c64 = e ? atoi(e) : 0;
-    }
+    // (256 x 64 tiles where 256 x 128 leave CUs idle lost: 26.3 vs 27.3 us at 256 -> 256 @16^2 but 44.2 vs 41.4 us at 512 -> 256;
+    //  the 64 -> 64 channel layers through 256 x 64 halo tiles lost to conv3x3_c64_kernel: 135.1 vs 120.4 us at 128^2)
     const long long tm256 = (long long)(p.M + 255) / 256;
-    const int nj = (sizeof(T) == 2 && p.N <= 64) ? 1 : ((tm256 * ((p.N + 127) / 128) >= halo_min || !halo_nj1 || sizeof(T) == 1) ? 2 : 1);
+    const int nj = 2;
     const long long t256 = tm256 * ((p.N + 64 * nj - 1) / (64 * nj));
     // tile width = image width (16 / 32 / 64), or 64-column tiles of four rows on wider images (128^2: the 64-channel layers)
     halo_logw = p.W == 16 ? 4 : (p.W == 32 ? 5 : ((p.W % 64 == 0 && p.H % 4 == 0) ? 6 : 0));
     if (halo_min > 0 && halo_logw && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad_t == 1 && p.pad_l == 1 && plain &&
-        !p.a2 && p.H == p.Ho && p.W == p.Wo && hw_shift >= 8 && p.Cin % CPC == 0 && p.N >= 64 && (p.N > 64 || (halo_c64 && sizeof(T) == 2)) &&
+        !p.a2 && p.H == p.Ho && p.W == p.Wo && hw_shift >= 8 && p.Cin % CPC == 0 && p.N > 64 &&
         t256 >= halo_min && p.split_k <= 1 && batch == 1 && fits31 && p.osy == 0 && !p.ln_colsum && !p.geglu && !p.softmax8 &&
         !p.out2 && !p.gn_part && !p.defer_epilogue && p.out_dtype == SDMI_BF16)
       halo_nj = nj;
@@ -764,11 +726,7 @@ int dispatch(const SdmiGemmArgs& p, hipStream_t st, bool plan_only = false) {
   else if (!big && batch == 1 && p.workspace && p.osy == 0) {
     const long long t64 = (long long)((p.M + 63) / 64) * ((p.N + 63) / 64);
     const int nk = (kbytes + (wide ? 127 : 63)) / (wide ? 128 : 64);
-    static int sk_target = -1;           // workgroups a split-K launch aims for (experiment knob)
-    if (sk_target < 0) {
-      const char* e = getenv("SDMI_IGEMM_SPLIT_TARGET");
-      sk_target = e ? atoi(e) : 384;
-    }
+    constexpr int sk_target = 384;       // workgroups a split-K launch aims for
     while (t64 * split_k < sk_target && split_k * 2 <= nk / 4 && split_k < 16) split_k *= 2;
   }
   if (split_k > 1 && !p.workspace) split_k = 1;
@@ -780,48 +738,14 @@ int dispatch(const SdmiGemmArgs& p, hipStream_t st, bool plan_only = false) {
       p.out_dtype == SDMI_BF16 && p.ldc % 8 == 0 && p.N % 8 == 0 && !p.bias_m &&
       (!p.residual || p.ldr % 8 == 0) &&
       (long long)p.B * (p.H / 4) * (p.W / 64) >= 2 * device_cus()) {
-    static int c64_rows = -1;               // SDMI_C64_ROWS=1: the row-major epilogue of epi_rows.h for N = 64 launches
-    if (c64_rows < 0) {                     // (off: 119.1 vs 124.4 us per launch in a dependent chain at 128^2, and the train
-      const char* e = getenv("SDMI_C64_ROWS");   //  step 27.39 vs 27.23 ms -- same box, two runs each: the chain does not decide)
-      c64_rows = e ? atoi(e) : 0;
-    }
-    const bool rows = c64_rows && p.N == 64;
     SDMI_OPTIN_LDS(conv3x3_c64_kernel<false>, D33_SMEM, "igemm (direct 3x3 c64)");
-    SDMI_OPTIN_LDS(conv3x3_c64_kernel<true>, D33_SMEM, "igemm (direct 3x3 c64, row-major epilogue)");
     SdmiGemmArgs q = p;
     q.split_k = 1;
     int grid = device_cus();
     const long long n_tiles = (long long)p.B * (p.H / 4) * (p.W / 64);
     if (grid > n_tiles) grid = (int)n_tiles;
-    if (rows) hipLaunchKernelGGL(conv3x3_c64_kernel<true>, dim3(grid), dim3(256), D33_SMEM, st, q, hw_shift);
-    else hipLaunchKernelGGL(conv3x3_c64_kernel<false>, dim3(grid), dim3(256), D33_SMEM, st, q, hw_shift);
+    hipLaunchKernelGGL(conv3x3_c64_kernel<false>, dim3(grid), dim3(256), D33_SMEM, st, q, hw_shift);
     return sdmi_check_launch("igemm (direct 3x3 c64)");
-  }
-  // ping-pong kernel (igemm_pp.h): 256 x 128 tiles, one workgroup per CU -- bf16, 1x1 / plain convolutions, plain
-  // epilogue, launches with about a tile per CU or more and a K loop deep enough to amortise prologue + epilogue
-  if constexpr (sizeof(T) == 2) {
-    static int pp_min = -1, pp_minkt = -1;   // SDMI_IGEMM_PP: fewest 256 x 128 tiles that take it (0 = off)
-    if (pp_min < 0) {
-      const char* e = getenv("SDMI_IGEMM_PP");
-      pp_min = e ? atoi(e) : 0;       // off: no faster than the 128 x 128 kernels without the halo staging
-      const char* e2 = getenv("SDMI_IGEMM_PP_MINKT");
-      pp_minkt = e2 ? atoi(e2) : 8;
-    }
-    const long long t256 = ((long long)(p.M + 255) / 256) * ((p.N + 127) / 128);
-    bool ok = pp_min > 0 && p.N > 64 && t256 >= pp_min && (p.K + 63) / 64 >= pp_minkt && split_k == 1 && batch == 1 &&
-              fits31 && !p.ln_colsum && !p.geglu && !p.softmax8 && !p.out2 && !p.defer_epilogue &&
-              (is1x1 || (plain && p.KH * p.KW <= 32 && p.Cin % 64 == 0));
-    if (ok && p.a2) {
-      const long long a2_bytes = (long long)p.M * p.lda2 * 2, a3_bytes = p.a3 ? (long long)p.M * p.lda3 * 2 : 0;
-      const int kend2 = p.a3 ? p.K2 : p.K;
-      const bool same = p.stride == 1 && p.H == p.Ho && p.W == p.Wo;
-      ok = (is1x1 || same) && p.K1 == p.KH * p.KW * p.Cin && kend2 > p.K1 && (!p.a3 || p.K > p.K2) && p.K1 % 64 == 0 &&
-           (kend2 - p.K1) % 64 == 0 && (p.K - kend2) % 64 == 0 && p.lda2 % VEC == 0 && (!p.a3 || p.lda3 % VEC == 0) &&
-           a2_bytes < (1ll << 31) && a3_bytes < (1ll << 31);
-    }
-    if (ok) {
-      return sdmi_launch_pp(p, is1x1, hw_shift, st, device_cus());
-    }
   }
   // symmetric-wave kernel (igemm_sym.h): 128 x 128 tiles, bf16, 1x1 / plain convolutions, plain epilogue
   if constexpr (sizeof(T) == 2) {
@@ -854,36 +778,6 @@ int dispatch(const SdmiGemmArgs& p, hipStream_t st, bool plan_only = false) {
 #undef SDMI_SYM
     }
   }
-  // symmetric-wave kernel + split-K for the deep-K plain convolutions that would otherwise take 64 x 64 tiles (the
-  // 8^2 / 4^2 levels at B = 64): a 64 x 64 tile asks for 128 B/clk of operand feed at full matrix rate, a 128 x 128
-  // tile for 64 (~38 are there), and the K split supplies the workgroups
-  if constexpr (sizeof(T) == 2) {
-    static int sym_split = -1;
-    if (sym_split < 0) {
-      const char* e = getenv("SDMI_IGEMM_SYM_SPLIT");
-      sym_split = e ? atoi(e) : 0;
-    }
-    if (sym_split && !p.defer_epilogue && shape == T64x64 && !is1x1 && plain && !p.a2 && p.split_k == 0 && p.workspace && batch == 1 && p.osy == 0 &&
-        fits31 && p.KH * p.KW <= 32 && p.Cin % 64 == 0 && kbytes >= 2048 && p.N > 64 && p.M >= 512 && !p.ln_colsum && !p.geglu &&
-        !p.softmax8 && !p.out2) {
-      const int n_cu = device_cus();
-      const int nk = (p.K + 63) / 64;
-      int sk = (int)((2 * n_cu + t128 - 1) / t128);
-      if (sk > 16) sk = 16;
-      if (sk > nk / 4) sk = nk / 4;
-      if (sk >= 2) {
-        int rc = launch_sym<2, 2>(p, hw_shift, st, n_cu, sk);
-        if (rc) return rc;
-        SdmiGemmArgs q = p;
-        q.split_k = sk;
-        const long long total = (long long)p.M * p.N;
-        int blocks = (int)((total + 255) / 256);
-        if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(blocks), dim3(256), 0, st, q, hw_shift);
-        return sdmi_check_launch("igemm splitk epilogue");
-      }
-    }
-  }
   if (p.a2) {       // extra A sources (sdmi.h: a2 / a3): 1x1, or a stride-1 "same" convolution on the fast path
     const int bk = (wide ? 128 : 64) / (int)sizeof(T);
     const long long a2_bytes = (long long)p.M * p.lda2 * (long long)sizeof(T);
@@ -907,11 +801,6 @@ int dispatch(const SdmiGemmArgs& p, hipStream_t st, bool plan_only = false) {
       if (shape == T128x128)
         return is1x1 ? launch_cfg<T, 128, 128, 128, 1, 0, true>(p, split_k, hw_shift, st)
                      : launch_cfg<T, 128, 128, 128, 2, 0, true>(p, split_k, hw_shift, st);
-      if constexpr (sizeof(T) == 2) {
-        if (t12864_stages() && !is1x1 && split_k == 1 && batch == 1 && p.M % 128 == 0 && p.N % 64 == 0 &&
-            (long long)(p.M / 128) * (p.N / 64) >= 128)
-          return launch_dma<T, 128, 64, 4, 2, 4, true>(p, hw_shift, st);
-      }
       if (sizeof(T) == 2 && dma64_min())
         return is1x1 ? launch_dma<T, 64, 64, 4, 1, 4, true>(p, hw_shift, st, split_k)
                      : launch_dma<T, 64, 64, 4, 2, 4, true>(p, hw_shift, st, split_k);
@@ -945,13 +834,8 @@ int dispatch(const SdmiGemmArgs& p, hipStream_t st, bool plan_only = false) {
         sdmi_set_error("igemm: LayerNorm-fold / GEGLU epilogues need a plain 1x1 problem without residual / rowvec");
         return SDMI_EUNSUPPORTED;
       }
-      static int lnf_tile = -1;
-      if (lnf_tile < 0) {
-        const char* e = getenv("SDMI_LNF_TILE");
-        lnf_tile = e ? atoi(e) : 0;
-      }
       // GEGLU pairs tiles inside a 64-column wave block: 128 x 128 only
-      const bool t128 = (epi & 2) || (shape == T128x128 && lnf_tile != 64);
+      const bool t128 = (epi & 2) || shape == T128x128;
       if constexpr (sizeof(T) == 2)
         if (epi == 1 && !t128 && dma64_min() && kbytes >= dma64_min())
           return launch_dma<T, 64, 64, 4, 1, 4, false, 1>(p, hw_shift, st, 1);
@@ -984,21 +868,8 @@ int dispatch(const SdmiGemmArgs& p, hipStream_t st, bool plan_only = false) {
       // (tools/exp/conv_chain.py, B = 64): about one tile per CU and a deep K -- the 16^2 level's 3x3
       // convolutions, 30.0 -> 27.8 us (256 -> 256) and 50.4 -> 42.4 us (512 -> 256); neutral or slower elsewhere
       const long long t256 = ((p.M + 255) / 256) * ((p.N + 127) / 128) * batch;
-      static int dma_lw = -1;
-      if (dma_lw < 0) {
-        const char* e = getenv("SDMI_IGEMM_DMA_LW");
-        dma_lw = e ? atoi(e) : 8;
-      }
-      static int dma_all = -1;              // experiment: every 128 x 128 deep-K plain convolution
-      if (dma_all < 0) {
-        const char* e = getenv("SDMI_IGEMM_DMA_ALL");
-        dma_all = e ? atoi(e) : 0;
-      }
-      const bool pick = dma_all ? (t128 >= 192 && kbytes >= 1024 * 2) : (t128 >= 192 && t256 < 192 && kbytes >= 2048 * 2);
-      if (pick && !is1x1)
-        return dma_lw == 85 ? launch_dma<T, 128, 128, 5, 2, 8>(p, hw_shift, st)
-               : dma_lw == 8 ? launch_dma<T, 128, 128, 4, 2, 8>(p, hw_shift, st)
-                             : launch_dma<T, 128, 128, 4, 2>(p, hw_shift, st);
+      // (eight loader waves: a wave issues one 1 KB DMA piece per ~150 cycles, four cap the feed at ~27 B/clk/CU)
+      if (t128 >= 192 && t256 < 192 && kbytes >= 2048 * 2 && !is1x1) return launch_dma<T, 128, 128, 4, 2, 8>(p, hw_shift, st);
     } else if (dma_ok) {
       const long long t256 = ((p.M + 255) / 256) * ((p.N + 127) / 128) * batch;
       if (t256 >= 192) {
@@ -1015,22 +886,9 @@ int dispatch(const SdmiGemmArgs& p, hipStream_t st, bool plan_only = false) {
     // LDS-DMA kernel on 64 x 64 tiles (4 stages of 16 KB: two workgroups per CU), split-K as below: the 8^2 /
     // 4^2 levels' convolutions 12 - 17 % faster in dependent chains (29.0 -> 24.3 us 384 -> 384 @8^2, 50.6 -> 41.9
     // 768 -> 384), sampling pass 94.7 -> 92.9 ms, train step 29.58 -> 29.33 ms (same-box A/B, twice each).
-    // 128 x 64 tiles for the 64 x 64-tile convolutions whose grid allows it (the 8^2 level at B = 64: 192 instead of
-    // 384 workgroups): these launches are bound by the LDS-DMA issue rate, i.e. by operand bytes per tile
-    // = K (BM + BN) 2 -- 1.5x the bytes for 2x the flops.  tools/exp/conv_chain.py SHAPES=low, us per launch:
-    // 384 -> 384 25.1 -> 23.6, 768 -> 384 42.2 -> 36.1, 640 -> 384 34.0 -> 30.5, 256 -> 384 17.2 -> 16.6 (four LDS
-    // stages, one workgroup per CU; three stages = two per CU: 22.9 / 39.5 / 33.2 / 16.5).  Inside the replayed
-    // sampler the same build is SLOWER (same box, twice each: 74.84 -> 75.41 ms per pass) and so is the train step
-    // (26.78 -> 26.97 ms): 192 workgroups leave a quarter of the CUs idle for the whole launch, and behind a
-    // GroupNorm the operands come from L2, where the 64 x 64 grid's 384 shorter workgroups overlap better.  Off.
-    if (t12864_stages() && sizeof(T) == 2 && shape == T64x64 && !p.a2 && split_k == 1 && batch == 1 && fits31 &&
-        kbytes >= 2048 && p.M % 128 == 0 && p.N % 64 == 0 && (long long)(p.M / 128) * (p.N / 64) >= 128 && !is1x1 &&
-        plain && p.KH * p.KW <= 32 && p.Cin % 64 == 0 && !p.ln_colsum && !p.geglu && !p.softmax8 && !p.out2) {
-      if constexpr (sizeof(T) == 2) {
-        if (t12864_stages() == 3) return launch_dma<T, 128, 64, 3, 2, 4>(p, hw_shift, st);
-        return launch_dma<T, 128, 64, 4, 2, 4>(p, hw_shift, st);
-      }
-    }
+    // (128 x 64 tiles for the 8^2 level: faster per launch in isolation -- 384 -> 384 25.1 -> 23.6 us -- and slower inside the
+    // replayed sampler, 74.84 -> 75.41 ms, and the train step, 26.78 -> 26.97 ms: 192 workgroups leave a quarter of the CUs
+    // idle; deleted)
     const int dma64 = dma64_min();
     if (dma64 && shape == T64x64 && !p.a2 && kbytes >= dma64 && fits31 && (batch == 1 || p.parity4)) {
       if (is1x1) return launch_dma<T, 64, 64, 4, 1, 4>(p, hw_shift, st, split_k);

@@ -787,13 +787,8 @@ __global__ __launch_bounds__(256) void gn_part_reduce_kernel(SdmiGroupNormArgs p
 
 static constexpr int GN_PART_MIN_SLAB = 2048;
 
-static bool gn_v2_enabled() {
-  static int v2 = -1;
-  if (v2 < 0) {
-    const char* e = getenv("SDMI_GN_V2");
-    v2 = e ? atoi(e) : 1;
-  }
-  return v2 != 0;
+static constexpr bool gn_v2_enabled() {
+  return true;
 }
 
 extern "C" int sdmi_groupnorm(const SdmiGroupNormArgs* a, void* stream) {

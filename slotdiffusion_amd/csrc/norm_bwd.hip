@@ -825,11 +825,7 @@ extern "C" int sdmi_groupnorm_bwd(const SdmiGroupNormBwdArgs* a, void* stream) {
       while (cvp < cv) cvp <<= 1;
       const int RR = cvp < 64 ? gg.T / 64 : gg.T / cvp;
       const size_t smem = ((size_t)RR * cvp * vec * 2 + 2 * 256) * sizeof(float);
-      static int v2 = -1;
-      if (v2 < 0) {
-        const char* e = getenv("SDMI_GN_V2");
-        v2 = e ? atoi(e) : 1;
-      }
+      constexpr int v2 = 1;
       const int cpg = a->C / a->groups;
       // (the 1024-thread and the 16-vector instantiations of the second form spill at their register budgets and
       // measured slower than the first form: 43 vs 36 us at [64][32^2][128])

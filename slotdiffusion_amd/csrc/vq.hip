@@ -265,12 +265,7 @@ __global__ __launch_bounds__(256) void vq_reg_kernel(SdmiVqArgs p) {
 extern "C" int sdmi_vq_nearest(const SdmiVqArgs* a, void* stream) {
   SDMI_REQUIRE(a && a->z && a->codebook && (a->idx || a->zq), "null pointer");
   SDMI_REQUIRE(a->dim == 3, "embed_dim must be 3 (every LDM config)");
-  static int use_reg = -1;             // SDMI_VQ_REG=0: the LDS scan for every codebook size
-  if (use_reg < 0) {
-    const char* e = getenv("SDMI_VQ_REG");
-    use_reg = e ? atoi(e) : 1;
-  }
-  if (use_reg && a->n_codes <= 4 * 128 * 16 && a->R >= 512) {
+  if (a->n_codes <= 4 * 128 * 16 && a->R >= 512) {
     const dim3 grid((a->R + VQ_LAT - 1) / VQ_LAT);
     if (a->n_codes <= 4 * 128 * 4) hipLaunchKernelGGL(vq_reg_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, *a);
     else if (a->n_codes <= 4 * 128 * 8) hipLaunchKernelGGL(vq_reg_kernel<8>, grid, dim3(256), 0, (hipStream_t)stream, *a);

@@ -781,25 +781,14 @@ int dispatch_wgrad_bf16(const SdmiWgradArgs& a, hipStream_t st) {
   const bool is1x1 = wgrad_is1x1(a);
   const bool n64 = a.N <= 64, k64 = a.K <= 64;
   // "same" stride-1 convolution on a power-of-two image: the input pixel is linear in m
-  static int lin_any = -1;              // SDMI_WGRAD_LIN_ANY=0: the fast loaders only for power-of-two images
-  if (lin_any < 0) {
-    const char* e = getenv("SDMI_WGRAD_LIN_ANY");
-    lin_any = e ? atoi(e) : 1;
-  }
-  const bool lin = !is1x1 && !a.ups && a.stride == 1 && a.H == a.Ho && a.W == a.Wo &&
-                   (lin_any || ((a.H & (a.H - 1)) == 0 && (a.W & (a.W - 1)) == 0));
+  const bool lin = !is1x1 && !a.ups && a.stride == 1 && a.H == a.Ho && a.W == a.Wo;
   // the scalar-only loaders address a split's rows with 31-bit byte offsets
   const long long mps = ((long long)a.M + a.splits - 1) / a.splits + 64;
   const long long ld = a.lda > a.ldy ? a.lda : a.ldy;
   const bool fits = (mps + (long long)(a.KH + 1) * a.W + 64) * ld * 2 < (1ll << 31);
   // direct kernel for the 64 -> 64 channel 3x3 layers at full resolution (one workgroup per M-split slot)
   {
-    static int d33 = -1;
-    if (d33 < 0) {
-      const char* e = getenv("SDMI_WGRAD_D33");
-      d33 = e ? atoi(e) : 1;
-    }
-    if (d33 && a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad_t == 1 && a.pad_l == 1 && !a.ups && a.Cin == 64 &&
+    if (a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad_t == 1 && a.pad_l == 1 && !a.ups && a.Cin == 64 &&
         a.N == 64 && a.K == 576 && a.H == a.Ho && a.W == a.Wo && a.W % 64 == 0 && a.H % 4 == 0 && a.splits >= 2 &&
         (long long)a.B * (a.H / 4) * (a.W / 64) >= a.splits && (long long)a.B * a.H * a.W * (a.lda > a.ldy ? a.lda : a.ldy) < (1ll << 40))
       return launch_wgrad3x3_c64(a, st);

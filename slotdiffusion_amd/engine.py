@@ -6,13 +6,11 @@ kernel calls instead of nn.Module graphs.  `K` is a kernel provider (kern.Kern f
 kern.KernGrad for training -- same program, autograd-recording kernels).  Reference call sites
 are cited per function.
 """
-import os
-
 import torch
 
-from . import ops, spec
+from . import ops, policy, spec
 
-_DEFER_SPLITK = os.environ.get('SDMI_DEFER_SPLITK', '1') != '0'
+_DEFER_SPLITK = bool(policy.flag('DEFER_SPLITK'))
 
 
 # ------------------------------------------------------------------------------------------

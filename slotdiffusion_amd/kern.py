@@ -16,7 +16,7 @@ import os
 
 import torch
 
-from . import _lib, ops
+from . import _lib, ops, policy
 from ._lib import call
 
 _DT = {torch.float32: _lib.F32, torch.bfloat16: _lib.BF16}
@@ -30,8 +30,7 @@ def _st():
     return torch.cuda.current_stream().cuda_stream
 
 
-import os as _os
-_DEBUG = _os.environ.get('SDMI_DEBUG_BWD', '') == '1'
+_DEBUG = False            # (set by hand: prints the norm of every gradient the backward kernels produce)
 
 
 def _dbg(tag, **tensors):
@@ -42,10 +41,8 @@ def _dbg(tag, **tensors):
 
 
 FP8_ACT_SCALE = 8.0        # activations -> e4m3fn: +-56 representable, 2^-9 resolution near zero
-_WG_MAIN_BELOW = float(os.environ.get('SDMI_WGRAD_MAIN_BELOW_GF', '0')) * 1e9
-_LN_UNFOLD_ROWS = int(os.environ.get('SDMI_LN_UNFOLD_ROWS', str(1 << 30)))     # folded LayerNorm only below this many rows (default: always folded)
-_LAZY_CAT = os.environ.get('SDMI_LAZY_CAT', '1') != '0'
-_GEGLU_FUSE = os.environ.get('SDMI_GEGLU_FUSE', '1') != '0'     # training: GEGLU in the FF GEMM's epilogue
+_LAZY_CAT = bool(policy.flag('LAZY_CAT'))
+_GEGLU_FUSE = bool(policy.flag('GEGLU_FUSE'))     # training: GEGLU in the FF GEMM's epilogue
 
 
 class CatPair:
@@ -63,39 +60,21 @@ class CatPair:
         return ops.concat_channels(self.a, self.b)
 
 
-_RES_MERGE = os.environ.get('SDMI_RES_MERGE', '1') != '0'
-_FF_MERGE = os.environ.get('SDMI_FF_MERGE', '1') != '0'
-_CROSS_FOLD = os.environ.get('SDMI_CROSS_FOLD', '1') != '0'
-# most slots the folded cross-attention path takes (16-row groups per head from 9 slots; SDMI_CROSS_MAX_SLOTS=7: round 4)
-_CROSS_MAX_SLOTS = int(os.environ.get('SDMI_CROSS_MAX_SLOTS', '16'))
-_LN_FOLD = os.environ.get('SDMI_LN_FOLD', '1') != '0'
-_ST_FUSED = os.environ.get('SDMI_ST_FUSED', '1') != '0'     # fused SpatialTransformer block (sdmi_st_block)
-# 3x3 layers whose data gradient has at least this many 256 x 128 tiles leave the pair launch: data gradient through the
-# halo-staged kernel (igemm_halo.h), weight gradient through its twin on channel pairs (wgrad3x3_halo_kernel) on a side
-# stream.  0 (default) = every layer stays paired.  Both kernels are 1.3 - 1.8x their implicit-GEMM counterparts alone, and
-# the step does not move: 26.93 / 26.90 / 26.90 ms paired against 26.92 / 26.87 / 26.94 un-paired (128; same box, rotated
-# order) -- the M-split partials of an un-paired weight gradient (256 workgroups x 147 KB = 37.7 MB per layer) need their own
-# fold launch, 35 us each next to the main stream's kernels: +1.2 ms of summed kernel time per step, hidden only because the
-# side streams overlap it; with the implicit-GEMM weight gradient next to the halo kernel the step is 0.25 ms
-# SLOWER (a kernel that fills a CU's LDS excludes the side-stream launches that used to co-reside).
-_HALO_DGRAD = int(os.environ.get('SDMI_HALO_DGRAD', '0'))
-_WGRAD_HALO = os.environ.get('SDMI_WGRAD_HALO', '1') != '0'    # direct 3x3 weight gradient on channel pairs (wgrad3x3_halo_kernel)
-# folded slot cross-attention as ONE launch (sdmi_cross_fold) up to this many tokens per image (0 = off)
-_CROSS_ONE = int(os.environ.get('SDMI_CROSS_ONE', '64'))
-_UPS_PARITY = os.environ.get('SDMI_UPS_PARITY', '1') != '0'   # upsample convolutions as four 2x2 parity convolutions
-# ... launched concurrently (one on the current stream, three on side streams) when the input has at most this many
-# pixels over the batch.  Off (0): measured SLOWER inside the replayed sampler -- rotated same-box A/B, ms per 20-NFE
-# pass: 76.53 / 76.36 / 76.29 one after the other, 77.70 / 78.22 / 77.66 forked at all three levels, 78.30 / 78.34 /
-# 77.97 forked at 4^2 -> 8^2 only: a fork / join pair in the graph costs ~20 us, more than the 128-workgroup launches
-# lose by running alone (profiles/r05_pp_ablation.txt)
-_UPS_FORK = int(os.environ.get('SDMI_UPS_FORK', '0'))
-_UPS_ONE = os.environ.get('SDMI_UPS_ONE', '1') != '0'         # ... or as ONE launch over the parity index (sdmi.h: parity4)
-# ... only when its grid (one workgroup per 64 token rows) fills a good part of the chip: at B = 64 the 8^2 level gives 64
-# workgroups that each stream the block's 4 MB of weights -- 119 us against 108 us for the per-layer launches
-_ST_MIN_WGS = int(os.environ.get('SDMI_ST_MIN_WGS', '128'))
-# token rows per workgroup: 0 = 64 when that gives >= 192 workgroups, else 32 (twice the workgroups, each multiplying
-# half the rows against the same weight stream: 64 images at 8^2 are 64 / 128 workgroups); 64 / 32 force one
-_ST_ROWS = int(os.environ.get('SDMI_ST_ROWS', '0'))
+_RES_MERGE = bool(policy.flag('RES_MERGE'))
+_FF_MERGE = bool(policy.flag('FF_MERGE'))
+_CROSS_FOLD = bool(policy.flag('CROSS_FOLD'))
+_CROSS_MAX_SLOTS = 16      # most slots the folded cross-attention path takes (16-row groups per head from 9 slots)
+_LN_FOLD = bool(policy.flag('LN_FOLD'))
+_ST_FUSED = bool(policy.flag('ST_FUSED'))     # fused SpatialTransformer block (sdmi_st_block)
+_WGRAD_HALO = bool(policy.flag('WGRAD_HALO'))    # direct 3x3 weight gradient on channel pairs (wgrad3x3_halo_kernel)
+_CROSS_ONE = 64            # folded slot cross-attention as ONE launch (sdmi_cross_fold) up to this many tokens per image
+_UPS_PARITY = bool(policy.flag('UPS_PARITY'))   # upsample convolutions as four 2x2 parity convolutions in one launch
+# the fused inference block only when its grid (one workgroup per 64 / 32 token rows) fills a good part of the chip: at
+# B = 64 the 8^2 level gives 64 workgroups that each stream the block's 4 MB of weights -- 119 us against 108 us for the
+# per-layer launches (tests set these module variables)
+_ST_MIN_WGS = 128
+# token rows per workgroup: 0 = 64 when that gives >= 192 workgroups, else 32; 64 / 32 force one
+_ST_ROWS = 0
 
 
 def _copy_group(items):
@@ -264,41 +243,22 @@ class WeightBank:
         # before the optimiser): they run on a second HIP stream, concurrently with the dgrad
         # chain, and are joined when the autograd pass ends.  Their operands are kept alive until
         # the join (HBM is plentiful), so no allocator stream bookkeeping is needed.
-        self.overlap_wgrad = os.environ.get('SDMI_WGRAD_STREAM', '1') != '0'
-        self.n_side = max(1, int(os.environ.get('SDMI_WGRAD_STREAMS', '4')))
+        self.overlap_wgrad = bool(policy.flag('WGRAD_STREAM'))
+        self.n_side = 4
         self._sides = []
-        self._fq = []
-        # deferred grouped folds of the split weight-gradient partials (16 layers per launch at the
-        # autograd join): ~130 launches fewer per step, but +0.2 ms (same-box A/B 32.24 / 32.11 vs
-        # 31.90 / 31.98 ms): the partials are read cold instead of right behind their producer.  Off.
-        self.defer_fold = os.environ.get('SDMI_DEFER_FOLD', '0') != '0'
         self._pending, self._side_of = [], {}
         self._join_queued = False
-        # grouped weight gradients: 1x1 / linear bf16 problems are queued and launched together
-        # (sdmi_wgrad_group) once their tiles can fill the chip -- see queue_wgrad()
-        self.group_wgrad = os.environ.get('SDMI_WGRAD_GROUP', '0') != '0'
-        self._wq, self._wq_keep, self._wq_items, self._wq_bytes = [], [], 0, 0
-        # ... and the exact-fp32 problems of the Slot Attention / predictor layers (M = images x slots rows: 9 - 36
-        # workgroups and ~20 us each, ~25 of them per step, every one behind its own cross-stream edge): queued and
-        # launched 16 at a time (queue_wgrad32).  Off: the region of the step it shortens (Slot Attention backward:
-        # 930 -> 707 us of wall time in the launch list) is not what bounds the step -- the side streams' backlog of
-        # large weight gradients fills the idle CUs of that region either way -- rotated same-box A/B 26.63 / 26.87 /
-        # 26.75 ms off, 26.73 / 26.95 / 26.91 on (profiles/r05_pp_ablation.txt)
-        self.group_wgrad32 = os.environ.get('SDMI_WGRAD_GROUP32', '0') != '0'
-        self._wq32, self._wq32_keep = [], []
-        self.defer_colsum = os.environ.get('SDMI_DEFER_COLSUM', '1') != '0'
+        # grouped weight gradients (sdmi_wgrad_group): the fused SpatialTransformer backward queues a block's problems
+        # and launches them together (StBlockFn.backward_fused)
+        self._wq, self._wq_keep = [], []
+        self.defer_colsum = bool(policy.flag('DEFER_COLSUM'))
         # data gradient + weight gradient of a layer in ONE launch on the main stream (sdmi_bwd_pair):
         # no side-stream fork / join per layer, the M-split partials of a layer are folded by extra
         # workgroups of the NEXT layer's launch (`_pfold`: the pending fold), the last one at the join
-        self.pair_bwd = os.environ.get('SDMI_BWD_PAIR', '1') != '0'
-        # same-size convolutions on images that are not powers of two (28^2 latents) take the pair launch as well
-        self.pair_any_size = os.environ.get('SDMI_PAIR_ANY', '1') != '0'
-        # experiment knob: layers whose data gradient has fewer 128 x 128 tiles than this keep separate launches
-        self.pair_min_t128 = int(os.environ.get('SDMI_PAIR_MIN_T128', '0'))
-        self.pair_slots = int(os.environ.get('SDMI_PAIR_SLOTS', '512'))       # resident workgroups (2 per CU)
-        self.pair_dgrad = int(os.environ.get('SDMI_PAIR_DGRAD', '256'))       # of which walk dX tiles
-        self.pair_min_steps = int(os.environ.get('SDMI_PAIR_MIN_STEPS', '8'))  # 64-row steps per wgrad workgroup
-        self.pair_wt64 = int(os.environ.get('SDMI_PAIR_WT64_BELOW', '96'))     # 64 x 64 dW tiles below this many wgrad workgroups (0: never)
+        self.pair_bwd = bool(policy.flag('BWD_PAIR'))
+        # geometry of a pair launch (round-3 sweeps, profiles/r03_pair_sweep.txt): resident workgroups (2 per CU), of
+        # which walk dX tiles, 64-row steps per weight-gradient workgroup, 64 x 64 dW tiles below this many of them
+        self.pair_slots, self.pair_dgrad, self.pair_min_steps, self.pair_wt64 = 512, 256, 8, 96
         self._pfold = None
         # gradient destinations a side-stream launch of this backward wrote: a main-stream writer of the same
         # destination (pair launch, pending fold) waits for that stream first
@@ -343,77 +303,16 @@ class WeightBank:
         self._pending.append(tensors)
         self.ensure_join()
 
-    # ---- grouped weight gradients -----------------------------------------------------------
-    WQ_MAX, WQ_BYTES = 16, 96 << 20
-    WQ_ITEMS = int(os.environ.get('SDMI_WQ_ITEMS', '448'))
-    WQ_TARGET = float(os.environ.get('SDMI_WQ_TARGET', '512'))
-
-    def queue_wgrad(self, kw, keep, tiles, steps, nbytes):
-        """Queue one eligible problem (kw = sdmi_wgrad fields, splits decided at flush).  The queue
-        is launched when it holds enough tiles for the chip, 16 problems, or operands worth more
-        than the Infinity Cache keeps hot -- and at the end of the backward pass (join)."""
-        if any(q[0]['dw'] == kw['dw'] for q in self._wq):     # same parameter twice: keep the order
-            self.flush_wgrad()
-        self._wq.append((kw, tiles, steps))
-        self._wq_keep.extend(keep)
-        self._wq_items += tiles
-        self._wq_bytes += nbytes
-        self.ensure_join()
-        if len(self._wq) >= self.WQ_MAX or self._wq_items >= self.WQ_ITEMS or self._wq_bytes >= self.WQ_BYTES:
-            self.flush_wgrad()
-
-    def queue_wgrad32(self, kw, keep):
-        """Queue one small fp32 1x1 / linear problem (kw = sdmi_wgrad fields, splits = 1: written straight into dw).
-        Launched when 16 are queued, when a parameter comes again (Slot Attention iterations: accumulation order) and
-        at the end of the backward pass (join) -- all on ONE side stream, so that groups touching the same parameter
-        stay ordered."""
-        if any(q['dw'] == kw['dw'] for q in self._wq32):
-            self.flush_wgrad32()
-        self._wq32.append(kw)
-        self._wq32_keep.extend(keep)
-        self.ensure_join()
-        if len(self._wq32) >= self.WQ_MAX:
-            self.flush_wgrad32()
-
-    def flush_wgrad32(self):
-        if not self._wq32:
-            return
-        q, keep = self._wq32, self._wq32_keep
-        self._wq32, self._wq32_keep = [], []
-        import ctypes
-        arr = (_lib.CSTRUCT['SdmiWgradArgs'] * len(q))()
-        flops = 0.0
-        for a, kw in zip(arr, q):
-            for k, v in kw.items():
-                setattr(a, k, v)
-            a.splits = 1
-            flops += 2.0 * kw['M'] * kw['N'] * kw['K']
-        side = self.side_stream('wgrad-group-f32')
-        if side is not None:
-            ev = torch.cuda.Event()
-            ev.record()
-            side.wait_event(ev)
-            for kw in q:             # an earlier launch into one of these destinations on ANOTHER side stream goes first
-                for d in (kw['dw'], kw.get('dbias')):
-                    prev = self._side_dst.get(d) if d else None
-                    if prev is not None and prev is not side:
-                        side.wait_stream(prev)
-        else:
-            self._after_side_writers(*[kw['dw'] for kw in q], *[kw['dbias'] for kw in q if kw.get('dbias')])
-        with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
-            call('sdmi_wgrad_group', _st(), problems=ctypes.addressof(arr), n=len(q), _meta=dict(flops=flops))
-        if side is not None:
-            for kw in q:
-                self._side_dst[kw['dw']] = side
-                if kw.get('dbias'):
-                    self._side_dst[kw['dbias']] = side
-        self._pending.append(tuple(keep))
+    # ---- grouped weight gradients (sdmi_wgrad_group) ----------------------------------------------
+    WQ_TARGET = 512.0          # workgroups of a grouped launch, shared by the problems in proportion to their work
 
     def flush_wgrad(self):
+        """Launch the queued bf16 1x1 / linear weight-gradient problems (`_wq`: (sdmi_wgrad fields, 128 x 128 tiles, 64-row
+        steps)) as ONE sdmi_wgrad_group call on a side stream; M-splits chosen here.  -> the stream it ran on."""
         if not self._wq:
-            return
+            return None
         q, keep = self._wq, self._wq_keep
-        self._wq, self._wq_keep, self._wq_items, self._wq_bytes = [], [], 0, 0
+        self._wq, self._wq_keep = [], []
         # M-splits: ~512 workgroups over the group, shared in proportion to each problem's work
         # (tiles x 64-row steps), every split keeping >= 8 steps
         work = [t * st for _, t, st in q]
@@ -455,36 +354,6 @@ class WeightBank:
         self._cq = getattr(self, '_cq', [])
         self._cq.append((partial, nblk, C, out0, out1))
         self.ensure_join()
-
-    def queue_fold(self, kw, ws):
-        self._fq.append((kw, ws))
-        self.ensure_join()
-
-    def flush_folds(self):
-        """Deferred folds of the split weight-gradient partials: after the side streams have been
-        joined, 16 layers per launch, destinations distinct within a launch (a parameter used several
-        times per step folds in successive launches, in order)."""
-        q, self._fq = self._fq, []
-        if not q:
-            return
-        import ctypes
-        Item = _lib.CSTRUCT['SdmiWgradArgs']
-        chunks = []
-        for kw, ws in q:
-            for ch in chunks:
-                if len(ch[0]) < 16 and kw['dw'] not in ch[1]:
-                    break
-            else:
-                ch = ([], set())
-                chunks.append(ch)
-            ch[0].append(kw)
-            ch[1].add(kw['dw'])
-        for chunk, _ in chunks:
-            arr = (Item * len(chunk))()
-            for a, kw in zip(arr, chunk):
-                for k, v in kw.items():
-                    setattr(a, k, v)
-            call('sdmi_wgrad_fold_group', _st(), problems=ctypes.addressof(arr), n=len(chunk))
 
     def flush_colsum(self):
         q = getattr(self, '_cq', [])
@@ -592,11 +461,9 @@ class WeightBank:
     def join(self):
         self.flush_pending_fold()
         self.flush_wgrad()
-        self.flush_wgrad32()
         self.flush_colsum()
         for side in self._sides:
             torch.cuda.current_stream().wait_stream(side)
-        self.flush_folds()
         self._pending.clear()
         self._side_dst.clear()
         self._join_queued = False
@@ -1138,32 +1005,9 @@ class Kern:
             ws = self.wb.ups_parity_weights(wname, x.dtype)
             out = torch.empty((B, 2 * H, 2 * W_, ws[0, 0].shape[0]), dtype=x.dtype, device=x.device)
             bias = self.wb.b(bname)
-            if _UPS_ONE:          # all four parities in one launch (sdmi.h: parity4; the filters are one [4][N][4 Cin] tensor)
-                w4 = next(iter(ws.values()))._base
-                return ops.conv2d(x, w4, bias, kh=2, kw=2, out=out, parity4=True)
-            if _UPS_FORK and B * H * W_ <= _UPS_FORK:
-                # the four parity launches are independent and small (128 workgroups each at 4^2 -> 8^2, B = 64): three
-                # of them run on side streams next to the first -- fork / join by events, capturable -- so the chip
-                # sees 4x the workgroups instead of four dependent-looking launches of 14 - 20 us
-                cur = torch.cuda.current_stream()
-                if not hasattr(self, '_ups_sides'):
-                    self._ups_sides = [torch.cuda.Stream() for _ in range(3)]
-                ev = torch.cuda.Event()
-                ev.record(cur)
-                for i, ((py, px), w) in enumerate(ws.items()):
-                    st = cur if i == 0 else self._ups_sides[i - 1]
-                    if i:
-                        st.wait_event(ev)
-                    with torch.cuda.stream(st):
-                        ops.conv2d(x, w, bias, kh=2, kw=2, pad=(1 - py, py, 1 - px, px), out=out, split_k=1,
-                                   sub=(2, 2, py, px))
-                for st in self._ups_sides:
-                    cur.wait_stream(st)
-                return out
-            for (py, px), w in ws.items():
-                ops.conv2d(x, w, bias, kh=2, kw=2, pad=(1 - py, py, 1 - px, px), out=out,
-                           split_k=1, sub=(2, 2, py, px))
-            return out
+            # all four parities in one launch (sdmi.h: parity4; the filters are one [4][N][4 Cin] tensor)
+            w4 = next(iter(ws.values()))._base
+            return ops.conv2d(x, w4, bias, kh=2, kw=2, out=out, parity4=True)
         if x.dtype == torch.uint8 or self.fp8_ok(x, wname, kh * kw, ups):
             # BASELINE "fp8 MFMA UNet": e4m3fn operands (activations at a fixed scale -- written by
             # the GroupNorm in front when there is one -- weights at 448 / amax), fp32 accumulation,
@@ -1220,14 +1064,9 @@ class Kern:
         GEMM (sdmi.h: ln_colsum), the gated activation into its epilogue.  -> (out, x for the
         residual branch).  bf16 (throughput) path only: the fp32 path keeps the reference's kernel
         sequence for the parity tests.  SDMI_LN_FOLD=0: the unfused sequence everywhere."""
-        rows = x.numel() // x.shape[-1]
-        # The fold's row sums are VALU work of the MFMA waves, so a folded GEMM on 128 x 128 tiles costs ~1.45x a
-        # plain one (tools/exp/short_k.py).  With the round-2 epilogue the unfolded sequence (LayerNorm kernel +
-        # plain GEMM) won above 4096 rows (sampling 95.97 -> 94.6 ms); with the streamlined epilogue stores the
-        # fold wins again end to end (94.75 vs 95.6 / 95.8 ms, same box): one dependent launch less per site is
-        # worth more than the slower GEMM.  SDMI_LN_UNFOLD_ROWS=4096 restores the unfolded form above that size.
-        unfold = rows >= (_LN_UNFOLD_ROWS if not geglu else 4 * _LN_UNFOLD_ROWS)
-        if not _LN_FOLD or x.dtype != torch.bfloat16 or unfold:
+        # (the folded GEMM costs ~1.45x a plain one on 128 x 128 tiles but saves a dependent launch per site: it wins end
+        # to end at every size -- 94.75 vs 95.6 / 95.8 ms per sampling pass, round 3)
+        if not _LN_FOLD or x.dtype != torch.bfloat16:
             h = self.linear(self.ln(x, ln_name, eps), wnames, bnames, act=act)
             return (self.geglu(h) if geglu else h), x
         w, colsum, bias = self.wb.ln_folded(ln_name, wnames, bnames, x.dtype)
@@ -1630,73 +1469,45 @@ class GemmFn(torch.autograd.Function):
                 splits = halo_splits
         bdst = _grads_of(wb, bnames) if bnames is not None else None
         lda = Cin if is_conv else x.stride(-2)
-        if (wb.group_wgrad32 and dt == torch.float32 and kh == 1 and kw == 1 and stride == 1 and not ups
-                and pad[0] == 0 and pad[2] == 0 and direct and (bnames is None or bdst is not None) and M <= 16 * mt
-                and Cin % 4 == 0 and lda % 4 == 0 and ldy % 4 == 0 and ((N + 63) // 64) * ((K + 63) // 64) <= 64):
-            # small exact-fp32 problem (Slot Attention, predictor): queued for a grouped launch
-            wb.flush_pending_fold((_p(dst), _p(bdst)))
-            wb.queue_wgrad32(dict(a=_p(x), dy=_p(dy), dw=_p(dst), dbias=_p(bdst), dtype=_DT[dt], M=M, N=N, K=K, lda=lda,
-                                  ldy=ldy, B=B, H=H, W=W_, Cin=Cin, Ho=Ho, Wo=Wo, KH=1, KW=1, stride=1, pad_t=0,
-                                  pad_l=0, ups=0, accumulate=1), (x, dy))
-        elif (wb.group_wgrad and dt == torch.bfloat16 and kh == 1 and kw == 1 and stride == 1 and not ups
-                and pad[0] == 0 and pad[2] == 0 and N > 64 and K > 64 and direct
-                and (bnames is None or bdst is not None) and (M + 128) * max(lda, ldy) * 2 < (1 << 31)):
-            # 1x1 / linear: queued for a grouped launch with the block's other weight gradients
-            tiles = ((N + 127) // 128) * ((K + 127) // 128) + (((N + 127) // 128) if bnames is not None else 0)
-            wb.queue_wgrad(dict(a=_p(x), dy=_p(dy), dw=_p(dst), dbias=_p(bdst), dtype=_DT[dt], M=M, N=N,
-                                K=K, lda=lda, ldy=ldy, B=B, H=H, W=W_, Cin=Cin, Ho=Ho, Wo=Wo, KH=1, KW=1,
-                                stride=1, pad_t=0, pad_l=0, ups=0, accumulate=1),
-                           (x, dy), tiles, (M + 63) // 64, (x.numel() + dy.numel()) * 2)
-        else:
-            # ---- data + weight gradient in ONE launch (sdmi_bwd_pair) when both are of the same loader
-            # class: 1x1 / linear, or a stride-1 same-size convolution
-            same = is_conv and stride == 1 and not ups and Ho == H and Wo == W_
-            pow2 = ((H & (H - 1)) == 0 and (W_ & (W_ - 1)) == 0) or wb.pair_any_size
-            one = kh == 1 and kw == 1 and stride == 1 and not ups and pad[0] == 0 and pad[2] == 0
-            kd = kh * kw * ldy                                   # contraction depth of the data gradient
-            bk = 64 if kd * 2 >= 512 else 32
-            pair = (wb.pair_bwd and need_dx and dt == torch.bfloat16 and direct and N > 64 and K > 64 and Cin > 64
-                    and (bnames is None or bdst is not None) and Cin % 8 == 0 and ldy % 8 == 0
-                    and (one or (same and pow2 and kh * kw <= 32 and ldy % bk == 0
-                                 and pad[0] == pad[1] == (kh - 1) // 2 and pad[2] == pad[3] == (kw - 1) // 2))
-                    and (dalias is None or dalias.shape[-1] == Cin)
-                    and ((M + 127) // 128) * ((Cin + 127) // 128) >= wb.pair_min_t128
-                    and (M + (kh + 1) * W_ + 128) * max(lda, ldy, Cin) * 2 < (1 << 31) and N * kd * 2 < (1 << 31))
-            # 3x3 layers whose data gradient takes the halo-staged kernel (igemm_halo.h: the activation patch of a
-            # 256-pixel tile staged once per 64-channel chunk) run it as its own launch, weight gradient on a side stream
-            if (pair and _HALO_DGRAD and is_conv and kh == 3 and kw == 3 and W_ in (16, 32, 64) and ldy % 64 == 0
-                    and (H * W_) % 256 == 0 and ((H * W_) & (H * W_ - 1)) == 0
-                    and (M // 256) * ((Cin + 127) // 128) >= _HALO_DGRAD):
-                pair = False
-            if pair:
-                wd = wb.wd(wnames, dt, kh, kw, Cin)
-                dx = torch.empty(x.shape if not is_conv else (B, H, W_, Cin), dtype=dt, device=x.device)
-                wb.pair_launch(
-                    dict(a=_p(dy), w=_p(wd), out=_p(dx), dtype=_DT[dt], out_dtype=_DT[dt], M=M, N=Cin, K=kd,
-                         lda=ldy, ldw=kd, ldc=Cin, B=B, H=Ho, W=Wo, Cin=ldy, Ho=H, Wo=W_, KH=kh, KW=kw, stride=1,
-                         pad_t=kh - 1 - pad[0], pad_l=kw - 1 - pad[2], ups=0, act=0, alpha=1.0, split_k=1, batch=1,
-                         residual=_p(dalias), ldr=Cin),
-                    dict(a=_p(x), dy=_p(dy), dw=_p(dst), dbias=_p(bdst), dtype=_DT[dt], M=M, N=N, K=K, lda=lda,
-                         ldy=ldy, B=B, H=H, W=W_, Cin=Cin, Ho=Ho, Wo=Wo, KH=kh, KW=kw, stride=stride,
-                         pad_t=pad[0], pad_l=pad[2], ups=0, accumulate=1),
-                    (x, dy, dx))
-                return dx, dy, (N, ldy, B, Ho, Wo, dt)
-            wb.flush_pending_fold((_p(dst), _p(bdst)))     # (a pending fold into this parameter goes first)
-            side = wb.side_stream(names[0])
-            if side is not None and 2.0 * M * N * K < _WG_MAIN_BELOW:
-                side = None                  # small contraction: not worth a cross-stream edge
-            if side is not None:
-                ev = torch.cuda.Event()
-                ev.record()
-                side.wait_event(ev)          # dy is ready
-            with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
-                GemmFn._wgrad(wb, x, dy, dt, names, bnames, dst, direct, splits, M, N, K, Cin, ldy, B,
-                              H, W_, Ho, Wo, kh, kw, stride, pad, ups, is_conv)
-            if side is not None:
-                wb.defer(x, dy)
-                wb._side_dst[_p(dst)] = side
-                if bdst is not None:
-                    wb._side_dst[_p(bdst)] = side
+        # ---- data + weight gradient in ONE launch (sdmi_bwd_pair) when both are of the same loader
+        # class: 1x1 / linear, or a stride-1 same-size convolution
+        same = is_conv and stride == 1 and not ups and Ho == H and Wo == W_
+        one = kh == 1 and kw == 1 and stride == 1 and not ups and pad[0] == 0 and pad[2] == 0
+        kd = kh * kw * ldy                                   # contraction depth of the data gradient
+        bk = 64 if kd * 2 >= 512 else 32
+        pair = (wb.pair_bwd and need_dx and dt == torch.bfloat16 and direct and N > 64 and K > 64 and Cin > 64
+                and (bnames is None or bdst is not None) and Cin % 8 == 0 and ldy % 8 == 0
+                and (one or (same and kh * kw <= 32 and ldy % bk == 0
+                             and pad[0] == pad[1] == (kh - 1) // 2 and pad[2] == pad[3] == (kw - 1) // 2))
+                and (dalias is None or dalias.shape[-1] == Cin)
+                and (M + (kh + 1) * W_ + 128) * max(lda, ldy, Cin) * 2 < (1 << 31) and N * kd * 2 < (1 << 31))
+        if pair:
+            wd = wb.wd(wnames, dt, kh, kw, Cin)
+            dx = torch.empty(x.shape if not is_conv else (B, H, W_, Cin), dtype=dt, device=x.device)
+            wb.pair_launch(
+                dict(a=_p(dy), w=_p(wd), out=_p(dx), dtype=_DT[dt], out_dtype=_DT[dt], M=M, N=Cin, K=kd,
+                     lda=ldy, ldw=kd, ldc=Cin, B=B, H=Ho, W=Wo, Cin=ldy, Ho=H, Wo=W_, KH=kh, KW=kw, stride=1,
+                     pad_t=kh - 1 - pad[0], pad_l=kw - 1 - pad[2], ups=0, act=0, alpha=1.0, split_k=1, batch=1,
+                     residual=_p(dalias), ldr=Cin),
+                dict(a=_p(x), dy=_p(dy), dw=_p(dst), dbias=_p(bdst), dtype=_DT[dt], M=M, N=N, K=K, lda=lda,
+                     ldy=ldy, B=B, H=H, W=W_, Cin=Cin, Ho=Ho, Wo=Wo, KH=kh, KW=kw, stride=stride,
+                     pad_t=pad[0], pad_l=pad[2], ups=0, accumulate=1),
+                (x, dy, dx))
+            return dx, dy, (N, ldy, B, Ho, Wo, dt)
+        wb.flush_pending_fold((_p(dst), _p(bdst)))     # (a pending fold into this parameter goes first)
+        side = wb.side_stream(names[0])
+        if side is not None:
+            ev = torch.cuda.Event()
+            ev.record()
+            side.wait_event(ev)          # dy is ready
+        with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+            GemmFn._wgrad(wb, x, dy, dt, names, bnames, dst, direct, splits, M, N, K, Cin, ldy, B,
+                          H, W_, Ho, Wo, kh, kw, stride, pad, ups, is_conv)
+        if side is not None:
+            wb.defer(x, dy)
+            wb._side_dst[_p(dst)] = side
+            if bdst is not None:
+                wb._side_dst[_p(bdst)] = side
         # ---- data gradient: the forward kernel on the flipped operand
         dx = None
         if need_dx:
@@ -1788,17 +1599,11 @@ class GemmFn(torch.autograd.Function):
                 btmp = torch.empty((N,), dtype=torch.float32, device=x.device)
                 if acc:
                     ops.zero_(btmp)
-        # direct destinations with split partials: the fold is deferred to the autograd join and done
-        # for 16 layers per launch (wb.queue_fold) instead of one small launch behind every layer
-        defer = int(wb.defer_fold and direct and splits > 1 and not stage_bias)
         call('sdmi_wgrad', _st(), a=_p(x), dy=_p(dy), dw=_p(dwbuf), dbias=_p(btmp),
              workspace=_p(ws), dtype=_DT[dt], M=M, N=N, K=K,
              lda=(Cin if is_conv else x.stride(-2)), ldy=ldy, B=B, H=H, W=W_,
              Cin=Cin, Ho=Ho, Wo=Wo, KH=kh, KW=kw, stride=stride, pad_t=pad[0], pad_l=pad[2],
-             ups=int(ups), splits=splits, accumulate=acc, defer_fold=defer)
-        if defer:
-            wb.queue_fold(dict(dw=_p(dwbuf), dbias=_p(btmp), workspace=_p(ws), N=N, K=K, splits=splits,
-                               accumulate=acc), ws)
+             ups=int(ups), splits=splits, accumulate=acc)
         # non-direct destinations (channel-padded Cin, non-adjacent fused parameters) ACCUMULATE like
         # the direct path does: a parameter used several times per step (per-frame modules,
         # gradient accumulation over micro-batches) keeps every contribution
@@ -2130,10 +1935,10 @@ def _gn_bwd_plain(wb, name, x, stats, dy, extras=()):
     return dx
 
 
-_ST_TRAIN = os.environ.get('SDMI_ST_TRAIN', '1') != '0'        # fused training form of the SpatialTransformer block
-_ST_TRAIN_MIN_WGS = int(os.environ.get('SDMI_ST_TRAIN_MIN_WGS', '96'))
-_ST_TRAIN_BWD = os.environ.get('SDMI_ST_TRAIN_BWD', '1') != '0'
-_ST_WGRAD_GROUP = os.environ.get('SDMI_ST_WGRAD_GROUP', '1') != '0'   # the block's weight gradients as two grouped launches    # ... and its backward data path (sdmi_st_train_bwd)
+_ST_TRAIN = bool(policy.flag('ST_TRAIN'))        # fused training form of the SpatialTransformer block
+_ST_TRAIN_MIN_WGS = 96      # ... when its grid has at least this many workgroups (tests set it to 0)
+_ST_TRAIN_BWD = bool(policy.flag('ST_TRAIN_BWD'))
+_ST_WGRAD_GROUP = bool(policy.flag('ST_WGRAD_GROUP'))   # the block's weight gradients as two grouped launches    # ... and its backward data path (sdmi_st_train_bwd)
 
 
 class StBlockFn(torch.autograd.Function):

@@ -17,7 +17,6 @@ import torch
 from . import dpm, engine, kern, ops, spec
 from .module import FlatModule, _Node
 
-_VQ_COMB = os.environ.get('SDMI_VQ_COMB', '1') != '0'      # sampler: x0 formed inside the VQ search
 _DTYPES = {'fp32': torch.float32, 'float32': torch.float32, 'bf16': torch.bfloat16,
            'bfloat16': torch.bfloat16}
 
@@ -135,7 +134,6 @@ class LDM(_Owned):
                   n=hi - lo, one_minus_decay=float(np.float32(1.0) - decay))
 
     # -- a7/a8 ---------------------------------------------------------------------------
-    x0_prefetched = None
 
     def encode_x0(self, img):
         """Frozen VQ-VAE encode of a batch of images -> x0 [B,h,w,4] fp32 (ldm.py:61-63, under no_grad)."""
@@ -151,9 +149,7 @@ class LDM(_Owned):
         B = img.shape[0]
         train_draw = bool(r.training and torch.is_grad_enabled())    # (read before the no_grad block below)
         with torch.no_grad():
-            # (optim.GraphedTrainStep(prefetch=True) encodes the batch ahead of the step -- the VQ-VAE is frozen, the
-            #  latents depend on the images alone -- and hands them over here)
-            x0 = self.x0_prefetched if self.x0_prefetched is not None else self.encode_x0(img)
+            x0 = self.encode_x0(img)
             tf = None
             if t is None and noise is None:
                 # the reference's two draws (ldm.py:65-69) + the schedule gathers in ONE launch of
@@ -546,7 +542,7 @@ class SADiffusion(SlotModelBase):
         def data_pred(xc, e):
             rv = rv_all[nfe[0]:nfe[0] + 1].expand(B, -1)      # pitch-0 view: same row for all b
             nfe[0] += 1
-            if not (x_start or v_pred) and _VQ_COMB:
+            if not (x_start or v_pred):           # x0 formed inside the VQ search (SdmiVqArgs.z2)
                 # x0 = (x_t - sigma_t eps) / alpha_t is formed inside the VQ search (sdmi.h: SdmiVqArgs.z2): no launch
                 # of its own, and the pad channel of eps is never read (no zero fill either)
                 eps = u.forward(Kp, self._unet_in(xc), rv, ctx_kv, zero_pad=False)
@@ -608,11 +604,6 @@ class SADiffusion(SlotModelBase):
         self._begin_train_forward()
         slots, masks = self.encode(data_dict['img'])
         return {'masks': masks, 'slots': slots}
-
-    def prefetch_latents(self, data_dict):
-        """x0 of the batch's images, as calc_train_loss would encode them (frozen VQ-VAE: a function of the images
-        alone, so a training loop may compute it ahead of the step)."""
-        return self.dm_decoder.encode_x0(data_dict['img'])
 
     def calc_train_loss(self, data_dict, out_dict):
         """sa_diffusion.py:206-213."""
@@ -698,9 +689,6 @@ class SAViDiffusion(SADiffusion):
     def encode(self, img, prev_slots=None):
         """savi_diffusion.py:169-216: img [B,T,3,H,W] -> slots [B,T,N,D], masks [B,T,N,*,*]."""
         return _encode_clip(self, img, prev_slots)
-
-    def prefetch_latents(self, data_dict):
-        return self.dm_decoder.encode_x0(data_dict['img'].flatten(0, 1))
 
     def calc_train_loss(self, data_dict, out_dict):
         """savi_diffusion.py:252-264: the LDM sees the B*T frames as independent images."""

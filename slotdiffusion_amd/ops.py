@@ -46,8 +46,8 @@ def zeros(shape, dtype, device):
 # ------------------------------------------------------------------------------------------
 # implicit GEMM
 # ------------------------------------------------------------------------------------------
-_SPLITK_BELOW = int(__import__('os').environ.get('SDMI_SPLITK_BELOW', '384'))     # output tiles (64 x 64)
-_SPLITK_MINKB = int(__import__('os').environ.get('SDMI_SPLITK_MINKB', '2048'))    # bytes of K per row
+_SPLITK_BELOW = 384       # output tiles (64 x 64)
+_SPLITK_MINKB = 2048      # bytes of K per row
 
 
 def splitk_workspace(M, N, K, elt, device):
@@ -69,7 +69,7 @@ def splitk_workspace(M, N, K, elt, device):
 # pending tensor inside the context would see unwritten memory.  Every consumer inside `UNetRunner.forward` is a library
 # call; SDMI_DEBUG_DEFER=1 makes a violation visible instead of silent: a deferring convolution first fills its output
 # with NaN (the finishing kernel overwrites every element), so any reader that slipped past the hook yields NaN.
-_DEBUG_DEFER = __import__('os').environ.get('SDMI_DEBUG_DEFER', '0') != '0'
+_DEBUG_DEFER = bool(__import__('slotdiffusion_amd.policy', fromlist=['flag']).flag('DEBUG_DEFER'))
 
 
 class _PendingSplit:
@@ -116,8 +116,8 @@ class defer_splitk:
 _GN_LAST = [None]
 # Measured SLOWER in the sampler (the 32 x 32-tile statistics cost the symmetric-wave kernel +2.8 us per
 # launch, and the apply pass with 8 - 32 partials to fold per group is a two-round-trip latency chain like the
-# single-pass kernel it replaces: 75.4 -> 76.8 ms per pass): off unless SDMI_GN_EPILOGUE_STATS=1.
-GN_EPILOGUE_STATS = __import__('os').environ.get('SDMI_GN_EPILOGUE_STATS', '0') != '0'
+# single-pass kernel it replaces: 75.4 -> 76.8 ms per pass): off.
+GN_EPILOGUE_STATS = False          # (module variable: the test of the mechanism turns it on)
 
 
 def _pre_call():

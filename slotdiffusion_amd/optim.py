@@ -186,18 +186,11 @@ class GraphedTrainStep:
     the denoiser's backward (97 % of the gradient bytes), then the all-reduce of that gradient
     range starts on the collective stream while graph B (the slot encoder's backward: the
     64-channel convolutions at full resolution) runs; the small encoder range follows, then the
-    update graph.  `allreduce` may be the legacy callable (whole arena, no overlap) or True.
-
-    prefetch=True (models with `prefetch_latents`: the frozen VQ-VAE encode of the LDM, ldm.py:61-63): the latents x0 of
-    a batch depend on its images alone, so they are computed by a third graph AHEAD of the step -- for the batch passed
-    as `next_batch`, on a side stream, while this step's update graph runs: the clip + Adam tail is bound by HBM
-    (0.9 ms at 5.2 TB/s, the matrix cores idle), the encoder's convolutions by the matrix cores / LDS.  Every step still
-    runs one encode; a step without a prefetched batch (the first one, or next_batch=None) encodes in line."""
+    update graph.  `allreduce` may be the legacy callable (whole arena, no overlap) or True."""
 
     def __init__(self, model, opt, example_batch, allreduce=None, loss_key='denoise_loss',
-                 loss_weight=1.0, world=None, wire=None, prefetch=False):
+                 loss_weight=1.0, world=None, wire=None):
         self.model, self.opt, self.allreduce = model, opt, allreduce
-        self.prefetch = bool(prefetch) and hasattr(model, 'prefetch_latents') and hasattr(model, 'dm_decoder')
         self.loss_key, self.loss_weight = loss_key, loss_weight
         from . import configure_runtime
         configure_runtime(warn=False)      # (normally too late here: the entry points call it first)
@@ -230,8 +223,6 @@ class GraphedTrainStep:
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            if self.prefetch:                       # (warm-up of the encode's lazy operands)
-                model.prefetch_latents(self.static)
             for _ in range(2):                      # warm-up: lazy operands, func attributes
                 opt.set_lr_for_next_step()
                 opt.step_count += 1
@@ -258,15 +249,6 @@ class GraphedTrainStep:
         model.weights_updated()
         del snap
         torch.cuda.synchronize()
-        self.g_pre = None
-        if self.prefetch:
-            # its own memory pool: this graph replays NEXT TO the update graph
-            self.static_pre = {'img': self.static['img'].clone()}
-            self.g_pre = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.g_pre, capture_error_mode=CAPTURE_MODE):
-                self.x0_buf = model.prefetch_latents(self.static_pre)
-            self._pre_stream, self._ev_pre, self._x0_valid = torch.cuda.Stream(), torch.cuda.Event(), False
-            model.dm_decoder.x0_prefetched = self.x0_buf      # (captured below as the loss's x0; reset after capture)
         self.g_fb = torch.cuda.CUDAGraph()
         self.g_enc = None
         if self.overlap:
@@ -281,8 +263,6 @@ class GraphedTrainStep:
         self.g_up = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.g_up, pool=self.g_fb.pool(), capture_error_mode=CAPTURE_MODE):
             self._update()
-        if self.prefetch:
-            model.dm_decoder.x0_prefetched = None
 
     # -- pieces ---------------------------------------------------------------------------
     def _forward_loss(self):
@@ -322,28 +302,12 @@ class GraphedTrainStep:
         else:
             self.opt.step(capturable=True)
 
-    def __call__(self, batch, next_batch=None):
+    def __call__(self, batch):
         for k, v in batch.items():
             self.static[k].copy_(v, non_blocking=True)
-        if self.prefetch:
-            if self._x0_valid:                 # encoded during the previous step's update
-                torch.cuda.current_stream().wait_event(self._ev_pre)
-            else:
-                self.static_pre['img'].copy_(batch['img'], non_blocking=True)
-                self.g_pre.replay()
         self.opt.set_lr_for_next_step()
         self.opt.step_count += 1
         self.g_fb.replay()
-        self._x0_valid = False
-        if self.prefetch and next_batch is not None:
-            ev = torch.cuda.Event()
-            ev.record()                        # (x0 of this step has been read)
-            with torch.cuda.stream(self._pre_stream):
-                self._pre_stream.wait_event(ev)
-                self.static_pre['img'].copy_(next_batch['img'], non_blocking=True)
-                self.g_pre.replay()
-                self._ev_pre.record()
-            self._x0_valid = True
         if self.overlap:
             works = self._start_reduce(self.dec_runs)
             self.g_enc.replay()

@@ -1,7 +1,7 @@
-"""The 256 x 128 ping-pong implicit GEMM (csrc/igemm_pp.h) through sdmi_igemm's dispatch, against torch fp32
-convolutions of the bf16-rounded operands -- the shapes that take it at the benchmark's batch (>= 192 tiles of
-256 x 128, >= 8 K tiles): the UNet's 32^2 convolutions (unet.py:219-259), the skip-concat forms of the sampler
-(two / three A sources), linear layers, ragged M / N / K, several output tiles per workgroup."""
+"""The large-tile implicit GEMMs behind sdmi_igemm's dispatch (halo-staged 3x3 kernel csrc/igemm_halo.h, symmetric-wave
+and LDS-DMA 128 x 128 kernels) against torch fp32 convolutions of the bf16-rounded operands, at the benchmark's batch
+(>= 192 tiles of 256 x 128, >= 8 K tiles): the UNet's 32^2 convolutions (unet.py:219-259), the skip-concat forms of the
+sampler (two / three A sources), linear layers, ragged M / N / K, several output tiles per workgroup."""
 import pytest
 import torch
 import torch.nn.functional as F
@@ -28,7 +28,7 @@ def _ref_conv(x, w4, bias=None, k=3):
                                       (64, 32, 256, 256),      # 512 tiles: two per workgroup (flat pipeline)
                                       (50, 32, 192, 192),      # 200 x 2 tiles, ragged N (1.5 tiles), Cin = 3 K tiles per tap
                                       (99, 24, 128, 128)])     # non-power-of-two image, ragged M (222.75 tiles)
-def test_pp_conv3x3_plain(B, H, C, N):
+def test_big_conv3x3_plain(B, H, C, N):
     ops = _ops()
     g = torch.Generator(device=DEV).manual_seed(B + H + C + N)
     w = (torch.randn(N, 3, 3, C, device=DEV, generator=g) / (9 * C) ** 0.5).bfloat16()
@@ -69,7 +69,7 @@ def test_halo_conv3x3_geometries(B, H, C, N):
         assert torch.equal(ops.conv2d(x, w, bias, rowvec=rowvec, residual=res), y)
 
 
-def test_pp_conv3x3_full_epilogue():
+def test_big_conv3x3_full_epilogue():
     """bias + per-image time-embedding row + residual + SiLU (the ResBlock forms, unet.py:271-285)."""
     ops = _ops()
     B, H, C, N = 64, 32, 128, 128
@@ -87,7 +87,7 @@ def test_pp_conv3x3_full_epilogue():
 
 
 @pytest.mark.parametrize('three', [False, True])
-def test_pp_conv3x3_extra_sources(three):
+def test_big_conv3x3_extra_sources(three):
     """out_layers.3 + skip_connection as one GEMM over [im2col(h) | skip a | skip b] (kern.res_tail)."""
     ops = _ops()
     B, H, C, N, C2, C3 = 64, 32, 128, 128, 128, 64
@@ -108,7 +108,7 @@ def test_pp_conv3x3_extra_sources(three):
 
 
 @pytest.mark.parametrize('M,N,K', [(65536, 256, 512), (65536, 128, 520), (50000, 384, 1024)])
-def test_pp_linear(M, N, K):
+def test_big_linear(M, N, K):
     """1x1 / linear problems incl. a K tail (520 = 8 K tiles + 8 columns) and ragged M."""
     ops = _ops()
     g = torch.Generator(device=DEV).manual_seed(M + N + K)
