@@ -146,8 +146,9 @@ def cpu_baseline(model, cfg, mode, quick=False):
 
 # kernels behind the C-ABI entry points the roofline legs price (csrc/igemm.hip, wgrad.hip, norm.hip, norm_bwd.hip)
 FAMILIES = {
-    'sdmi_igemm': ('igemm_kernel', 'igemm_kernel_tall', 'igemm_dma_kernel', 'igemm_sym_kernel', 'igemm_pp_kernel',
-                   'igemm_halo_kernel', 'conv3x3_c64_kernel', 'splitk_epilogue_kernel', 'bwd_pair_kernel', 'st_block_a_kernel', 'st_block_b_kernel'),
+    'sdmi_igemm': ('igemm_kernel', 'igemm_kernel_tall', 'igemm_dma_kernel', 'igemm_sym_kernel',
+                   'igemm_halo_kernel', 'conv3x3_c64_kernel', 'splitk_epilogue_kernel', 'bwd_pair_kernel', 'st_block_a_kernel', 'st_block_b_kernel',
+                   'st_train_a_kernel', 'st_train_b_kernel', 'st_train_bwd_b1_kernel', 'st_train_bwd_b2_kernel', 'st_train_bwd_a_kernel'),
     'sdmi_wgrad': ('wgrad_kernel', 'wgrad_tr_kernel', 'wgrad3x3_c64_kernel', 'wgrad3x3_halo_kernel', 'wgrad_group_kernel',
                    'wgrad_group_reduce_kernel', 'wgrad_reduce_kernel'),
     'sdmi_groupnorm': ('gn_fused_kernel', 'gn_fused2_kernel', 'gn_stats_kernel', 'gn_apply_kernel'),
@@ -238,7 +239,7 @@ def replayed_trace(argv, steps, mode):
 # entry point -> the kernels of which each of its calls launches exactly ONE (second stages -- split-K epilogues, folds,
 # the statistics pass of a two-pass GroupNorm -- are extra dispatches of the same call)
 PRIMARY = {
-    'sdmi_igemm': ('igemm_kernel', 'igemm_kernel_tall', 'igemm_dma_kernel', 'igemm_sym_kernel', 'igemm_pp_kernel',
+    'sdmi_igemm': ('igemm_kernel', 'igemm_kernel_tall', 'igemm_dma_kernel', 'igemm_sym_kernel',
                    'igemm_halo_kernel', 'conv3x3_c64_kernel'),
     'sdmi_wgrad': ('wgrad_kernel', 'wgrad_tr_kernel', 'wgrad3x3_c64_kernel', 'wgrad3x3_halo_kernel'),
     'sdmi_groupnorm': ('gn_fused_kernel', 'gn_fused2_kernel', 'gn_apply_kernel'),
@@ -629,20 +630,25 @@ def main():
 
         def fam_ms(entry):
             if trace is None:
-                return summ[entry]['ms'], summ[entry]['calls']
+                return summ.get(entry, {}).get('ms', 0.0), summ.get(entry, {}).get('calls', 0)
             t_ms = sum(trace[k][1] for k in FAMILIES[entry] if k in trace)
             n = sum(trace[k][0] for k in FAMILIES[entry] if k in trace)
             return t_ms, n
         # the igemm family = sdmi_igemm launches + the fused data / weight gradient launches (sdmi_bwd_pair:
         # igemm's tile body + the weight-gradient body in one kernel; its flops count both gradients)
         pr = summ.get('sdmi_bwd_pair', {})
-        stb = summ.get('sdmi_st_block', {})          # fused SpatialTransformer blocks: their GEMMs + attention contractions
-        ig = {k: summ['sdmi_igemm'].get(k, 0.0) + pr.get(k, 0.0) + stb.get(k, 0.0) for k in ('calls', 'ms', 'flops', 'bytes')}
+        # fused SpatialTransformer blocks (inference: sdmi_st_block; training: sdmi_st_train_fwd / _bwd): their GEMMs + the
+        # attention contractions inside them
+        stb = [summ.get(e, {}) for e in ('sdmi_st_block', 'sdmi_st_train_fwd', 'sdmi_st_train_bwd')]
+        ig = {k: summ['sdmi_igemm'].get(k, 0.0) + pr.get(k, 0.0) + sum(x.get(k, 0.0) for x in stb)
+              for k in ('calls', 'ms', 'flops', 'bytes')}
         ig_flops = ig['flops']
         ig_ms, ig_kernels = fam_ms('sdmi_igemm')
         if trace is None:
             ig_ms = ig['ms']
-        wg = summ.get('sdmi_wgrad', {})
+        wg = {k: summ.get('sdmi_wgrad', {}).get(k, 0.0) + summ.get('sdmi_wgrad_group', {}).get(k, 0.0)
+              for k in ('calls', 'ms', 'flops', 'bytes')}      # stand-alone and grouped weight gradients
+        wg = wg if wg['calls'] else {}
         wg_ms, wg_kernels = fam_ms('sdmi_wgrad') if wg else (0.0, 0)
         if trace is None and wg:
             wg_ms = wg['ms']
@@ -656,8 +662,8 @@ def main():
         ach = fam_flops / (fam_time * 1e-3) / 1e12
         rf = {
             'bound': 'mfma', 'kernel': 'GEMM family (sdmi_igemm: implicit-GEMM conv/linear fwd + dgrad; sdmi_bwd_pair: '
-                                       'dgrad + wgrad of a layer in one launch; sdmi_st_block: fused SpatialTransformer block; '
-                                       'sdmi_wgrad: stand-alone weight gradients): '
+                                       'dgrad + wgrad of a layer in one launch; sdmi_st_block / sdmi_st_train_fwd / _bwd: fused SpatialTransformer blocks; '
+                                       'sdmi_wgrad / sdmi_wgrad_group: stand-alone and grouped weight gradients): '
                                        + ', '.join(FAMILIES['sdmi_igemm'] + FAMILIES['sdmi_wgrad']),
             'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak,
             'igemm_only': {'achieved': ig_flops / (ig_ms * 1e-3) / 1e12, 'frac': ig_flops / (ig_ms * 1e-3) / 1e12 / peak,
