@@ -38,12 +38,23 @@ def _rel(a, b):
     return float((a - b).norm() / b.norm().clamp_min(1e-20))
 
 
-def _ref_block(m, n, x, kv, heads):
+def _ref_weights(m, n, requires_grad=False):
+    """{name: fp32 leaf} of block `n`: matrices rounded to bf16 (what the kernels multiply), vectors as they are."""
+    out = {}
+    for k, p in m.named_parameters():
+        if k.startswith(n + '.'):
+            v = p.detach().float()
+            v = v.reshape(v.shape[0], -1).bfloat16().float() if v.dim() > 1 else v.clone()
+            out[k] = v.requires_grad_(requires_grad)
+    return out
+
+
+def _ref_block(m, n, x, kv, heads, W=None):
     """fp32 torch restatement on the bf16-rounded weights; x [B,S,C], kv [B,N,2C] fp32 -> dict of every stored tensor."""
     t = n + '.transformer_blocks.0'
-    sd = dict(m.named_parameters())
-    Wt = lambda k: sd[k].detach().float().reshape(sd[k].shape[0], -1).bfloat16().float()
-    Vt = lambda k: sd[k].detach().float()
+    W = W if W is not None else _ref_weights(m, n)
+    Wt = lambda k: W[k]
+    Vt = lambda k: W[k]
     B, S, Cc = x.shape
     r = {}
     r['hgn'] = F.group_norm(x.permute(0, 2, 1), 32, Vt(n + '.norm.weight'), Vt(n + '.norm.bias'), 1e-6).permute(0, 2, 1)
@@ -247,3 +258,46 @@ def test_fused_backward_data_path_matches_the_per_layer_kernels(name, hw, B, n_s
     p2 = run(False)
     badp = {k: float((p[k] - p2[k]).abs().max()) for k in p if not torch.equal(p[k], p2[k])}
     assert not bad, f'fused backward is not repeatable run to run: {bad} (per-layer form: {badp})'
+
+
+@pytest.mark.parametrize('name,hw,B,n_slots,rows', [('input_blocks.4.1', 16, 2, 7, 64), ('output_blocks.5.1', 8, 4, 11, 32),
+                                                    ('input_blocks.8.1', 8, 3, 15, 32), ('output_blocks.8.1', 16, 2, 15, 64)])
+def test_fused_training_block_gradients_match_torch_autograd(name, hw, B, n_slots, rows):
+    """Fused forward + fused backward against torch autograd through the fp32 restatement of the reference block
+    (attention.py:297-308, 247-251, 182-206, 44-65) on the bf16-rounded weights: output, input / slot gradients and every
+    parameter gradient, bf16 bar 2e-2 (rel-L2)."""
+    from slotdiffusion_amd import kern
+    m = _model(seed=11)
+    u, n, heads, Cc, x, kv = _inputs(m, name, hw, B, n_slots)
+    g = torch.Generator().manual_seed(13)
+    dout = torch.randn(x.shape, generator=g).bfloat16().cuda()
+    S = hw * hw
+    # reference (CPU, fp32)
+    W = _ref_weights(m, n, requires_grad=True)
+    W = {k: v.cpu().detach().requires_grad_(True) for k, v in W.items()}
+    xr = x.float().cpu().view(B, S, Cc).requires_grad_(True)
+    kvr = kv.float().cpu().requires_grad_(True)
+    ref = _ref_block(m, n, xr, kvr, heads, W)['out']
+    ref.backward(dout.float().cpu().view(B, S, Cc))
+    # fused path
+    old = kern._ST_TRAIN, kern._ST_TRAIN_MIN_WGS, kern._ST_ROWS
+    kern._ST_TRAIN, kern._ST_TRAIN_MIN_WGS, kern._ST_ROWS = True, 0, rows
+    try:
+        ga = m.grad_arena()
+        ga.zero_()
+        xi, kvi = x.clone().requires_grad_(True), kv.clone().requires_grad_(True)
+        out = u._st(m.KG(), name, xi, heads, kvi)
+        assert isinstance(out.grad_fn, kern.StBlockFn._backward_cls), 'the block must take the fused training path'
+        out.backward(dout)
+        torch.cuda.synchronize()
+    finally:
+        kern._ST_TRAIN, kern._ST_TRAIN_MIN_WGS, kern._ST_ROWS = old
+    errs = dict(out=_rel(out.detach().view(B, S, Cc), ref.detach()), dx=_rel(xi.grad.view(B, S, Cc), xr.grad),
+                dkv=_rel(kvi.grad, kvr.grad))
+    for k, p_ in m.named_parameters():
+        if k.startswith(n + '.') and 'attn2.to_k' not in k and 'attn2.to_v' not in k:
+            errs[k[len(n) + 1:]] = _rel(p_.grad.reshape(W[k].shape), W[k].grad)
+    print(f'{name} C={Cc} S={S} B={B} slots={n_slots} rows={rows}: ' + ' '.join(f'{k}={v:.1e}' for k, v in errs.items()))
+    assert errs['out'] < 1e-2
+    worst = max(errs, key=errs.get)
+    assert errs[worst] < 2e-2, (worst, errs[worst])
