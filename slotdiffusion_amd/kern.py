@@ -1936,7 +1936,10 @@ def _gn_bwd_plain(wb, name, x, stats, dy, extras=()):
 
 
 _ST_TRAIN = bool(policy.flag('ST_TRAIN'))        # fused training form of the SpatialTransformer block
-_ST_TRAIN_MIN_WGS = 96      # ... when its grid has at least this many workgroups (tests set it to 0)
+# ... when its grid has at least this many workgroups (tests set it to 0).  At B = 64 the 16^2 level has 256 workgroups of
+# 64 rows, the 8^2 level 128 of 32 rows: fusing the 8^2 blocks as well LOSES 0.1 - 0.2 ms per step (half the chip streams
+# the block's weights while the other half idles; 26.41 / 26.41 ms with them fused, 26.33 / 26.22 ms per-layer, same box)
+_ST_TRAIN_MIN_WGS = 200
 _ST_TRAIN_BWD = bool(policy.flag('ST_TRAIN_BWD'))
 _ST_WGRAD_GROUP = bool(policy.flag('ST_WGRAD_GROUP'))   # the block's weight gradients as two grouped launches    # ... and its backward data path (sdmi_st_train_bwd)
 

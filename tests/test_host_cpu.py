@@ -266,3 +266,55 @@ def test_runtime_knob_is_set_by_entry_points_not_by_import(monkeypatch):
     assert slotdiffusion_amd.configure_runtime() == '2'
     monkeypatch.setenv('DEBUG_HIP_FORCE_GRAPH_QUEUES', '4')
     assert slotdiffusion_amd.configure_runtime() == '4'
+
+
+def test_policy_table_is_the_only_kernel_selection_switchboard(monkeypatch):
+    """Every switch has a default and a description; SDMI_<NAME> overrides it; no other module of the package reads an
+    SDMI_* environment name for kernel selection (the few remaining names are run configuration, not kernel choice)."""
+    import os
+    import re
+    from slotdiffusion_amd import policy
+    assert all(isinstance(v[0], int) and isinstance(v[1], str) and v[1] for v in policy.SWITCHES.values())
+    assert policy.flag('ST_TRAIN') == policy.SWITCHES['ST_TRAIN'][0]
+    monkeypatch.setenv('SDMI_ST_TRAIN', '0')
+    assert policy.flag('ST_TRAIN') == 0
+    allowed = {'SDMI_LIBPATH', 'SDMI_CALL_LOG', 'SDMI_GRAPH', 'SDMI_DTYPE', 'SDMI_GRAD_BF16', 'SDMI_BUILD_FORCE'}
+    root = os.path.dirname(policy.__file__)
+    for dirpath, _, files in os.walk(root):
+        for f in files:
+            if f.endswith('.py') and f != 'policy.py':
+                names = set(re.findall(r"environ\.get\('(SDMI_[A-Z0-9_]+)'", open(os.path.join(dirpath, f)).read()))
+                assert names <= allowed, (f, names - allowed)
+    assert len(policy.SWITCHES) + len(allowed) <= 25
+
+
+def test_fused_training_stream_geometry_matches_the_kernels():
+    """Unit counts of the weight streams (kern.st_train_units) = what csrc/st_train.hip consumes per wave (StTrGeom /
+    StTrBwdGeom: UA, UB, UB1, UB2), every unit inside its matrix, forward units row-major and backward units transposed."""
+    from slotdiffusion_amd import kern
+    for C in (256, 384):
+        NSL, KT, NHC = C // 128, C // 64, C // 32
+        u = kern.st_train_units(C)
+        want = dict(a=4 * KT * NSL, b=4 * KT * NSL + NHC * (2 * KT + 2 * NSL), b1=2 * KT * NSL + NHC * (KT + 4 * NSL),
+                    b2=2 * KT * NSL, ba=4 * KT * NSL)
+        shapes = {'in': (C, C), 'q': (C, C), 'k': (C, C), 'v': (C, C), 'o': (C, C), 'q2': (C, C), 'o2': (C, C),
+                  'ff1': (8 * C, C), 'ff2': (C, 4 * C), 'po': (C, C)}
+        for k, n in want.items():
+            assert len(u[k]) == 8 and all(len(w) == n for w in u[k]), (C, k)
+            for w in u[k]:
+                for key, r0, k0, tr in w:
+                    rows, cols = shapes[key]
+                    assert tr == (k in ('b1', 'b2', 'ba'))
+                    if tr:      # unit rows walk the matrix's columns
+                        assert r0 + 16 <= cols and k0 + 64 <= rows and r0 % 16 == 0 and k0 % 64 == 0
+                    else:
+                        assert r0 + 16 <= rows and k0 + 64 <= cols and r0 % 16 == 0 and k0 % 64 == 0
+        # every weight element is streamed exactly once per direction
+        for keys in (('a', 'b'), ('b1', 'b2', 'ba')):
+            seen = {}
+            for k in keys:
+                for w in u[k]:
+                    for key, r0, k0, tr in w:
+                        seen[(key, r0, k0)] = seen.get((key, r0, k0), 0) + 1
+            assert set(seen.values()) == {1}
+            assert sum(16 * 64 for _ in seen) == sum(r * c for r, c in shapes.values())
