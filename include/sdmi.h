@@ -476,6 +476,12 @@ typedef struct {
   int B, S, C, slots, phase;        /* slots <= 8: 8-column score groups; 9..16 (C = 256 only: heads * 16 = 128 columns): 16 */
   float gn_eps, ln_eps, attn_scale;
   int rows;   /* token rows per workgroup: 0 / 64, or 32 (twice the workgroups: small grids, e.g. 64 images at 8^2) */
+  /* ff_split = 2 (phase B): every 32 / 64 token rows are served by a PAIR of workgroups, each streaming half of the
+   * feed-forward's hidden chunks (half the weight bytes per workgroup, twice the workgroups: grids that leave half the
+   * chip idle).  The pair's fp32 partial outputs go to part [2][B*S][C] instead of `out`; out = part[0] + part[1] +
+   * vec_b's output bias + x is finished by the next kernel exactly like a split-K convolution's second stage
+   * (sdmi_groupnorm's part source, or sdmi_splitk_finish). */
+  float* part; int ff_split;
 } SdmiStBlockArgs;
 int sdmi_st_block(const SdmiStBlockArgs* a, void* stream);
 

@@ -66,6 +66,8 @@ struct StRing {
   int pos_con;          // ring position of the next unit to consume
   lds_char* ring;       // this wave's ring
   int voff;             // lane * 16
+  int jump_at = 1 << 30, jump = 0;   // shared-stream units from `jump_at` on lie `jump` units further (a workgroup that skips
+                                     // part of the stream: the feed-forward split of st_fused.hip's phase B)
 
   __device__ __forceinline__ void issue_one() {
     int g = g_iss < total ? g_iss : total - 1;          // (steps past the end re-fetch the last unit: static vmcnt)
@@ -75,7 +77,9 @@ struct StRing {
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_img, (lds_void*)dst, 16, voff, so, 0, 0);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_img, (lds_void*)(dst + 1024), 16, voff, so + 1024, 0, 0);
     } else {
-      const int so = (g >= n1 ? g - n_img : g) * ST_UNIT;
+      int gs = g >= n1 ? g - n_img : g;
+      if (gs >= jump_at) gs += jump;
+      const int so = gs * ST_UNIT;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_sh, (lds_void*)dst, 16, voff, so, 0, 0);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_sh, (lds_void*)(dst + 1024), 16, voff, so + 1024, 0, 0);
     }

@@ -251,7 +251,10 @@ __global__ __launch_bounds__(512, 2) void st_block_b_kernel(SdmiStBlockArgs p) {
   const int wgs_per_img = p.S / ROWS;
   // block b runs on XCD b % 8 (observed placement; speed only): every XCD gets a contiguous range of workgroup
   // ids, so the S / ROWS workgroups of an image share one L2 (they all read the image's x / K / V)
-  const int vid = st_xcd_id((int)blockIdx.x, (int)gridDim.x);
+  const int vid0 = st_xcd_id((int)blockIdx.x, (int)gridDim.x);
+  const int ffs = p.ff_split == 2 ? 2 : 1;
+  const int half = ffs == 2 ? (vid0 & 1) : 0;            // (the two workgroups of a pair: neighbours on one XCD)
+  const int vid = ffs == 2 ? (vid0 >> 1) : vid0;
   const int b = vid / wgs_per_img, rb = vid - b * wgs_per_img;
   const long long row0 = (long long)b * p.S + rb * ROWS;
   const int S = p.S;
@@ -399,6 +402,11 @@ __global__ __launch_bounds__(512, 2) void st_block_b_kernel(SdmiStBlockArgs p) {
   rg.rs_img = __builtin_amdgcn_make_buffer_rsrc(
       (void*)((const char*)p.wstream_img + ((long long)b * 8 + w) * G::UIMG * ST_UNIT), 0, G::UIMG * ST_UNIT, 0x00020000);
   rg.g_iss = 0; rg.n1 = G::UB1; rg.n_img = G::UIMG; rg.total = G::UB1 + G::UIMG + G::UB2;
+  constexpr int UCH = KT * 2 + 2 * NSL;                 // units of one hidden chunk
+  if (ffs == 2) {                                        // this workgroup's half of the hidden chunks
+    rg.total -= (G::NHC / 2) * UCH;
+    if (half) { rg.jump_at = G::UB1 + KT * NSL; rg.jump = (G::NHC / 2) * UCH; }
+  }
   rg.pos_iss = 0; rg.pos_con = 0;
   rg.ring = smem + G::RING_OFF + w * D * ST_UNIT;
   rg.voff = lane * 16;
@@ -567,12 +575,14 @@ __global__ __launch_bounds__(512, 2) void st_block_b_kernel(SdmiStBlockArgs p) {
 #pragma unroll
   for (int kt = 0; kt < KT; ++kt) st_gemm_step<D, NSL, true, 0, TT>(rg, Y, yaddr, kt, 16 * PITCH, woff, acc, sx, sxx);
   st_ln_stats<TT>(sx, sxx, 1.f / (float)C, p.ln_eps, mean, rstd);
+  if (half) zero_acc();                                  // (the x2 Wpo^T term belongs to the first workgroup of the pair)
   const float* cs_ff = vb + 2 * C;
   const float* bi_ff = vb + 10 * C;
   ST_TL_DECL
   ST_TL_BEGIN
+  const int hc0 = half * (G::NHC / 2), hc1 = ffs == 2 ? hc0 + G::NHC / 2 : G::NHC;
 #pragma unroll 1
-  for (int hc = 0; hc < G::NHC; ++hc) {
+  for (int hc = hc0; hc < hc1; ++hc) {
     f32x4 vg[2][TT];                                     // [value | gate] columns hc * 128 + w * 16 + 4 lg ..
     const f32x4 csv = st_vec4(cs_ff + hc * 128 + w * 16, lg);
     const f32x4 csg = st_vec4(cs_ff + 4 * C + hc * 128 + w * 16, lg);
@@ -615,6 +625,16 @@ __global__ __launch_bounds__(512, 2) void st_block_b_kernel(SdmiStBlockArgs p) {
   ST_TL_FLUSH;
   // ---- + b' + x  -> out   (only dummy re-fetches are in flight now: drain them, then ordinary loads are safe)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (ffs == 2) {          // this workgroup's fp32 partial; the pair is summed (+ b' + x) by the kernel behind
+    float* pp = p.part + ((long long)half * p.B * p.S + row0) * C;
+#pragma unroll
+    for (int s = 0; s < NSL; ++s)
+#pragma unroll
+      for (int tt = 0; tt < TT; ++tt)
+        *reinterpret_cast<f32x4*>(pp + (long long)(tt * 16 + l15) * C + (w * NSL + s) * 16 + 4 * lg) = acc[s][tt];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return;
+  }
   {
     const bf16_t* xr = (const bf16_t*)p.x + row0 * C;
 #pragma unroll
@@ -663,7 +683,7 @@ int st_launch(const SdmiStBlockArgs& a, hipStream_t st) {
   }
   if (a.phase == 0 || a.phase == 2) {
     SDMI_OPTIN_LDS((st_block_b_kernel<C, TT>), 160 * 1024, "st_block (phase B)");
-    hipLaunchKernelGGL((st_block_b_kernel<C, TT>), dim3(grid), dim3(512), smem_b, st, a);
+    hipLaunchKernelGGL((st_block_b_kernel<C, TT>), dim3(grid * (a.ff_split == 2 ? 2 : 1)), dim3(512), smem_b, st, a);
     return sdmi_check_launch("st_block (phase B)");
   }
   return SDMI_OK;
@@ -682,6 +702,7 @@ extern "C" int sdmi_st_block(const SdmiStBlockArgs* a, void* stream) {
   SDMI_REQUIRE(a->slots >= 1 && (a->slots <= 8 || (a->slots <= 16 && a->C == 256)),
                "1..8 slots (C = 256: up to 16, in 16-column score groups)");
   SDMI_REQUIRE(a->phase >= 0 && a->phase <= 2, "phase: 0 = both, 1 = A, 2 = B");
+  SDMI_REQUIRE(a->ff_split == 0 || a->ff_split == 1 || (a->ff_split == 2 && a->part), "ff_split: 0 / 1, or 2 with a partials buffer");
   hipStream_t st = (hipStream_t)stream;
   if (rows == 64) return a->C == 256 ? st_launch<256, 4>(*a, st) : st_launch<384, 4>(*a, st);
   return a->C == 256 ? st_launch<256, 2>(*a, st) : st_launch<384, 2>(*a, st);

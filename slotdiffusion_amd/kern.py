@@ -66,6 +66,7 @@ _CROSS_FOLD = bool(policy.flag('CROSS_FOLD'))
 _CROSS_MAX_SLOTS = 16      # most slots the folded cross-attention path takes (16-row groups per head from 9 slots)
 _LN_FOLD = bool(policy.flag('LN_FOLD'))
 _ST_FUSED = bool(policy.flag('ST_FUSED'))     # fused SpatialTransformer block (sdmi_st_block)
+_ST_FF_SPLIT = bool(policy.flag('ST_FF_SPLIT'))   # ... its feed-forward over workgroup pairs where the grid is half the chip
 _WGRAD_HALO = bool(policy.flag('WGRAD_HALO'))    # direct 3x3 weight gradient on channel pairs (wgrad3x3_halo_kernel)
 _CROSS_ONE = 64            # folded slot cross-attention as ONE launch (sdmi_cross_fold) up to this many tokens per image
 _UPS_PARITY = bool(policy.flag('UPS_PARITY'))   # upsample convolutions as four 2x2 parity convolutions in one launch
@@ -1225,12 +1226,23 @@ class Kern:
         g = st_geometry(C)
         flops = 2.0 * B * S * (C * C * 4 + C * C + 2 * 128 * C + 8 * C * C + 5 * C * C) + 4.0 * B * S * S * C
         wbytes = 2.0 * (wts['wa'].numel() + wts['wb'].numel()) + 2.0 * fold['st_img'].numel()
+        # a grid that leaves half the chip idle (64 images at 8^2: 128 workgroups of 32 rows): the feed-forward of phase B
+        # split over workgroup PAIRS, each streaming half of the hidden chunks; the pair's fp32 partials are summed (+ bias
+        # + x) by the kernel behind like a split-K convolution's second stage (ops.defer_splitk: the next GroupNorm's
+        # prologue, or sdmi_splitk_finish in front of any other reader)
+        split = 2 if (_ST_FF_SPLIT and ops._DEFER[0] and B * S // rows <= 128) else 1
+        part = torch.empty((2 * B * S * C,), dtype=torch.float32, device=x.device) if split == 2 else None
         call('sdmi_st_block', _st(), x=_p(x), tok=_p(tok), qkv=_p(qkv), out=_p(out),
              gn_gamma=_p(self.wb.f(n + '.norm.weight')), gn_beta=_p(self.wb.f(n + '.norm.bias')),
              wstream_a=_p(wts['wa']), vec_a=_p(wts['va']), wstream_b=_p(wts['wb']), vec_b=_p(wts['vb']),
              wstream_img=_p(fold['st_img']), vec_img=_p(fold['st_vec']), B=B, S=S, C=C, slots=fold['slots'],
-             phase=0, gn_eps=1e-6, ln_eps=1e-5, attn_scale=32.0 ** -0.5, rows=rows,
+             phase=0, gn_eps=1e-6, ln_eps=1e-5, attn_scale=32.0 ** -0.5, rows=rows, part=_p(part), ff_split=split,
              _meta=dict(flops=flops, bytes=2.0 * B * S * C * 2 + wbytes))
+        if split == 2:
+            bias = wts['vb'][18 * C:19 * C]
+            kw = dict(out=_p(out), workspace=_p(part), bias=_p(bias), residual=_p(x), ldr=C, dtype=_lib.BF16,
+                      out_dtype=_lib.BF16, M=B * S, N=C, ldc=C, B=B, H=H, W=W, Ho=H, Wo=W, alpha=1.0, act=0, batch=1)
+            ops._PENDING[out.data_ptr()] = ops._PendingSplit(out, kw, 2, (part, bias, None, x, 1.0))
         return out
 
     def geglu(self, h):

@@ -9,6 +9,7 @@ import os
 SWITCHES = {
     # --- inference (sampler) fusions
     'ST_FUSED':      (1, 'fused SpatialTransformer block at inference (sdmi_st_block: 2 launches instead of 10-13)'),
+    'ST_FF_SPLIT':   (1, 'feed-forward of that block split over workgroup pairs where its grid leaves half the chip idle'),
     'CROSS_FOLD':    (1, 'slot cross-attention folded into per-image projection weights (<= 16 slots)'),
     'LN_FOLD':       (1, 'LayerNorm folded into the linear layer behind it (bf16 inference)'),
     'RES_MERGE':     (1, 'ResBlock out_layers.3 + 1x1 skip convolution as one implicit GEMM'),

@@ -149,3 +149,52 @@ def test_folded_cross_attention_with_sixteen_wide_groups(name, hw, n_slots):
     e_f, e_x = _rel(folded, ref), _rel(explicit, ref)
     assert torch.isfinite(folded.float()).all()
     assert e_f < 1.5e-2 and e_f < 2.0 * e_x + 2e-3, (e_f, e_x)
+
+
+@pytest.mark.parametrize('name,hw,B', [('input_blocks.7.1', 8, 64), ('output_blocks.5.1', 8, 20), ('input_blocks.4.1', 16, 8)])
+def test_fused_block_feed_forward_split_over_workgroup_pairs(name, hw, B):
+    """sdmi.h: ff_split = 2 -- every 32 token rows served by a pair of workgroups that each stream half of the hidden
+    chunks; the pair's fp32 partials are finished (+ bias + x) by the kernel behind: the GroupNorm's prologue (part
+    source) or sdmi_splitk_finish.  Both finishes against the unsplit launch and the oracle; repeatable."""
+    from oracle import slotdiff_oracle as O
+    from slotdiffusion_amd import kern, ops
+    m = _model()
+    kern._ST_MIN_WGS, kern._ST_ROWS = 0, 32
+    K, u = m.K(), m.unet()
+    n = u.P + name
+    heads = u.heads_of[name]
+    Cc = heads * 32
+    g = torch.Generator().manual_seed(31 + hw + B)
+    x = torch.randn(B, hw, hw, Cc, generator=g).bfloat16().cuda()
+    slots = torch.randn(B, 7, 192, generator=g).bfloat16().cuda()
+    gam, bet = (1 + 0.1 * torch.randn(Cc, generator=g)).cuda(), (0.1 * torch.randn(Cc, generator=g)).cuda()
+    try:
+        with torch.no_grad():
+            t = n + '.transformer_blocks.0'
+            kv = K.linear_multi(slots, [(t + '.attn2.to_k.weight', t + '.attn2.to_v.weight')])[0]
+            kvp = {'kv': kv, 'fold': K.cross_prepare(kv, t, heads)}
+            plain = K.st_fused(x, n, heads, kvp)                     # outside the deferring context: one workgroup per 32 rows
+            y_plain = ops.group_norm(plain, gam, bet, eps=1e-5, act='silu')
+            outs = []
+            for finish in ('flush', 'groupnorm', 'flush'):
+                with ops.defer_splitk():
+                    o = K.st_fused(x, n, heads, kvp)
+                    assert (B * hw * hw // 32 <= 128) == (o.data_ptr() in ops._PENDING)
+                    if finish == 'groupnorm':
+                        y = ops.group_norm(o, gam, bet, eps=1e-5, act='silu')     # finishes the pair sums in its prologue
+                        assert o.data_ptr() not in ops._PENDING
+                outs.append(o.clone())
+        torch.cuda.synchronize()
+    finally:
+        kern._ST_MIN_WGS, kern._ST_ROWS = 128, 0
+    if B * hw * hw // 32 > 128:
+        assert all(torch.equal(o, plain) for o in outs)      # (a grid that fills the chip keeps the single launch)
+        return
+    W = {k: v.detach().float().cpu() for k, v in m.state_dict().items()}
+    ref = O._spatial_transformer(W, n, x.float().cpu().permute(0, 3, 1, 2), slots.float().cpu(), heads).permute(0, 2, 3, 1)
+    e_s, e_p = _rel(outs[0], ref), _rel(plain, ref)
+    print(f'{name} B={B}: split vs oracle {e_s:.3e}, unsplit {e_p:.3e}, split vs unsplit {_rel(outs[0], plain):.3e}')
+    assert e_s < 1.5e-2 and e_s < 1.5 * e_p + 1e-3
+    assert _rel(outs[0], plain) < 3e-3
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])     # both finishes, run to run
+    assert _rel(y, y_plain) < 4e-3
