@@ -47,15 +47,25 @@ __global__ __launch_bounds__(512, 2) void st_block_a_kernel(SdmiStBlockArgs p) {
   const int wgs_per_img = p.S / ROWS;
   // block b runs on XCD b % 8 (observed placement; speed only): every XCD gets a contiguous range of workgroup
   // ids, so the S / ROWS workgroups of an image share one L2 (they all read the image's x / K / V)
-  const int vid = st_xcd_id((int)blockIdx.x, (int)gridDim.x);
+  // ff_split = 2: a PAIR of workgroups per ROWS token rows -- both run the GroupNorm and proj_in (tok is written twice with
+  // the same bytes), the first takes the q pass, the second k and v: 2 C^2 / 3 C^2 of weights per workgroup instead of 4 C^2
+  const int vid0 = st_xcd_id((int)blockIdx.x, (int)gridDim.x);
+  const int ffs = p.ff_split == 2 ? 2 : 1;
+  const int half = ffs == 2 ? (vid0 & 1) : 0;
+  const int vid = ffs == 2 ? (vid0 >> 1) : vid0;
   const int b = vid / wgs_per_img, rb = vid - b * wgs_per_img;
   const long long row0 = (long long)b * p.S + rb * ROWS;     // first token row of this workgroup
+  const int pass0 = half ? 1 : 0, pass1 = (ffs == 2 && !half) ? 1 : 3;
 
   StRing<D> rg;
   rg.rs_sh = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.wstream_a + (long long)w * G::UA * ST_UNIT), 0,
                                                G::UA * ST_UNIT, 0x00020000);
   rg.rs_img = rg.rs_sh;
   rg.g_iss = 0; rg.n1 = G::UA; rg.n_img = 0; rg.total = G::UA; rg.pos_iss = 0; rg.pos_con = 0;
+  if (ffs == 2) {
+    rg.total = half ? 3 * KT * NSL : 2 * KT * NSL;
+    if (half) { rg.jump_at = KT * NSL; rg.jump = KT * NSL; }      // (skips the q units)
+  }
   rg.ring = smem + G::RING_OFF + w * D * ST_UNIT;
   rg.voff = lane * 16;
 #pragma unroll
@@ -190,7 +200,7 @@ __global__ __launch_bounds__(512, 2) void st_block_a_kernel(SdmiStBlockArgs p) {
   // ---- q | k | v = LayerNorm(tok) W^T through the fold: three passes of N = C over the same operand
   float mean[TT], rstd[TT];
 #pragma unroll 1
-  for (int pass = 0; pass < 3; ++pass) {
+  for (int pass = pass0; pass < pass1; ++pass) {
     const float* colsum = p.vec_a + C + pass * C;
     const float* bias = p.vec_a + 4 * C + pass * C;
 #pragma unroll
@@ -201,7 +211,7 @@ __global__ __launch_bounds__(512, 2) void st_block_a_kernel(SdmiStBlockArgs p) {
       for (int tt = 0; tt < TT; ++tt) acc[s][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     // (the NSL * 4 row stores of the epilogue before this pass are younger than every DMA in flight)
-    if (pass == 0) {
+    if (pass == pass0) {
       st_gemm_step<D, NSL, true, NSL * TT, TT>(rg, Y, yaddr, 0, 16 * PITCH, woff, acc, sx, sxx);
 #pragma unroll
       for (int kt = 1; kt < KT; ++kt) st_gemm_step<D, NSL, true, 0, TT>(rg, Y, yaddr, kt, 16 * PITCH, woff, acc, sx, sxx);
@@ -677,7 +687,7 @@ int st_launch(const SdmiStBlockArgs& a, hipStream_t st) {
   const int grid = a.B * (a.S / G::ROWS);
   if (a.phase == 0 || a.phase == 1) {
     SDMI_OPTIN_LDS((st_block_a_kernel<C, TT>), G::SMEM_GEMM, "st_block (phase A)");
-    hipLaunchKernelGGL((st_block_a_kernel<C, TT>), dim3(grid), dim3(512), G::SMEM_GEMM, st, a);
+    hipLaunchKernelGGL((st_block_a_kernel<C, TT>), dim3(grid * (a.ff_split == 2 ? 2 : 1)), dim3(512), G::SMEM_GEMM, st, a);
     const int rc = sdmi_check_launch("st_block (phase A)");
     if (rc) return rc;
   }

@@ -8,7 +8,7 @@ for i in 1 2 3; do
     SDMI_ST_FF_SPLIT=$v $B 2>/dev/null | grep '^{' | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['value'])" >> gpurun_out/ffsplit.txt
   done
 done
-for c in movid11x6; do
+for c in ; do
   for v in 0 1; do
     echo "$c ST_FF_SPLIT=$v" >> gpurun_out/ffsplit.txt
     SDMI_ST_FF_SPLIT=$v $B --config $c 2>/dev/null | grep '^{' | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['value'])" >> gpurun_out/ffsplit.txt
