@@ -632,6 +632,17 @@ int launch_dma(const SdmiGemmArgs& p, int hw_shift, hipStream_t st, int split_k 
   return rc;
 }
 
+// SDMI_IGEMM_DMA: 0 off, 1 / 2 experiments (all eligible shapes), 3 the measured-faster shapes, 4 = 3 without the
+// extra-source form (A/B of the merged ResBlock tails)
+static int dma_mode() {
+  static int dma_env = -1;
+  if (dma_env < 0) {
+    const char* e = getenv("SDMI_IGEMM_DMA");
+    dma_env = e ? atoi(e) : SDMI_IGEMM_DMA;
+  }
+  return dma_env;
+}
+
 // smallest K (bytes per row) that takes the 64 x 64 LDS-DMA kernel
 static constexpr int dma64_min() { return 256; }
 
@@ -798,9 +809,17 @@ int dispatch(const SdmiGemmArgs& p, hipStream_t st, bool plan_only = false) {
         sdmi_set_error("igemm: extra A sources need K >= 512 bytes per row and N > 64");
         return SDMI_EUNSUPPORTED;
       }
-      if (shape == T128x128)
+      if (shape == T128x128) {
+        // merged ResBlock tails of the 16^2 level (3x3 over h + 1x1 over the skip sources, about one tile per CU): the
+        // twelve-wave LDS-DMA kernel the plain 3x3 layers of that level take (below), with the extra-source loaders
+        if constexpr (sizeof(T) == 2) {
+          const long long t256x = ((p.M + 255) / 256) * ((p.N + 127) / 128);
+          if (dma_mode() == 3 && !is1x1 && split_k == 1 && t128 >= 192 && t256x < 192 && kbytes >= 2048 * 2)
+            return launch_dma<T, 128, 128, 4, 2, 8, true>(p, hw_shift, st);
+        }
         return is1x1 ? launch_cfg<T, 128, 128, 128, 1, 0, true>(p, split_k, hw_shift, st)
                      : launch_cfg<T, 128, 128, 128, 2, 0, true>(p, split_k, hw_shift, st);
+      }
       if (sizeof(T) == 2 && dma64_min())
         return is1x1 ? launch_dma<T, 64, 64, 4, 1, 4, true>(p, hw_shift, st, split_k)
                      : launch_dma<T, 64, 64, 4, 2, 4, true>(p, hw_shift, st, split_k);
@@ -856,14 +875,10 @@ int dispatch(const SdmiGemmArgs& p, hipStream_t st, bool plan_only = false) {
   // LDS-DMA kernels (one workgroup per CU, 3-4 LDS stages): deep-K 1x1 / plain convolutions with
   // wide outputs, no split-K
   {
-    static int dma_env = -1;
-    if (dma_env < 0) {
-      const char* e = getenv("SDMI_IGEMM_DMA");
-      dma_env = e ? atoi(e) : SDMI_IGEMM_DMA;
-    }
+    const int dma_env = dma_mode();
     const bool dma_ok = sizeof(T) != 1 && !p.a2 && !p.parity4 && dma_env && wide && kbytes >= 8 * 128 && split_k == 1 && p.N > 64 && fits31 &&
                         (is1x1 || (plain && p.Cin % (128 / (int)sizeof(T)) == 0)) && p.KH * p.KW <= 32;
-    if (dma_ok && dma_env == 3) {
+    if (dma_ok && dma_env >= 3) {
       // default: the 4-stage 128 x 128 LDS-DMA kernel where it measured faster in dependent chains on MI355X
       // (tools/exp/conv_chain.py, B = 64): about one tile per CU and a deep K -- the 16^2 level's 3x3
       // convolutions, 30.0 -> 27.8 us (256 -> 256) and 50.4 -> 42.4 us (512 -> 256); neutral or slower elsewhere

@@ -87,10 +87,12 @@ def test_big_conv3x3_full_epilogue():
 
 
 @pytest.mark.parametrize('three', [False, True])
-def test_big_conv3x3_extra_sources(three):
-    """out_layers.3 + skip_connection as one GEMM over [im2col(h) | skip a | skip b] (kern.res_tail)."""
+@pytest.mark.parametrize('shape', [(64, 32, 128, 128, 128, 64), (64, 16, 256, 256, 256, 128), (64, 16, 256, 256, 128, 64)])
+def test_big_conv3x3_extra_sources(three, shape):
+    """out_layers.3 + skip_connection as one GEMM over [im2col(h) | skip a | skip b] (kern.res_tail): the 32^2 level
+    (symmetric-wave kernel) and the 16^2 level at B = 64 (twelve-wave LDS-DMA kernel with extra-source loaders)."""
     ops = _ops()
-    B, H, C, N, C2, C3 = 64, 32, 128, 128, 128, 64
+    B, H, C, N, C2, C3 = shape
     g = torch.Generator(device=DEV).manual_seed(8 + three)
     h = torch.randn(B, H, H, C, device=DEV, generator=g).bfloat16()
     a = torch.randn(B, H, H, C2, device=DEV, generator=g).bfloat16()
