@@ -115,7 +115,7 @@ def test_train_step_gradients():
     slots, _ = O.sa_encode(W, c['img'], c['rplan'], 3, training=True)
     loss, _, _ = O.ldm_loss(W, c['uplan'], c['ed'], c['img'], slots, G['t'], G['noise'])
     loss.backward()
-    assert abs(float(loss) - float(G['train_loss'])) < 1e-5
+    assert abs(float(loss.detach()) - float(G['train_loss'])) < 1e-5
     gn = sum(float((W[k].grad.double() ** 2).sum()) for k in train) ** 0.5
     assert abs(gn - float(G['grad_global_norm'])) < 1e-4 * float(G['grad_global_norm'])
     for k in G:
@@ -268,6 +268,7 @@ def test_plain_sa_oracle_matches_reference():
     loss, recon, masks, slots = O.sa_forward_loss(W, img, plan, dplan, cfg['dec_dict']['dec_resolution'],
                                                   cfg['slot_dict']['num_iterations'])
     loss.backward()
+    loss, recon, masks, slots = loss.detach(), recon.detach(), masks.detach(), slots.detach()
     assert float((slots - G['slots']).abs().max()) <= 2e-5
     assert float((recon[:, :, 1::2, ::2] - G['recon_img_sub2']).abs().max()) <= 2e-5
     assert float((masks[:, :, 0, ::4, 1::4] - G['masks_sub4']).abs().max()) <= 2e-5
@@ -418,6 +419,7 @@ def test_savi_oracle_matches_reference():
         cfg['dec_dict']['dec_resolution'], cfg['slot_dict']['num_iterations'],
         cfg['pred_dict']['pred_num_layers'], cfg['pred_dict']['pred_num_heads'])
     loss.backward()
+    loss, recon, masks, slots = loss.detach(), recon.detach(), masks.detach(), slots.detach()
     assert float((slots - G['slots']).abs().max()) <= 2e-5
     assert float((recon[:, :, :, 1::2, ::2] - G['recon_img_sub2']).abs().max()) <= 2e-5
     assert float((masks[:, :, :, 0, ::4, 1::4] - G['masks_sub4']).abs().max()) <= 2e-5
@@ -471,7 +473,7 @@ def test_vqvae_training_gradients_oracle_matches_reference():
         rel = (gn - V[key]).abs() / (V[key].abs() + 1e-9)
         assert float(rel.max()) <= 5e-3, (key, float(rel.max()))
         if w == 0.:
-            assert abs(float(r['recon_loss']) - float(V['train_recon_loss'])) <= 1e-6
+            assert abs(float(r['recon_loss'].detach()) - float(V['train_recon_loss'])) <= 1e-6
             for n in ('quantize.embedding.weight', 'decoder.mid.attn_1.k.weight'):
                 ref = V['grad/' + n]
                 assert float((W[n].grad - ref).abs().max()) <= 2e-3 * float(ref.abs().max()) + 1e-9, n
