@@ -1,4 +1,4 @@
-// Row-major epilogue of a wave's 64 x 64 accumulator block (round 5; igemm_pp.h, igemm_halo.h).
+// Row-major epilogue of a wave's 64 x 64 accumulator block (round 5; igemm_halo.h; conv3x3_c64_kernel keeps an un-instantiated ROWS form).
 //
 // The column-per-lane epilogue of rounds 1 - 4 (wave_epilogue_fast) stores 2 bytes per lane: a store instruction
 // writes two 64-byte row segments, 64 instructions per 64 x 64 block -- measured 6.5 us per 256 x 128 output tile when

@@ -1,7 +1,8 @@
 // 3x3 stride-1 convolution as a ping-pong implicit GEMM whose activation operand is staged ONCE per 64-channel chunk
 // (round 5).
 //
-// igemm_pp.h's ablations (profiles/r05_pp_ablation.txt; 3x3 256 -> 256 at 32^2, B = 64, us per launch): full kernel 87.7,
+// Ablations of the same ping-pong tile WITHOUT halo staging (igemm_pp, deleted in round 6: DESIGN section 8;
+// profiles/r05_pp_ablation.txt; 3x3 256 -> 256 at 32^2, B = 64, us per launch): full kernel 87.7,
 // MFMAs + fragment reads without any operand fetch 51.0 (the matrix pipes at the clock the chip sustains under this
 // load, ~1.67 GHz), with the weight pieces only 59.2, with the activation pieces only 69.7 -- the activation operand
 // of an implicit GEMM (every input pixel fetched again for each of the nine taps: 32 KB per K tile, cold in the
@@ -10,7 +11,17 @@
 // rows above / below the image -- goes into LDS once (43 KB at W = 32) and serves all nine taps: a tap only shifts the
 // fragment address by (kh (W + 2) + kw) patch pixels.  Activation traffic per K tile 32 KB -> 4.8 KB; with the 16 KB
 // weight tile 21 KB instead of 48.
-//   * structure, hazards and the staggered groups: igemm_pp.h (four barrier intervals per K tile, 8 MFMAs each);
+//   * structure: 256 x 128 output tile, eight waves as 4 (M) x 2 (N), each a 64 x 64 block = four 32x32 accumulators
+//     (16 MFMAs per 16 ds_read_b128 and K tile).  The two waves of a SIMD belong to different GROUPS (waves 0-3 / 4-7)
+//     that run the same program one barrier apart: while one group is in its MFMA segment (8 back-to-back
+//     v_mfma_f32_32x32x16_bf16 = 256 cycles of the SIMD's matrix pipe) the other is in its LOAD segment (fragment reads
+//     for its next half K tile + its DMA pieces), then they swap -- matrix beside memory on every SIMD, four barrier
+//     intervals per K tile (step);
+//   * hazards by barrier count (interval i = between barrier i and i + 1; group 0 runs L(s,0) M(s,0) L(s,1) M(s,1) in
+//     intervals 4s .. 4s+3, group 1 one interval later): the last ds_read of step s is group 1's L(s,1) in interval 4s+3,
+//     retired by lgkmcnt(0) before barrier 4s+4; a weight stage is refilled (step s+3's tile) from the L segments of
+//     step s+1, interval >= 4s+4.  At an output-tile boundary group 0 idles one interval so that both groups store their
+//     accumulators in the same interval, then group 1 idles one to restore the stagger;
 //   * LDS: two patch buffers (chunk c + 1 arrives while chunk c is multiplied: wave w issues patch piece 8 t + w
 //     during tap t <= 6) + three 16 KB weight stages (the tile of step s + 2 is issued during step s); a wave waits
 //     for the weight pieces of step s + 1 at the end of step s with vmcnt(2 or 3) -- patch pieces are older than the
